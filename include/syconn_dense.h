@@ -1,0 +1,132 @@
+/*
+ * syconn_dense.h -- C ABI of libsyconn_dense_hip.so: the MI355X (gfx950) compute layer under SyConn's chunked
+ * dense 3D-CNN prediction path.
+ *
+ * The reference has NO FFI on this path: its boundary is the Python API of
+ *   syconn/handler/prediction.py:594-868  (predict_dense_to_kd / dense_predictor / dense_predicton_helper)
+ * which calls the third-party elektronn3.inference.Predictor (prediction.py:770-781, 863) which in turn runs a
+ * TorchScript elektronn3 U-Net through torch/cuDNN.  This header is the C ABI the build adds UNDER that Python
+ * API; every entry point cites the reference step it replaces.  INTEGRATION.md shows the
+ * ctypes binding a SyConn maintainer would add.
+ *
+ * Conventions
+ *   - return 0 (SD_OK) on success, negative on error; sd_last_error() gives the message (thread-local).
+ *     SD_ERR_NOMEM is mapped by the Python layer to RuntimeError so that the reference's tile-halving retry
+ *     loop (prediction.py:783-794) keeps working.
+ *   - all device buffers are CALLER-OWNED (the host framework's allocator); the library owns only the packed
+ *     weights inside an sd_model.  Pointers are plain device addresses, sizes are bytes / elements as stated.
+ *   - every launch is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream); the caller
+ *     synchronises.  A handle is bound to one device and is not thread-safe.
+ *   - volumes are z,y,x (x fastest).  Network input is one channel, planar.  Network output is planar
+ *     (C, D, H, W).  Activations inside the workspace are voxel-major / channel-minor ("channels-last") in the
+ *     model's activation dtype; that layout is private to the library.
+ */
+#ifndef SYCONN_DENSE_H
+#define SYCONN_DENSE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SD_OK 0
+#define SD_ERR_INVALID (-1) /* bad argument / unsupported layer combination */
+#define SD_ERR_NOMEM (-2)   /* workspace too small or device allocation failed */
+#define SD_ERR_HIP (-3)     /* HIP runtime error */
+#define SD_ERR_NODEVICE (-4)
+
+/* element types of caller-visible buffers */
+enum sd_dtype { SD_U8 = 0, SD_F32 = 1, SD_BF16 = 2, SD_F16 = 3, SD_U64 = 4 };
+
+/* what sd_forward writes: raw logits (model(inp)), softmax(1) (Predictor(apply_softmax=True), prediction.py:779),
+ * or floor(255*softmax) as uint8 (dense_predicton_helper, prediction.py:864-865) */
+enum sd_out_kind { SD_OUT_LOGITS_F32 = 0, SD_OUT_PROBS_F32 = 1, SD_OUT_PROBS_U8 = 2 };
+
+/* layer kinds of the network plan (the elektronn3 U-Net block structure) */
+enum sd_op_kind {
+    SD_OP_CONV = 1,      /* Conv3d k=(3,3,3)|(1,3,3), 'same' zero padding, +bias, +folded eval-BatchNorm, +ReLU;
+                            src1 >= 0: input is cat((crop(src0), src1), channel) (UpConv merge, autocrop) */
+    SD_OP_POOL = 2,      /* MaxPool3d k=(2,2,2)|(1,2,2), ceil_mode=True */
+    SD_OP_UPCONV = 3,    /* ConvTranspose3d k=s=(2,2,2)|(1,2,2), +bias, +folded eval-BatchNorm, +ReLU */
+    SD_OP_GROUPNORM = 4, /* in-place GroupNorm(groups) + ReLU on buffer src0, statistics over the region cropped to
+                            the shape of buffer src1 (if >= 0) */
+    SD_OP_FINAL = 5      /* Conv3d k=1 to `cout` classes (+ softmax / uint8 epilogue chosen at sd_forward) */
+};
+
+/* One layer.  Buffer id 0 is the network input (1 channel); every other id names an activation buffer inside the
+ * workspace.  All *_off fields are FLOAT offsets into the weight blob given to sd_model_create, -1 if absent.
+ * Weights are in PyTorch layout: Conv3d [cout][cin][kz][ky][kx], ConvTranspose3d [cin][cout][kz][ky][kx]. */
+typedef struct sd_op_desc {
+    int32_t kind;
+    int32_t src0, src1, dst;
+    int32_t cin0, cin1, cout;
+    int32_t kz, ky, kx;
+    int32_t relu;
+    int32_t norm;   /* 0: none, 1: eval-mode BatchNorm folded into the layer (gamma/beta/mean/var offsets) */
+    int32_t groups; /* SD_OP_GROUPNORM */
+    float eps;
+    int64_t w_off, b_off, gamma_off, beta_off, mean_off, var_off;
+} sd_op_desc;
+
+typedef struct sd_model sd_model;
+
+/* Bind the calling thread to a device (replaces Predictor's device pick, row P1).  Returns SD_ERR_NODEVICE when no
+ * gfx950 device is visible -- there is no CPU fallback in this library. */
+int sd_init(int device_ordinal);
+
+/* Number of visible HIP devices (0 if none). */
+int sd_device_count(void);
+
+/* Build a model: validate the plan, fold BatchNorm, convert + pack weights into MFMA fragment order and upload
+ * them.  Replaces torch.jit.load(model.pts).to(device) (prediction.py:777, 1061-1062).
+ * act_dtype: SD_BF16 or SD_F16 (storage type of activations / MFMA operands; accumulation is fp32). */
+int sd_model_create(const sd_op_desc* ops, int n_ops, const float* weights, size_t n_floats, int act_dtype,
+                    sd_model** out);
+void sd_model_destroy(sd_model* m);
+
+/* Workspace bytes sd_forward needs for a (D,H,W) input tile; 0 on error. */
+size_t sd_workspace_bytes(const sd_model* m, int D, int H, int W);
+
+/* One forward pass of the network on one tile = Predictor._predict (row P4: model(inp) [+ softmax(1)]).
+ * in_dev: (D,H,W) planar, in_dtype SD_U8 (normalised as float32(v)/255, prediction.py:808) or SD_F32.
+ * out_dev: (cout_final, D, H, W) planar, float32 or uint8 according to out_kind. */
+int sd_forward(sd_model* m, const void* in_dev, int in_dtype, int D, int H, int W, void* out_dev, int out_kind,
+               void* workspace_dev, size_t ws_bytes, void* stream);
+
+/* tiled_apply helpers (row P3).  Gather: copy the (TD,TH,TW) box starting at (oz,oy,ox) -- which may lie partly
+ * outside the (VD,VH,VW) volume -- into a dense tile, zeros outside (zero-padded tile extraction).
+ * dtype: SD_U8 or SD_F32 (copied verbatim). */
+int sd_tile_gather(const void* vol_dev, int dtype, int VD, int VH, int VW, int oz, int oy, int ox, void* tile_dev,
+                   int TD, int TH, int TW, void* stream);
+/* Scatter: for each of C channels copy tile[c, cz:cz+KD, cy:cy+KH, cx:cx+KW] (tile is (C,TD,TH,TW)) into
+ * vol[c, oz:oz+KD, oy:oy+KH, ox:ox+KW] (vol is (C,VD,VH,VW)); the crop-only stitching of tiled_apply and the
+ * halo crop of prediction.py:812.  dtype: SD_U8 or SD_F32. */
+int sd_tile_scatter(const void* tile_dev, int dtype, int C, int TD, int TH, int TW, int cz, int cy, int cx, int KD,
+                    int KH, int KW, void* vol_dev, int VD, int VH, int VW, int oz, int oy, int ox, void* stream);
+
+/* The label rule of prediction.py:813-833 for ONE multi-id target: out[v] = 0; for i in order:
+ * if (probs[ids[i]][v] > thresholds[i]) out[v] = ids[i].  probs: (C, nvox) uint8; `ids` / `thresholds` are HOST
+ * arrays (n_ids <= 16), thresholds already resolved by the caller (None -> 127.5, t<1 -> 255*t) and compared
+ * exactly as numpy compares uint8 with a float64; out_dtype SD_U8 or SD_U64 (save_seg takes uint64). */
+int sd_postproc_labels(const uint8_t* probs_dev, int C, size_t nvox, const int32_t* ids, const double* thresholds,
+                       int n_ids, void* out_dev, int out_dtype, void* stream);
+
+/* Measurement / test support.  Profiling brackets every layer launch with HIP events on the launch stream;
+ * sd_profile_read returns the per-layer milliseconds of the LAST sd_forward (after the caller synchronised). */
+int sd_profile_enable(sd_model* m, int enable);
+int sd_profile_read(sd_model* m, float* ms_per_op, int n_ops);
+/* Copy activation buffer `buf` of the last sd_forward out of the workspace as float32 planar (C, d, h, w);
+ * dims are returned in dims4 = {C, d, h, w}.  out_dev may be NULL to query dims only. */
+int sd_debug_read_buffer(sd_model* m, int buf, const void* workspace_dev, float* out_dev, int32_t* dims4,
+                         void* stream);
+int sd_model_num_ops(const sd_model* m);
+
+const char* sd_last_error(void);
+const char* sd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SYCONN_DENSE_H */

@@ -1,0 +1,77 @@
+"""ctypes binding of ``libsyconn_dense_hip.so`` (C ABI: ``include/syconn_dense.h``).
+
+There is deliberately no fallback: if the shared library is missing (not built) loading raises, and if no
+MI355X is visible ``sd_init`` returns ``SD_ERR_NODEVICE`` which is raised as ``RuntimeError``.
+"""
+import ctypes as C
+import os
+
+SD_OK, SD_ERR_INVALID, SD_ERR_NOMEM, SD_ERR_HIP, SD_ERR_NODEVICE = 0, -1, -2, -3, -4
+SD_U8, SD_F32, SD_BF16, SD_F16, SD_U64 = 0, 1, 2, 3, 4
+SD_OUT_LOGITS_F32, SD_OUT_PROBS_F32, SD_OUT_PROBS_U8 = 0, 1, 2
+SD_OP_CONV, SD_OP_POOL, SD_OP_UPCONV, SD_OP_GROUPNORM, SD_OP_FINAL = 1, 2, 3, 4, 5
+
+LIB_NAME = 'libsyconn_dense_hip.so'
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+# every symbol include/syconn_dense.h declares (checked by tests/test_abi.py)
+EXPORTS = ['sd_init', 'sd_device_count', 'sd_model_create', 'sd_model_destroy', 'sd_workspace_bytes', 'sd_forward',
+           'sd_tile_gather', 'sd_tile_scatter', 'sd_postproc_labels', 'sd_profile_enable', 'sd_profile_read',
+           'sd_debug_read_buffer', 'sd_model_num_ops', 'sd_last_error', 'sd_version']
+
+
+class OpDesc(C.Structure):
+    """Mirror of ``sd_op_desc``."""
+    _fields_ = [('kind', C.c_int32), ('src0', C.c_int32), ('src1', C.c_int32), ('dst', C.c_int32),
+                ('cin0', C.c_int32), ('cin1', C.c_int32), ('cout', C.c_int32),
+                ('kz', C.c_int32), ('ky', C.c_int32), ('kx', C.c_int32),
+                ('relu', C.c_int32), ('norm', C.c_int32), ('groups', C.c_int32), ('eps', C.c_float),
+                ('w_off', C.c_int64), ('b_off', C.c_int64), ('gamma_off', C.c_int64), ('beta_off', C.c_int64),
+                ('mean_off', C.c_int64), ('var_off', C.c_int64)]
+
+
+_lib = None
+
+
+def load():
+    """Load the library once; raise if it has not been built (``python -c 'import __graft_entry__ as g; g.build()'``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError(f'{LIB_PATH} not found: build it with `make -C syconn_amd/csrc` '
+                          f'(or __graft_entry__.build()); syconn_amd has no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
+    lib.sd_init.argtypes = [i32]; lib.sd_init.restype = i32
+    lib.sd_device_count.argtypes = []; lib.sd_device_count.restype = i32
+    lib.sd_model_create.argtypes = [C.POINTER(OpDesc), i32, C.POINTER(C.c_float), sz, i32, C.POINTER(vp)]
+    lib.sd_model_create.restype = i32
+    lib.sd_model_destroy.argtypes = [vp]; lib.sd_model_destroy.restype = None
+    lib.sd_workspace_bytes.argtypes = [vp, i32, i32, i32]; lib.sd_workspace_bytes.restype = sz
+    lib.sd_forward.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp, sz, vp]; lib.sd_forward.restype = i32
+    lib.sd_tile_gather.argtypes = [vp, i32] + [i32] * 6 + [vp] + [i32] * 3 + [vp]; lib.sd_tile_gather.restype = i32
+    lib.sd_tile_scatter.argtypes = [vp, i32] + [i32] * 10 + [vp] + [i32] * 6 + [vp]; lib.sd_tile_scatter.restype = i32
+    lib.sd_postproc_labels.argtypes = [vp, i32, sz, C.POINTER(C.c_int32), C.POINTER(C.c_double), i32, vp, i32, vp]
+    lib.sd_postproc_labels.restype = i32
+    lib.sd_profile_enable.argtypes = [vp, i32]; lib.sd_profile_enable.restype = i32
+    lib.sd_profile_read.argtypes = [vp, C.POINTER(C.c_float), i32]; lib.sd_profile_read.restype = i32
+    lib.sd_debug_read_buffer.argtypes = [vp, i32, vp, vp, C.POINTER(C.c_int32), vp]
+    lib.sd_debug_read_buffer.restype = i32
+    lib.sd_model_num_ops.argtypes = [vp]; lib.sd_model_num_ops.restype = i32
+    lib.sd_last_error.argtypes = []; lib.sd_last_error.restype = C.c_char_p
+    lib.sd_version.argtypes = []; lib.sd_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ''):
+    """Map library error codes to the exceptions the reference's callers expect
+    (RuntimeError == 'out of device memory' for the tile-halving loop)."""
+    if rc == SD_OK:
+        return
+    msg = load().sd_last_error().decode(errors='replace')
+    text = f'{what}: {msg}' if what else msg
+    if rc == SD_ERR_INVALID:
+        raise ValueError(text)
+    raise RuntimeError(text)

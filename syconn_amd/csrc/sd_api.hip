@@ -1,0 +1,556 @@
+// Host side of libsyconn_dense_hip.so: the C ABI of include/syconn_dense.h.  Owns the network plan, folds
+// BatchNorm, packs weights into MFMA fragment order, plans the workspace and enqueues the gfx950 kernels.
+#include "sd_internal.h"
+#include "../../include/syconn_dense.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess)                                                                               \
+            return fail(_e == hipErrorOutOfMemory ? SD_ERR_NOMEM : SD_ERR_HIP,                              \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                                 \
+    } while (0)
+
+inline int rup(int v, int m) { return (v + m - 1) / m * m; }
+inline size_t rup_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+// float -> bf16 (round to nearest even) / fp16 bits
+inline uint16_t f2bf16(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline uint16_t f2f16(float f) {
+    _Float16 h = (_Float16)f;
+    uint16_t b;
+    std::memcpy(&b, &h, 2);
+    return b;
+}
+inline uint16_t cvt(float f, int act_dtype) { return act_dtype == SD_BF16 ? f2bf16(f) : f2f16(f); }
+
+struct Dims { int d = 0, h = 0, w = 0; };
+
+struct Op {
+    sd_op_desc d{};
+    // device pointers (into the model's weight blob)
+    size_t wpack_off = 0, bias_off = 0, aux_off = 0;   // byte offsets
+    int NT = 1, NB = 1;
+    bool first = false;    // conv reading the network input (cin = 1)
+};
+
+}  // namespace
+
+struct sd_model {
+    int device = 0;
+    int act_dtype = SD_BF16;
+    std::vector<Op> ops;
+    int nbuf = 0;
+    std::vector<int> bufC;    // real channels per buffer id
+    std::vector<int> bufCp;   // padded channel stride
+    char* dev_blob = nullptr; // packed weights
+    size_t blob_bytes = 0;
+    float* dev_lut = nullptr;
+    // last forward
+    std::vector<Dims> dims;
+    std::vector<size_t> buf_off;
+    bool profile = false;
+    std::vector<hipEvent_t> events;
+    int final_cout = 0;
+};
+
+namespace {
+
+constexpr size_t WS_SCRATCH = 16384;  // GroupNorm sums (double[2*C]) + scale/shift (float[2*C]) at workspace start
+
+// shape inference for an input tile; fills dims[] per buffer.
+int infer_shapes(const sd_model* m, int D, int H, int W, std::vector<Dims>& dims) {
+    dims.assign(m->nbuf, Dims{});
+    dims[0] = {D, H, W};
+    for (const Op& op : m->ops) {
+        const sd_op_desc& d = op.d;
+        switch (d.kind) {
+        case SD_OP_CONV: {
+            const Dims a = dims[d.src0];
+            Dims o = a;
+            if (d.src1 >= 0) {
+                o = dims[d.src1];
+                if (a.d < o.d || a.h < o.h || a.w < o.w) return fail(SD_ERR_INVALID, "merge conv: src0 smaller than src1");
+            }
+            if (o.d <= 0) return fail(SD_ERR_INVALID, "conv input not produced yet");
+            dims[d.dst] = o;
+            break;
+        }
+        case SD_OP_POOL: {
+            const Dims a = dims[d.src0];
+            dims[d.dst] = {d.kz == 2 ? (a.d + 1) / 2 : a.d, (a.h + 1) / 2, (a.w + 1) / 2};
+            break;
+        }
+        case SD_OP_UPCONV: {
+            const Dims a = dims[d.src0];
+            dims[d.dst] = {a.d * d.kz, a.h * 2, a.w * 2};
+            break;
+        }
+        case SD_OP_GROUPNORM:
+        case SD_OP_FINAL: break;
+        default: return fail(SD_ERR_INVALID, "unknown op kind");
+        }
+    }
+    return SD_OK;
+}
+
+size_t plan_workspace(const sd_model* m, const std::vector<Dims>& dims, std::vector<size_t>& off) {
+    off.assign(m->nbuf, 0);
+    size_t cur = WS_SCRATCH;
+    for (int b = 1; b < m->nbuf; ++b) {
+        off[b] = cur;
+        const size_t bytes = (size_t)dims[b].d * dims[b].h * dims[b].w * m->bufCp[b] * 2;
+        cur += rup_sz(bytes, 256);
+    }
+    return cur;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sd_last_error(void) { return g_err.c_str(); }
+const char* sd_version(void) { return "syconn_dense_hip 0.1 (gfx950)"; }
+
+int sd_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sd_init(int device_ordinal) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(SD_ERR_NODEVICE, "no HIP device visible; libsyconn_dense_hip has no CPU fallback");
+    if (device_ordinal < 0 || device_ordinal >= n) return fail(SD_ERR_INVALID, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device_ordinal));
+    return SD_OK;
+}
+
+int sd_model_num_ops(const sd_model* m) { return m ? (int)m->ops.size() : 0; }
+
+int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_floats, int act_dtype,
+                    sd_model** out) {
+    if (!ops || n_ops <= 0 || !W || !out) return fail(SD_ERR_INVALID, "null argument");
+    if (act_dtype != SD_BF16 && act_dtype != SD_F16) return fail(SD_ERR_INVALID, "act_dtype must be SD_BF16 or SD_F16");
+    sd_model* m = new sd_model();
+    m->act_dtype = act_dtype;
+    if (hipGetDevice(&m->device) != hipSuccess) { delete m; return fail(SD_ERR_NODEVICE, "no current HIP device"); }
+
+    auto chk = [&](int64_t off, size_t n) { return off >= 0 && (size_t)off + n <= n_floats; };
+    int nbuf = 1;
+    for (int i = 0; i < n_ops; ++i) {
+        nbuf = std::max(nbuf, std::max(ops[i].src0, std::max(ops[i].src1, ops[i].dst)) + 1);
+    }
+    m->nbuf = nbuf;
+    m->bufC.assign(nbuf, 0);
+    m->bufCp.assign(nbuf, 0);
+    m->bufC[0] = 1;
+    m->bufCp[0] = 1;
+
+    std::vector<char> blob;  // host image of the packed weights
+    auto blob_alloc = [&](size_t bytes) { size_t o = rup_sz(blob.size(), 256); blob.resize(o + bytes, 0); return o; };
+    int rc = SD_OK;
+    std::string err;
+#define MODEL_FAIL(msg) do { err = (msg); rc = SD_ERR_INVALID; goto done; } while (0)
+
+    for (int i = 0; i < n_ops; ++i) {
+        Op op;
+        op.d = ops[i];
+        const sd_op_desc& d = op.d;
+        // folded per-output-channel scale / shift of an eval-mode BatchNorm
+        std::vector<float> sc, sh;
+        auto fold_bn = [&](int cout) -> bool {
+            sc.assign(cout, 1.f);
+            sh.assign(cout, 0.f);
+            if (d.norm == 1) {
+                if (!chk(d.gamma_off, cout) || !chk(d.beta_off, cout) || !chk(d.mean_off, cout) || !chk(d.var_off, cout))
+                    return false;
+                for (int c = 0; c < cout; ++c) {
+                    const float s = W[d.gamma_off + c] / std::sqrt(W[d.var_off + c] + d.eps);
+                    sc[c] = s;
+                    sh[c] = W[d.beta_off + c] - W[d.mean_off + c] * s;
+                }
+            }
+            return true;
+        };
+        switch (d.kind) {
+        case SD_OP_CONV: {
+            if (d.ky != 3 || d.kx != 3 || (d.kz != 1 && d.kz != 3)) MODEL_FAIL("conv: only 3x3x3 and 1x3x3 kernels");
+            if (d.src0 < 0 || d.dst <= 0 || d.cout <= 0) MODEL_FAIL("conv: bad buffer ids");
+            const int cin = d.cin0 + (d.src1 >= 0 ? d.cin1 : 0);
+            const int taps = d.kz * 9;
+            if (!chk(d.w_off, (size_t)d.cout * cin * taps) || !chk(d.b_off, d.cout)) MODEL_FAIL("conv: weight offsets");
+            if (!fold_bn(d.cout)) MODEL_FAIL("conv: norm offsets");
+            const int Cd = rup(d.cout, SD_CHUNK);
+            m->bufC[d.dst] = d.cout;
+            m->bufCp[d.dst] = Cd;
+            const float* w = W + d.w_off;
+            auto wat = [&](int co, int ci, int kz, int t9) {
+                return w[((size_t)co * cin + ci) * taps + kz * 9 + t9] * sc[co];
+            };
+            if (d.src0 == 0) {
+                if (d.cin0 != 1 || d.src1 >= 0) MODEL_FAIL("first conv must have exactly one input channel");
+                op.first = true;
+                const int ntile = (Cd + 31) / 32, nstep = (taps + 1) / 2;
+                op.wpack_off = blob_alloc((size_t)ntile * nstep * 64 * 4);
+                op.bias_off = blob_alloc((size_t)ntile * 32 * 4 + 16);
+                float* wp = reinterpret_cast<float*>(blob.data() + op.wpack_off);
+                float* bp = reinterpret_cast<float*>(blob.data() + op.bias_off);
+                for (int nt = 0; nt < ntile; ++nt)
+                    for (int s = 0; s < nstep; ++s)
+                        for (int l = 0; l < 64; ++l) {
+                            const int n = nt * 32 + (l & 31), tap = 2 * s + (l >> 5);
+                            wp[(nt * nstep + s) * 64 + l] = (n < d.cout && tap < taps) ? wat(n, 0, tap / 9, tap % 9) : 0.f;
+                        }
+                for (int n = 0; n < d.cout; ++n) bp[n] = W[d.b_off + n] * sc[n] + sh[n];
+            } else {
+                if (m->bufC[d.src0] != d.cin0) MODEL_FAIL("conv: cin0 does not match producer of src0");
+                if (d.src1 >= 0 && m->bufC[d.src1] != d.cin1) MODEL_FAIL("conv: cin1 does not match producer of src1");
+                const int nch0 = m->bufCp[d.src0] / SD_CHUNK, nch1 = d.src1 >= 0 ? m->bufCp[d.src1] / SD_CHUNK : 0;
+                const int ntile = (d.cout + 31) / 32;
+                op.NT = ntile >= 2 ? 2 : 1;
+                op.NB = (ntile + op.NT - 1) / op.NT;
+                const int nchunks = nch0 + nch1;
+                const size_t gbytes = (size_t)9 * op.NT * 1024;
+                op.wpack_off = blob_alloc((size_t)op.NB * nchunks * d.kz * gbytes);
+                op.bias_off = blob_alloc((size_t)op.NB * op.NT * 32 * 4 + 16);
+                uint16_t* wp = reinterpret_cast<uint16_t*>(blob.data() + op.wpack_off);
+                float* bp = reinterpret_cast<float*>(blob.data() + op.bias_off);
+                for (int nb = 0; nb < op.NB; ++nb)
+                    for (int c = 0; c < nchunks; ++c)
+                        for (int kz = 0; kz < d.kz; ++kz)
+                            for (int t9 = 0; t9 < 9; ++t9)
+                                for (int j = 0; j < op.NT; ++j)
+                                    for (int l = 0; l < 64; ++l)
+                                        for (int e = 0; e < 8; ++e) {
+                                            const int n = (nb * op.NT + j) * 32 + (l & 31);
+                                            int ci;  // index into the concatenated weight input-channel axis
+                                            if (c < nch0) {
+                                                const int k = c * SD_CHUNK + (l >> 5) * 8 + e;
+                                                ci = k < d.cin0 ? k : -1;
+                                            } else {
+                                                const int k = (c - nch0) * SD_CHUNK + (l >> 5) * 8 + e;
+                                                ci = k < d.cin1 ? d.cin0 + k : -1;
+                                            }
+                                            const float v = (n < d.cout && ci >= 0) ? wat(n, ci, kz, t9) : 0.f;
+                                            const size_t idx =
+                                                ((((((size_t)nb * nchunks + c) * d.kz + kz) * 9 + t9) * op.NT + j) * 64 + l) * 8 + e;
+                                            wp[idx] = cvt(v, act_dtype);
+                                        }
+                for (int n = 0; n < d.cout; ++n) bp[n] = W[d.b_off + n] * sc[n] + sh[n];
+            }
+            break;
+        }
+        case SD_OP_POOL: {
+            if (d.src0 <= 0 || d.dst <= 0 || (d.kz != 1 && d.kz != 2)) MODEL_FAIL("pool: bad arguments");
+            m->bufC[d.dst] = m->bufC[d.src0];
+            m->bufCp[d.dst] = m->bufCp[d.src0];
+            break;
+        }
+        case SD_OP_UPCONV: {
+            if (d.src0 <= 0 || d.dst <= 0 || (d.kz != 1 && d.kz != 2)) MODEL_FAIL("upconv: bad arguments");
+            if (m->bufC[d.src0] != d.cin0) MODEL_FAIL("upconv: cin0 does not match producer");
+            const int taps = d.kz * 4;
+            if (!chk(d.w_off, (size_t)d.cin0 * d.cout * taps) || !chk(d.b_off, d.cout)) MODEL_FAIL("upconv: weight offsets");
+            if (!fold_bn(d.cout)) MODEL_FAIL("upconv: norm offsets");
+            const int Cd = rup(d.cout, SD_CHUNK);
+            m->bufC[d.dst] = d.cout;
+            m->bufCp[d.dst] = Cd;
+            const int ntot = taps * Cd;
+            op.NT = 2;
+            op.NB = (ntot + 63) / 64;
+            const int nchunk = m->bufCp[d.src0] / SD_CHUNK;
+            op.wpack_off = blob_alloc((size_t)op.NB * nchunk * 2 * 64 * 8 * 2);
+            op.bias_off = blob_alloc((size_t)op.NB * 64 * 4 + 16);
+            uint16_t* wp = reinterpret_cast<uint16_t*>(blob.data() + op.wpack_off);
+            float* bp = reinterpret_cast<float*>(blob.data() + op.bias_off);
+            const float* w = W + d.w_off;
+            for (int nb = 0; nb < op.NB; ++nb)
+                for (int c = 0; c < nchunk; ++c)
+                    for (int j = 0; j < 2; ++j)
+                        for (int l = 0; l < 64; ++l)
+                            for (int e = 0; e < 8; ++e) {
+                                const int n = (nb * 2 + j) * 32 + (l & 31);
+                                const int tap = n / Cd, co = n % Cd;
+                                const int ci = c * SD_CHUNK + (l >> 5) * 8 + e;
+                                float v = 0.f;
+                                if (tap < taps && co < d.cout && ci < d.cin0)
+                                    v = w[((size_t)ci * d.cout + co) * taps + tap] * sc[co];
+                                wp[((((size_t)nb * nchunk + c) * 2 + j) * 64 + l) * 8 + e] = cvt(v, act_dtype);
+                            }
+            for (int n = 0; n < ntot; ++n) {
+                const int co = n % Cd;
+                bp[n] = co < d.cout ? W[d.b_off + co] * sc[co] + sh[co] : 0.f;
+            }
+            break;
+        }
+        case SD_OP_GROUPNORM: {
+            if (d.src0 <= 0 || d.groups <= 0) MODEL_FAIL("groupnorm: bad arguments");
+            const int C = m->bufC[d.src0], Cp = m->bufCp[d.src0];
+            if (C % d.groups) MODEL_FAIL("groupnorm: channels not divisible by groups");
+            if (192 % (Cp / 8)) MODEL_FAIL("groupnorm: unsupported channel count");
+            if ((size_t)Cp * 24 > WS_SCRATCH) MODEL_FAIL("groupnorm: too many channels");
+            if (!chk(d.gamma_off, C) || !chk(d.beta_off, C)) MODEL_FAIL("groupnorm: offsets");
+            op.aux_off = blob_alloc((size_t)2 * Cp * 4);
+            float* gp = reinterpret_cast<float*>(blob.data() + op.aux_off);
+            for (int c = 0; c < C; ++c) { gp[c] = W[d.gamma_off + c]; gp[Cp + c] = W[d.beta_off + c]; }
+            break;
+        }
+        case SD_OP_FINAL: {
+            if (d.src0 <= 0 || d.cout <= 0 || d.cout > 8) MODEL_FAIL("final conv: 1..8 output classes supported");
+            if (m->bufC[d.src0] != d.cin0) MODEL_FAIL("final: cin0 does not match producer");
+            if (!chk(d.w_off, (size_t)d.cout * d.cin0) || !chk(d.b_off, d.cout)) MODEL_FAIL("final: weight offsets");
+            const int Cs = m->bufCp[d.src0];
+            op.wpack_off = blob_alloc((size_t)8 * Cs * 4);
+            op.bias_off = blob_alloc(8 * 4);
+            float* wp = reinterpret_cast<float*>(blob.data() + op.wpack_off);
+            float* bp = reinterpret_cast<float*>(blob.data() + op.bias_off);
+            for (int co = 0; co < d.cout; ++co) {
+                for (int ci = 0; ci < d.cin0; ++ci) wp[co * Cs + ci] = W[d.w_off + (size_t)co * d.cin0 + ci];
+                bp[co] = W[d.b_off + co];
+            }
+            m->final_cout = d.cout;
+            break;
+        }
+        default: MODEL_FAIL("unknown op kind");
+        }
+        m->ops.push_back(op);
+    }
+    if (m->ops.empty() || m->ops.back().d.kind != SD_OP_FINAL) MODEL_FAIL("the plan must end with SD_OP_FINAL");
+
+    {
+        m->blob_bytes = rup_sz(blob.size(), 256);
+        hipError_t e = hipMalloc((void**)&m->dev_blob, m->blob_bytes + 1024);
+        if (e == hipSuccess) e = hipMemcpy(m->dev_blob, blob.data(), blob.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            float lut[256];
+            for (int v = 0; v < 256; ++v) lut[v] = (float)v / 255.0f;  // == np.float32(v) / 255.
+            m->dev_lut = reinterpret_cast<float*>(m->dev_blob + m->blob_bytes);
+            e = hipMemcpy(m->dev_lut, lut, sizeof(lut), hipMemcpyHostToDevice);
+        }
+        if (e != hipSuccess) {
+            err = std::string("weight upload: ") + hipGetErrorString(e);
+            rc = e == hipErrorOutOfMemory ? SD_ERR_NOMEM : SD_ERR_HIP;
+            goto done;
+        }
+    }
+done:
+#undef MODEL_FAIL
+    if (rc != SD_OK) {
+        sd_model_destroy(m);
+        return fail(rc, err);
+    }
+    *out = m;
+    return SD_OK;
+}
+
+void sd_model_destroy(sd_model* m) {
+    if (!m) return;
+    for (hipEvent_t e : m->events) (void)hipEventDestroy(e);
+    if (m->dev_blob) (void)hipFree(m->dev_blob);
+    delete m;
+}
+
+size_t sd_workspace_bytes(const sd_model* m, int D, int H, int W) {
+    if (!m || D <= 0 || H <= 0 || W <= 0) { fail(SD_ERR_INVALID, "bad tile shape"); return 0; }
+    std::vector<Dims> dims;
+    std::vector<size_t> off;
+    if (infer_shapes(m, D, H, W, dims) != SD_OK) return 0;
+    return plan_workspace(m, dims, off);
+}
+
+int sd_profile_enable(sd_model* m, int enable) {
+    if (!m) return fail(SD_ERR_INVALID, "null model");
+    m->profile = enable != 0;
+    if (m->profile && m->events.empty()) {
+        m->events.resize(m->ops.size() + 1);
+        for (auto& e : m->events) HIP_TRY(hipEventCreate(&e));
+    }
+    return SD_OK;
+}
+
+int sd_profile_read(sd_model* m, float* ms, int n_ops) {
+    if (!m || !ms || m->events.empty()) return fail(SD_ERR_INVALID, "profiling not enabled");
+    const int n = std::min<int>(n_ops, (int)m->ops.size());
+    for (int i = 0; i < n; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], m->events[i], m->events[i + 1]));
+    return SD_OK;
+}
+
+int sd_forward(sd_model* m, const void* in_dev, int in_dtype, int D, int H, int W, void* out_dev, int out_kind,
+               void* ws, size_t ws_bytes, void* stream) {
+    if (!m || !in_dev || !out_dev || !ws) return fail(SD_ERR_INVALID, "null argument");
+    if (in_dtype != SD_U8 && in_dtype != SD_F32) return fail(SD_ERR_INVALID, "in_dtype must be SD_U8 or SD_F32");
+    if (out_kind < 0 || out_kind > 2) return fail(SD_ERR_INVALID, "bad out_kind");
+    if (D <= 0 || H <= 0 || W <= 0) return fail(SD_ERR_INVALID, "bad tile shape");
+    int rc = infer_shapes(m, D, H, W, m->dims);
+    if (rc != SD_OK) return rc;
+    const size_t need = plan_workspace(m, m->dims, m->buf_off);
+    if (need > ws_bytes) return fail(SD_ERR_NOMEM, "workspace too small");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    char* const wsb = reinterpret_cast<char*>(ws);
+    auto bufp = [&](int b) -> void* { return wsb + m->buf_off[b]; };
+
+    for (size_t i = 0; i < m->ops.size(); ++i) {
+        const Op& op = m->ops[i];
+        const sd_op_desc& d = op.d;
+        if (m->profile) HIP_TRY(hipEventRecord(m->events[i], s));
+        switch (d.kind) {
+        case SD_OP_CONV: {
+            const Dims o = m->dims[d.dst];
+            const int BZ = sd_bz(d.kz), BY = sd_by(d.kz);
+            if (op.first) {
+                FirstParams p{};
+                p.in = in_dev; p.D = o.d; p.H = o.h; p.W = o.w;
+                p.dst = bufp(d.dst); p.Cd = m->bufCp[d.dst];
+                p.wpack = reinterpret_cast<const float*>(m->dev_blob + op.wpack_off);
+                p.bias = reinterpret_cast<const float*>(m->dev_blob + op.bias_off);
+                p.lut = m->dev_lut; p.relu = d.relu;
+                p.nbx = (o.w + SD_BX - 1) / SD_BX; p.nby = (o.h + BY - 1) / BY; p.nbz = (o.d + BZ - 1) / BZ;
+                rc = launch_first(p, m->act_dtype, in_dtype, d.kz, s);
+            } else {
+                ConvParams p{};
+                const Dims a = m->dims[d.src0];
+                p.src0 = bufp(d.src0); p.C0 = m->bufCp[d.src0]; p.H0 = a.h; p.W0 = a.w;
+                p.nchunk0 = p.C0 / SD_CHUNK;
+                if (d.src1 >= 0) {
+                    const Dims b = m->dims[d.src1];
+                    p.src1 = bufp(d.src1); p.C1 = m->bufCp[d.src1]; p.H1 = b.h; p.W1 = b.w;
+                    p.nchunk1 = p.C1 / SD_CHUNK;
+                }
+                p.dst = bufp(d.dst); p.Cd = m->bufCp[d.dst];
+                p.D = o.d; p.H = o.h; p.W = o.w;
+                p.wpack = m->dev_blob + op.wpack_off;
+                p.bias = reinterpret_cast<const float*>(m->dev_blob + op.bias_off);
+                p.relu = d.relu;
+                p.nbx = (o.w + SD_BX - 1) / SD_BX; p.nby = (o.h + BY - 1) / BY; p.nbz = (o.d + BZ - 1) / BZ;
+                rc = launch_conv(p, m->act_dtype, d.kz, op.NT, op.NB, s);
+            }
+            break;
+        }
+        case SD_OP_POOL: {
+            PoolParams p{};
+            const Dims a = m->dims[d.src0], o = m->dims[d.dst];
+            p.src = bufp(d.src0); p.dst = bufp(d.dst); p.C = m->bufCp[d.src0];
+            p.D = a.d; p.H = a.h; p.W = a.w; p.Do = o.d; p.Ho = o.h; p.Wo = o.w; p.kz = d.kz;
+            rc = launch_pool(p, m->act_dtype, s);
+            break;
+        }
+        case SD_OP_UPCONV: {
+            UpconvParams p{};
+            const Dims a = m->dims[d.src0];
+            p.src = bufp(d.src0); p.Cs = m->bufCp[d.src0]; p.nchunk = p.Cs / SD_CHUNK;
+            p.D = a.d; p.H = a.h; p.W = a.w;
+            p.dst = bufp(d.dst); p.Cd = m->bufCp[d.dst]; p.kz = d.kz;
+            p.wpack = m->dev_blob + op.wpack_off;
+            p.bias = reinterpret_cast<const float*>(m->dev_blob + op.bias_off);
+            p.relu = d.relu; p.ntot = d.kz * 4 * p.Cd;
+            rc = launch_upconv(p, m->act_dtype, op.NB, s);
+            break;
+        }
+        case SD_OP_GROUPNORM: {
+            GnParams p{};
+            const Dims a = m->dims[d.src0];
+            const Dims r = d.src1 >= 0 ? m->dims[d.src1] : a;
+            p.buf = bufp(d.src0); p.C = m->bufCp[d.src0];
+            p.D = r.d; p.H = r.h; p.W = r.w; p.Hs = a.h; p.Ws = a.w;
+            p.groups = d.groups; p.cout = m->bufC[d.src0]; p.eps = d.eps;
+            p.gamma = reinterpret_cast<const float*>(m->dev_blob + op.aux_off);
+            p.beta = p.gamma + p.C;
+            p.sums = reinterpret_cast<double*>(wsb);
+            p.scale_shift = reinterpret_cast<float*>(wsb + (size_t)2 * p.C * 8);
+            p.relu = d.relu;
+            rc = launch_groupnorm(p, m->act_dtype, s);
+            break;
+        }
+        case SD_OP_FINAL: {
+            FinalParams p{};
+            const Dims a = m->dims[d.src0];
+            p.src = bufp(d.src0); p.Cs = m->bufCp[d.src0]; p.cin = d.cin0;
+            p.w = reinterpret_cast<const float*>(m->dev_blob + op.wpack_off);
+            p.bias = reinterpret_cast<const float*>(m->dev_blob + op.bias_off);
+            p.cout = d.cout; p.out = out_dev; p.out_kind = out_kind;
+            p.nvox = (long)a.d * a.h * a.w;
+            if (a.d != D || a.h != H || a.w != W) return fail(SD_ERR_INVALID, "final layer shape != input shape");
+            rc = launch_final(p, m->act_dtype, s);
+            break;
+        }
+        default: rc = SD_ERR_INVALID;
+        }
+        if (rc != SD_OK) {
+            char msg[128];
+            snprintf(msg, sizeof msg, "launch of op %zu (kind %d) failed: %s", i, d.kind,
+                     hipGetErrorString(hipGetLastError()));
+            return fail(rc, msg);
+        }
+    }
+    if (m->profile) HIP_TRY(hipEventRecord(m->events[m->ops.size()], s));
+    return SD_OK;
+}
+
+int sd_tile_gather(const void* vol, int dtype, int VD, int VH, int VW, int oz, int oy, int ox, void* tile, int TD, int TH,
+                   int TW, void* stream) {
+    if (!vol || !tile || (dtype != SD_U8 && dtype != SD_F32)) return fail(SD_ERR_INVALID, "sd_tile_gather: bad argument");
+    int rc = launch_tile_gather(vol, dtype == SD_U8 ? 1 : 4, VD, VH, VW, oz, oy, ox, tile, TD, TH, TW,
+                                reinterpret_cast<hipStream_t>(stream));
+    return rc == SD_OK ? rc : fail(rc, "sd_tile_gather launch failed");
+}
+
+int sd_tile_scatter(const void* tile, int dtype, int C, int TD, int TH, int TW, int cz, int cy, int cx, int KD, int KH,
+                    int KW, void* vol, int VD, int VH, int VW, int oz, int oy, int ox, void* stream) {
+    if (!vol || !tile || (dtype != SD_U8 && dtype != SD_F32)) return fail(SD_ERR_INVALID, "sd_tile_scatter: bad argument");
+    if (cz < 0 || cy < 0 || cx < 0 || cz + KD > TD || cy + KH > TH || cx + KW > TW || oz < 0 || oy < 0 || ox < 0)
+        return fail(SD_ERR_INVALID, "sd_tile_scatter: crop outside tile");
+    int rc = launch_tile_scatter(tile, dtype == SD_U8 ? 1 : 4, C, TD, TH, TW, cz, cy, cx, KD, KH, KW, vol, VD, VH, VW,
+                                 oz, oy, ox, reinterpret_cast<hipStream_t>(stream));
+    return rc == SD_OK ? rc : fail(rc, "sd_tile_scatter launch failed");
+}
+
+int sd_postproc_labels(const uint8_t* probs, int C, size_t nvox, const int32_t* ids, const double* thresholds, int n_ids,
+                       void* out, int out_dtype, void* stream) {
+    if (!probs || !ids || !thresholds || !out || n_ids <= 0 || n_ids > 16)
+        return fail(SD_ERR_INVALID, "sd_postproc_labels: bad argument");
+    if (out_dtype != SD_U8 && out_dtype != SD_U64) return fail(SD_ERR_INVALID, "sd_postproc_labels: out_dtype");
+    LabelArgs a{};
+    a.n = n_ids;
+    for (int i = 0; i < n_ids; ++i) {
+        if (ids[i] < 0 || ids[i] >= C) return fail(SD_ERR_INVALID, "sd_postproc_labels: id out of range");
+        a.ids[i] = ids[i];
+        const double t = thresholds[i];
+        // (uint8 p > t) <=> p >= floor(t) + 1, exact for any real t
+        a.cuts[i] = t < 0 ? 0 : (t >= 255.0 ? 256 : (int)std::floor(t) + 1);
+    }
+    int rc = launch_labels(probs, nvox, a, out, out_dtype == SD_U64, reinterpret_cast<hipStream_t>(stream));
+    return rc == SD_OK ? rc : fail(rc, "sd_postproc_labels launch failed");
+}
+
+int sd_debug_read_buffer(sd_model* m, int buf, const void* ws, float* out, int32_t* dims4, void* stream) {
+    if (!m || buf <= 0 || buf >= m->nbuf || m->dims.empty()) return fail(SD_ERR_INVALID, "sd_debug_read_buffer: bad argument");
+    const Dims a = m->dims[buf];
+    if (dims4) { dims4[0] = m->bufC[buf]; dims4[1] = a.d; dims4[2] = a.h; dims4[3] = a.w; }
+    if (!out) return SD_OK;
+    int rc = launch_read_buffer(reinterpret_cast<const char*>(ws) + m->buf_off[buf], m->act_dtype, m->bufC[buf],
+                                m->bufCp[buf], a.d, a.h, a.w, out, reinterpret_cast<hipStream_t>(stream));
+    return rc == SD_OK ? rc : fail(rc, "sd_debug_read_buffer launch failed");
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+// Internal interface between the host-side plan executor (sd_api.hip) and the gfx950 kernels (sd_kernels.hip).
+// Nothing here is part of the C ABI (include/syconn_dense.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// Activation tensors are voxel-major / channel-minor: element (z,y,x,c) at ((z*H + y)*W + x)*C + c, with C the
+// padded channel stride (multiple of 16).  A "chunk" is 16 consecutive channels = one MFMA k-step.
+constexpr int SD_CHUNK = 16;
+
+// geometry of one workgroup of the LDS-staged MFMA convolution: 256 output voxels = 8 MFMA column tiles of
+// (2 y-rows x 16 x); 3x3x3: 2x8x16 voxels, 1x3x3: 1x16x16 voxels.
+constexpr int SD_BX = 16;
+__host__ __device__ constexpr int sd_bz(int KZ) { return KZ == 3 ? 2 : 1; }
+__host__ __device__ constexpr int sd_by(int KZ) { return KZ == 3 ? 8 : 16; }
+
+struct ConvParams {
+    const void* src0;  // first input (for a merged conv: the up-convolved tensor, cropped by reading fewer voxels)
+    const void* src1;  // second input or nullptr
+    int C0, H0, W0;    // channel stride and y/x extents (strides) of src0
+    int C1, H1, W1;
+    int nchunk0, nchunk1;
+    void* dst;
+    int Cd;            // channel stride of dst; channels >= Cd are not stored
+    int D, H, W;       // output extent
+    const void* wpack; // [nb][chunk][kz][9][NT][64 lanes][8] of T
+    const float* bias; // padded to NB*NT*32
+    int relu;
+    int nbx, nby, nbz; // workgroup grid over the output volume
+};
+
+struct FirstParams {
+    const void* in;    // (D,H,W) planar uint8 or float
+    int D, H, W;
+    void* dst;
+    int Cd;
+    const float* wpack;  // [ntile][nstep][64 lanes] float
+    const float* bias;   // padded to ntile*32
+    const float* lut;    // 256 floats: float(v)/255
+    int relu;
+    int nbx, nby, nbz;
+};
+
+struct UpconvParams {
+    const void* src;   // (D,H,W,Cs)
+    int Cs, nchunk;
+    int D, H, W;
+    void* dst;         // (D*kz, 2H, 2W, Cd)
+    int Cd;
+    int kz;            // 1 or 2
+    const void* wpack; // [nb][chunk][NT=2][64][8]
+    const float* bias; // per n = tap*Cd + co, padded to NB*64
+    int relu;
+    int ntot;          // ntaps*Cd
+};
+
+struct PoolParams {
+    const void* src; void* dst;
+    int C;             // channel stride (same for src and dst)
+    int D, H, W;       // src dims
+    int Do, Ho, Wo;    // dst dims
+    int kz;            // 1 or 2
+};
+
+struct FinalParams {
+    const void* src; int Cs; int cin;
+    const float* w;    // [cout][Cs] float (zero padded)
+    const float* bias; // [cout]
+    int cout;
+    void* out;         // planar (cout, nvox)
+    int out_kind;
+    long nvox;
+};
+
+struct GnParams {
+    void* buf; int C;          // channel stride
+    int D, H, W;               // logical region
+    int Hs, Ws;                // strides (buffer y/x extents)
+    int groups, cout;          // real channel count
+    float eps;
+    const float* gamma; const float* beta;   // padded to C
+    double* sums;              // [2*C] workspace (sum, sumsq)
+    float* scale_shift;        // [2*C]
+    int relu;
+};
+
+int launch_conv(const ConvParams& p, int act_dtype, int KZ, int NT, int NB, hipStream_t s);
+int launch_first(const FirstParams& p, int act_dtype, int in_dtype, int KZ, hipStream_t s);
+int launch_upconv(const UpconvParams& p, int act_dtype, int NB, hipStream_t s);
+int launch_pool(const PoolParams& p, int act_dtype, hipStream_t s);
+int launch_final(const FinalParams& p, int act_dtype, hipStream_t s);
+int launch_groupnorm(const GnParams& p, int act_dtype, hipStream_t s);
+int launch_tile_gather(const void* vol, int esize, int VD, int VH, int VW, int oz, int oy, int ox, void* tile, int TD,
+                       int TH, int TW, hipStream_t s);
+int launch_tile_scatter(const void* tile, int esize, int C, int TD, int TH, int TW, int cz, int cy, int cx, int KD,
+                        int KH, int KW, void* vol, int VD, int VH, int VW, int oz, int oy, int ox, hipStream_t s);
+struct LabelArgs { int n; int ids[16]; int cuts[16]; };
+int launch_labels(const uint8_t* probs, size_t nvox, const LabelArgs& a, void* out, int out_u64, hipStream_t s);
+int launch_read_buffer(const void* buf, int act_dtype, int C, int Cs, int D, int H, int W, float* out, hipStream_t s);

@@ -1,0 +1,162 @@
+"""Thin Python handle on an ``sd_model`` of the HIP library plus the device-side tiling helpers.
+
+PyTorch is used for device memory (caching allocator), streams and H2D/D2H only; every computation is a
+hand-written gfx950 kernel behind the C ABI (``include/syconn_dense.h``).
+"""
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .plan import plan_from_model
+
+_ACT = {'bf16': L.SD_BF16, 'bfloat16': L.SD_BF16, 'f16': L.SD_F16, 'fp16': L.SD_F16, 'float16': L.SD_F16}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(device_index: int = 0):
+    """Fail loudly when the HIP path cannot run (no CPU fallback exists)."""
+    lib = L.load()
+    if not torch.cuda.is_available():
+        raise RuntimeError('syconn_amd: no MI355X visible to PyTorch-ROCm; this package has no CPU fallback')
+    L.check(lib.sd_init(int(device_index)), 'sd_init')
+    return lib
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.uint8:
+        return L.SD_U8
+    if t.dtype == torch.float32:
+        return L.SD_F32
+    raise ValueError(f'unsupported buffer dtype {t.dtype}')
+
+
+class DenseModel:
+    """One network (plan + packed weights) resident on one GPU."""
+
+    def __init__(self, model, act_dtype: str = 'bf16', device: Optional[torch.device] = None,
+                 group_norm_groups: Optional[int] = None):
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('syconn_amd.DenseModel needs a ROCm device (no CPU fallback)')
+        self.lib = require_gpu(self.device.index or 0)
+        torch.cuda.set_device(self.device)
+        ops, blob, info = plan_from_model(model, group_norm_groups)
+        self.info = info
+        self.n_ops = len(ops)
+        self.op_kinds = [int(o.kind) for o in ops]
+        self.ops = ops
+        self.out_channels = info['out_channels']
+        self.act_dtype = act_dtype
+        arr = (L.OpDesc * len(ops))(*ops)
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        handle = C.c_void_p()
+        L.check(self.lib.sd_model_create(arr, len(ops), blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size,
+                                         _ACT[act_dtype], C.byref(handle)), 'sd_model_create')
+        self._h = handle
+        self._ws: Optional[torch.Tensor] = None
+        self._profile = False
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h is not None and h.value:
+            self.lib.sd_model_destroy(h)
+            self._h = None
+
+    # -- workspace ------------------------------------------------------------------------------------
+    def workspace_bytes(self, shape: Sequence[int]) -> int:
+        n = self.lib.sd_workspace_bytes(self._h, int(shape[0]), int(shape[1]), int(shape[2]))
+        if n == 0:
+            raise ValueError('sd_workspace_bytes: ' + self.lib.sd_last_error().decode())
+        return int(n)
+
+    def _workspace(self, shape) -> torch.Tensor:
+        need = self.workspace_bytes(shape)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            # torch.cuda.OutOfMemoryError is a RuntimeError -> the reference's tile-halving loop keeps working
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    # -- forward --------------------------------------------------------------------------------------
+    def forward(self, inp: torch.Tensor, out_kind: int = L.SD_OUT_PROBS_F32, out: Optional[torch.Tensor] = None):
+        """inp: (D,H,W) uint8 (normalised in-kernel as float32(v)/255) or float32, on this device.
+        Returns (C,D,H,W) float32 (logits / probabilities) or uint8 (floor(255*p))."""
+        assert inp.is_cuda and inp.dim() == 3 and inp.is_contiguous()
+        D, H, W = inp.shape
+        ws = self._workspace((D, H, W))
+        odt = torch.uint8 if out_kind == L.SD_OUT_PROBS_U8 else torch.float32
+        if out is None:
+            out = torch.empty((self.out_channels, D, H, W), dtype=odt, device=self.device)
+        assert out.dtype == odt and out.is_contiguous() and out.numel() == self.out_channels * D * H * W
+        L.check(self.lib.sd_forward(self._h, inp.data_ptr(), _dtype_code(inp), D, H, W, out.data_ptr(), out_kind,
+                                    ws.data_ptr(), ws.numel(), _stream()), 'sd_forward')
+        return out
+
+    def read_buffer(self, buf: int) -> torch.Tensor:
+        """Activation buffer `buf` of the last forward as float32 (C,d,h,w) -- test support."""
+        dims = (C.c_int32 * 4)()
+        L.check(self.lib.sd_debug_read_buffer(self._h, buf, self._ws.data_ptr(), None, dims, _stream()))
+        out = torch.empty(tuple(int(d) for d in dims), dtype=torch.float32, device=self.device)
+        L.check(self.lib.sd_debug_read_buffer(self._h, buf, self._ws.data_ptr(), out.data_ptr(), dims, _stream()))
+        return out
+
+    def profile(self, enable: bool = True):
+        L.check(self.lib.sd_profile_enable(self._h, int(enable)), 'sd_profile_enable')
+        self._profile = enable
+
+    def profile_read(self) -> np.ndarray:
+        torch.cuda.synchronize(self.device)
+        ms = (C.c_float * self.n_ops)()
+        L.check(self.lib.sd_profile_read(self._h, ms, self.n_ops), 'sd_profile_read')
+        return np.asarray(list(ms), dtype=np.float64)
+
+
+# -- tiled_apply helpers on the device (SURVEY.md row P3 / kernels K1, K12, K11) ----------------------------
+def tile_gather(vol: torch.Tensor, origin, tile_shape, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = L.load()
+    VD, VH, VW = vol.shape
+    TD, TH, TW = (int(t) for t in tile_shape)
+    if out is None:
+        out = torch.empty((TD, TH, TW), dtype=vol.dtype, device=vol.device)
+    L.check(lib.sd_tile_gather(vol.data_ptr(), _dtype_code(vol), VD, VH, VW, int(origin[0]), int(origin[1]),
+                               int(origin[2]), out.data_ptr(), TD, TH, TW, _stream()), 'sd_tile_gather')
+    return out
+
+
+def tile_scatter(tile: torch.Tensor, crop_lo, keep, vol: torch.Tensor, origin):
+    lib = L.load()
+    Cn, TD, TH, TW = tile.shape
+    _, VD, VH, VW = vol.shape
+    assert vol.shape[0] == Cn and vol.dtype == tile.dtype
+    L.check(lib.sd_tile_scatter(tile.data_ptr(), _dtype_code(tile), Cn, TD, TH, TW,
+                                int(crop_lo[0]), int(crop_lo[1]), int(crop_lo[2]),
+                                int(keep[0]), int(keep[1]), int(keep[2]), vol.data_ptr(), VD, VH, VW,
+                                int(origin[0]), int(origin[1]), int(origin[2]), _stream()), 'sd_tile_scatter')
+
+
+def postproc_labels(probs_u8: torch.Tensor, ids: Sequence[int], thresholds: Sequence[float],
+                    out_dtype=torch.uint8) -> torch.Tensor:
+    """Label rule of /root/reference/syconn/handler/prediction.py:813-833 on the device.
+    `thresholds[i]` is the already resolved float threshold of ids[i]."""
+    lib = L.load()
+    assert probs_u8.dtype == torch.uint8 and probs_u8.is_contiguous()
+    Cn = probs_u8.shape[0]
+    nvox = probs_u8[0].numel()
+    n = len(ids)
+    ids_a = (C.c_int32 * n)(*[int(i) for i in ids])
+    thr_a = (C.c_double * n)(*[float(t) for t in thresholds])
+    if out_dtype == torch.uint8:
+        out = torch.empty(probs_u8.shape[1:], dtype=torch.uint8, device=probs_u8.device)
+        code = L.SD_U8
+    else:
+        out = torch.empty(probs_u8.shape[1:], dtype=torch.int64, device=probs_u8.device)  # bit pattern of uint64
+        code = L.SD_U64
+    L.check(lib.sd_postproc_labels(probs_u8.data_ptr(), Cn, nvox, ids_a, thr_a, n, out.data_ptr(), code, _stream()),
+            'sd_postproc_labels')
+    return out

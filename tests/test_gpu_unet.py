@@ -1,0 +1,129 @@
+"""GPU parity of the HIP U-Net forward (through the C ABI) against the torch-CPU oracle.
+
+Two references per case:
+* the fp32 oracle (``oracle.unet_ref.UNet``) -- tolerance `TOL_FP32` states what bf16/fp16 storage costs;
+* the reduced-precision emulation of the same graph (``unet_forward_emulated``: weights + stored activations
+  rounded to the activation dtype, fp32 accumulate) -- differs from the HIP path only by summation order, so the
+  tolerance is tight and catches indexing bugs a loose bf16 tolerance would hide.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle.unet_ref import build_cnn3, build_unet, unet_forward_emulated
+
+pytestmark = pytest.mark.gpu
+
+# stated tolerances (relative to max|logit| of the case)
+TOL_EMU = {'bf16': 6e-3, 'f16': 2e-3}    # HIP vs same-precision emulation
+TOL_FP32 = {'bf16': 4e-2, 'f16': 8e-3}   # HIP vs fp32 oracle
+
+
+def _input(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(0, 256, shape, generator=g, dtype=torch.uint8)
+
+
+def _run_case(gpu, model, shape, act, seed=0, check_layers=True):
+    from syconn_amd import _lib as L
+    from syconn_amd.engine import DenseModel
+    raw = _input(shape, seed)
+    x = (raw.to(torch.float32) / 255.)[None, None]
+    with torch.no_grad():
+        ref = model(x)[0]
+        col = []
+        dt = torch.bfloat16 if act == 'bf16' else torch.float16
+        emu = unet_forward_emulated(model, x, dtype=dt, collect=col)[0]
+    dm = DenseModel(model, act_dtype=act, device=gpu)
+    out = dm.forward(raw.to(gpu), out_kind=L.SD_OUT_LOGITS_F32).cpu()
+    scale = float(ref.abs().max())
+    e_emu = float((out - emu).abs().max()) / scale
+    e_ref = float((out - ref).abs().max()) / scale
+    msg = f'act={act} shape={shape}: rel err vs emu {e_emu:.2e}, vs fp32 {e_ref:.2e}'
+    if check_layers and (e_emu > TOL_EMU[act]):
+        for i, t in enumerate(col):
+            got = dm.read_buffer(i + 1).cpu()
+            t = t[0]
+            g = got[:, :t.shape[1], :t.shape[2], :t.shape[3]]
+            err = float((g - t).abs().max()) / max(float(t.abs().max()), 1e-6)
+            msg += f'\n  buffer {i + 1} {tuple(t.shape)}: rel err {err:.2e}'
+    print(msg)
+    assert e_emu <= TOL_EMU[act], msg
+    assert e_ref <= TOL_FP32[act], msg
+    # same input as float32 (Predictor.predict's path) must give the same result as the uint8 fast path
+    out_f = dm.forward((raw.to(torch.float32) / 255.).to(gpu), out_kind=L.SD_OUT_LOGITS_F32).cpu()
+    assert torch.equal(out_f, out), 'uint8 (LUT) and float32 input paths differ'
+    return out, ref, emu
+
+
+@pytest.mark.parametrize('act', ['bf16', 'f16'])
+def test_small_unet_even(gpu, act):
+    model = build_unet('myelin', seed=1, n_blocks=3, start_filts=16)
+    _run_case(gpu, model, (8, 32, 32), act)
+
+
+@pytest.mark.parametrize('shape', [(13, 27, 29), (5, 17, 50), (4, 16, 16)])
+def test_small_unet_odd_shapes(gpu, shape):
+    """ceil-mode pooling + autocrop and partial workgroup tiles."""
+    model = build_unet('myelin', seed=2, n_blocks=3, start_filts=16)
+    _run_case(gpu, model, shape, 'bf16')
+
+
+@pytest.mark.parametrize('arch', ['myelin', 'er', 'syntype', 'syntype_enh', 'semseg_spine', 'semseg_axon'])
+def test_syconn_architectures(gpu, arch):
+    """Every BatchNorm architecture SyConn instantiates (full size) on a small odd tile."""
+    model = build_unet(arch, seed=3)
+    _run_case(gpu, model, (10, 37, 43), 'bf16', check_layers=True)
+
+
+def test_mivcsj_groupnorm(gpu):
+    """GroupNorm(8) U-Net with 5 blocks (cnn_cellorganelles.py:69-77): runtime statistics per tile."""
+    model = build_unet('mivcsj', seed=4)
+    _run_case(gpu, model, (12, 35, 41), 'bf16')
+
+
+def test_mivcsj_fp16(gpu):
+    model = build_unet('mivcsj', seed=5)
+    _run_case(gpu, model, (8, 32, 48), 'f16')
+
+
+def test_cnn3_config1(gpu):
+    """BASELINE.json config 1: 3-layer CNN (8 channels -> padded to one 16-channel chunk)."""
+    from syconn_amd import _lib as L
+    from syconn_amd.engine import DenseModel
+    model = build_cnn3(0)
+    raw = _input((20, 33, 30), 7)
+    with torch.no_grad():
+        ref = model((raw.float() / 255.)[None, None])[0]
+    dm = DenseModel(model, act_dtype='bf16', device=gpu)
+    out = dm.forward(raw.to(gpu), out_kind=L.SD_OUT_LOGITS_F32).cpu()
+    err = float((out - ref).abs().max()) / float(ref.abs().max())
+    print('cnn3 rel err', err)
+    assert err < 2e-2
+
+
+def test_outputs_softmax_u8_and_argmax(gpu):
+    """softmax / floor(255 p) epilogues and label agreement where the fp32 margin exceeds the stated tolerance."""
+    from syconn_amd import _lib as L
+    from syconn_amd.engine import DenseModel
+    model = build_unet('semseg_spine', seed=6, final_scale=8.0)
+    shape = (12, 40, 48)
+    raw = _input(shape, 11)
+    with torch.no_grad():
+        logits = model((raw.float() / 255.)[None, None])[0]
+    dm = DenseModel(model, act_dtype='bf16', device=gpu)
+    lg = dm.forward(raw.to(gpu), out_kind=L.SD_OUT_LOGITS_F32).cpu()
+    pr = dm.forward(raw.to(gpu), out_kind=L.SD_OUT_PROBS_F32).cpu()
+    u8 = dm.forward(raw.to(gpu), out_kind=L.SD_OUT_PROBS_U8).cpu()
+    assert torch.allclose(pr, lg.softmax(0), atol=2e-6)
+    assert torch.allclose(pr.sum(0), torch.ones(shape), atol=1e-5)
+    # uint8 = truncation of 255*p computed from the SAME device probabilities (prediction.py:864-865)
+    assert torch.equal(u8, torch.from_numpy((pr.numpy() * 255).astype(np.uint8)))
+    tol = TOL_FP32['bf16'] * float(logits.abs().max())
+    top2 = logits.topk(2, dim=0).values
+    safe = (top2[0] - top2[1]) > 2 * tol
+    agree = lg.argmax(0) == logits.argmax(0)
+    print(f'argmax: {int(safe.sum())}/{safe.numel()} voxels have margin > 2*tol; '
+          f'mismatches inside margin-safe set: {int((~agree & safe).sum())}, outside: {int((~agree & ~safe).sum())}')
+    assert bool((agree | ~safe).all()), 'argmax label differs on a voxel whose fp32 margin exceeds the tolerance'
+    assert float(safe.float().mean()) > 0.5, 'test input has too few margin-safe voxels to be meaningful'
