@@ -113,10 +113,12 @@ int sd_tile_scatter(const void* tile_dev, int dtype, int C, int TD, int TH, int 
 int sd_postproc_labels(const uint8_t* probs_dev, int C, size_t nvox, const int32_t* ids, const double* thresholds,
                        int n_ids, void* out_dev, int out_dtype, void* stream);
 
-/* Measurement / test support.  Profiling brackets every layer launch with HIP events on the launch stream;
- * sd_profile_read returns the per-layer milliseconds of the LAST sd_forward (after the caller synchronised). */
-int sd_profile_enable(sd_model* m, int enable);
-int sd_profile_read(sd_model* m, float* ms_per_op, int n_ops);
+/* Measurement / test support.  With n_slots > 0 every layer launch of an sd_forward is bracketed by HIP events
+ * recorded on the launch stream; forward number k uses event set k % n_slots (counted from this call), so a timed
+ * region of many forwards can be read back afterwards without synchronising inside it.  n_slots = 0 switches off.
+ * sd_profile_read returns the per-layer milliseconds of one slot (the caller synchronised the stream before). */
+int sd_profile_enable(sd_model* m, int n_slots);
+int sd_profile_read(sd_model* m, int slot, float* ms_per_op, int n_ops);
 /* Copy activation buffer `buf` of the last sd_forward out of the workspace as float32 planar (C, d, h, w);
  * dims are returned in dims4 = {C, d, h, w}.  out_dev may be NULL to query dims only. */
 int sd_debug_read_buffer(sd_model* m, int buf, const void* workspace_dev, float* out_dev, int32_t* dims4,

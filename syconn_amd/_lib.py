@@ -55,7 +55,7 @@ def load():
     lib.sd_postproc_labels.argtypes = [vp, i32, sz, C.POINTER(C.c_int32), C.POINTER(C.c_double), i32, vp, i32, vp]
     lib.sd_postproc_labels.restype = i32
     lib.sd_profile_enable.argtypes = [vp, i32]; lib.sd_profile_enable.restype = i32
-    lib.sd_profile_read.argtypes = [vp, C.POINTER(C.c_float), i32]; lib.sd_profile_read.restype = i32
+    lib.sd_profile_read.argtypes = [vp, i32, C.POINTER(C.c_float), i32]; lib.sd_profile_read.restype = i32
     lib.sd_debug_read_buffer.argtypes = [vp, i32, vp, vp, C.POINTER(C.c_int32), vp]
     lib.sd_debug_read_buffer.restype = i32
     lib.sd_model_num_ops.argtypes = [vp]; lib.sd_model_num_ops.restype = i32

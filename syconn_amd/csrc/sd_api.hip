@@ -68,14 +68,15 @@ struct sd_model {
     // last forward
     std::vector<Dims> dims;
     std::vector<size_t> buf_off;
-    bool profile = false;
-    std::vector<hipEvent_t> events;
+    int profile_slots = 0;             // 0 = off; else ring of event sets, one per sd_forward
+    long n_forward = 0;
+    std::vector<hipEvent_t> events;    // [slot][n_ops + 1]
     int final_cout = 0;
 };
 
 namespace {
 
-constexpr size_t WS_SCRATCH = 16384;  // GroupNorm sums (double[2*C]) + scale/shift (float[2*C]) at workspace start
+constexpr size_t WS_SCRATCH = 65536;  // GroupNorm sums (double[2*C]) + scale/shift (float[2*C]) at workspace start
 
 // shape inference for an input tile; fills dims[] per buffer.
 int infer_shapes(const sd_model* m, int D, int H, int W, std::vector<Dims>& dims) {
@@ -379,20 +380,25 @@ size_t sd_workspace_bytes(const sd_model* m, int D, int H, int W) {
     return plan_workspace(m, dims, off);
 }
 
-int sd_profile_enable(sd_model* m, int enable) {
-    if (!m) return fail(SD_ERR_INVALID, "null model");
-    m->profile = enable != 0;
-    if (m->profile && m->events.empty()) {
-        m->events.resize(m->ops.size() + 1);
+int sd_profile_enable(sd_model* m, int n_slots) {
+    if (!m || n_slots < 0) return fail(SD_ERR_INVALID, "sd_profile_enable: bad argument");
+    for (hipEvent_t e : m->events) (void)hipEventDestroy(e);
+    m->events.clear();
+    m->profile_slots = n_slots;
+    m->n_forward = 0;
+    if (n_slots > 0) {
+        m->events.resize((size_t)n_slots * (m->ops.size() + 1));
         for (auto& e : m->events) HIP_TRY(hipEventCreate(&e));
     }
     return SD_OK;
 }
 
-int sd_profile_read(sd_model* m, float* ms, int n_ops) {
-    if (!m || !ms || m->events.empty()) return fail(SD_ERR_INVALID, "profiling not enabled");
+int sd_profile_read(sd_model* m, int slot, float* ms, int n_ops) {
+    if (!m || !ms || m->profile_slots <= 0 || slot < 0 || slot >= m->profile_slots)
+        return fail(SD_ERR_INVALID, "sd_profile_read: profiling not enabled or bad slot");
     const int n = std::min<int>(n_ops, (int)m->ops.size());
-    for (int i = 0; i < n; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], m->events[i], m->events[i + 1]));
+    const hipEvent_t* ev = m->events.data() + (size_t)slot * (m->ops.size() + 1);
+    for (int i = 0; i < n; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
     return SD_OK;
 }
 
@@ -409,11 +415,15 @@ int sd_forward(sd_model* m, const void* in_dev, int in_dtype, int D, int H, int 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     char* const wsb = reinterpret_cast<char*>(ws);
     auto bufp = [&](int b) -> void* { return wsb + m->buf_off[b]; };
+    hipEvent_t* ev = nullptr;
+    if (m->profile_slots > 0)
+        ev = m->events.data() + (size_t)(m->n_forward % m->profile_slots) * (m->ops.size() + 1);
+    ++m->n_forward;
 
     for (size_t i = 0; i < m->ops.size(); ++i) {
         const Op& op = m->ops[i];
         const sd_op_desc& d = op.d;
-        if (m->profile) HIP_TRY(hipEventRecord(m->events[i], s));
+        if (ev) HIP_TRY(hipEventRecord(ev[i], s));
         switch (d.kind) {
         case SD_OP_CONV: {
             const Dims o = m->dims[d.dst];
@@ -503,7 +513,7 @@ int sd_forward(sd_model* m, const void* in_dev, int in_dtype, int D, int H, int 
             return fail(rc, msg);
         }
     }
-    if (m->profile) HIP_TRY(hipEventRecord(m->events[m->ops.size()], s));
+    if (ev) HIP_TRY(hipEventRecord(ev[m->ops.size()], s));
     return SD_OK;
 }
 

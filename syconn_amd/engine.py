@@ -106,14 +106,16 @@ class DenseModel:
         L.check(self.lib.sd_debug_read_buffer(self._h, buf, self._ws.data_ptr(), out.data_ptr(), dims, _stream()))
         return out
 
-    def profile(self, enable: bool = True):
-        L.check(self.lib.sd_profile_enable(self._h, int(enable)), 'sd_profile_enable')
-        self._profile = enable
+    def profile(self, n_slots: int = 1):
+        """Bracket every layer launch with HIP events; forward k records into slot k % n_slots (0 = off)."""
+        L.check(self.lib.sd_profile_enable(self._h, int(n_slots)), 'sd_profile_enable')
+        self._profile = n_slots
 
-    def profile_read(self) -> np.ndarray:
+    def profile_read(self, slot: int = 0) -> np.ndarray:
+        """Per-layer milliseconds of the forward recorded in `slot` (synchronises the device first)."""
         torch.cuda.synchronize(self.device)
         ms = (C.c_float * self.n_ops)()
-        L.check(self.lib.sd_profile_read(self._h, ms, self.n_ops), 'sd_profile_read')
+        L.check(self.lib.sd_profile_read(self._h, int(slot), ms, self.n_ops), 'sd_profile_read')
         return np.asarray(list(ms), dtype=np.float64)
 
 
@@ -141,7 +143,7 @@ def tile_scatter(tile: torch.Tensor, crop_lo, keep, vol: torch.Tensor, origin):
 
 
 def postproc_labels(probs_u8: torch.Tensor, ids: Sequence[int], thresholds: Sequence[float],
-                    out_dtype=torch.uint8) -> torch.Tensor:
+                    out_dtype=torch.uint8, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Label rule of /root/reference/syconn/handler/prediction.py:813-833 on the device.
     `thresholds[i]` is the already resolved float threshold of ids[i]."""
     lib = L.load()
@@ -151,11 +153,16 @@ def postproc_labels(probs_u8: torch.Tensor, ids: Sequence[int], thresholds: Sequ
     n = len(ids)
     ids_a = (C.c_int32 * n)(*[int(i) for i in ids])
     thr_a = (C.c_double * n)(*[float(t) for t in thresholds])
+    if out is not None:
+        out_dtype = out.dtype
+        assert out.is_contiguous() and out.numel() == nvox and out_dtype in (torch.uint8, torch.int64)
     if out_dtype == torch.uint8:
-        out = torch.empty(probs_u8.shape[1:], dtype=torch.uint8, device=probs_u8.device)
+        if out is None:
+            out = torch.empty(probs_u8.shape[1:], dtype=torch.uint8, device=probs_u8.device)
         code = L.SD_U8
     else:
-        out = torch.empty(probs_u8.shape[1:], dtype=torch.int64, device=probs_u8.device)  # bit pattern of uint64
+        if out is None:
+            out = torch.empty(probs_u8.shape[1:], dtype=torch.int64, device=probs_u8.device)  # uint64 bit pattern
         code = L.SD_U64
     L.check(lib.sd_postproc_labels(probs_u8.data_ptr(), Cn, nvox, ids_a, thr_a, n, out.data_ptr(), code, _stream()),
             'sd_postproc_labels')

@@ -1,0 +1,384 @@
+"""Drop-in for the dense part of ``syconn.handler.prediction`` (/root/reference/syconn/handler/prediction.py:594-868)
+plus the ``elektronn3.inference.Predictor`` subset SyConn uses on this path.
+
+Same names, argument meaning and error behaviour as the reference; the compute underneath is the HIP library
+(``include/syconn_dense.h``).  There is no CPU fallback: without the built library / an MI355X every entry point
+that needs compute raises.
+"""
+import itertools
+import logging
+import os
+import shutil
+from logging import Logger
+from typing import Any, Iterable, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from .. import global_params
+from ..knossos import ChunkDataset, KnossosDataset
+from . import basics
+from .basics import chunkify
+from .config import initialize_logging
+
+log_main = logging.getLogger('syconn_amd.handler')
+log_reps = log_main
+
+
+# ------------------------------------------------------------------------------------------------------
+# axis helpers (prediction.py:279-307)
+def xyz2zyx(vol: np.ndarray) -> np.ndarray:
+    """[..., X, Y, Z] -> [..., Z, Y, X] (prediction.py:279-292)."""
+    return vol.swapaxes(-1, -3)
+
+
+def zyx2xyz(vol: np.ndarray) -> np.ndarray:
+    """[..., Z, Y, X] -> [..., X, Y, Z] (prediction.py:295-307)."""
+    return vol.swapaxes(-1, -3)
+
+
+# ------------------------------------------------------------------------------------------------------
+class Predictor:
+    """MI355X implementation of ``elektronn3.inference.Predictor`` (third-party; constructed at
+    prediction.py:777-779 and :1062): tiled, overlap-and-crop inference of a 3D U-Net.
+
+    Supported (= what SyConn's dense path uses): `model` as ``nn.Module`` or path to a TorchScript ``.pts`` /
+    pickled ``.pt`` file, `state_dict_src`, `device`, `tile_shape`/`overlap_shape` (z,y,x), `out_shape`
+    (C,z,y,x), `strict_shapes`, `apply_softmax`, `apply_argmax`, `float16`, `batch_size`, `verbose`.
+    `transform`, `augmentations`, `offset` (valid convolutions) and `argmax_with_threshold` are unused by SyConn
+    and rejected.  Extra keyword `act_dtype` ('bf16' default, 'f16'; `float16=True` selects 'f16') names the storage
+    type of activations on the device; accumulation is fp32.
+
+    ``predict(inp)`` takes an ``np.ndarray`` / ``Tensor`` of shape (N,1,D,H,W) and any float dtype and returns a
+    float32 CPU tensor (N,C,D,H,W).  Device-memory exhaustion raises ``RuntimeError`` (the reference's
+    tile-halving loop relies on that, prediction.py:783-794); `strict_shapes` violations raise ``ValueError``.
+    """
+
+    def __init__(self, model, state_dict_src=None, device=None, batch_size=None, tile_shape=None,
+                 overlap_shape=None, offset=None, out_shape=None, out_dtype=None, float16=False,
+                 apply_softmax=True, transform=None, augmentations=None, strict_shapes=False, apply_argmax=False,
+                 argmax_with_threshold=None, verbose=False, report_inf_speed=False, act_dtype=None,
+                 group_norm_groups=None):
+        from ..engine import DenseModel
+        if transform is not None or augmentations is not None or argmax_with_threshold is not None:
+            raise NotImplementedError('transform / augmentations / argmax_with_threshold are not used by SyConn\'s '
+                                      'dense path and not implemented')
+        if offset is not None and np.any(np.asarray(offset) != 0):
+            raise NotImplementedError('valid-convolution offsets are not used by SyConn\'s dense path')
+        if isinstance(model, str):
+            model = os.path.expanduser(model)
+            if not os.path.isfile(model):
+                raise ValueError(f'Model path {model} not found.')
+            if model.endswith('.pts'):
+                model = torch.jit.load(model, map_location='cpu')
+            elif model.endswith('.pt'):
+                model = torch.load(model, map_location='cpu', weights_only=False)
+            else:
+                raise ValueError(f'{model} has an unknown file extension. Supported are: .pt and .pts')
+        if isinstance(state_dict_src, str):
+            state_dict_src = torch.load(state_dict_src, map_location='cpu', weights_only=False)
+            state_dict_src = state_dict_src.get('model_state_dict', state_dict_src)
+        if state_dict_src is not None and not isinstance(model, dict):
+            model.load_state_dict(state_dict_src)
+        if hasattr(model, 'eval'):
+            model.eval()
+        self.model = model
+        if device is None:
+            device = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else None
+        if device is None or torch.device(device).type != 'cuda':
+            raise RuntimeError('syconn_amd.Predictor needs an MI355X (ROCm device); there is no CPU fallback')
+        self.device = torch.device(device)
+        self.batch_size = batch_size
+        self.tile_shape = None if tile_shape is None else np.asarray(tile_shape, dtype=np.int64)
+        self.overlap_shape = None if overlap_shape is None else np.asarray(overlap_shape, dtype=np.int64)
+        if self.overlap_shape is not None and np.any(self.overlap_shape < 0):
+            raise ValueError('overlap_shape must be non-negative')
+        self.out_shape = None if out_shape is None else tuple(int(s) for s in out_shape)
+        self.out_dtype = torch.float32 if out_dtype is None else out_dtype
+        self.float16 = float16
+        self.apply_softmax = apply_softmax
+        self.strict_shapes = strict_shapes
+        self.apply_argmax = apply_argmax
+        self.verbose = verbose
+        self.report_inf_speed = report_inf_speed
+        if act_dtype is None:
+            act_dtype = 'f16' if float16 else 'bf16'
+        self.act_dtype = act_dtype
+        self._dm = DenseModel(model, act_dtype=act_dtype, device=self.device, group_norm_groups=group_norm_groups)
+        self.out_channels = self._dm.out_channels
+
+    # -- geometry --------------------------------------------------------------------------------------
+    def _geometry(self, spatial: np.ndarray):
+        tile = spatial.copy() if self.tile_shape is None else self.tile_shape
+        ol = np.zeros(3, dtype=np.int64) if self.overlap_shape is None else self.overlap_shape
+        if len(tile) != 3 or len(ol) != 3:
+            raise ValueError('tile_shape / overlap_shape must have 3 entries (z, y, x)')
+        if self.out_shape is not None:
+            if self.out_shape[0] != self.out_channels:
+                raise ValueError(f'out_shape[0]={self.out_shape[0]} but the model predicts {self.out_channels} '
+                                 f'channels')
+            if tuple(self.out_shape[1:]) != tuple(int(s) for s in spatial):
+                raise ValueError(f'out_shape {self.out_shape} does not match the input shape {tuple(spatial)}')
+        if np.any(spatial % tile != 0):
+            if self.strict_shapes:
+                raise ValueError(f'spatial inp shape {tuple(spatial)} has to be divisible by '
+                                 f'tile_shape {tuple(tile)} (strict_shapes=True)')
+            if np.any(tile > spatial):
+                tile = np.minimum(tile, spatial)
+        ntiles = np.ceil(spatial / tile).astype(np.int64)
+        return tile, ol, ntiles
+
+    def _tiled(self, vol: torch.Tensor, out: torch.Tensor, out_kind: int):
+        """tiled_apply (elektronn3) on the device: zero-padded tile extraction, forward,
+        crop of the overlap, write into `out` (C,D,H,W).  vol: (D,H,W) uint8 / float32 on the device."""
+        from ..engine import tile_gather, tile_scatter
+        spatial = np.asarray(vol.shape, dtype=np.int64)
+        tile, ol, ntiles = self._geometry(spatial)
+        tin = tile + 2 * ol
+        single = bool(np.all(ntiles == 1) and np.all(ol == 0) and np.all(tile == spatial))
+        if single:
+            self._dm.forward(vol, out_kind, out)
+            return
+        tbuf = torch.empty(tuple(int(t) for t in tin), dtype=vol.dtype, device=self.device)
+        obuf = torch.empty((self.out_channels, *[int(t) for t in tin]), dtype=out.dtype, device=self.device)
+        for pos in itertools.product(*[range(int(n)) for n in ntiles]):   # z-major, like itertools.product upstream
+            pos = np.asarray(pos, dtype=np.int64)
+            lo = tile * pos
+            keep = np.minimum(tile, spatial - lo)
+            tile_gather(vol, lo - ol, tin, tbuf)
+            self._dm.forward(tbuf, out_kind, obuf)
+            tile_scatter(obuf, ol, keep, out, lo)
+
+    # -- public API ------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def predict(self, inp: Union[np.ndarray, torch.Tensor]) -> torch.Tensor:
+        """(N,1,D,H,W) float -> (N,C,D,H,W) float32 CPU tensor (rows P2/P4; called at prediction.py:781, 863)."""
+        if isinstance(inp, np.ndarray):
+            inp = torch.from_numpy(np.ascontiguousarray(inp))
+        if inp.dim() != 5:
+            raise ValueError(f'expected (N, C, D, H, W) input, got shape {tuple(inp.shape)}')
+        if inp.shape[1] != 1:
+            raise ValueError('the dense path feeds single-channel EM data (C must be 1)')
+        n = inp.shape[0]
+        spatial = tuple(int(s) for s in inp.shape[2:])
+        out = torch.empty((n, self.out_channels, *spatial), dtype=torch.float32)
+        kind = L.SD_OUT_PROBS_F32 if self.apply_softmax else L.SD_OUT_LOGITS_F32
+        torch.cuda.set_device(self.device)
+        out_dev = torch.empty((self.out_channels, *spatial), dtype=torch.float32, device=self.device)
+        for b in range(n):
+            vol = inp[b, 0].to(torch.float32).contiguous().to(self.device)
+            self._tiled(vol, out_dev, kind)
+            out[b] = out_dev.cpu()
+        if self.apply_argmax:
+            out = out.argmax(1)
+        return out
+
+    @torch.no_grad()
+    def predict_proba_u8_device(self, raw_u8: torch.Tensor) -> torch.Tensor:
+        """Fast path of ``dense_predicton_helper(raw.astype(float32)/255., self)``: `raw_u8` is the (D,H,W) uint8
+        chunk ON THE DEVICE; returns uint8 ``floor(255*softmax)`` (C,D,H,W) on the device.  Bit-identical to the
+        slow path by construction: the kernel normalises with the table float32(v)/255 (prediction.py:808) and
+        truncates the float32 product p*255 (prediction.py:864-865)."""
+        if not self.apply_softmax:
+            raise ValueError('uint8 probabilities need apply_softmax=True')
+        assert raw_u8.dtype == torch.uint8 and raw_u8.dim() == 3
+        torch.cuda.set_device(self.device)
+        raw_u8 = raw_u8.contiguous()
+        out = torch.empty((self.out_channels, *raw_u8.shape), dtype=torch.uint8, device=self.device)
+        self._tiled(raw_u8, out, L.SD_OUT_PROBS_U8)
+        return out
+
+
+# ------------------------------------------------------------------------------------------------------
+def dense_predicton_helper(raw: np.ndarray, predictor: 'Predictor', is_zyx=False, return_zyx=False) -> np.ndarray:
+    """prediction.py:846-868.  `raw`: float array (X,Y,Z) or (Z,Y,X) already scaled to 0..1; returns the
+    inference result as uint8 (C, ...) between 0..255 (truncated ``pred*255``)."""
+    if not is_zyx:
+        raw = xyz2zyx(raw)
+    pred = predictor.predict(raw[None, None]).numpy()
+    pred = np.array(pred[0]) * 255  # remove N-axis
+    pred = pred.astype(np.uint8)
+    if not return_zyx:
+        pred = zyx2xyz(pred)
+    return pred
+
+
+def _resolve_threshold(t) -> float:
+    """prediction.py:824-827: ``None -> 255/2``; ``t < 1 -> 255*t``."""
+    if t is None:
+        t = 255 / 2
+    if t < 1.:
+        t = 255 * t
+    return float(t)
+
+
+def dense_predictor(args):
+    """Worker of the dense prediction (one process = one GPU), prediction.py:723-843.  `args` is the reference's
+    14-tuple ``(chunk_ids, kd_p, target_p, model_p, overlap_shape, overlap_shape_tiles, tile_shape, chunk_size,
+    n_channel, target_channels, target_kd_path_list, channel_thresholds, mag, cube_of_interest)``.
+
+    Differences to the reference are confined to WHERE the arithmetic runs: the uint8 chunk goes to the GPU once,
+    normalisation, tiling, U-Net, softmax, uint8 cast, halo crop and the label rule run there, and only uint8
+    results come back (the reference moves fp32 tiles over PCIe in both directions)."""
+    from ..engine import postproc_labels, tile_scatter
+    chunk_ids, kd_p, target_p, model_p, overlap_shape, overlap_shape_tiles, tile_shape, chunk_size, n_channel, \
+        target_channels, target_kd_path_list, channel_thresholds, mag, cube_of_interest = args
+
+    kd = KnossosDataset()
+    kd.initialize_from_knossos_path(kd_p)
+    cd = ChunkDataset()
+    cd.initialize(kd, cube_of_interest[1], chunk_size, target_p + '/cd_tmp/', box_coords=cube_of_interest[0],
+                  list_of_coords=[], fit_box_size=True, overlap=overlap_shape)
+    target_kd_dict = {path: basics.kd_factory(path) for path in target_kd_path_list}
+
+    ix = 0
+    tile_shape = np.array(tile_shape)
+    overlap_shape = np.asarray(overlap_shape)
+    overlap_shape_tiles = np.asarray(overlap_shape_tiles)
+    chunk_size = np.asarray(chunk_size)
+    act_dtype = global_params.config['dense_prediction']['act_dtype'] if _wd_set() else 'bf16'
+    while True:
+        try:
+            out_shape = (chunk_size + 2 * np.array(overlap_shape)).astype(np.int32)[::-1]  # ZYX
+            out_shape = np.insert(out_shape, 0, n_channel)  # output must equal chunk size
+            predictor = Predictor(model_p, strict_shapes=True, tile_shape=tile_shape[::-1], out_shape=out_shape,
+                                  overlap_shape=overlap_shape_tiles[::-1], apply_softmax=True, act_dtype=act_dtype)
+            try:
+                predictor.model.ae = False
+            except Exception:  # ScriptModules refuse new attributes; elektronn3's flag has no meaning here
+                pass
+            # warm-up / memory probe on a full-size chunk (prediction.py:781 uses float64 zeros)
+            _ = predictor.predict_proba_u8_device(
+                torch.zeros(tuple(int(s) for s in out_shape[1:]), dtype=torch.uint8, device=predictor.device))
+            break
+        except RuntimeError:  # device MemoryError
+            if np.all(tile_shape % 2):
+                raise ValueError('Cannot reduce tile shape anymore. Please adapt the tile/overlap/chunk shape in '
+                                 'the function that is calling `dense_predictor`.')
+            while tile_shape[ix] % 2:
+                ix += 1
+            tile_sh_orig = np.array(tile_shape)
+            tile_shape[ix] = tile_shape[ix] // 2
+            log_main.warning(f'Changed tile shape from {tile_sh_orig} to {tile_shape} to reduce memory requirements.')
+            ix = (ix + 1) % 3
+
+    dev = predictor.device
+    for ch_id in chunk_ids:
+        ch = cd.chunk_dict[ch_id]
+        ol = ch.overlap
+        size = np.array(np.array(ch.size) + 2 * np.array(ol), dtype=np.int32)
+        coords = np.array(np.array(ch.coordinates) - np.array(ol), dtype=np.int32)
+        raw = kd.load_raw(size=size * mag, offset=coords * mag, mag=mag)          # uint8, ZYX
+        raw_dev = torch.from_numpy(np.ascontiguousarray(raw)).to(dev)
+        pred_dev = predictor.predict_proba_u8_device(raw_dev)                     # (C, Z, Y, X) uint8
+        # slice out the original input volume along ZYX (prediction.py:812)
+        zyx = tuple(int(s) for s in np.asarray(ch.size)[::-1])
+        crop = torch.empty((pred_dev.shape[0], *zyx), dtype=torch.uint8, device=dev)
+        tile_scatter(pred_dev, (int(ol[2]), int(ol[1]), int(ol[0])), zyx, crop, (0, 0, 0))
+        for j in range(len(target_channels)):
+            ids = target_channels[j]
+            path = target_kd_path_list[j]
+            save_as_raw = not (len(ids) > 1)
+            if save_as_raw:
+                # no thresholding and only one label in the target KnossosDataset -> store probability map
+                data = crop[ids[-1]].cpu().numpy()
+                target_kd_dict[path].save_raw(offset=ch.coordinates * mag, data=data.astype(np.uint8), data_mag=mag,
+                                              mags=[mag, mag * 2, mag * 4], fast_resampling=True, upsample=False)
+            else:
+                thr = [_resolve_threshold(channel_thresholds[label]) for label in ids]
+                lab = postproc_labels(crop, ids, thr, out_dtype=torch.uint8).cpu().numpy()
+                target_kd_dict[path].save_seg(offset=ch.coordinates * mag, data=lab.astype(np.uint64), data_mag=mag,
+                                              mags=[mag, mag * 2, mag * 4], fast_resampling=True, upsample=False)
+
+
+def _wd_set() -> bool:
+    try:
+        _ = global_params.config.working_dir
+        return True
+    except ValueError:
+        return False
+
+
+def predict_dense_to_kd(kd_path: str, target_path: str, model_path: str, n_channel: int,
+                        target_names: Optional[Iterable[str]] = None,
+                        target_channels: Optional[Iterable[Iterable[int]]] = None,
+                        channel_thresholds: Optional[Iterable[Union[float, Any]]] = None,
+                        log: Optional[Logger] = None, mag: int = 1,
+                        overlap_shape_tiles: Tuple[int, int, int] = (40, 40, 20),
+                        cube_of_interest: Optional[Tuple[np.ndarray]] = None, overwrite: bool = False,
+                        cube_shape_kd: Optional[Tuple[int]] = None):
+    """Dense prediction of a whole KnossosDataset into target KnossosDataset(s), prediction.py:594-720: builds the
+    chunk grid, creates the target datasets, partitions the chunk ids round-robin over ``config.ngpu_total`` workers
+    (``chunkify``) and dispatches one worker per GPU.
+
+    As in the reference the keyword `overlap_shape_tiles` is overridden by the configured geometry
+    (prediction.py:671-677 hard-codes it; here it is ``config['dense_prediction']``, same defaults)."""
+    from ..mp import batchjob_utils as qu
+    if log is None:
+        log = initialize_logging('dense_predictions', global_params.config.working_dir + '/logs/', overwrite=False)
+    if target_names is None:
+        target_names = ['pred']
+    if target_channels is None:
+        target_channels = [[ix for ix in range(n_channel)]]
+    if not len(target_names) == len(target_channels):
+        msg = 'For every target name the target channels have to be specified.'
+        log_reps.error(msg)
+        raise ValueError(msg)
+    if channel_thresholds is None:
+        channel_thresholds = [None for _ in range(n_channel)]
+
+    kd = basics.kd_factory(kd_path)
+    if cube_of_interest is None:
+        cube_of_interest = (np.zeros(3, ), kd.boundary // mag)
+    if cube_shape_kd is None:
+        cube_shape_kd = (256, 256, 256)
+    geo = global_params.config['dense_prediction']
+    overlap_shape_tiles = np.array(geo['overlap_shape_tiles'])
+    overlap_shape = overlap_shape_tiles
+    chunk_size = np.array(geo['chunk_size'])
+    tile_shape = list(geo['tile_shape'])
+
+    cd = ChunkDataset()
+    cd.initialize(kd, cube_of_interest[1], chunk_size, target_path + '/cd_tmp/', box_coords=cube_of_interest[0],
+                  list_of_coords=[], fit_box_size=True, overlap=overlap_shape)
+    chunk_ids = list(cd.chunk_dict.keys())
+    # init target KnossosDatasets
+    target_kd_path_list = [target_path + '/{}/'.format(tn) for tn in target_names]
+    for path in target_kd_path_list:
+        if os.path.isdir(path):
+            if not overwrite:
+                msg = f'Found existing KD at "{path}" but overwrite is set to False.'
+                log.error(msg)
+                raise ValueError(msg)
+            log.debug('Found existing KD at {}. Removing it now.'.format(path))
+            shutil.rmtree(path)
+    for path in target_kd_path_list:
+        target_kd = KnossosDataset()
+        target_kd._cube_shape = cube_shape_kd
+        scale = np.array(global_params.config['scaling'])
+        target_kd.scales = [scale, ]
+        target_kd.initialize_without_conf(path, kd.boundary, kd.scale, kd.experiment_name,
+                                          [2 ** x for x in range(6)], create_pyk_conf=False,
+                                          create_knossos_conf=True)
+        try:  # make sure init works
+            basics.kd_factory(path)
+        except ValueError as e:
+            log.error(f'Could not initialize KnossosDataset at "{path}". {e}')
+    # init batchjob parameters
+    multi_params = chunk_ids
+    multi_params = chunkify(multi_params, global_params.config.ngpu_total)
+    multi_params = [(ch_ids, kd_path, target_path, model_path, overlap_shape, overlap_shape_tiles, tile_shape,
+                     chunk_size, n_channel, target_channels, target_kd_path_list, channel_thresholds, mag,
+                     cube_of_interest) for ch_ids in multi_params]
+    log.info('Started dense prediction of {} in {:d} chunk(s).'.format(", ".join(target_names), len(chunk_ids)))
+    n_cores_per_job = global_params.config['ncores_per_node'] // global_params.config['ngpus_per_node'] if \
+        qu.batchjob_enabled() else global_params.config['ncores_per_node']
+    qu.batchjob_script(multi_params, "predict_dense", n_cores=n_cores_per_job, suffix='_' + '_'.join(target_names),
+                       remove_jobfolder=True, log=log, additional_flags="--gres=gpu:1")
+    log.info('Finished dense prediction of {}'.format(", ".join(target_names)))
+
+
+def get_myelin_cnn():
+    """prediction.py:1047-1063: ``Predictor(torch.jit.load(mpath_myelin))`` with the default tiling of that loader."""
+    return Predictor(global_params.config.mpath_myelin, strict_shapes=False, apply_softmax=True)

@@ -1,0 +1,260 @@
+"""Minimal in-repo stand-in for ``knossos_utils`` (KnossosDataset + chunky.ChunkDataset).
+
+``knossos_utils`` (branch ``syconn2``, /root/reference/environment.yml:88) is a third-party dependency that is
+neither vendored in the reference nor installed on the build / GPU boxes, so the dense path cannot do volume I/O
+without this file.  It implements only what /root/reference/syconn/handler/prediction.py:666-706, 753-767, 806,
+835-843 call, with the published KNOSSOS raw-cube layout (marked "restated, not verified
+against source" there):
+
+* ``<root>/mag<M>/x%04d/y%04d/z%04d/<exp>_mag<M>_x%04d_y%04d_z%04d.raw`` -- uint8 cubes, x fastest;
+* ``<root>/mag<M>/knossos.conf`` with experiment name / boundary / scale / magnification;
+* ``load_raw(size, offset, mag)``: `size`, `offset` in mag-1 voxels (x,y,z); returns a (z,y,x) uint8 array of
+  ``size // mag`` voxels, zeros outside the dataset;
+* ``save_raw / save_seg(offset, mags, data, data_mag, fast_resampling, upsample)``: `data` is (z,y,x) at `data_mag`;
+  written to every mag in `mags` >= data_mag by order-0 (strided) down-sampling.
+
+Deviation (documented in DESIGN.md): the overlay channel is stored as raw little-endian uint64 cubes
+(``*.seg.raw``) instead of snappy-compressed ``*.seg.sz.zip`` -- no snappy codec exists in this image.  The real
+on-disk overlay format is row 1 of SURVEY.md section 8(f) ("next").
+"""
+import os
+import re
+from typing import Dict, Iterable, List, Optional, Sequence
+
+import numpy as np
+
+
+class KnossosDataset:
+    def __init__(self):
+        self._cube_shape = (128, 128, 128)
+        self._experiment_name = None
+        self._boundary = np.zeros(3, dtype=np.int64)
+        self._scale = np.ones(3, dtype=np.float64)
+        self._knossos_path = None
+        self._mags: List[int] = [1]
+        self.scales = []
+        self._initialized = False
+
+    # -- properties used by the dense path ---------------------------------------------------------
+    @property
+    def boundary(self) -> np.ndarray:
+        return self._boundary
+
+    @property
+    def scale(self) -> np.ndarray:
+        return self._scale
+
+    @property
+    def experiment_name(self) -> str:
+        return self._experiment_name
+
+    @property
+    def knossos_path(self) -> str:
+        return self._knossos_path
+
+    @property
+    def cube_shape(self):
+        return tuple(int(c) for c in self._cube_shape)
+
+    # -- initialisation ----------------------------------------------------------------------------
+    @staticmethod
+    def _parse_conf(path: str) -> Dict:
+        txt = open(path).read()
+        out = {'boundary': np.zeros(3, dtype=np.int64), 'scale': np.ones(3), 'mag': 1, 'name': None}
+        m = re.search(r'experiment name\s+"([^"]*)"', txt)
+        if m:
+            out['name'] = m.group(1)
+        for i, ax in enumerate('xyz'):
+            m = re.search(rf'boundary {ax}\s+(\d+)', txt)
+            if m:
+                out['boundary'][i] = int(m.group(1))
+            m = re.search(rf'scale {ax}\s+([0-9.eE+-]+)', txt)
+            if m:
+                out['scale'][i] = float(m.group(1))
+        m = re.search(r'magnification\s+(\d+)', txt)
+        if m:
+            out['mag'] = int(m.group(1))
+        return out
+
+    def initialize_from_knossos_path(self, path: str, **_):
+        """`path`: a ``knossos.conf`` file, a ``mag*`` folder or the dataset root."""
+        path = os.path.expanduser(path)
+        if os.path.isfile(path):
+            conf = path
+        elif os.path.isfile(os.path.join(path, 'knossos.conf')):
+            conf = os.path.join(path, 'knossos.conf')
+        elif os.path.isfile(os.path.join(path, 'mag1', 'knossos.conf')):
+            conf = os.path.join(path, 'mag1', 'knossos.conf')
+        else:
+            raise ValueError(f'Could not find knossos.conf at {path}.')
+        c = self._parse_conf(conf)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(conf)))
+        self._knossos_path = root + '/'
+        self._experiment_name = c['name']
+        self._boundary = c['boundary'] * c['mag']   # the mag-M conf stores the boundary in mag-M voxels
+        self._scale = c['scale'] / c['mag']
+        self._mags = sorted(int(m.group(1)) for d in os.listdir(root) for m in [re.fullmatch(r'mag(\d+)', d)] if m)
+        cs = os.path.join(root, 'cube_shape.txt')
+        if os.path.isfile(cs):
+            self._cube_shape = tuple(int(v) for v in open(cs).read().split())
+        self._initialized = True
+        return self
+
+    initialize_from_conf = initialize_from_knossos_path
+    initialize_from_pyknossos_path = initialize_from_knossos_path
+
+    def initialize_without_conf(self, path: str, boundary, scale, experiment_name: str, mags=None,
+                                make_mag_folders: bool = True, create_knossos_conf: bool = True,
+                                create_pyk_conf: bool = False, **_):
+        self._knossos_path = os.path.abspath(os.path.expanduser(path)) + '/'
+        self._boundary = np.asarray(boundary, dtype=np.int64)
+        self._scale = np.asarray(scale, dtype=np.float64)
+        self._experiment_name = experiment_name
+        self._mags = [1] if mags is None else [int(m) for m in mags]
+        os.makedirs(self._knossos_path, exist_ok=True)
+        with open(self._knossos_path + 'cube_shape.txt', 'w') as f:
+            f.write(' '.join(str(int(c)) for c in self._cube_shape))
+        for mag in self._mags:
+            d = f'{self._knossos_path}mag{mag}/'
+            if make_mag_folders:
+                os.makedirs(d, exist_ok=True)
+            if create_knossos_conf:
+                b = self._boundary // mag
+                s = self._scale * mag
+                with open(d + 'knossos.conf', 'w') as f:
+                    f.write(f'experiment name "{experiment_name}";\n')
+                    for i, ax in enumerate('xyz'):
+                        f.write(f'boundary {ax} {int(b[i])};\n')
+                    for i, ax in enumerate('xyz'):
+                        f.write(f'scale {ax} {float(s[i])};\n')
+                    f.write(f'magnification {mag};\n')
+        self._initialized = True
+        return self
+
+    # -- cube I/O ------------------------------------------------------------------------------------
+    def _cube_file(self, mag: int, cx: int, cy: int, cz: int, ext: str) -> str:
+        return (f'{self._knossos_path}mag{mag}/x{cx:04d}/y{cy:04d}/z{cz:04d}/'
+                f'{self._experiment_name}_mag{mag}_x{cx:04d}_y{cy:04d}_z{cz:04d}.{ext}')
+
+    def _load(self, size, offset, mag: int, ext: str, dtype) -> np.ndarray:
+        size = np.asarray(size, dtype=np.int64) // mag
+        off = np.asarray(offset, dtype=np.int64) // mag
+        out = np.zeros(tuple(size[::-1]), dtype=dtype)   # z,y,x
+        cs = np.asarray(self._cube_shape, dtype=np.int64)
+        bnd = self._boundary // mag
+        lo = np.maximum(off, 0)
+        hi = np.minimum(off + size, bnd)
+        if np.any(hi <= lo):
+            return out
+        c_lo, c_hi = lo // cs, (hi - 1) // cs
+        for cx in range(c_lo[0], c_hi[0] + 1):
+            for cy in range(c_lo[1], c_hi[1] + 1):
+                for cz in range(c_lo[2], c_hi[2] + 1):
+                    fn = self._cube_file(mag, cx, cy, cz, ext)
+                    if not os.path.isfile(fn):
+                        continue
+                    cube = np.fromfile(fn, dtype=dtype).reshape(tuple(cs[::-1]))
+                    c0 = np.array([cx, cy, cz]) * cs
+                    a = np.maximum(lo, c0)
+                    b = np.minimum(hi, c0 + cs)
+                    src = tuple(slice(int(a[i] - c0[i]), int(b[i] - c0[i])) for i in (2, 1, 0))
+                    dst = tuple(slice(int(a[i] - off[i]), int(b[i] - off[i])) for i in (2, 1, 0))
+                    out[dst] = cube[src]
+        return out
+
+    def load_raw(self, size, offset, mag: int = 1, **_) -> np.ndarray:
+        return self._load(size, offset, mag, 'raw', np.uint8)
+
+    def load_seg(self, size, offset, mag: int = 1, **_) -> np.ndarray:
+        return self._load(size, offset, mag, 'seg.raw', np.uint64)
+
+    def _save(self, offset, mags: Sequence[int], data: np.ndarray, data_mag: int, ext: str, dtype,
+              fast_resampling: bool = True, upsample: bool = False):
+        off1 = np.asarray(offset, dtype=np.int64)
+        cs = np.asarray(self._cube_shape, dtype=np.int64)
+        for mag in mags:
+            if mag < data_mag:
+                if not upsample:
+                    continue
+                raise NotImplementedError('upsampling is not used by the dense path')
+            r = mag // data_mag
+            d = data if r == 1 else data[::r, ::r, ::r]      # order-0 ("fast") resampling
+            d = np.ascontiguousarray(d, dtype=dtype)
+            off = off1 // mag
+            size = np.asarray(d.shape[::-1], dtype=np.int64)
+            bnd = self._boundary // mag
+            lo, hi = np.maximum(off, 0), np.minimum(off + size, bnd)
+            if np.any(hi <= lo):
+                continue
+            c_lo, c_hi = lo // cs, (hi - 1) // cs
+            for cx in range(c_lo[0], c_hi[0] + 1):
+                for cy in range(c_lo[1], c_hi[1] + 1):
+                    for cz in range(c_lo[2], c_hi[2] + 1):
+                        fn = self._cube_file(mag, cx, cy, cz, ext)
+                        c0 = np.array([cx, cy, cz]) * cs
+                        a, b = np.maximum(lo, c0), np.minimum(hi, c0 + cs)
+                        whole = np.all(a == c0) and np.all(b == c0 + cs)
+                        if os.path.isfile(fn) and not whole:
+                            cube = np.fromfile(fn, dtype=dtype).reshape(tuple(cs[::-1]))
+                        else:
+                            cube = np.zeros(tuple(cs[::-1]), dtype=dtype)
+                            os.makedirs(os.path.dirname(fn), exist_ok=True)
+                        dst = tuple(slice(int(a[i] - c0[i]), int(b[i] - c0[i])) for i in (2, 1, 0))
+                        src = tuple(slice(int(a[i] - off[i]), int(b[i] - off[i])) for i in (2, 1, 0))
+                        cube[dst] = d[src]
+                        tmp = fn + f'.tmp{os.getpid()}'
+                        cube.tofile(tmp)
+                        os.replace(tmp, fn)
+
+    def save_raw(self, offset, mags, data, data_mag: int = 1, fast_resampling: bool = True, upsample: bool = True,
+                 **_):
+        self._save(offset, mags, data, data_mag, 'raw', np.uint8, fast_resampling, upsample)
+
+    def save_seg(self, offset, mags, data, data_mag: int = 1, fast_resampling: bool = True, upsample: bool = True,
+                 **_):
+        self._save(offset, mags, data, data_mag, 'seg.raw', np.uint64, fast_resampling, upsample)
+
+
+class Chunk:
+    def __init__(self, number: int, coordinates, size, overlap):
+        self.number = number
+        self.coordinates = np.asarray(coordinates, dtype=np.int64)
+        self.size = np.asarray(size, dtype=np.int64)
+        self.overlap = np.asarray(overlap, dtype=np.int64)
+
+
+class ChunkDataset:
+    """Regular chunk grid over a box (``knossos_utils.chunky.ChunkDataset.initialize`` as called at
+    prediction.py:679-683 / 757-760).  Chunk ids enumerate the grid x-outermost, z-innermost."""
+
+    def __init__(self):
+        self.chunk_dict: Dict[int, Chunk] = {}
+        self.box_size = None
+        self.chunk_size = None
+        self.box_coords = None
+        self.overlap = None
+        self.path_head_folder = None
+
+    def initialize(self, knossos_dataset_object, box_size, chunk_size, path_head_folder: str, overlap=(0, 0, 0),
+                   list_of_coords: Optional[Iterable] = None, box_coords=None, fit_box_size: bool = False):
+        chunk_size = np.asarray(chunk_size, dtype=np.int64)
+        box_size = np.asarray(box_size, dtype=np.int64)
+        box_coords = np.zeros(3, dtype=np.int64) if box_coords is None else np.asarray(box_coords, dtype=np.int64)
+        if fit_box_size:
+            box_size = (np.ceil(box_size / chunk_size) * chunk_size).astype(np.int64)
+        self.box_size, self.chunk_size, self.box_coords = box_size, chunk_size, box_coords
+        self.overlap = np.asarray(overlap, dtype=np.int64)
+        self.path_head_folder = path_head_folder
+        self.chunk_dict = {}
+        n = 0
+        if list_of_coords:
+            for c in list_of_coords:
+                self.chunk_dict[n] = Chunk(n, c, chunk_size, self.overlap)
+                n += 1
+            return self
+        for x in range(int(box_coords[0]), int(box_coords[0] + box_size[0]), int(chunk_size[0])):
+            for y in range(int(box_coords[1]), int(box_coords[1] + box_size[1]), int(chunk_size[1])):
+                for z in range(int(box_coords[2]), int(box_coords[2] + box_size[2]), int(chunk_size[2])):
+                    self.chunk_dict[n] = Chunk(n, (x, y, z), chunk_size, self.overlap)
+                    n += 1
+        return self

@@ -1,0 +1,115 @@
+"""Single-node multi-GPU execution of the dense prediction path: one process per GPU, ``torch.distributed``
+(backend "nccl" == RCCL over xGMI on ROCm; "gloo" for the CPU unit tests of the sharding logic).
+
+The path shards naturally: chunks / tiles are independent given read-only input with halo, so
+there is NO collective inside the compute.  The reference's multi-GPU mode is share-nothing processes on a shared
+file system (prediction.py:708-719); the MI355X-native variant keeps the same static round-robin ownership
+(``chunkify``, basics.py:545-561) and adds exactly the two root-centric exchanges the north star names:
+
+* ``broadcast_weights``: rank 0 -> all, the flat float32 parameter vector (16-150 MB), once per model;
+* ``gather_to_root``: every rank's uint8 results -> rank 0 (1 byte per voxel and target; widened to uint64 only by
+  the writer), issued per step and overlappable with the next step's compute.
+"""
+import os
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from .handler.basics import chunkify
+
+
+def init_distributed(backend: Optional[str] = None):
+    """Initialise from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).
+    Returns (rank, world_size, local_rank).  World size 1 needs no process group."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def world_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_units(units: Sequence, rank: Optional[int] = None, world: Optional[int] = None) -> list:
+    """Units (chunk ids / tile ids) owned by `rank`: ``chunkify(units, world)[rank]`` -- identical to the
+    reference's chunk -> worker assignment (prediction.py:708-709).  Ranks beyond ``len(units)`` own nothing."""
+    r, w = world_info()
+    rank = r if rank is None else rank
+    world = w if world is None else world
+    parts = chunkify(list(units), world)
+    return list(parts[rank]) if rank < len(parts) else []
+
+
+def flatten_state(model: torch.nn.Module) -> torch.Tensor:
+    """All parameters and buffers that define the network as one float32 vector (deterministic key order)."""
+    sd = model.state_dict()
+    return torch.cat([v.detach().reshape(-1).to(torch.float32) for k, v in sd.items()
+                      if not k.endswith('num_batches_tracked')])
+
+
+def unflatten_state(model: torch.nn.Module, flat: torch.Tensor) -> None:
+    sd = model.state_dict()
+    off = 0
+    new = {}
+    for k, v in sd.items():
+        if k.endswith('num_batches_tracked'):
+            new[k] = v
+            continue
+        n = v.numel()
+        new[k] = flat[off:off + n].reshape(v.shape).to(v.dtype).cpu()
+        off += n
+    if off != flat.numel():
+        raise ValueError('flat parameter vector does not match the model')
+    model.load_state_dict(new)
+
+
+def broadcast_weights(model: torch.nn.Module, src: int = 0, device: Optional[torch.device] = None) -> None:
+    """Make every rank's `model` equal to rank `src`'s (Coll-1 of SURVEY.md section 2.2)."""
+    _, world = world_info()
+    if world == 1:
+        return
+    flat = flatten_state(model)
+    if device is not None:
+        flat = flat.to(device)
+    dist.broadcast(flat, src=src)
+    unflatten_state(model, flat.cpu())
+
+
+def gather_to_root(local: torch.Tensor, dst: int = 0) -> Optional[List[torch.Tensor]]:
+    """Gather equally-shaped uint8 result tensors on `dst` (Coll-3).  Returns the list on `dst`, None elsewhere."""
+    rank, world = world_info()
+    if world == 1:
+        return [local]
+    bufs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
+    dist.gather(local, gather_list=bufs, dst=dst)
+    return bufs
+
+
+def barrier():
+    _, world = world_info()
+    if world > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device: Optional[torch.device] = None) -> float:
+    _, world = world_info()
+    if world == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -1,0 +1,275 @@
+"""GPU parity of the drop-in API (Predictor / dense_predicton_helper / dense_predictor / predict_dense_to_kd and the
+device-side tiling + label kernels) against the oracle and the committed golden vectors."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.predictor_ref import PredictorRef, dense_predicton_helper_ref, label_rule_ref
+from oracle.unet_ref import build_cnn3, build_unet
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), 'golden')
+
+# stated tolerance on softmax probabilities for bf16 storage (fp32 accumulate): absolute, on p in [0,1]
+TOL_P = 2.5e-2
+# => on uint8 probabilities floor(255 p): 255*TOL_P + 1 levels
+TOL_U8 = int(255 * TOL_P) + 1
+
+
+def test_tile_gather_scatter_identity(gpu):
+    """K1/K12: zero-padded tile extraction + crop-only stitching reproduce the volume (pins the index math)."""
+    from syconn_amd.engine import tile_gather, tile_scatter
+    rng = np.random.default_rng(0)
+    vol = torch.from_numpy(rng.random((24, 40, 36)).astype(np.float32)).to(gpu)
+    tile, ol = np.array([12, 20, 18]), np.array([4, 6, 5])
+    out = torch.zeros((1, 24, 40, 36), device=gpu)
+    for pos in np.ndindex(2, 2, 2):
+        lo = tile * np.array(pos)
+        t = tile_gather(vol, lo - ol, tile + 2 * ol)
+        ref = torch.zeros(tuple(tile + 2 * ol))
+        padded = torch.zeros((24 + 8, 40 + 12, 36 + 10))
+        padded[4:-4, 6:-6, 5:-5] = vol.cpu()
+        ref = padded[lo[0]:lo[0] + 20, lo[1]:lo[1] + 32, lo[2]:lo[2] + 28]
+        assert torch.equal(t.cpu(), ref)
+        tile_scatter(t[None].contiguous(), ol, tile, out, lo)
+    assert torch.equal(out[0], vol)
+    v8 = torch.from_numpy(rng.integers(0, 256, (9, 11, 13), dtype=np.uint8)).to(gpu)
+    t8 = tile_gather(v8, (-2, 3, 5), (8, 8, 8)).cpu()
+    assert t8[:2].sum() == 0 and torch.equal(t8[2:, :, :], v8.cpu()[:6, 3:11, 5:13])
+
+
+def test_label_rule_on_device_matches_reference_goldens(gpu):
+    """K11 against vectors produced by the reference's own label code (prediction.py:813-833)."""
+    from syconn_amd.engine import postproc_labels
+    from syconn_amd.handler.prediction import _resolve_threshold
+    g = np.load(f'{G}/g3_label_rule.npz')
+    cases = json.load(open(f'{G}/g3_label_rule_cases.json'))
+    pred = torch.from_numpy(g['pred']).to(gpu)
+    n = 0
+    for name, c in cases.items():
+        for j, ids in enumerate(c['target_channels']):
+            if len(ids) < 2:
+                continue
+            thr = [_resolve_threshold(c['thresholds'][i]) for i in ids]
+            for dt in (torch.uint8, torch.int64):
+                out = postproc_labels(pred, ids, thr, out_dtype=dt).cpu().numpy().astype(np.uint64)
+                assert np.array_equal(out, g[f'{name}_{j}_data']), (name, j)
+            n += 1
+    assert n >= 5
+    # exhaustive: every uint8 value against awkward thresholds, vs numpy
+    vals = torch.arange(256, dtype=torch.uint8).repeat(2, 1).reshape(2, 1, 16, 16).contiguous().to(gpu)
+    for t in [0.0, 0.2, 0.3, 50.99999999999999, 51.00000000000001, 127.5, 254.999, 255.0, 300.0]:
+        tt = _resolve_threshold(t)
+        ref, _ = label_rule_ref(vals.cpu().numpy(), (1, 1), [None, t])
+        out = postproc_labels(vals, (1, 1), [tt, tt]).cpu().numpy()
+        assert np.array_equal(out, ref.astype(np.uint8)), t
+
+
+def _em_like(shape, seed):
+    """structured synthetic EM: smoothed noise rescaled to 0..255."""
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.default_rng(seed)
+    v = gaussian_filter(rng.random(shape), 2.0)
+    v = (v - v.min()) / (v.max() - v.min())
+    return (v * 255).astype(np.uint8)
+
+
+def test_predictor_tiled_matches_oracle(gpu):
+    """Predictor.predict with 2x2x2 tiles + halo vs the oracle's tiled_apply (same tile grid, same zero padding)."""
+    from syconn_amd.handler.prediction import Predictor
+    model = build_unet('myelin', seed=101, n_blocks=3, start_filts=8)
+    g = np.load(f'{G}/g5_tiled_apply.npz')
+    vol = g['vol']
+    kw = dict(tile_shape=(12, 20, 20), overlap_shape=(4, 6, 6), out_shape=(2, 24, 40, 40), strict_shapes=True)
+    p = Predictor(model, apply_softmax=True, **kw)
+    out = p.predict(vol)
+    assert isinstance(out, torch.Tensor) and out.device.type == 'cpu' and out.dtype == torch.float32
+    assert tuple(out.shape) == (1, 2, 24, 40, 40)
+    err = np.abs(out.numpy() - g['unet_tiled_probs']).max()
+    print('tiled probs max abs err vs oracle golden', err)
+    assert err < TOL_P
+    # float64 input (the reference's warm-up passes float64 zeros, prediction.py:781) and Tensor input
+    out64 = p.predict(vol.astype(np.float64))
+    assert torch.equal(out64, out)
+    assert torch.equal(p.predict(torch.from_numpy(vol)), out)
+    # tiling must change nothing but the border effects: tile-interior == same call through the oracle
+    ref = PredictorRef(model, apply_softmax=True, **kw).predict(vol)
+    assert np.abs(out.numpy() - ref.numpy()).max() < TOL_P
+    # logits + argmax options
+    lg = Predictor(model, apply_softmax=False, **kw).predict(vol)
+    assert torch.allclose(lg.softmax(1), out, atol=1e-5)
+    am = Predictor(model, apply_softmax=True, apply_argmax=True, **kw).predict(vol)
+    assert torch.equal(am, out.argmax(1))
+    # error conventions
+    with pytest.raises(ValueError):
+        Predictor(model, tile_shape=(11, 20, 20), overlap_shape=(0, 0, 0), out_shape=(2, 24, 40, 40),
+                  strict_shapes=True).predict(vol)
+    with pytest.raises(ValueError):
+        Predictor(model, out_shape=(3, 24, 40, 40)).predict(vol)
+    with pytest.raises(ValueError):
+        Predictor('/nonexistent/model.pts')
+    # non-strict shapes: trailing partial tiles are zero-padded and cropped
+    pn = Predictor(model, tile_shape=(16, 32, 32), overlap_shape=(4, 6, 6), strict_shapes=False)
+    on = pn.predict(vol)
+    assert tuple(on.shape) == (1, 2, 24, 40, 40) and bool(torch.isfinite(on).all())
+
+
+def test_predictor_loads_torchscript_like_syconn(gpu, tmp_path):
+    """SyConn ships TorchScript traces (cnn_myelin.py:107 -> model.pts, loaded by path at prediction.py:777)."""
+    from syconn_amd.handler.prediction import Predictor
+    model = build_unet('myelin', seed=7, n_blocks=3, start_filts=16)
+    ts = torch.jit.trace(model, torch.randn(1, 1, 8, 16, 16))
+    path = str(tmp_path / 'model.pts')
+    ts.save(path)
+    vol = (_em_like((16, 32, 32), 3).astype(np.float32) / 255.)[None, None]
+    a = Predictor(path).predict(vol)
+    b = Predictor(model).predict(vol)
+    assert torch.equal(a, b)
+    with torch.no_grad():
+        ref = model(torch.from_numpy(vol)).softmax(1)
+    assert (a - ref).abs().max() < TOL_P
+    torch.save(model, str(tmp_path / 'model.pt'))
+    assert torch.equal(Predictor(str(tmp_path / 'model.pt')).predict(vol), b)
+
+
+def test_dense_predicton_helper_fast_path_is_bit_identical(gpu):
+    """uint8 on the device (LUT normalisation, fused floor(255 p)) == reference-order host math on the same
+    device probabilities (raw.astype(f32)/255 -> predict -> *255 -> astype(uint8))."""
+    from syconn_amd.handler.prediction import Predictor, dense_predicton_helper
+    model = build_unet('semseg_spine', seed=8, n_blocks=3, start_filts=16, final_scale=4.0)
+    raw = _em_like((24, 40, 40), 4)
+    p = Predictor(model, tile_shape=(12, 20, 20), overlap_shape=(4, 6, 6), out_shape=(5, 24, 40, 40),
+                  strict_shapes=True, apply_softmax=True)
+    slow = dense_predicton_helper(raw.astype(np.float32) / 255., p, is_zyx=True, return_zyx=True)
+    fast = p.predict_proba_u8_device(torch.from_numpy(raw).to(gpu)).cpu().numpy()
+    assert slow.dtype == np.uint8 and np.array_equal(slow, fast)
+    # and against the oracle within the stated tolerance
+    ref = dense_predicton_helper_ref(raw.astype(np.float32) / 255.,
+                                     PredictorRef(model, tile_shape=(12, 20, 20), overlap_shape=(4, 6, 6),
+                                                  out_shape=(5, 24, 40, 40), strict_shapes=True), True, True)
+    d = np.abs(slow.astype(np.int16) - ref.astype(np.int16))
+    print('uint8 prob diff vs oracle: max', d.max(), 'mean', d.mean())
+    assert d.max() <= TOL_U8
+    # xyz in / xyz out
+    xyz = dense_predicton_helper(np.ascontiguousarray((raw.astype(np.float32) / 255.).swapaxes(0, 2)), p)
+    assert np.array_equal(xyz, slow.swapaxes(-1, -3))
+
+
+def test_config1_cnn3_end_to_end(gpu):
+    """BASELINE.json config 1 through the HIP path vs the committed oracle output."""
+    from syconn_amd.handler.prediction import Predictor, dense_predicton_helper
+    g = np.load(f'{G}/g6_config1.npz')
+    vol = np.random.default_rng(0).integers(0, 256, (64, 64, 64), dtype=np.uint8)
+    p = Predictor(build_cnn3(0), tile_shape=(32, 32, 32), overlap_shape=(8, 8, 8), out_shape=(2, 64, 64, 64),
+                  strict_shapes=True, apply_softmax=True)
+    out = dense_predicton_helper(vol.astype(np.float32) / 255., p, is_zyx=True, return_zyx=True)
+    d = np.abs(out.astype(np.int16) - g['out_u8'].astype(np.int16))
+    print('config 1 uint8 diff: max', d.max(), 'frac != 0:', (d > 0).mean())
+    assert out.shape == (2, 64, 64, 64) and d.max() <= 3
+    assert np.array_equal(out.argmax(0)[d.max(0) == 0], g['out_u8'].argmax(0)[d.max(0) == 0])
+
+
+def _make_wd(tmp_path, model, arch_name, shape_xyz, seed, geo, ngpus=1):
+    from syconn_amd import global_params
+    from syconn_amd.handler.config import generate_default_conf
+    from syconn_amd.knossos import KnossosDataset
+    wd = str(tmp_path / 'wd')
+    kd_path = str(tmp_path / 'kd_raw')
+    generate_default_conf(wd, scaling=(10, 10, 25), kd_seg=kd_path,
+                          key_value_pairs=[('ngpus_per_node', ngpus), ('nnodes_total', 1), ('dense_prediction', geo)])
+    os.makedirs(f'{wd}/models/{arch_name}', exist_ok=True)
+    ts = torch.jit.trace(model, torch.randn(1, 1, 8, 16, 16))
+    ext = 'pt' if arch_name == 'mivcsj' else 'pts'
+    if ext == 'pts':
+        ts.save(f'{wd}/models/{arch_name}/model.pts')
+    else:
+        torch.save(model, f'{wd}/models/{arch_name}/model.pt')
+    kd = KnossosDataset()
+    kd.initialize_without_conf(kd_path, boundary=shape_xyz, scale=(10, 10, 25), experiment_name='synth',
+                               mags=[1, 2, 4])
+    vol = _em_like(tuple(shape_xyz[::-1]), seed)
+    kd.save_raw(offset=(0, 0, 0), mags=[1, 2, 4], data=vol, data_mag=1, fast_resampling=True, upsample=False)
+    os.environ.pop('syconn_wd', None)
+    global_params.wd = wd
+    return wd, kd_path, vol
+
+
+def _oracle_volume(model, vol, geo, box_xyz, n_channel):
+    """Reference-order CPU computation of the whole volume: chunks + halo, tiles + halo, uint8, crop."""
+    cs, ol, ts = (np.array(geo[k]) for k in ('chunk_size', 'overlap_shape_tiles', 'tile_shape'))
+    nz, ny, nx = [int(np.ceil(box_xyz[i] / cs[i])) for i in (2, 1, 0)]
+    out = np.zeros((n_channel, nz * cs[2], ny * cs[1], nx * cs[0]), np.uint8)
+    pad = np.zeros(tuple(np.array(out.shape[1:]) + 2 * ol[::-1]), np.uint8)
+    D, H, W = vol.shape
+    pad[ol[2]:ol[2] + D, ol[1]:ol[1] + H, ol[0]:ol[0] + W] = vol
+    pr = PredictorRef(model, tile_shape=ts[::-1], overlap_shape=ol[::-1],
+                      out_shape=(n_channel, *(cs + 2 * ol)[::-1]), strict_shapes=True, apply_softmax=True)
+    for ix in range(nx):
+        for iy in range(ny):
+            for iz in range(nz):
+                z0, y0, x0 = iz * cs[2], iy * cs[1], ix * cs[0]
+                raw = pad[z0:z0 + cs[2] + 2 * ol[2], y0:y0 + cs[1] + 2 * ol[1], x0:x0 + cs[0] + 2 * ol[0]]
+                pred = dense_predicton_helper_ref(raw.astype(np.float32) / 255., pr, True, True)
+                pred = pred[..., ol[2]:-ol[2], ol[1]:-ol[1], ol[0]:-ol[0]]
+                out[:, z0:z0 + cs[2], y0:y0 + cs[1], x0:x0 + cs[0]] = pred
+    return out[:, :D, :H, :W]
+
+
+def test_predict_myelin_end_to_end(gpu, tmp_path):
+    """exec_dense_prediction.predict_myelin -> predict_dense_to_kd -> worker process -> dense_predictor on a small
+    synthetic KnossosDataset (mag 4 like the reference), compared with the oracle run in reference order."""
+    from syconn_amd import global_params
+    from syconn_amd.exec.exec_dense_prediction import predict_myelin
+    from syconn_amd.handler.basics import kd_factory
+    model = build_unet('myelin', seed=11, n_blocks=3, start_filts=8, final_scale=4.0)
+    geo = {'overlap_shape_tiles': [6, 6, 4], 'chunk_size': [40, 40, 24], 'tile_shape': [26, 26, 16],
+           'act_dtype': 'bf16'}
+    shape_xyz = (280, 240, 160)                          # at mag 4: 70 x 60 x 40 -> 2x2x2 chunks, 8 tiles each
+    wd, kd_path, vol = _make_wd(tmp_path, model, 'myelin', shape_xyz, 21, geo)
+    predict_myelin()
+    kd_out = kd_factory(f'{wd}/knossosdatasets/myelin/')
+    got = kd_out.load_raw(size=shape_xyz, offset=(0, 0, 0), mag=4)                  # z,y,x at mag 4
+    vol4 = vol[::4, ::4, ::4]
+    ref = _oracle_volume(model, vol4, geo, (70, 60, 40), 2)[1]
+    assert got.shape == ref.shape
+    d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
+    print('myelin prob map vs oracle: max diff', d.max(), 'mean', d.mean())
+    assert d.max() <= TOL_U8
+    # pyramid written with order-0 resampling (mags [4, 8, 16])
+    got8 = kd_out.load_raw(size=shape_xyz, offset=(0, 0, 0), mag=8)
+    assert np.array_equal(got8, got[::2, ::2, ::2][:got8.shape[0], :got8.shape[1], :got8.shape[2]])
+    # existing target without overwrite -> ValueError (prediction.py:686-691)
+    with pytest.raises(ValueError):
+        predict_myelin()
+    global_params.wd = None
+
+
+def test_predict_cellorganelles_labels_end_to_end(gpu, tmp_path):
+    """3-head mivcsj target: GroupNorm U-Net, label rule with default thresholds, uint64 overlay (config 5 path)."""
+    from syconn_amd import global_params
+    from syconn_amd.exec.exec_dense_prediction import predict_cellorganelles
+    from syconn_amd.handler.basics import kd_factory
+    model = build_unet('mivcsj', seed=12, n_blocks=3, start_filts=8, final_scale=6.0)
+    geo = {'overlap_shape_tiles': [6, 6, 4], 'chunk_size': [40, 40, 24], 'tile_shape': [26, 26, 16],
+           'act_dtype': 'f16'}
+    shape_xyz = (70, 60, 40)
+    wd, kd_path, vol = _make_wd(tmp_path, model, 'mivcsj', shape_xyz, 22, geo)
+    predict_cellorganelles()
+    kd_out = kd_factory(f'{wd}/knossosdatasets/mivcsj/')
+    got = kd_out.load_seg(size=shape_xyz, offset=(0, 0, 0), mag=1)
+    assert got.dtype == np.uint64
+    probs = _oracle_volume(model, vol, geo, shape_xyz, 4)
+    ref, raw_flag = label_rule_ref(probs, (1, 2, 3), [None] * 4)
+    assert not raw_flag
+    # label must match wherever every involved uint8 probability is further than the tolerance from its threshold
+    tol = 6                                                     # fp16 storage: 255 * 8e-3 + GroupNorm slack
+    safe = np.all(np.abs(probs[1:].astype(np.int16) - 127.5) > tol, axis=0)
+    mism = got != ref
+    print(f'labels: {safe.mean():.3f} of voxels margin-safe; mismatches safe {int((mism & safe).sum())}, '
+          f'unsafe {int((mism & ~safe).sum())}; label hist {np.bincount(ref.ravel().astype(np.int64), minlength=4)}')
+    assert not (mism & safe).any() and safe.mean() > 0.5
+    assert len(np.unique(ref)) >= 2
+    global_params.wd = None

@@ -1,0 +1,194 @@
+"""CPU: the product's host-side logic (no compute calls) against the reference-pinned golden vectors."""
+import json
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.unet_ref import ARCHS, build_cnn3, build_unet
+
+G = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+class StubPredictor:
+    def predict(self, inp):
+        x = torch.as_tensor(np.asarray(inp), dtype=torch.float32)
+        return (torch.cat([x, 1 - x, torch.full_like(x, 0.5)], dim=1) * 3).softmax(1)
+
+
+def test_wrapper_math_matches_reference_goldens():
+    from syconn_amd.handler.prediction import dense_predicton_helper, xyz2zyx, zyx2xyz
+    g = np.load(f'{G}/g1_wrapper.npz')
+    raw = g['raw_xyz']
+    for a in (0, 1):
+        for b in (0, 1):
+            out = dense_predicton_helper(raw, StubPredictor(), is_zyx=bool(a), return_zyx=bool(b))
+            assert out.dtype == np.uint8 and np.array_equal(out, g[f'out_{a}{b}'])
+    assert np.array_equal(xyz2zyx(raw), g['xyz2zyx']) and np.array_equal(zyx2xyz(raw), g['zyx2xyz'])
+
+
+def test_chunkify_matches_reference_goldens():
+    from syconn_amd.handler.basics import chunkify
+    g = np.load(f'{G}/g2_chunkify.npz')
+    for n_items, n in [(75, 8), (3, 8), (8, 8), (10, 3), (0, 4), (1, 1)]:
+        parts = chunkify(list(range(n_items)), n)
+        assert [len(p) for p in parts] == g[f'n{n_items}_k{n}_len'].tolist()
+        assert [v for p in parts for v in p] == g[f'n{n_items}_k{n}_flat'].tolist()
+
+
+def test_threshold_resolution_and_integer_cut():
+    """The device label kernel compares uint8 >= cut with cut = floor(t)+1; check against numpy's uint8 > float."""
+    from syconn_amd.handler.prediction import _resolve_threshold
+    assert _resolve_threshold(None) == 127.5 and _resolve_threshold(0.3) == 255 * 0.3 and _resolve_threshold(100) == 100
+    vals = np.arange(256, dtype=np.uint8)
+    for t in [None, 0.0, 0.2, 0.3, 0.5, 0.999, 1.0, 50.99999999999999, 51.00000000000001, 127.5, 254.999, 255, 300]:
+        tt = _resolve_threshold(t)
+        cut = 0 if tt < 0 else (256 if tt >= 255 else int(np.floor(tt)) + 1)
+        assert np.array_equal(vals > tt, vals.astype(np.int64) >= cut), t
+
+
+@pytest.mark.parametrize('arch', sorted(ARCHS))
+def test_plan_from_unet(arch):
+    from syconn_amd import _lib as L
+    from syconn_amd.plan import plan_from_model
+    model = build_unet(arch, seed=0)
+    ops, blob, info = plan_from_model(model)
+    kw = ARCHS[arch]
+    kinds = [o.kind for o in ops]
+    nb = kw['n_blocks']
+    assert kinds.count(L.SD_OP_POOL) == nb - 1 and kinds.count(L.SD_OP_UPCONV) == nb - 1
+    assert kinds.count(L.SD_OP_CONV) == 2 * nb + 2 * (nb - 1) and kinds[-1] == L.SD_OP_FINAL
+    assert ops[-1].cout == kw['out_channels'] and info['out_channels'] == kw['out_channels']
+    n_gn = kinds.count(L.SD_OP_GROUPNORM)
+    assert n_gn == (2 * nb + 3 * (nb - 1) if kw['normalization'].startswith('group') else 0)
+    # planar blocks -> kz == 1 for convs and pools of that level
+    convs = [o for o in ops if o.kind == L.SD_OP_CONV]
+    for i in range(nb):
+        assert convs[2 * i].kz == (1 if i in kw['planar_blocks'] else 3)
+    # legacy batch_norm=True layout: no norm after the first conv of a block
+    if not kw.get('full_norm', True):
+        assert convs[0].norm == 0 and convs[1].norm == 1
+    # the same plan comes out of a TorchScript trace (how SyConn ships models: cnn_myelin.py:107)
+    if arch == 'myelin':
+        ts = torch.jit.trace(model, torch.randn(1, 1, 8, 16, 16))
+        ops2, blob2, _ = plan_from_model(ts)
+        assert len(ops2) == len(ops) and np.array_equal(blob, blob2)
+        for a, b in zip(ops, ops2):
+            assert bytes(a) == bytes(b)
+
+
+def test_plan_from_sequential_and_rejections():
+    from syconn_amd import _lib as L
+    from syconn_amd.plan import plan_from_model
+    ops, blob, info = plan_from_model(build_cnn3(0))
+    assert [o.kind for o in ops] == [L.SD_OP_CONV, L.SD_OP_CONV, L.SD_OP_FINAL] and ops[0].relu == 1
+    with pytest.raises(ValueError):
+        plan_from_model(torch.nn.Sequential(torch.nn.Conv3d(1, 4, 5, padding=2), torch.nn.Conv3d(4, 2, 1)))
+    with pytest.raises(ValueError):
+        plan_from_model({'foo.weight': torch.zeros(1)})
+
+
+def test_knossos_roundtrip_and_chunk_grid(tmp_path):
+    from syconn_amd.handler.basics import kd_factory
+    from syconn_amd.knossos import ChunkDataset, KnossosDataset
+    rng = np.random.default_rng(5)
+    kd = KnossosDataset()
+    kd.initialize_without_conf(str(tmp_path / 'raw'), boundary=(150, 140, 70), scale=(10, 10, 25),
+                               experiment_name='synth', mags=[1, 2, 4])
+    vol = rng.integers(0, 256, (70, 140, 150), dtype=np.uint8)   # z,y,x
+    kd.save_raw(offset=(0, 0, 0), mags=[1, 2, 4], data=vol, data_mag=1, fast_resampling=True, upsample=False)
+    kd2 = kd_factory(str(tmp_path / 'raw'))
+    assert kd2.experiment_name == 'synth' and kd2.boundary.tolist() == [150, 140, 70]
+    sub = kd2.load_raw(size=(40, 30, 20), offset=(100, 120, 60), mag=1)
+    assert sub.shape == (20, 30, 40)
+    ref = np.zeros((20, 30, 40), np.uint8)
+    ref[:10, :20, :] = vol[60:70, 120:140, 100:140]
+    assert np.array_equal(sub, ref)                                # zeros outside the boundary
+    neg = kd2.load_raw(size=(20, 20, 20), offset=(-10, -10, -10), mag=1)
+    assert np.array_equal(neg[10:, 10:, 10:], vol[:10, :10, :10]) and not neg[:10].any()
+    m2 = kd2.load_raw(size=(150, 140, 70), offset=(0, 0, 0), mag=2)
+    assert np.array_equal(m2, vol[::2, ::2, ::2][:35, :70, :75])
+    lab = rng.integers(0, 2 ** 40, (10, 12, 14), dtype=np.uint64)
+    kd2.save_seg(offset=(3, 4, 5), mags=[1], data=lab, data_mag=1)
+    assert np.array_equal(kd2.load_seg(size=(14, 12, 10), offset=(3, 4, 5), mag=1), lab)
+    # chunk grid of BASELINE config 4 in reference geometry: 2048x2048x512 -> 5x5x3 = 75 chunks
+    class _KD:  # noqa
+        boundary = np.array([2048, 2048, 512])
+    cd = ChunkDataset()
+    cd.initialize(_KD(), np.array([2048, 2048, 512]), np.array([482, 481, 236]), str(tmp_path / 'cd'),
+                  box_coords=np.zeros(3), fit_box_size=True, overlap=np.array([30, 31, 20]))
+    assert len(cd.chunk_dict) == 75
+    assert cd.chunk_dict[1].coordinates.tolist() == [0, 0, 236] and cd.chunk_dict[3].coordinates.tolist() == [0, 481, 0]
+
+
+def test_config_and_wrappers_bind_reference_parameters(tmp_path, monkeypatch):
+    """exec_dense_prediction wrappers bind exactly the reference's parameters (exec_dense_prediction.py:52-150)."""
+    from syconn_amd import global_params
+    from syconn_amd.exec import exec_dense_prediction as E
+    from syconn_amd.handler.config import generate_default_conf
+    wd = str(tmp_path / 'wd')
+    generate_default_conf(wd, scaling=(10, 10, 25), kd_seg='/data/kd_seg/',
+                          key_value_pairs=[('ngpus_per_node', 4), ('nnodes_total', 2)])
+    monkeypatch.delenv('syconn_wd', raising=False)
+    global_params.wd = wd
+    cfg = global_params.config
+    assert cfg.working_dir == os.path.abspath(wd) and cfg.ngpu_total == 8 and cfg['scaling'] == [10, 10, 25]
+    assert cfg.mpath_myelin.endswith('/models//myelin/model.pts') and cfg.mpath_mivcsj.endswith('/mivcsj/model.pt')
+    assert cfg['dense_prediction']['chunk_size'] == [482, 481, 236]
+    calls = []
+    monkeypatch.setattr(E, 'predict_dense_to_kd', lambda *a, **k: calls.append((a, k)))
+    E.predict_myelin(); E.predict_synapsetype(); E.predict_cellorganelles(); E.predict_er(); E.predict_golgi()
+    got = [(k['n_channel'], k['mag'], list(map(tuple, k['target_channels'])), k['target_names']) for _, k in calls]
+    assert got == [(2, 4, [(1,)], ['myelin']), (4, 1, [(1, 2)], ['syntype_v2']), (4, 1, [(1, 2, 3)], ['mivcsj']),
+                   (2, 1, [(1,)], ['er']), (2, 1, [(1,)], ['golgi'])]
+    assert calls[0][0][0] == '/data/kd_seg/' and calls[0][0][2] == cfg.mpath_myelin
+    # env syconn_wd (set for worker processes) wins over global_params.wd
+    wd2 = str(tmp_path / 'wd2')
+    generate_default_conf(wd2)
+    monkeypatch.setenv('syconn_wd', wd2)
+    assert global_params.config.working_dir == os.path.abspath(wd2)
+    monkeypatch.delenv('syconn_wd')
+    global_params.wd = None
+
+
+def test_predict_dense_to_kd_argument_errors(tmp_path, monkeypatch):
+    """ValueError conventions of prediction.py:659-662 and :686-691 (no GPU needed: they fire before dispatch)."""
+    from syconn_amd import global_params
+    from syconn_amd.handler.config import generate_default_conf
+    from syconn_amd.handler.prediction import predict_dense_to_kd
+    from syconn_amd.knossos import KnossosDataset
+    wd = str(tmp_path / 'wd')
+    generate_default_conf(wd)
+    monkeypatch.delenv('syconn_wd', raising=False)
+    global_params.wd = wd
+    kd = KnossosDataset()
+    kd.initialize_without_conf(str(tmp_path / 'raw'), (64, 64, 64), (1, 1, 1), 'synth', mags=[1])
+    with pytest.raises(ValueError):
+        predict_dense_to_kd(str(tmp_path / 'raw'), str(tmp_path / 'out'), 'nomodel.pts', 2,
+                            target_names=['a', 'b'], target_channels=[(1,)])
+    os.makedirs(tmp_path / 'out' / 'pred')
+    with pytest.raises(ValueError):
+        predict_dense_to_kd(str(tmp_path / 'raw'), str(tmp_path / 'out'), 'nomodel.pts', 2, overwrite=False)
+    global_params.wd = None
+
+
+def test_job_pickle_stream_contract(tmp_path):
+    """in.pkl = one pickle per tuple element (batchjob_utils.py:478-480), read back by the worker loop
+    (batchjob_predict_dense.py:9-15)."""
+    params = ([1, 2, 3], 'kd', 'target', 'model', np.array([30, 31, 20]), np.array([30, 31, 20]), [271, 181, 138],
+              np.array([482, 481, 236]), 2, [(1,)], ['p/'], [None, None], 4, (np.zeros(3), np.ones(3)))
+    fn = tmp_path / 'job_0.pkl'
+    with open(fn, 'wb') as f:
+        for p in params:
+            pickle.dump(p, f)
+    args = []
+    with open(fn, 'rb') as f:
+        while True:
+            try:
+                args.append(pickle.load(f))
+            except EOFError:
+                break
+    assert len(args) == 14 and args[0] == [1, 2, 3] and args[12] == 4
