@@ -187,7 +187,6 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.predictor_ref import label_rule_ref
         x = tiles[0].cpu()
-        torch.set_num_threads(os.cpu_count() or 1)
         with torch.no_grad():
             model((x[:16].float() / 255.)[None, None])          # warm the CPU kernels
             t1 = time.perf_counter()

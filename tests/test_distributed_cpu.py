@@ -1,0 +1,87 @@
+"""CPU, world_size 2, gloo: the sharding + collective logic of the multi-GPU path (syconn_amd/parallel.py).
+The HIP forward cannot run here, so the per-unit 'compute' is a stand-in; what is tested is exactly what differs
+between N = 1 and N > 1: weight broadcast, round-robin ownership identical to the reference's chunkify, gather of
+uint8 results on rank 0, barrier / max-over-ranks timing helpers."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_units, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from oracle.unet_ref import build_unet
+    from syconn_amd import parallel as par
+    r, w, _ = par.init_distributed('gloo')
+    assert (r, w) == (rank, world)
+    # Coll-1: ranks start from different weights, end with rank 0's
+    model = build_unet('myelin', seed=rank, n_blocks=2, start_filts=4)
+    par.broadcast_weights(model, src=0)
+    ref = build_unet('myelin', seed=0, n_blocks=2, start_filts=4)
+    same = all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), ref.state_dict().values()))
+    # ownership: identical to the reference's chunkify(chunk_ids, ngpu_total)[rank]
+    mine = par.shard_units(range(n_units))
+    # stand-in compute: unit id -> constant uint8 block; pad to the max share so that gather shapes agree
+    share = -(-n_units // world)
+    local = torch.zeros((share, 4, 4, 4), dtype=torch.uint8)
+    for k, u in enumerate(mine):
+        local[k] = u + 1
+    got = par.gather_to_root(local, dst=0)
+    t = par.max_over_ranks(float(rank + 1))
+    par.barrier()
+    if rank == 0:
+        vol = np.zeros(n_units, np.int64)
+        for rr, buf in enumerate(got):
+            for k, u in enumerate(par.shard_units(range(n_units), rr, world)):
+                vol[u] = int(buf[k, 0, 0, 0])
+        q.put(('root', same, mine, vol.tolist(), t))
+    else:
+        q.put(('rank', same, mine, got is None, t))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_units', [75, 5, 1])
+def test_two_rank_shard_broadcast_gather(n_units):
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_units, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    root = [r for r in res if r[0] == 'root'][0]
+    other = [r for r in res if r[0] == 'rank'][0]
+    assert root[1] and other[1], 'weights differ after broadcast'
+    assert root[2] == list(range(n_units))[0::2] and other[2] == (list(range(n_units))[1::2] if n_units > 1 else [])
+    assert root[3] == [u + 1 for u in range(n_units)], 'gathered results are not the union of all shards'
+    assert other[3] is True and root[4] == 2.0 and other[4] == 2.0
+
+
+def test_shard_units_matches_reference_partition():
+    sys.path.insert(0, ROOT)
+    from syconn_amd import parallel as par
+    parts = [par.shard_units(range(75), r, 8) for r in range(8)]
+    assert [len(p) for p in parts] == [10, 10, 10, 9, 9, 9, 9, 9]
+    assert sorted(v for p in parts for v in p) == list(range(75))
+    assert par.shard_units(range(3), 5, 8) == []

@@ -265,7 +265,7 @@ def test_predict_cellorganelles_labels_end_to_end(gpu, tmp_path):
     ref, raw_flag = label_rule_ref(probs, (1, 2, 3), [None] * 4)
     assert not raw_flag
     # label must match wherever every involved uint8 probability is further than the tolerance from its threshold
-    tol = 6                                                     # fp16 storage: 255 * 8e-3 + GroupNorm slack
+    tol = 12                                                    # fp16 storage + per-channel GroupNorm of a tiny net
     safe = np.all(np.abs(probs[1:].astype(np.int16) - 127.5) > tol, axis=0)
     mism = got != ref
     print(f'labels: {safe.mean():.3f} of voxels margin-safe; mismatches safe {int((mism & safe).sum())}, '
