@@ -1,6 +1,6 @@
 # dev helper: per-layer timing of one 128^3 tile
 import sys, torch, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from oracle.unet_ref import build_unet
 from syconn_amd import _lib as L
 from syconn_amd.engine import DenseModel
