@@ -4,6 +4,7 @@
 #include "../../include/syconn_dense.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -51,6 +52,9 @@ struct Op {
     size_t wpack_off = 0, bias_off = 0, aux_off = 0;   // byte offsets
     int NT = 1, NB = 1;
     bool first = false;    // conv reading the network input (cin = 1)
+    int fuse_pool = -1;    // index of the MaxPool op computed in this conv's epilogue
+    int fuse_final = -1;   // index of the final 1x1x1 op computed in this conv's epilogue
+    bool skipped = false;  // op is executed inside its producer
 };
 
 }  // namespace
@@ -65,6 +69,7 @@ struct sd_model {
     char* dev_blob = nullptr; // packed weights
     size_t blob_bytes = 0;
     float* dev_lut = nullptr;
+    void* dev_zero = nullptr;
     // last forward
     std::vector<Dims> dims;
     std::vector<size_t> buf_off;
@@ -72,6 +77,7 @@ struct sd_model {
     long n_forward = 0;
     std::vector<hipEvent_t> events;    // [slot][n_ops + 1]
     int final_cout = 0;
+    bool keep_all = false;   // SD_KEEP_ALL=1: also store activations that only feed a fused consumer (tests)
 };
 
 namespace {
@@ -155,6 +161,7 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
     if (act_dtype != SD_BF16 && act_dtype != SD_F16) return fail(SD_ERR_INVALID, "act_dtype must be SD_BF16 or SD_F16");
     sd_model* m = new sd_model();
     m->act_dtype = act_dtype;
+    m->keep_all = getenv("SD_KEEP_ALL") != nullptr;
     if (hipGetDevice(&m->device) != hipSuccess) { delete m; return fail(SD_ERR_NODEVICE, "no current HIP device"); }
 
     auto chk = [&](int64_t off, size_t n) { return off >= 0 && (size_t)off + n <= n_floats; };
@@ -338,10 +345,27 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
         m->ops.push_back(op);
     }
     if (m->ops.empty() || m->ops.back().d.kind != SD_OP_FINAL) MODEL_FAIL("the plan must end with SD_OP_FINAL");
+    // epilogue fusions (SD_NO_FUSE=1 keeps every layer a separate launch, for layer-wise debugging)
+    if (!getenv("SD_NO_FUSE")) {
+        for (size_t i = 0; i + 1 < m->ops.size(); ++i) {
+            Op& c = m->ops[i];
+            Op& nx = m->ops[i + 1];
+            if (c.d.kind != SD_OP_CONV || c.first) continue;
+            if (nx.d.kind == SD_OP_POOL && nx.d.src0 == c.d.dst && (c.d.kz == 3) == (nx.d.kz == 2)) {
+                c.fuse_pool = (int)(i + 1);
+                nx.skipped = true;
+            } else if (nx.d.kind == SD_OP_FINAL && nx.d.src0 == c.d.dst && c.NB == 1 && i + 2 == m->ops.size()) {
+                c.fuse_final = (int)(i + 1);
+                nx.skipped = true;
+            }
+        }
+    }
 
     {
         m->blob_bytes = rup_sz(blob.size(), 256);
-        hipError_t e = hipMalloc((void**)&m->dev_blob, m->blob_bytes + 1024);
+        hipError_t e = hipMalloc((void**)&m->dev_blob, m->blob_bytes + 1024 + 256);
+        if (e == hipSuccess) e = hipMemset(m->dev_blob + m->blob_bytes + 1024, 0, 256);
+        m->dev_zero = m->dev_blob + m->blob_bytes + 1024;
         if (e == hipSuccess) e = hipMemcpy(m->dev_blob, blob.data(), blob.size(), hipMemcpyHostToDevice);
         if (e == hipSuccess) {
             float lut[256];
@@ -424,6 +448,7 @@ int sd_forward(sd_model* m, const void* in_dev, int in_dtype, int D, int H, int 
         const Op& op = m->ops[i];
         const sd_op_desc& d = op.d;
         if (ev) HIP_TRY(hipEventRecord(ev[i], s));
+        if (op.skipped) continue;
         switch (d.kind) {
         case SD_OP_CONV: {
             const Dims o = m->dims[d.dst];
@@ -451,7 +476,20 @@ int sd_forward(sd_model* m, const void* in_dev, int in_dtype, int D, int H, int 
                 p.D = o.d; p.H = o.h; p.W = o.w;
                 p.wpack = m->dev_blob + op.wpack_off;
                 p.bias = reinterpret_cast<const float*>(m->dev_blob + op.bias_off);
-                p.relu = d.relu;
+                p.relu = d.relu; p.zero = m->dev_zero;
+                p.store_main = 1;
+                if (op.fuse_pool >= 0) {
+                    const sd_op_desc& pd = m->ops[op.fuse_pool].d;
+                    p.pool_dst = bufp(pd.dst); p.pH = m->dims[pd.dst].h; p.pW = m->dims[pd.dst].w;
+                }
+                if (op.fuse_final >= 0) {
+                    const Op& fo = m->ops[op.fuse_final];
+                    if (o.d != D || o.h != H || o.w != W) return fail(SD_ERR_INVALID, "final layer shape != input shape");
+                    p.final_w = reinterpret_cast<const float*>(m->dev_blob + fo.wpack_off);
+                    p.final_b = reinterpret_cast<const float*>(m->dev_blob + fo.bias_off);
+                    p.final_cout = fo.d.cout; p.final_kind = out_kind; p.final_out = out_dev;
+                    p.store_main = m->keep_all ? 1 : 0;
+                }
                 p.nbx = (o.w + SD_BX - 1) / SD_BX; p.nby = (o.h + BY - 1) / BY; p.nbz = (o.d + BZ - 1) / BZ;
                 rc = launch_conv(p, m->act_dtype, d.kz, op.NT, op.NB, s);
             }

@@ -8,8 +8,8 @@
 // padded channel stride (multiple of 16).  A "chunk" is 16 consecutive channels = one MFMA k-step.
 constexpr int SD_CHUNK = 16;
 
-// geometry of one workgroup of the LDS-staged MFMA convolution: 256 output voxels = 8 MFMA column tiles of
-// (2 y-rows x 16 x); 3x3x3: 2x8x16 voxels, 1x3x3: 1x16x16 voxels.
+// geometry of one workgroup of the first-layer convolution: 256 output voxels = 8 MFMA column tiles of
+// (2 y-rows x 16 x); 3x3x3: 2x8x16 voxels, 1x3x3: 1x16x16 voxels.  (The generic conv picks its own, ConvGeo.)
 constexpr int SD_BX = 16;
 __host__ __device__ constexpr int sd_bz(int KZ) { return KZ == 3 ? 2 : 1; }
 __host__ __device__ constexpr int sd_by(int KZ) { return KZ == 3 ? 8 : 16; }
@@ -27,6 +27,14 @@ struct ConvParams {
     const float* bias; // padded to NB*NT*32
     int relu;
     int nbx, nby, nbz; // workgroup grid over the output volume
+    const void* zero;  // >= 16 zero bytes (DMA source of out-of-volume halo voxels)
+    int store_main;    // write dst (0 when only the fused final output is needed)
+    void* pool_dst;    // fused MaxPool(ceil): pooled tensor (same channel stride), or nullptr
+    int pH, pW;        // y/x extents of the pooled tensor
+    const float* final_w;   // fused conv_final: [8][Cd] float, or nullptr
+    const float* final_b;
+    int final_cout, final_kind;
+    void* final_out;   // planar (cout, D*H*W)
 };
 
 struct FirstParams {

@@ -8,6 +8,7 @@
 // contiguous pieces of the channels-last output row.
 #include "sd_internal.h"
 #include "../../include/syconn_dense.h"
+#include <cstdlib>
 
 typedef __bf16 bf16_t;
 typedef _Float16 f16_t;
@@ -42,68 +43,133 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 }
 
-// Store one 32(channel) x 32(voxel) accumulator tile: lane owns voxel column lane&31 and channel rows
-// (r&3) + 8*(r>>2) + 4*(lane>>5).
+// Cross-lane helpers (gfx950): v_permlane32_swap exchanges the upper half-wave of `a` with the lower half-wave
+// of `b`; v_permlane16_swap exchanges odd 16-lane rows of `a` with even rows of `b`.  Inline asm on purpose:
+// with the builtin hipcc (ROCm 7.2) folds away arithmetic that combines the two results when both inputs hold the
+// same value (tools/probe/pool.hip shows the dropped v_max).  `s_nop 1` = the 2 wait states a VALU write of an
+// operand needs before v_permlane*_swap reads it (nothing pads hazards inside an asm statement).
+__device__ __forceinline__ void swap32(unsigned& a, unsigned& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float max_xor1(float m) {       // max with lane^1 (DPP quad_perm [1,0,3,2])
+    return fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xF,
+                                                                            0xF, true)));
+}
+__device__ __forceinline__ float max_xor16(float m) {      // max with lane^16, result in both lanes
+    unsigned a = __builtin_bit_cast(unsigned, m), b = a;
+    swap16(a, b);                                           // a = rows [0,0,2,2], b = rows [1,1,3,3]
+    return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+}
+
+// Store the 32 channels x 32 voxels of one accumulator tile whose values are already packed as 4 x (4 channels):
+// o[q] = channels cbase + 4*(lane>>5) + 8q + 0..3 of voxel (lane&31).  The lane pair (l, l^32) first trades
+// quads so that each lane owns 16 CONSECUTIVE channels (32 contiguous bytes) -> two 16-byte stores per lane
+// instead of four 8-byte ones.  Must be called by all 64 lanes (stores are predicated, swaps are not).
 template <typename T>
-__device__ __forceinline__ void store_acc_tile(const f32x16& acc, T* vox, bool valid, int nbase,
+__device__ __forceinline__ void store_tile_rows(typename Act<T>::v4 (&o)[4], T* vox, bool valid, int cbase, int half,
+                                                int Cd) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u2;
+    typedef __attribute__((ext_vector_type(4))) unsigned u4;
+    u2 a0 = __builtin_bit_cast(u2, o[0]), a1 = __builtin_bit_cast(u2, o[1]);
+    u2 a2 = __builtin_bit_cast(u2, o[2]), a3 = __builtin_bit_cast(u2, o[3]);
+    unsigned x;
+    x = a0.x; { unsigned y = a2.x; swap32(x, y); a0.x = x; a2.x = y; }
+    x = a0.y; { unsigned y = a2.y; swap32(x, y); a0.y = x; a2.y = y; }
+    x = a1.x; { unsigned y = a3.x; swap32(x, y); a1.x = x; a3.x = y; }
+    x = a1.y; { unsigned y = a3.y; swap32(x, y); a1.y = x; a3.y = y; }
+    const int n0 = cbase + half * 16;
+    if (valid && n0 < Cd) { u4 v = {a0.x, a0.y, a2.x, a2.y}; *reinterpret_cast<u4*>(vox + n0) = v; }
+    if (valid && n0 + 8 < Cd) { u4 v = {a1.x, a1.y, a3.x, a3.y}; *reinterpret_cast<u4*>(vox + n0 + 8) = v; }
+}
+
+// + bias, ReLU, round to the storage type and store one accumulator tile (lane owns voxel column lane&31 and
+// channel rows (r&3) + 8*(r>>2) + 4*(lane>>5)).
+template <typename T>
+__device__ __forceinline__ void store_acc_tile(const f32x16& acc, T* vox, bool valid, int cbase, int half,
                                                const float* __restrict__ bias, int relu, int Cd) {
     using v4 = typename Act<T>::v4;
+    v4 o[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int n = nbase + 8 * q;
-        if (valid && n < Cd) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(bias + n);
-            v4 o;
+        const int n = cbase + 4 * half + 8 * q;
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (n < Cd) b = *reinterpret_cast<const f32x4*>(bias + n);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = acc[4 * q + e] + b[e];
-                if (relu) v = fmaxf(v, 0.f);
-                o[e] = (T)v;
-            }
-            *reinterpret_cast<v4*>(vox + n) = o;
+        for (int e = 0; e < 4; ++e) {
+            float v = acc[4 * q + e] + b[e];
+            if (relu) v = fmaxf(v, 0.f);
+            o[q][e] = (T)v;
         }
     }
+    store_tile_rows<T>(o, vox, valid, cbase, half, Cd);
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// K2/K3: 3x3x3 / 1x3x3 'same' convolution, C_in >= 16, as a tap-looped implicit GEMM.
-//   per workgroup: 256 output voxels x (NT*32) output channels; the input halo block of one 16-channel chunk is
-//   staged in LDS (48-byte voxel pitch -> conflict-free 16-byte fragment reads) and re-used by all 9 / 27 taps;
-//   the weight fragments of one (chunk, kz) group (9 taps) are double-buffered in LDS.
-template <typename T, int KZ, int NT>
-__global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvParams p) {
+// K2/K3: 3x3x3 / 1x3x3 'same' convolution, C_in >= 16, as a tap-looped implicit GEMM on the matrix cores,
+// software-pipelined with LDS-DMA (global_load_lds, 16 B per lane).  Per workgroup: WAVES*64 output voxels x
+// (NT*32) output channels; K = taps x C_in is walked in stages of (one 16-channel chunk) x (one kz plane):
+//   * the halo block of chunk c+1 and the weight group of stage s+1 are DMA'd straight into LDS while stage s
+//     computes -- no VGPR staging, ONE barrier per stage (stage = one 16-channel chunk x one kz plane = 9 taps);
+//   * halo voxels are unpadded 32-byte records (DMA needs a lane-linear image); the two 16-byte halves of a
+//     record are swapped on odd halo rows, which makes every ds_read_b128 of a 2x16-voxel fragment conflict-free
+//     (checked exhaustively against the gfx950 lane groups); the swap is applied on the DMA source side;
+//   * WAVES = 8: 512 output voxels per workgroup (3x3x3: 4x8x16, 1x3x3: 1x32x16) -> half the weight traffic and
+//     less halo per voxel; WAVES = 4: 256 voxels for layers with few voxels.
+template <int KZ, int WAVES> struct ConvGeo {
+    static constexpr int BZ = KZ == 3 ? (WAVES == 8 ? 4 : 2) : 1;
+    static constexpr int BY = KZ == 3 ? 8 : (WAVES == 8 ? 32 : 16);
+    static constexpr int BX = 16;
+};
+
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <typename T, int KZ, int NT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 2) void k_conv_mfma(const ConvParams p) {
     using v8 = typename Act<T>::v8;
-    constexpr int BZ = sd_bz(KZ), BY = sd_by(KZ), BX = SD_BX;
+    using G = ConvGeo<KZ, WAVES>;
+    constexpr int BZ = G::BZ, BY = G::BY, BX = G::BX;
     constexpr int PZ = KZ / 2;
     constexpr int HZ = BZ + KZ - 1, HY = BY + 2, HX = BX + 2;
     constexpr int NH = HZ * HY * HX;
-    constexpr int VSTR = 48;
-    constexpr int A_BYTES = NH * VSTR;
-    constexpr int B_BYTES = 9 * NT * 1024;
-    constexpr int NIT_A = (NH * 2 + 255) / 256;
-    constexpr int NIT_B = (B_BYTES / 16 + 255) / 256;
-    __shared__ __attribute__((aligned(16))) char smem[A_BYTES + 2 * B_BYTES];
+    constexpr int A_INSTR = (NH * 2 + 63) / 64;          // 1 KiB DMA instructions per halo block
+    constexpr int A_BYTES = A_INSTR * 1024;
+    constexpr int B_INSTR = 9 * NT;
+    constexpr int B_BYTES = B_INSTR * 1024;
+    constexpr int SLICE = HY * HX * 32;
+    __shared__ __attribute__((aligned(16))) char smem[2 * A_BYTES + 2 * B_BYTES];
     char* const ldsA = smem;
-    char* const ldsB = smem + A_BYTES;
+    char* const ldsB = smem + 2 * A_BYTES;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nsb = p.nbx * p.nby * p.nbz;
     const int lb = xcd_remap(blockIdx.x, nsb);
     const int bx = lb % p.nbx, by = (lb / p.nbx) % p.nby, bz = lb / (p.nbx * p.nby);
     const int x0 = bx * BX, y0 = by * BY, z0 = bz * BZ;
     const int nb = blockIdx.y;
     const int nchunks = p.nchunk0 + p.nchunk1;
-    const int ngroups = nchunks * KZ;
+    const int nstages = nchunks * KZ;
 
-    // per-lane fragment read offsets of the wave's two voxel tiles
-    int xoff[2];
+    // wave -> two voxel tiles of (2 y-rows x 16 x); z-neighbours (3D) / y-neighbours (planar) share a wave
+    int tzs[2], tys[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int t = wave * 2 + i;
-        const int tz = (KZ == 3) ? (t >> 2) : 0;
-        const int ty0 = (KZ == 3) ? ((t & 3) * 2) : (t * 2);
-        const int vy = ty0 + ((lane & 31) >> 4), vx = lane & 15;
-        xoff[i] = ((tz * HY + vy) * HX + vx) * VSTR + (lane >> 5) * 16;
+        if (KZ == 3) { tzs[i] = (WAVES == 8 ? 2 * (wave >> 2) : 0) + i; tys[i] = 2 * (wave & 3); }
+        else { tzs[i] = 0; tys[i] = 4 * wave + 2 * i; }
+    }
+    const int dy = (lane & 31) >> 4, dxl = lane & 15, half = lane >> 5;
+    int xoffE[2], xoffO[2];   // fragment read offsets for even / odd ky (row-parity swizzle of the 16-byte halves)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int hv = (tzs[i] * HY + tys[i] + dy) * HX + dxl;
+        xoffE[i] = hv * 32 + ((half ^ (dy & 1)) << 4);
+        xoffO[i] = hv * 32 + ((half ^ (dy & 1) ^ 1) << 4);
     }
 
     f32x16 acc[2][NT];
@@ -114,70 +180,63 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const char* const wbase = reinterpret_cast<const char*>(p.wpack) + (size_t)nb * ngroups * B_BYTES;
+    const char* const wbase = reinterpret_cast<const char*>(p.wpack) + (size_t)nb * nstages * B_BYTES;
 
-    // prologue: weight group 0 -> ldsB[0]
-    {
+    auto dma_weights = [&](int s) {
+        const char* src = wbase + (size_t)s * B_BYTES + lane * 16;
+        char* dst = ldsB + (s & 1) * B_BYTES;
 #pragma unroll
-        for (int it = 0; it < NIT_B; ++it) {
-            const int o = (tid + it * 256) * 16;
-            if (o < B_BYTES) *reinterpret_cast<v8*>(ldsB + o) = *reinterpret_cast<const v8*>(wbase + o);
+        for (int j = 0; j < (B_INSTR + WAVES - 1) / WAVES; ++j) {
+            const int k = wave + j * WAVES;
+            if (k < B_INSTR) glds16(src + k * 1024, dst + k * 1024);
         }
-    }
-
-    for (int c = 0; c < nchunks; ++c) {
+    };
+    auto dma_halo = [&](int c) {
         const char* sbase;
         int Cs, Hs, Ws, cc;
         if (c < p.nchunk0) { sbase = (const char*)p.src0; Cs = p.C0; Hs = p.H0; Ws = p.W0; cc = c; }
         else { sbase = (const char*)p.src1; Cs = p.C1; Hs = p.H1; Ws = p.W1; cc = c - p.nchunk0; }
-
-        // global -> registers (issued before the barrier so that the latency overlaps the previous chunk's tail)
-        v8 areg[NIT_A];
+        char* dst = ldsA + (c & 1) * A_BYTES;
 #pragma unroll
-        for (int it = 0; it < NIT_A; ++it) {
-            const int idx = tid + it * 256;
-            const int v = idx >> 1, half = idx & 1;
-            const int hx = v % HX, hy = (v / HX) % HY, hz = v / (HX * HY);
-            const int z = z0 + hz - PZ, y = y0 + hy - 1, x = x0 + hx - 1;
-            const bool ok = (idx < NH * 2) && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H &&
-                            (unsigned)x < (unsigned)p.W;
-            v8 val = {};
-            if (ok) {
-                const size_t e = ((size_t)(z * Hs + y) * Ws + x) * Cs + cc * SD_CHUNK + half * 8;
-                val = *reinterpret_cast<const v8*>(sbase + e * sizeof(T));
+        for (int j = 0; j < (A_INSTR + WAVES - 1) / WAVES; ++j) {
+            const int k = wave + j * WAVES;
+            if (k < A_INSTR) {
+                const int idx = k * 64 + lane;
+                const int hv = idx >> 1;
+                const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+                const int z = z0 + hz - PZ, y = y0 + hy - 1, x = x0 + hx - 1;
+                const bool ok = (idx < NH * 2) && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H &&
+                                (unsigned)x < (unsigned)p.W;
+                const int dh = (idx & 1) ^ (hy & 1);
+                const char* src = reinterpret_cast<const char*>(p.zero);
+                if (ok) src = sbase + (((size_t)(z * Hs + y) * Ws + x) * Cs + cc * SD_CHUNK + dh * 8) * sizeof(T);
+                glds16(src, dst + k * 1024);
             }
-            areg[it] = val;
         }
-        __syncthreads();  // S1: every wave is done reading the previous chunk's halo block
-#pragma unroll
-        for (int it = 0; it < NIT_A; ++it) {
-            const int idx = tid + it * 256;
-            if (idx < NH * 2) *reinterpret_cast<v8*>(ldsA + (idx >> 1) * VSTR + (idx & 1) * 16) = areg[it];
-        }
+    };
 
+    dma_halo(0);
+    dma_weights(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int s = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        const char* const abuf = ldsA + (c & 1) * A_BYTES;
 #pragma unroll 1
-        for (int kz = 0; kz < KZ; ++kz) {
-            const int g = c * KZ + kz;
-            __syncthreads();  // S2: halo block + weight group g visible; group g-1's buffer is free
-            // prefetch weight group g+1 into registers, written to LDS after this group's MFMAs
-            v8 breg[NIT_B];
-            const bool more = (g + 1 < ngroups);
-            if (more) {
-                const char* wsrc = wbase + (size_t)(g + 1) * B_BYTES;
-#pragma unroll
-                for (int it = 0; it < NIT_B; ++it) {
-                    const int o = (tid + it * 256) * 16;
-                    if (o < B_BYTES) breg[it] = *reinterpret_cast<const v8*>(wsrc + o);
-                }
-            }
-            const char* const bcur = ldsB + (g & 1) * B_BYTES + lane * 16;
-            const char* const acur = ldsA + kz * (HY * HX * VSTR);
+        for (int kz = 0; kz < KZ; ++kz, ++s) {
+            if (s + 1 < nstages) dma_weights(s + 1);
+            if (kz == 0 && c + 1 < nchunks) dma_halo(c + 1);
+            const char* const bcur = ldsB + (s & 1) * B_BYTES + lane * 16;
+            const char* const acur = abuf + kz * SLICE;
 #pragma unroll
             for (int t9 = 0; t9 < 9; ++t9) {
-                const int tapoff = ((t9 / 3) * HX + (t9 % 3)) * VSTR;
+                const int ky = t9 / 3, kx = t9 % 3;
+                const int tapoff = (ky * HX + kx) * 32;
                 v8 xf[2], wf[NT];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) xf[i] = *reinterpret_cast<const v8*>(acur + xoff[i] + tapoff);
+                for (int i = 0; i < 2; ++i)
+                    xf[i] = *reinterpret_cast<const v8*>(acur + ((ky & 1) ? xoffO[i] : xoffE[i]) + tapoff);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const v8*>(bcur + (t9 * NT + j) * 1024);
 #pragma unroll
@@ -185,30 +244,134 @@ __global__ __launch_bounds__(256, 2) void k_conv_mfma(const ConvParams p) {
 #pragma unroll
                     for (int j = 0; j < NT; ++j) acc[i][j] = Act<T>::mfma(wf[j], xf[i], acc[i][j]);
             }
-            if (more) {
-                char* bnext = ldsB + ((g + 1) & 1) * B_BYTES;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: + bias, ReLU, round to the storage type (kept in `acc` as the rounded value) ----------
+    using v4 = typename Act<T>::v4;
+    bool valid[2];
+    size_t voxoff[2];
 #pragma unroll
-                for (int it = 0; it < NIT_B; ++it) {
-                    const int o = (tid + it * 256) * 16;
-                    if (o < B_BYTES) *reinterpret_cast<v8*>(bnext + o) = breg[it];
+    for (int i = 0; i < 2; ++i) {
+        const int vz = z0 + tzs[i], vy = y0 + tys[i] + dy, vx = x0 + dxl;
+        valid[i] = vz < p.D && vy < p.H && vx < p.W;
+        voxoff[i] = ((size_t)(vz * p.H + vy) * p.W + vx) * p.Cd;
+    }
+    T* const dst = reinterpret_cast<T*>(p.dst);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int cbase = (nb * NT + j) * 32;
+        f32x4 b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = cbase + 4 * half + 8 * q;
+            b[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (n < p.Cd) b[q] = *reinterpret_cast<const f32x4*>(p.bias + n);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            v4 o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[i][j][4 * q + e] + b[q][e];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    o[q][e] = (T)v;
+                    acc[i][j][4 * q + e] = (float)o[q][e];
                 }
+            if (p.store_main) store_tile_rows<T>(o, dst + voxoff[i], valid[i], cbase, half, p.Cd);
+        }
+    }
+
+    // ---- fused MaxPool(ceil_mode): (kz,2,2) window = {the wave's two tiles (3D)} x {lane^16 (y)} x {lane^1 (x)} ----
+    if (p.pool_dst) {
+        T* const pdst = reinterpret_cast<T*>(p.pool_dst);
+        const bool writer = (dy == 0) && ((dxl & 1) == 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (KZ == 3 && i == 1) break;       // 3D: both tiles form ONE pooled tile (z pair)
+            const int pz = (KZ == 3) ? (z0 + tzs[0]) >> 1 : z0, py = (y0 + tys[i]) >> 1, px = (x0 + dxl) >> 1;
+            const size_t po = ((size_t)(pz * p.pH + py) * p.pW + px) * p.Cd;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                v4 o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float m = valid[i] ? acc[i][j][4 * q + e] : -INFINITY;
+                        if (KZ == 3) m = fmaxf(m, valid[1] ? acc[1][j][4 * q + e] : -INFINITY);
+                        o[q][e] = (T)max_xor16(max_xor1(m));
+                    }
+                store_tile_rows<T>(o, pdst + po, writer && valid[i], (nb * NT + j) * 32, half, p.Cd);
             }
         }
     }
 
-    // epilogue: + bias, ReLU, convert, 8-byte stores
-    T* const dst = reinterpret_cast<T*>(p.dst);
+    // ---- fused conv_final (1x1x1) + softmax + uint8: the lane pair (l, l^32) holds all channels of a voxel ---------
+    if (p.final_w) {
+        float* const wl = reinterpret_cast<float*>(smem);       // all LDS reads of the main loop are behind a barrier
+        for (int k = tid; k < 8 * p.Cd; k += WAVES * 64) wl[k] = p.final_w[k];
+        __syncthreads();
+        const long nvox = (long)p.D * p.H * p.W;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int t = wave * 2 + i;
-        const int tz = (KZ == 3) ? (t >> 2) : 0;
-        const int ty0 = (KZ == 3) ? ((t & 3) * 2) : (t * 2);
-        const int vz = z0 + tz, vy = y0 + ty0 + ((lane & 31) >> 4), vx = x0 + (lane & 15);
-        const bool valid = vz < p.D && vy < p.H && vx < p.W;
-        T* vox = dst + ((size_t)(vz * p.H + vy) * p.W + vx) * p.Cd;
+        for (int i = 0; i < 2; ++i) {
+            float lg[8];
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-            store_acc_tile<T>(acc[i][j], vox, valid, (nb * NT + j) * 32 + 4 * (lane >> 5), p.bias, p.relu, p.Cd);
+            for (int co = 0; co < 8; ++co) lg[co] = 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = j * 32 + 4 * half + 8 * q;
+                    if (n < p.Cd) {
+#pragma unroll
+                        for (int co = 0; co < 8; ++co) {
+                            if (co < p.final_cout) {
+                                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wl + co * p.Cd + n);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) lg[co] = fmaf(acc[i][j][4 * q + e], w4[e], lg[co]);
+                            }
+                        }
+                    }
+                }
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int co = 0; co < 8; ++co) {
+                if (co < p.final_cout) {
+                    unsigned a = __builtin_bit_cast(unsigned, lg[co]), b2 = a;
+                    swap32(a, b2);          // a: [own.lower, own.lower], b2: [own.upper, own.upper] (per half-wave)
+                    lg[co] = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b2) + p.final_b[co];
+                    mx = fmaxf(mx, lg[co]);
+                }
+            }
+            if (p.final_kind != SD_OUT_LOGITS_F32) {
+                float sum = 0.f;
+#pragma unroll
+                for (int co = 0; co < 8; ++co)
+                    if (co < p.final_cout) { lg[co] = expf(lg[co] - mx); sum += lg[co]; }
+#pragma unroll
+                for (int co = 0; co < 8; ++co) lg[co] = lg[co] / sum;
+            }
+            if (half == 0 && valid[i]) {
+                const size_t v = voxoff[i] / p.Cd;
+                if (p.final_kind == SD_OUT_PROBS_U8) {
+                    uint8_t* out = reinterpret_cast<uint8_t*>(p.final_out);
+#pragma unroll
+                    for (int co = 0; co < 8; ++co)
+                        if (co < p.final_cout) out[(size_t)co * nvox + v] = (uint8_t)(lg[co] * 255.f);
+                } else {
+                    float* out = reinterpret_cast<float*>(p.final_out);
+#pragma unroll
+                    for (int co = 0; co < 8; ++co)
+                        if (co < p.final_cout) out[(size_t)co * nvox + v] = lg[co];
+                }
+            }
+        }
     }
 }
 
@@ -275,7 +438,7 @@ __global__ __launch_bounds__(256) void k_conv_first(const FirstParams p) {
             const int vz = z0 + tz, vy = y0 + ly, vx = x0 + lx;
             const bool valid = vz < p.D && vy < p.H && vx < p.W;
             T* vox = dst + ((size_t)(vz * p.H + vy) * p.W + vx) * p.Cd;
-            store_acc_tile<T>(acc, vox, valid, nt * 32 + 4 * (lane >> 5), p.bias, p.relu, p.Cd);
+            store_acc_tile<T>(acc, vox, valid, nt * 32, lane >> 5, p.bias, p.relu, p.Cd);
         }
     }
 }
@@ -588,18 +751,27 @@ static inline int grid_for(long total, int per_block = 256, int cap = 256 * 16) 
 }
 #define SD_LAUNCH_CHECK() (hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP)
 
-template <typename T>
-static int launch_conv_t(const ConvParams& p, int KZ, int NT, int NB, hipStream_t s) {
-    dim3 grid(p.nbx * p.nby * p.nbz, NB), block(256);
-    if (KZ == 3 && NT == 2) hipLaunchKernelGGL((k_conv_mfma<T, 3, 2>), grid, block, 0, s, p);
-    else if (KZ == 3 && NT == 1) hipLaunchKernelGGL((k_conv_mfma<T, 3, 1>), grid, block, 0, s, p);
-    else if (KZ == 1 && NT == 2) hipLaunchKernelGGL((k_conv_mfma<T, 1, 2>), grid, block, 0, s, p);
-    else if (KZ == 1 && NT == 1) hipLaunchKernelGGL((k_conv_mfma<T, 1, 1>), grid, block, 0, s, p);
-    else return SD_ERR_INVALID;
+template <typename T, int KZ, int NT, int WAVES>
+static int launch_conv2_k(ConvParams p, int NB, hipStream_t s) {
+    using G = ConvGeo<KZ, WAVES>;
+    p.nbx = (p.W + G::BX - 1) / G::BX; p.nby = (p.H + G::BY - 1) / G::BY; p.nbz = (p.D + G::BZ - 1) / G::BZ;
+    dim3 grid(p.nbx * p.nby * p.nbz, NB), block(WAVES * 64);
+    hipLaunchKernelGGL((k_conv_mfma<T, KZ, NT, WAVES>), grid, block, 0, s, p);
     return SD_LAUNCH_CHECK();
 }
+template <typename T>
+static int launch_conv2_t(const ConvParams& p, int KZ, int NT, int NB, hipStream_t s) {
+    // 512-voxel workgroups when they still give every CU work, else 256-voxel workgroups
+    const long vox = (long)p.D * p.H * p.W;
+    const bool big = (vox / 512) * NB >= 512;
+    if (KZ == 3 && NT == 2) return big ? launch_conv2_k<T, 3, 2, 8>(p, NB, s) : launch_conv2_k<T, 3, 2, 4>(p, NB, s);
+    if (KZ == 3 && NT == 1) return big ? launch_conv2_k<T, 3, 1, 8>(p, NB, s) : launch_conv2_k<T, 3, 1, 4>(p, NB, s);
+    if (KZ == 1 && NT == 2) return big ? launch_conv2_k<T, 1, 2, 8>(p, NB, s) : launch_conv2_k<T, 1, 2, 4>(p, NB, s);
+    if (KZ == 1 && NT == 1) return big ? launch_conv2_k<T, 1, 1, 8>(p, NB, s) : launch_conv2_k<T, 1, 1, 4>(p, NB, s);
+    return SD_ERR_INVALID;
+}
 int launch_conv(const ConvParams& p, int act_dtype, int KZ, int NT, int NB, hipStream_t s) {
-    return act_dtype == SD_BF16 ? launch_conv_t<bf16_t>(p, KZ, NT, NB, s) : launch_conv_t<f16_t>(p, KZ, NT, NB, s);
+    return act_dtype == SD_BF16 ? launch_conv2_t<bf16_t>(p, KZ, NT, NB, s) : launch_conv2_t<f16_t>(p, KZ, NT, NB, s);
 }
 
 template <typename T, typename IN>

@@ -135,3 +135,31 @@ def test_outputs_softmax_u8_and_argmax(gpu):
           f'mismatches inside margin-safe set: {int((~agree & safe).sum())}, outside: {int((~agree & ~safe).sum())}')
     assert bool((agree | ~safe).all()), 'argmax label differs on a voxel whose fp32 margin exceeds the tolerance'
     assert float(safe.float().mean()) > 0.3, 'test input has too few margin-safe voxels to be meaningful'
+
+
+def test_epilogue_fusions_match_unfused(gpu, monkeypatch):
+    """MaxPool and conv_final+softmax+uint8 fused into the producing convolution's epilogue must reproduce the
+    separate-launch path: pooled activations bit-exact (max of the same rounded values), class probabilities up to
+    fp32 summation order."""
+    from syconn_amd import _lib as L
+    from syconn_amd.engine import DenseModel
+    for arch, shape in (('semseg_spine', (9, 35, 37)), ('syntype', (6, 20, 36)), ('semseg_axon', (4, 18, 34))):
+        model = build_unet(arch, seed=9, final_scale=4.0)
+        raw = _input(shape, 5).to(gpu)
+        monkeypatch.setenv('SD_NO_FUSE', '1')
+        plain = DenseModel(model, act_dtype='bf16', device=gpu)
+        monkeypatch.delenv('SD_NO_FUSE')
+        monkeypatch.setenv('SD_KEEP_ALL', '1')
+        fused = DenseModel(model, act_dtype='bf16', device=gpu)
+        monkeypatch.delenv('SD_KEEP_ALL')
+        a = plain.forward(raw, L.SD_OUT_PROBS_F32).cpu()
+        b = fused.forward(raw, L.SD_OUT_PROBS_F32).cpu()
+        assert float((a - b).abs().max()) < 1e-5, arch
+        for buf in range(1, plain.info['n_buffers']):
+            assert torch.equal(plain.read_buffer(buf), fused.read_buffer(buf)), (arch, buf)
+        a8 = plain.forward(raw, L.SD_OUT_PROBS_U8).cpu().to(torch.int16)
+        b8 = fused.forward(raw, L.SD_OUT_PROBS_U8).cpu().to(torch.int16)
+        assert int((a8 - b8).abs().max()) <= 1 and float(((a8 - b8) != 0).float().mean()) < 1e-3
+        al = plain.forward(raw, L.SD_OUT_LOGITS_F32).cpu()
+        bl = fused.forward(raw, L.SD_OUT_LOGITS_F32).cpu()
+        assert float((al - bl).abs().max()) < 1e-4 * float(al.abs().max())
