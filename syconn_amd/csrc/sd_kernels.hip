@@ -120,9 +120,9 @@ __device__ __forceinline__ void store_acc_tile(const f32x16& acc, T* vox, bool v
 //     (checked exhaustively against the gfx950 lane groups); the swap is applied on the DMA source side;
 //   * WAVES = 8: 512 output voxels per workgroup (3x3x3: 4x8x16, 1x3x3: 1x32x16) -> half the weight traffic and
 //     less halo per voxel; WAVES = 4: 256 voxels for layers with few voxels.
-template <int KZ, int WAVES> struct ConvGeo {
-    static constexpr int BZ = KZ == 3 ? (WAVES == 8 ? 4 : 2) : 1;
-    static constexpr int BY = KZ == 3 ? 8 : (WAVES == 8 ? 32 : 16);
+template <int KZ, int WAVES, int MT> struct ConvGeo {      // MT = voxel tiles (2 y-rows x 16 x) per wave
+    static constexpr int BZ = KZ == 3 ? (WAVES == 8 ? 2 * MT : MT) : 1;
+    static constexpr int BY = KZ == 3 ? 8 : WAVES * 2 * MT;
     static constexpr int BX = 16;
 };
 
@@ -131,15 +131,21 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// Persistent form: gridDim.x workgroups walk the output blocks round by round (block of round r = r*gridDim.x +
-// XCD-contiguous remap of blockIdx.x), prefetching the first halo chunk (and weight group) of their NEXT block
-// during the last stage of the current one, so the DMA pipeline never drains between blocks.
-// WRES = true: all weight groups of the layer stay resident in LDS (level-0 layers: 18-72 KiB), loaded once per
-// workgroup; WRES = false: weight groups are streamed, double-buffered.
-template <typename T, int KZ, int NT, int WAVES, bool WRES>
+// Persistent form (NSLOT > 0): gridDim.x workgroups walk the output blocks round by round (block of round r =
+// r*gridDim.x + XCD-contiguous remap of blockIdx.x) and ALL weight groups of the layer stay resident in LDS
+// (level-0 layers: 18-72 KiB, loaded once per workgroup).  The halo chunks then form one continuous stream across
+// blocks that is DMA'd through a ring of NSLOT LDS slots, NSLOT-1 chunks ahead of the MFMAs: these layers have few
+// FLOPs per byte, so what bounds them is bytes in flight per CU (HBM latency x bandwidth ~ 50 KiB/CU), not a
+// one-stage double buffer.  Every wave issues exactly AJ DMA instructions per chunk (padding ones go to a dummy
+// slot) so that the stage-end wait is the compile-time counted `s_waitcnt vmcnt((NSLOT-2)*AJ)`; nothing inside the
+// loop issues an ordinary VGPR load (bias and final-layer weights are preloaded), which would drain the ring.
+// NSLOT == 0: weight groups are streamed (double-buffered) and each workgroup computes one block.
+template <typename T, int KZ, int NT, int WAVES, int NSLOT, int MT>
 __global__ __launch_bounds__(WAVES * 64, 2) void k_conv_mfma(const ConvParams p) {
     using v8 = typename Act<T>::v8;
-    using G = ConvGeo<KZ, WAVES>;
+    using G = ConvGeo<KZ, WAVES, MT>;
+    constexpr bool WRES = NSLOT > 0;
+    constexpr int NA = WRES ? NSLOT : 2;                  // halo slots
     constexpr int BZ = G::BZ, BY = G::BY, BX = G::BX;
     constexpr int PZ = KZ / 2;
     constexpr int HZ = BZ + KZ - 1, HY = BY + 2, HX = BX + 2;
@@ -149,12 +155,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_conv_mfma(const ConvParams p)
     constexpr int B_INSTR = 9 * NT;
     constexpr int B_BYTES = B_INSTR * 1024;
     constexpr int SLICE = HY * HX * 32;
+    constexpr int AJ = (A_INSTR + WAVES - 1) / WAVES;    // halo DMA instructions per wave per chunk
+    constexpr int WAITN = WRES ? (NA - 2) * AJ : 0;      // DMA instructions allowed in flight at a stage end
+    static_assert(WAITN < 64, "vmcnt immediate");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nchunks = p.nchunk0 + p.nchunk1;
     const int nstages = nchunks * KZ;
     char* const ldsA = smem;
-    char* const ldsB = smem + 2 * A_BYTES;
-    float* const wl = reinterpret_cast<float*>(ldsB + (WRES ? nstages : 2) * B_BYTES);   // fused conv_final weights
+    char* const ldsB = smem + NA * A_BYTES;
+    float* const wl = reinterpret_cast<float*>(ldsB + (WRES ? nstages : 2) * B_BYTES);   // fused conv_final w + b
+    char* const ldsDummy = reinterpret_cast<char*>(wl) + 2048 + 64;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -162,20 +172,38 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_conv_mfma(const ConvParams p)
     const int nb = blockIdx.y;
     const int gsz = gridDim.x;
 
-    // wave -> two voxel tiles of (2 y-rows x 16 x); z-neighbours (3D) / y-neighbours (planar) share a wave
-    int tzs[2], tys[2];
+    // wave -> MT voxel tiles of (2 y-rows x 16 x); z-neighbours (3D) / y-neighbours (planar) share a wave
+    int tzs[MT], tys[MT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        if (KZ == 3) { tzs[i] = (WAVES == 8 ? 2 * (wave >> 2) : 0) + i; tys[i] = 2 * (wave & 3); }
-        else { tzs[i] = 0; tys[i] = 4 * wave + 2 * i; }
+    for (int i = 0; i < MT; ++i) {
+        if (KZ == 3) { tzs[i] = (WAVES == 8 ? MT * (wave >> 2) : 0) + i; tys[i] = 2 * (wave & 3); }
+        else { tzs[i] = 0; tys[i] = 2 * MT * wave + 2 * i; }
     }
     const int dy = (lane & 31) >> 4, dxl = lane & 15, half = lane >> 5;
-    int xoffE[2], xoffO[2];   // fragment read offsets for even / odd ky (row-parity swizzle of the 16-byte halves)
+    int xoffE[MT], xoffO[MT];   // fragment read offsets for even / odd ky (row-parity swizzle of the 16-byte halves)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MT; ++i) {
         const int hv = (tzs[i] * HY + tys[i] + dy) * HX + dxl;
         xoffE[i] = hv * 32 + ((half ^ (dy & 1)) << 4);
         xoffO[i] = hv * 32 + ((half ^ (dy & 1) ^ 1) << 4);
+    }
+
+    // everything that needs an ordinary (VGPR-destination) global load happens BEFORE the first DMA is issued
+    constexpr bool PRELOAD_BIAS = NA > 2;   // only a deep ring must keep VGPR loads out of the loop
+    f32x4 breg[PRELOAD_BIAS ? NT : 1][4];
+    if (PRELOAD_BIAS) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = (nb * NT + j) * 32 + 4 * half + 8 * q;
+                breg[j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (n < p.Cd) breg[j][q] = *reinterpret_cast<const f32x4*>(p.bias + n);
+            }
+    }
+    if (p.final_w) {
+        for (int k = tid; k < 8 * p.Cd; k += WAVES * 64) wl[k] = p.final_w[k];
+        if (tid < 8) wl[8 * p.Cd + tid] = tid < p.final_cout ? p.final_b[tid] : 0.f;
     }
 
     const char* const wbase = reinterpret_cast<const char*>(p.wpack) + (size_t)nb * nstages * B_BYTES;
@@ -191,7 +219,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_conv_mfma(const ConvParams p)
     };
     // halo voxel handled by this lane in its j-th DMA instruction of a chunk, packed hz<<20 | hy<<10 | hx<<1 | half
     // (the 16-byte halves of a 32-byte record are swapped on odd halo rows); -1 = beyond the halo block
-    constexpr int AJ = (A_INSTR + WAVES - 1) / WAVES;
     int hpack[AJ];
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
@@ -200,26 +227,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_conv_mfma(const ConvParams p)
         const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
         hpack[j] = (idx < NH * 2) ? ((hz << 20) | (hy << 10) | (hx << 1) | ((idx & 1) ^ (hy & 1))) : -1;
     }
-    auto dma_halo = [&](int c, int slot, int z0, int y0, int x0) {
-        const char* sbase;
-        int Cs, Hs, Ws, cc;
-        if (c < p.nchunk0) { sbase = (const char*)p.src0; Cs = p.C0; Hs = p.H0; Ws = p.W0; cc = c; }
-        else { sbase = (const char*)p.src1; Cs = p.C1; Hs = p.H1; Ws = p.W1; cc = c - p.nchunk0; }
-        sbase += (size_t)cc * SD_CHUNK * sizeof(T);
-        char* dst = ldsA + slot * A_BYTES + wave * 1024;
-#pragma unroll
-        for (int j = 0; j < AJ; ++j) {
-            if (wave + j * WAVES < A_INSTR) {
-                const int hp = hpack[j];
-                const int z = z0 - PZ + (hp >> 20), y = y0 - 1 + ((hp >> 10) & 1023), x = x0 - 1 + ((hp >> 1) & 511);
-                const bool ok = hp >= 0 && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H &&
-                                (unsigned)x < (unsigned)p.W;
-                const char* src = reinterpret_cast<const char*>(p.zero);
-                if (ok) src = sbase + (((size_t)(z * Hs + y) * Ws + x) * Cs + (hp & 1) * 8) * sizeof(T);
-                glds16(src, dst + j * (WAVES * 1024));
-            }
-        }
-    };
     // logical block of (round, this workgroup); -1 when the round has no block for it
     auto block_of = [&](int round) -> int {
         const int base = round * gsz;
@@ -229,27 +236,60 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_conv_mfma(const ConvParams p)
     auto coords = [&](int lb, int& z0, int& y0, int& x0) {
         x0 = (lb % p.nbx) * BX; y0 = ((lb / p.nbx) % p.nby) * BY; z0 = (lb / (p.nbx * p.nby)) * BZ;
     };
+    // DMA chunk c of the block at (z0,y0,x0) into halo slot `slot`; real == false issues the same number of
+    // instructions against the dummy slot (keeps the per-wave DMA count per chunk constant for the counted waits)
+    auto dma_halo = [&](int c, int slot, int z0, int y0, int x0, bool real) {
+        const char* sbase;
+        int Cs, Hs, Ws, cc;
+        if (c < p.nchunk0) { sbase = (const char*)p.src0; Cs = p.C0; Hs = p.H0; Ws = p.W0; cc = c; }
+        else { sbase = (const char*)p.src1; Cs = p.C1; Hs = p.H1; Ws = p.W1; cc = c - p.nchunk0; }
+        sbase += (size_t)cc * SD_CHUNK * sizeof(T);
+        char* dst = ldsA + slot * A_BYTES + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const bool inst = real && (wave + j * WAVES < A_INSTR);       // wave-uniform
+            if (inst || NA > 2) {
+                const int hp = hpack[j];
+                const int z = z0 - PZ + (hp >> 20), y = y0 - 1 + ((hp >> 10) & 1023), x = x0 - 1 + ((hp >> 1) & 511);
+                const bool ok = inst && hp >= 0 && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H &&
+                                (unsigned)x < (unsigned)p.W;
+                const char* src = reinterpret_cast<const char*>(p.zero);
+                if (ok) src = sbase + (((size_t)(z * Hs + y) * Ws + x) * Cs + (hp & 1) * 8) * sizeof(T);
+                glds16(src, inst ? dst + j * (WAVES * 1024) : ldsDummy);
+            }
+        }
+    };
+    // chunk number f of this workgroup's stream (f = round * nchunks + c) -> ring slot f % NA
+    auto dma_stream = [&](int f) {
+        const int rf = f / nchunks, cf = f - rf * nchunks;
+        const int lbf = block_of(rf);
+        int fz = 0, fy = 0, fx = 0;
+        if (lbf >= 0) coords(lbf, fz, fy, fx);
+        dma_halo(cf, f % NA, fz, fy, fx, lbf >= 0);
+    };
 
     int lb = block_of(0);
     if (lb < 0) return;
     int z0, y0, x0;
     coords(lb, z0, y0, x0);
-    if (WRES) { for (int s = 0; s < nstages; ++s) dma_weights(s, s); }
-    else dma_weights(0, 0);
-    dma_halo(0, 0, z0, y0, x0);
-    if (p.final_w) for (int k = tid; k < 8 * p.Cd; k += WAVES * 64) wl[k] = p.final_w[k];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (WRES) {
+        for (int s = 0; s < nstages; ++s) dma_weights(s, s);
+        for (int f = 0; f < NA - 1; ++f) dma_stream(f);
+    } else {
+        dma_weights(0, 0);
+        dma_halo(0, 0, z0, y0, x0, true);
+    }
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WAITN) : "memory");
 
-    int gc = 0, gs = 0;   // chunk / stage counters across blocks (double-buffer parity)
+    int gc = 0, gs = 0;   // chunk / stage counters across blocks (slot parity)
     for (int round = 0; lb >= 0; ++round) {
         const int nlb = WRES ? block_of(round + 1) : -1;   // streamed-weight layers: one block per workgroup
         int nz0 = 0, ny0 = 0, nx0 = 0;
         if (nlb >= 0) coords(nlb, nz0, ny0, nx0);
 
-        f32x16 acc[2][NT];
+        f32x16 acc[MT][NT];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -257,26 +297,24 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_conv_mfma(const ConvParams p)
 
         int s = 0;
         for (int c = 0; c < nchunks; ++c, ++gc) {
-            const char* const abuf = ldsA + (gc & 1) * A_BYTES;
+            const char* const abuf = ldsA + (gc % NA) * A_BYTES;
 #pragma unroll 1
             for (int kz = 0; kz < KZ; ++kz, ++s, ++gs) {
                 if (!WRES) {
                     if (s + 1 < nstages) dma_weights(s + 1, (gs + 1) & 1);
-                    else if (nlb >= 0) dma_weights(0, (gs + 1) & 1);
-                }
-                if (kz == 0) {
-                    if (c + 1 < nchunks) dma_halo(c + 1, (gc + 1) & 1, z0, y0, x0);
-                    else if (nlb >= 0) dma_halo(0, (gc + 1) & 1, nz0, ny0, nx0);
+                    if (kz == 0 && c + 1 < nchunks) dma_halo(c + 1, (gc + 1) & 1, z0, y0, x0, true);
+                } else if (kz == 0) {
+                    dma_stream(gc + NA - 1);
                 }
                 const char* const bcur = ldsB + (WRES ? s : (gs & 1)) * B_BYTES + lane * 16;
                 const char* const acur = abuf + kz * SLICE;
                 // software-pipelined over the 9 taps: the fragments of tap t+1 are in flight while tap t's MFMAs run
-                v8 xf[2][2], wf[2][NT];
+                v8 xf[2][MT], wf[2][NT];
                 auto load_tap = [&](int t9, int buf) {
                     const int ky = t9 / 3, kx = t9 % 3;
                     const int tapoff = (ky * HX + kx) * 32;
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < MT; ++i)
                         xf[buf][i] = *reinterpret_cast<const v8*>(acur + ((ky & 1) ? xoffO[i] : xoffE[i]) + tapoff);
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
@@ -287,22 +325,23 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_conv_mfma(const ConvParams p)
                 for (int t9 = 0; t9 < 9; ++t9) {
                     if (t9 + 1 < 9) load_tap(t9 + 1, (t9 + 1) & 1);
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < MT; ++i)
 #pragma unroll
                         for (int j = 0; j < NT; ++j)
                             acc[i][j] = Act<T>::mfma(wf[t9 & 1][j], xf[t9 & 1][i], acc[i][j]);
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
+                // all of this wave's LDS reads done + the next chunk's DMA landed, then the workgroup barrier (raw
+                // s_barrier: __syncthreads() would drain every DMA in flight with a vmcnt(0))
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WAITN) : "memory");
             }
         }
 
     // ---- epilogue: + bias, ReLU, round to the storage type (kept in `acc` as the rounded value) ----------
     using v4 = typename Act<T>::v4;
-    bool valid[2];
-    size_t voxoff[2];
+    bool valid[MT];
+    size_t voxoff[MT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MT; ++i) {
         const int vz = z0 + tzs[i], vy = y0 + tys[i] + dy, vx = x0 + dxl;
         valid[i] = vz < p.D && vy < p.H && vx < p.W;
         voxoff[i] = ((size_t)(vz * p.H + vy) * p.W + vx) * p.Cd;
@@ -315,11 +354,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_conv_mfma(const ConvParams p)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int n = cbase + 4 * half + 8 * q;
-            b[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (n < p.Cd) b[q] = *reinterpret_cast<const f32x4*>(p.bias + n);
+            if (PRELOAD_BIAS) b[q] = breg[PRELOAD_BIAS ? j : 0][q];
+            else {
+                b[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (n < p.Cd) b[q] = *reinterpret_cast<const f32x4*>(p.bias + n);
+            }
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MT; ++i) {
             v4 o[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -339,9 +381,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_conv_mfma(const ConvParams p)
         T* const pdst = reinterpret_cast<T*>(p.pool_dst);
         const bool writer = (dy == 0) && ((dxl & 1) == 0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (KZ == 3 && i == 1) break;       // 3D: both tiles form ONE pooled tile (z pair)
-            const int pz = (KZ == 3) ? (z0 + tzs[0]) >> 1 : z0, py = (y0 + tys[i]) >> 1, px = (x0 + dxl) >> 1;
+        for (int i = 0; i < MT; ++i) {
+            if (KZ == 3 && (i & 1)) continue;   // 3D: tiles (i, i+1) form ONE pooled tile (z pair)
+            const int pz = (KZ == 3) ? (z0 + tzs[i]) >> 1 : z0, py = (y0 + tys[i]) >> 1, px = (x0 + dxl) >> 1;
             const size_t po = ((size_t)(pz * p.pH + py) * p.pW + px) * p.Cd;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
@@ -351,7 +393,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_conv_mfma(const ConvParams p)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float m = valid[i] ? acc[i][j][4 * q + e] : -INFINITY;
-                        if (KZ == 3) m = fmaxf(m, valid[1] ? acc[1][j][4 * q + e] : -INFINITY);
+                        if (KZ == 3) m = fmaxf(m, valid[i | 1] ? acc[i | 1][j][4 * q + e] : -INFINITY);
                         o[q][e] = (T)max_xor16(max_xor1(m));
                     }
                 store_tile_rows<T>(o, pdst + po, writer && valid[i], (nb * NT + j) * 32, half, p.Cd);
@@ -365,6 +407,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_conv_mfma(const ConvParams p)
     // upper lane with those of tile 1's voxel -> every lane finishes (softmax, store) exactly one voxel.
     if (p.final_w) {
         const long nvox = (long)p.D * p.H * p.W;
+#pragma unroll
+        for (int tp = 0; tp < MT; tp += 2) {
         float lg[2][8];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -385,7 +429,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_conv_mfma(const ConvParams p)
                             if (co < p.final_cout) {
                                 const f32x4 w4 = *reinterpret_cast<const f32x4*>(wl + co * p.Cd + n);
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) lg[i][co] = fmaf(acc[i][j][4 * q + e], w4[e], lg[i][co]);
+                                for (int e = 0; e < 4; ++e) lg[i][co] = fmaf(acc[tp + i][j][4 * q + e], w4[e], lg[i][co]);
                             }
                         }
                     }
@@ -400,7 +444,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_conv_mfma(const ConvParams p)
             if (co < p.final_cout) {
                 unsigned a = __builtin_bit_cast(unsigned, lg[0][co]), b2 = __builtin_bit_cast(unsigned, lg[1][co]);
                 swap32(a, b2);          // a: [tile0.lower, tile1.lower], b2: [tile0.upper, tile1.upper]
-                l[co] = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b2) + p.final_b[co];
+                l[co] = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b2) + wl[8 * p.Cd + co];
                 mx = fmaxf(mx, l[co]);
             }
         }
@@ -413,8 +457,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_conv_mfma(const ConvParams p)
 #pragma unroll
             for (int co = 0; co < 8; ++co) l[co] *= inv;
         }
-        const bool vmine = half ? valid[1] : valid[0];
-        const size_t v = (half ? voxoff[1] : voxoff[0]) / p.Cd;
+        const bool vmine = half ? valid[tp + 1] : valid[tp];
+        const size_t v = (half ? voxoff[tp + 1] : voxoff[tp]) / p.Cd;
         if (vmine) {
             if (p.final_kind == SD_OUT_PROBS_U8) {
                 uint8_t* out = reinterpret_cast<uint8_t*>(p.final_out);
@@ -427,6 +471,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_conv_mfma(const ConvParams p)
                 for (int co = 0; co < 8; ++co)
                     if (co < p.final_cout) out[(size_t)co * nvox + v] = l[co];
             }
+        }
         }
     }
 
@@ -813,13 +858,22 @@ static inline int grid_for(long total, int per_block = 256, int cap = 256 * 16) 
 constexpr int SD_LDS_BYTES = 160 * 1024;
 constexpr int SD_NUM_CU = 256;
 
-template <typename T, int KZ, int NT, int WAVES, bool WRES>
-static int launch_conv_k(ConvParams p, int NB, size_t lds, hipStream_t s) {
-    using G = ConvGeo<KZ, WAVES>;
+template <int KZ, int NT, int WAVES, int MT, int NSLOT> static size_t conv_lds_bytes(int nstages) {
+    using G = ConvGeo<KZ, WAVES, MT>;
+    constexpr int NH = (G::BZ + KZ - 1) * (G::BY + 2) * (G::BX + 2);
+    constexpr int A_BYTES = (NH * 2 + 63) / 64 * 1024;
+    return (size_t)(NSLOT > 0 ? NSLOT : 2) * A_BYTES + (size_t)(NSLOT > 0 ? nstages : 2) * 9 * NT * 1024 + 2048 + 64 +
+           1024;
+}
+
+template <typename T, int KZ, int NT, int WAVES, int NSLOT, int MT = 2>
+static int launch_conv_k(ConvParams p, int NB, hipStream_t s) {
+    using G = ConvGeo<KZ, WAVES, MT>;
+    const size_t lds = conv_lds_bytes<KZ, NT, WAVES, MT, NSLOT>((p.nchunk0 + p.nchunk1) * KZ);
     p.nbx = (p.W + G::BX - 1) / G::BX; p.nby = (p.H + G::BY - 1) / G::BY; p.nbz = (p.D + G::BZ - 1) / G::BZ;
     static size_t attr_set = 0, occ_lds = 0;
     static int occ = 1;
-    auto kern = k_conv_mfma<T, KZ, NT, WAVES, WRES>;
+    auto kern = k_conv_mfma<T, KZ, NT, WAVES, NSLOT, MT>;
     if (lds > attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) return SD_ERR_HIP;
@@ -836,32 +890,28 @@ static int launch_conv_k(ConvParams p, int NB, size_t lds, hipStream_t s) {
     const int wg_per_cu = std::min(occ, (int)(SD_LDS_BYTES / lds));
     const int cap = std::max(8, SD_NUM_CU * wg_per_cu / NB / 8 * 8);
     static const bool no_persist = getenv("SD_NO_PERSIST") != nullptr;   // debugging aid
-    dim3 grid((WRES && !no_persist) ? std::min(nsb, cap) : nsb, NB), block(WAVES * 64);   // streamed weights: one block per workgroup
+    dim3 grid((NSLOT > 0 && !no_persist) ? std::min(nsb, cap) : nsb, NB), block(WAVES * 64);
     hipLaunchKernelGGL(kern, grid, block, lds, s, p);
     return SD_LAUNCH_CHECK();
 }
 
-template <int KZ, int NT, int WAVES> static size_t conv_lds_bytes(int nstages, bool wres) {
-    using G = ConvGeo<KZ, WAVES>;
-    constexpr int NH = (G::BZ + KZ - 1) * (G::BY + 2) * (G::BX + 2);
-    constexpr int A_BYTES = (NH * 2 + 63) / 64 * 1024;
-    return 2 * (size_t)A_BYTES + (size_t)(wres ? nstages : 2) * 9 * NT * 1024 + 2048;
-}
-
 template <typename T, int KZ, int NT>
 static int launch_conv_knt(const ConvParams& p, int NB, hipStream_t s) {
-    // 512-voxel workgroups when they still give every CU work, else 256-voxel workgroups
     const long vox = (long)p.D * p.H * p.W;
-    const bool big = (vox / 512) * NB >= 512;
     const int nstages = (p.nchunk0 + p.nchunk1) * KZ;
+    constexpr size_t LIM = SD_LDS_BYTES - 512;
+    // 512-voxel workgroups when they still give every CU work, else 256-voxel workgroups
+    const bool big = (vox / 512) * NB >= 512;
+    // Resident weights + persistent blocks where the whole layer's weights fit beside a 2-slot halo ring and two
+    // workgroups still share a CU (level-0 layers); else streamed weights, one block per workgroup.  Deeper rings
+    // (NSLOT 4/6, one workgroup per CU) were measured SLOWER on the level-0 layers (1.32 vs 1.23 ms per tile): those
+    // layers are bound by per-wave instruction latency, not by bytes in flight, so resident waves win over ring depth.
     if (big) {
-        const size_t res = conv_lds_bytes<KZ, NT, 8>(nstages, true);
-        if (res <= 96 * 1024) return launch_conv_k<T, KZ, NT, 8, true>(p, NB, res, s);
-        return launch_conv_k<T, KZ, NT, 8, false>(p, NB, conv_lds_bytes<KZ, NT, 8>(nstages, false), s);
+        if (conv_lds_bytes<KZ, NT, 8, 2, 2>(nstages) <= 96 * 1024) return launch_conv_k<T, KZ, NT, 8, 2>(p, NB, s);
+        return launch_conv_k<T, KZ, NT, 8, 0>(p, NB, s);
     }
-    const size_t res = conv_lds_bytes<KZ, NT, 4>(nstages, true);
-    if (res <= 80 * 1024) return launch_conv_k<T, KZ, NT, 4, true>(p, NB, res, s);
-    return launch_conv_k<T, KZ, NT, 4, false>(p, NB, conv_lds_bytes<KZ, NT, 4>(nstages, false), s);
+    if (conv_lds_bytes<KZ, NT, 4, 2, 2>(nstages) <= 80 * 1024) return launch_conv_k<T, KZ, NT, 4, 2>(p, NB, s);
+    return launch_conv_k<T, KZ, NT, 4, 0>(p, NB, s);
 }
 template <typename T>
 static int launch_conv2_t(const ConvParams& p, int KZ, int NT, int NB, hipStream_t s) {
