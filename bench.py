@@ -58,7 +58,16 @@ def layer_accounting(ops, L, D, H, W, act_bytes=2, out_bytes_per_class=1):
             taps = o.kz * 9
             flops = 2.0 * vox * cin * o.cout * taps
             inb = vox * (1 if o.src0 == 0 else cin * act_bytes)
-            rows.append(('conv%dx3x3' % o.kz, flops, inb + vox * o.cout * act_bytes))
+            # kernel instantiation the library dispatches (mirrors launch_conv_knt in sd_kernels.hip)
+            if o.src0 == 0:
+                name = 'k_conv_first<%dx3x3>' % o.kz
+            else:
+                ntile = (o.cout + 31) // 32
+                nt = 2 if ntile >= 2 else 1
+                nbk = (ntile + nt - 1) // nt
+                waves = 8 if (vox // 512) * nbk >= 512 else 4
+                name = 'k_conv_mfma<%dx3x3,NT=%d,%d waves>' % (o.kz, nt, waves)
+            rows.append((name, flops, inb + vox * o.cout * act_bytes))
             dims[o.dst], chans[o.dst] = d, o.cout
         elif o.kind == L.SD_OP_POOL:
             d = dims[o.src0]
@@ -177,6 +186,7 @@ def main():
         tr = json.load(open(tr_file))
         if tr.get('arch') == args.arch and tr.get('tile') == S and tr.get('act') == args.act:
             roof['traffic'] = tr.get('hbm_bytes_per_launch', {}).get(dom)
+            roof['traffic_note'] = tr.get('note')
     # whole-network view the north star asks for: algorithmic bytes of one tile / device time of one tile / 8 TB/s
     net = {'b_alg_bytes_per_tile': b_alg, 'gflop_per_tile': sum(r[1] for r in rows) / 1e9,
            'kernel_ms_per_tile': kern_ms, 'hbm_roofline_frac': b_alg / (kern_ms * 1e-3) / (PEAK_HBM_GBS * 1e9),
