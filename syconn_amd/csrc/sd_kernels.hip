@@ -121,7 +121,7 @@ __device__ __forceinline__ void store_acc_tile(const f32x16& acc, T* vox, bool v
 //   * WAVES = 8: 512 output voxels per workgroup (3x3x3: 4x8x16, 1x3x3: 1x32x16) -> half the weight traffic and
 //     less halo per voxel; WAVES = 4: 256 voxels for layers with few voxels.
 template <int KZ, int WAVES, int MT> struct ConvGeo {      // MT = voxel tiles (2 y-rows x 16 x) per wave
-    static constexpr int BZ = KZ == 3 ? (WAVES == 8 ? 2 * MT : MT) : 1;
+    static constexpr int BZ = KZ == 3 ? (WAVES / 4) * MT : 1;      // 4 waves cover the 8 y-rows of one z-pair group
     static constexpr int BY = KZ == 3 ? 8 : WAVES * 2 * MT;
     static constexpr int BX = 16;
 };
@@ -141,7 +141,7 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 // loop issues an ordinary VGPR load (bias and final-layer weights are preloaded), which would drain the ring.
 // NSLOT == 0: weight groups are streamed (double-buffered) and each workgroup computes one block.
 template <typename T, int KZ, int NT, int WAVES, int NSLOT, int MT>
-__global__ __launch_bounds__(WAVES * 64, 2) void k_conv_mfma(const ConvParams p) {
+__global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(const ConvParams p) {
     using v8 = typename Act<T>::v8;
     using G = ConvGeo<KZ, WAVES, MT>;
     constexpr bool WRES = NSLOT > 0;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void k_conv_mfma(const ConvParams p)
     int tzs[MT], tys[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        if (KZ == 3) { tzs[i] = (WAVES == 8 ? MT * (wave >> 2) : 0) + i; tys[i] = 2 * (wave & 3); }
+        if (KZ == 3) { tzs[i] = MT * (wave >> 2) + i; tys[i] = 2 * (wave & 3); }
         else { tzs[i] = 0; tys[i] = 2 * MT * wave + 2 * i; }
     }
     const int dy = (lane & 31) >> 4, dxl = lane & 15, half = lane >> 5;
