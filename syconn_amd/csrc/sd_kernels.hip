@@ -742,6 +742,94 @@ __global__ __launch_bounds__(256) void k_upconv_mfma(const UpconvParams p) {
     }
 }
 
+// K5, row-coalescing form for the HBM-bound up-convolutions (compile-time NCH input chunks, NTAB = C_out/16 MFMA
+// tiles per output row pair): one wave = 32 input voxels.  The activation fragments of all input chunks stay in
+// registers (HBM read once); for each output row pair (a,b) the wave computes the 2*C_out contiguous channels of the
+// two x-taps (= the two adjacent output voxels of every input voxel), rounds them, transposes them through a
+// wave-private LDS tile (XOR-swizzled 16-byte pieces) and writes them out as fully coalesced 16-byte pieces: every
+// input voxel yields one contiguous run of 2*C_out*sizeof(T) bytes per (a,b).
+template <typename T, int NCH, int NTAB>
+__global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
+    using v8 = typename Act<T>::v8;
+    using v4 = typename Act<T>::v4;
+    typedef __attribute__((ext_vector_type(4))) unsigned u4;
+    constexpr int CD = NTAB * 16;            // channel stride of the output
+    constexpr int ROW = 4 * CD;              // bytes per input voxel per (a,b): 2 taps * CD * 2 B
+    constexpr int PPV = ROW / 16;            // 16-byte pieces per voxel
+    constexpr int SWM = PPV >= 8 ? 7 : PPV - 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, vl = lane & 31;
+    char* const tile = smem + wave * (32 * ROW);
+    const long M = (long)p.D * p.H * p.W;
+    const T* const src = reinterpret_cast<const T*>(p.src);
+    const T* const wp = reinterpret_cast<const T*>(p.wpack);
+    char* const dst = reinterpret_cast<char*>(p.dst);
+    const int H2 = 2 * p.H, W2 = 2 * p.W;
+
+    const long m0 = ((long)blockIdx.x * 4 + wave) * 32;
+    if (m0 >= M) return;                     // wave-uniform; no workgroup barrier is used in this kernel
+    const long m = m0 + vl;
+    const bool mv = m < M;
+    v8 xf[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        v8 val = {};
+        if (mv) val = *reinterpret_cast<const v8*>(src + m * p.Cs + c * SD_CHUNK + half * 8);
+        xf[c] = val;
+    }
+    const int nab = p.kz * 2;
+#pragma unroll 1
+    for (int ab = 0; ab < nab; ++ab) {
+        f32x16 acc[NTAB];
+#pragma unroll
+        for (int j = 0; j < NTAB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+            for (int j = 0; j < NTAB; ++j) {
+                const int tl = ab * NTAB + j;             // global 32-column tile (n = tap*CD + co ordering)
+                const v8 wf = *reinterpret_cast<const v8*>(
+                    wp + ((((size_t)(tl >> 1) * NCH + c) * 2 + (tl & 1)) * 64 + lane) * 8);
+                acc[j] = Act<T>::mfma(wf, xf[c], acc[j]);
+            }
+        }
+        // accumulators -> rounded rows in the wave's LDS tile: voxel vl, columns 32j + 8q + 4*half + e
+#pragma unroll
+        for (int j = 0; j < NTAB; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = 32 * j + 8 * q + 4 * half;
+                const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + ab * 2 * CD + nl);
+                v4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[j][4 * q + e] + b[e];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    o[e] = (T)v;
+                }
+                const int pc = (4 * j + q) ^ (vl & SWM);
+                *reinterpret_cast<v4*>(tile + vl * ROW + pc * 16 + half * 8) = o;
+            }
+        }
+        // LDS -> global, 16 bytes per lane, consecutive lanes = consecutive pieces of consecutive voxels
+        const int a = (p.kz == 2) ? (ab >> 1) : 0, b = ab & 1;
+#pragma unroll
+        for (int it = 0; it < (32 * PPV) / 64; ++it) {
+            const int u = it * 64 + lane;
+            const int v = u / PPV, piece = u % PPV;
+            const long mm = m0 + v;
+            if (mm < M) {
+                const int x = (int)(mm % p.W), y = (int)((mm / p.W) % p.H), z = (int)(mm / ((long)p.W * p.H));
+                const size_t ov = ((size_t)(z * p.kz + a) * H2 + (2 * y + b)) * W2 + 2 * x;
+                const u4 val = *reinterpret_cast<const u4*>(tile + v * ROW + ((piece ^ (v & SWM)) * 16));
+                *reinterpret_cast<u4*>(dst + ov * (size_t)(CD * sizeof(T)) + piece * 16) = val;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // K4: MaxPool3d k=(kz,2,2), ceil_mode=True.  One thread per (output voxel, 8-channel group), 16-byte accesses.
 template <typename T>
@@ -1061,7 +1149,28 @@ int launch_first(const FirstParams& p, int act_dtype, int in_dtype, int KZ, hipS
     return in_dtype == SD_U8 ? launch_first_t<f16_t, uint8_t>(p, KZ, s) : launch_first_t<f16_t, float>(p, KZ, s);
 }
 
+template <typename T, int NCH, int NTAB>
+static int launch_upconv_rows(const UpconvParams& p, hipStream_t s) {
+    const long M = (long)p.D * p.H * p.W;
+    dim3 grid((unsigned)((M + 127) / 128)), block(256);
+    hipLaunchKernelGGL((k_upconv_rows<T, NCH, NTAB>), grid, block, 4 * 32 * 64 * NTAB, s, p);
+    return SD_LAUNCH_CHECK();
+}
+template <typename T>
+static int launch_upconv_t(const UpconvParams& p, int NB, hipStream_t s) {
+    // the store-bound full-resolution shape gets the row-coalescing kernel (64 -> 32 channels: 77 -> 52 us at 128^3);
+    // at 128 -> 64 channels it measured slower than the plain kernel (85 vs 63 us: 32 L2 weight loads per row pair)
+    if (p.nchunk == 4 && p.Cd == 32) return launch_upconv_rows<T, 4, 2>(p, s);
+    if (p.nchunk == 3 && p.Cd == 32) return launch_upconv_rows<T, 3, 2>(p, s);
+    if (p.nchunk == 2 && p.Cd == 16) return launch_upconv_rows<T, 2, 1>(p, s);
+    const long M = (long)p.D * p.H * p.W;
+    dim3 grid((unsigned)((M + 255) / 256), NB), block(256);
+    hipLaunchKernelGGL((k_upconv_mfma<T>), grid, block, 0, s, p);
+    return SD_LAUNCH_CHECK();
+}
 int launch_upconv(const UpconvParams& p, int act_dtype, int NB, hipStream_t s) {
+    if (!getenv("SD_UPCONV_OLD"))
+        return act_dtype == SD_BF16 ? launch_upconv_t<bf16_t>(p, NB, s) : launch_upconv_t<f16_t>(p, NB, s);
     const long M = (long)p.D * p.H * p.W;
     dim3 grid((unsigned)((M + 255) / 256), NB), block(256);
     if (act_dtype == SD_BF16) hipLaunchKernelGGL((k_upconv_mfma<bf16_t>), grid, block, 0, s, p);
