@@ -56,6 +56,7 @@ struct Op {
     int fuse_final = -1;   // index of the final 1x1x1 op computed in this conv's epilogue
     int fuse_up = -1;      // index of the ConvTranspose op whose output (this conv's src0) is produced on the fly
     size_t upw_off = 0, upb_off = 0;   // fused up-conv weights / bias (byte offsets)
+    size_t fwfrag_off = 0;             // fused final 1x1x1: hi/lo MFMA weight fragments
     bool skipped = false;  // op is executed inside its producer
 };
 
@@ -359,6 +360,26 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
             } else if (nx.d.kind == SD_OP_FINAL && nx.d.src0 == c.d.dst && c.NB == 1 && i + 2 == m->ops.size()) {
                 c.fuse_final = (int)(i + 1);
                 nx.skipped = true;
+                // fp32 final weights as hi + lo parts in the activation dtype, in MFMA A-fragment order: row = class
+                // (lane & 31), k-step s / element jj <-> channel j*32 + 8*(2s + (jj>>2)) + 4*(lane>>5) + (jj&3)
+                const sd_op_desc& fd = nx.d;
+                c.fwfrag_off = blob_alloc((size_t)c.NT * 2 * 2 * 64 * 8 * 2);
+                uint16_t* fp = reinterpret_cast<uint16_t*>(blob.data() + c.fwfrag_off);
+                auto back = [&](uint16_t bits) -> float {
+                    if (act_dtype == SD_BF16) { uint32_t u = (uint32_t)bits << 16; float f; std::memcpy(&f, &u, 4); return f; }
+                    _Float16 h; std::memcpy(&h, &bits, 2); return (float)h;
+                };
+                for (int j = 0; j < c.NT; ++j)
+                    for (int s2 = 0; s2 < 2; ++s2)
+                        for (int l = 0; l < 64; ++l)
+                            for (int jj = 0; jj < 8; ++jj) {
+                                const int co = l & 31, ch = j * 32 + 8 * (2 * s2 + (jj >> 2)) + 4 * (l >> 5) + (jj & 3);
+                                const float wv = (co < fd.cout && ch < fd.cin0) ? W[fd.w_off + (size_t)co * fd.cin0 + ch] : 0.f;
+                                const uint16_t hi = cvt(wv, act_dtype);
+                                const uint16_t lo = cvt(wv - back(hi), act_dtype);
+                                fp[((size_t)((j * 2 + s2) * 2 + 0) * 64 + l) * 8 + jj] = hi;
+                                fp[((size_t)((j * 2 + s2) * 2 + 1) * 64 + l) * 8 + jj] = lo;
+                            }
             }
         }
         // ConvTranspose (BatchNorm folded) -> merge conv: compute the up-convolved halo on the fly inside the conv.
@@ -529,6 +550,9 @@ int sd_forward(sd_model* m, const void* in_dev, int in_dtype, int D, int H, int 
                 p.bias = reinterpret_cast<const float*>(m->dev_blob + op.bias_off);
                 p.relu = d.relu; p.zero = m->dev_zero;
                 p.store_main = 1;
+#ifdef SD_TIMING
+                p.dbg = (getenv("SD_TIMING_OP") && atoi(getenv("SD_TIMING_OP")) == (int)i) ? reinterpret_cast<long long*>(wsb + m->buf_off[1]) : nullptr;
+#endif
                 if (op.fuse_up >= 0) {
                     const Op& uo = m->ops[op.fuse_up];
                     const Dims ud = m->dims[uo.d.src0];
@@ -545,7 +569,7 @@ int sd_forward(sd_model* m, const void* in_dev, int in_dtype, int D, int H, int 
                 if (op.fuse_final >= 0) {
                     const Op& fo = m->ops[op.fuse_final];
                     if (o.d != D || o.h != H || o.w != W) return fail(SD_ERR_INVALID, "final layer shape != input shape");
-                    p.final_w = reinterpret_cast<const float*>(m->dev_blob + fo.wpack_off);
+                    p.final_wfrag = m->dev_blob + op.fwfrag_off;
                     p.final_b = reinterpret_cast<const float*>(m->dev_blob + fo.bias_off);
                     p.final_cout = fo.d.cout; p.final_kind = out_kind; p.final_out = out_dev;
                     p.store_main = m->keep_all ? 1 : 0;

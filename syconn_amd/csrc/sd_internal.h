@@ -31,7 +31,7 @@ struct ConvParams {
     int store_main;    // write dst (0 when only the fused final output is needed)
     void* pool_dst;    // fused MaxPool(ceil): pooled tensor (same channel stride), or nullptr
     int pH, pW;        // y/x extents of the pooled tensor
-    const float* final_w;   // fused conv_final: [8][Cd] float, or nullptr
+    const void* final_wfrag; // fused conv_final: hi/lo weight fragments [NT][2 k-steps][2][64 lanes][8] of T, or nullptr
     const float* final_b;
     int final_cout, final_kind;
     void* final_out;   // planar (cout, D*H*W)
@@ -42,6 +42,7 @@ struct ConvParams {
     const void* up_w;       // [ceil(nchunk0/2)][up_nchunk][taps][64 lanes][8]
     const float* up_bias;   // folded bias per up channel, padded to ceil(nchunk0/2)*32
     int up_relu;
+    long long* dbg;         // SD_TIMING builds: per-wave cycle stamps
 };
 
 struct FirstParams {

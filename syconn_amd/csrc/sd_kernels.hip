@@ -195,22 +195,33 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         xoffO[i] = hv * 32 + ((half ^ (dy & 1) ^ 1) << 4);
     }
 
-    // everything that needs an ordinary (VGPR-destination) global load happens BEFORE the first DMA is issued
-    constexpr bool PRELOAD_BIAS = NA > 2;   // only a deep ring must keep VGPR loads out of the loop
-    f32x4 breg[PRELOAD_BIAS ? NT : 1][4];
-    if (PRELOAD_BIAS) {
+    // everything that needs an ordinary (VGPR-destination) global load happens BEFORE the first DMA is issued:
+    // the folded bias of this lane's output channels (it becomes the accumulators' initial value) and, for a fused
+    // final layer, the hi/lo halves of the 1x1x1 weights in MFMA A-fragment order plus the class biases
+    f32x4 breg[NT][4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = (nb * NT + j) * 32 + 4 * half + 8 * q;
+            breg[j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (n < p.Cd) breg[j][q] = *reinterpret_cast<const f32x4*>(p.bias + n);
+        }
+    v8 fw[NT][2][2];
+    float fb[8];
+#pragma unroll
+    for (int co = 0; co < 8; ++co) fb[co] = 0.f;
+    if (p.final_wfrag) {
+        const T* const fwp = reinterpret_cast<const T*>(p.final_wfrag);
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = (nb * NT + j) * 32 + 4 * half + 8 * q;
-                breg[j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (n < p.Cd) breg[j][q] = *reinterpret_cast<const f32x4*>(p.bias + n);
-            }
-    }
-    if (p.final_w) {
-        for (int k = tid; k < 8 * p.Cd; k += WAVES * 64) wl[k] = p.final_w[k];
-        if (tid < 8) wl[8 * p.Cd + tid] = tid < p.final_cout ? p.final_b[tid] : 0.f;
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl)
+                    fw[j][s2][hl] = *reinterpret_cast<const v8*>(fwp + ((size_t)((j * 2 + s2) * 2 + hl) * 64 + lane) * 8);
+#pragma unroll
+        for (int co = 0; co < 8; ++co) fb[co] = co < p.final_cout ? p.final_b[co] : 0.f;
     }
 
     const char* const wbase = reinterpret_cast<const char*>(p.wpack) + (size_t)nb * nstages * B_BYTES;
@@ -275,6 +286,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         dma_halo(cf, f % NA, fz, fy, fx, lbf >= 0);
     };
 
+#ifdef SD_TIMING
+    long long tstamp[8];
+    int tcount = 0;
+#define SD_T(i) do { if (tcount == 2) tstamp[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SD_T(i) do {} while (0)
+#endif
     int lb = block_of(0);
     if (lb < 0) return;
     int z0, y0, x0;
@@ -409,8 +427,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = breg[j][r >> 2][r & 3];
+#ifdef SD_TIMING
+        ++tcount;
+#endif
+        SD_T(0);
         int s = 0;
         for (int c = 0; c < nchunks; ++c, ++gc) {
             if constexpr (fuse_up) { if (c < p.nchunk0 && (c & 1) == 0) up_phase(c >> 1); }
@@ -422,8 +443,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                     if (kz == 0 && c + 1 < nchunks && !(fuse_up && c + 1 < p.nchunk0))
                         dma_halo(c + 1, (gc + 1) & 1, z0, y0, x0, true);
                 } else if (kz == 0) {
-                    dma_stream(gc + NA - 1);
-                }
+                    dma_stream(gc + NA - 1);     // (a hand-specialised NA == 2 form without the stream arithmetic
+                }                                //  measured 15 % SLOWER: hipcc allocates it worse)
                 const char* const bcur = ldsB + (WRES ? s : (gs & 1)) * B_BYTES + lane * 16;
                 const char* const acur = abuf + kz * SLICE;
                 // software-pipelined over the 9 taps: the fragments of tap t+1 are in flight while tap t's MFMAs run
@@ -448,12 +469,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                         for (int j = 0; j < NT; ++j)
                             acc[i][j] = Act<T>::mfma(wf[t9 & 1][j], xf[t9 & 1][i], acc[i][j]);
                 }
+                if (s == 0) SD_T(2);     // after the MFMAs of the first stage
                 // all of this wave's LDS reads done + the next chunk's DMA landed, then the workgroup barrier (raw
                 // s_barrier: __syncthreads() would drain every DMA in flight with a vmcnt(0))
                 asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WAITN) : "memory");
+                if (s == 0) SD_T(3);     // after the barrier of the first stage
             }
         }
 
+    SD_T(4);   // all stages done
     // ---- epilogue: + bias, ReLU, round to the storage type (kept in `acc` as the rounded value) ----------
     using v4 = typename Act<T>::v4;
     bool valid[MT];
@@ -465,35 +489,28 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         voxoff[i] = ((size_t)(vz * p.H + vy) * p.W + vx) * p.Cd;
     }
     T* const dst = reinterpret_cast<T*>(p.dst);
+    v4 oq[MT][NT][4];          // rounded outputs as packed quads: channels cbase + 8q + 4*half + 0..3
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int cbase = (nb * NT + j) * 32;
-        f32x4 b[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int n = cbase + 4 * half + 8 * q;
-            if (PRELOAD_BIAS) b[q] = breg[PRELOAD_BIAS ? j : 0][q];
-            else {
-                b[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (n < p.Cd) b[q] = *reinterpret_cast<const f32x4*>(p.bias + n);
-            }
-        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            v4 o[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = acc[i][j][4 * q + e] + b[q][e];
+                    float v = acc[i][j][4 * q + e];             // bias is already inside (accumulator init)
                     if (p.relu) v = fmaxf(v, 0.f);
-                    o[q][e] = (T)v;
-                    acc[i][j][4 * q + e] = (float)o[q][e];
+                    oq[i][j][q][e] = (T)v;
                 }
-            if (p.store_main) store_tile_rows<T>(o, dst + voxoff[i], valid[i], cbase, half, p.Cd);
+            if (p.store_main) {
+                v4 o[4] = {oq[i][j][0], oq[i][j][1], oq[i][j][2], oq[i][j][3]};
+                store_tile_rows<T>(o, dst + voxoff[i], valid[i], cbase, half, p.Cd);
+            }
         }
     }
 
+    SD_T(5);   // main store done
     // ---- fused MaxPool(ceil_mode): (kz,2,2) window = {the wave's two tiles (3D)} x {lane^16 (y)} x {lane^1 (x)} ----
     if (p.pool_dst) {
         T* const pdst = reinterpret_cast<T*>(p.pool_dst);
@@ -510,8 +527,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float m = valid[i] ? acc[i][j][4 * q + e] : -INFINITY;
-                        if (KZ == 3) m = fmaxf(m, valid[i | 1] ? acc[i | 1][j][4 * q + e] : -INFINITY);
+                        float m = valid[i] ? (float)oq[i][j][q][e] : -INFINITY;
+                        if (KZ == 3) m = fmaxf(m, valid[i | 1] ? (float)oq[i | 1][j][q][e] : -INFINITY);
                         o[q][e] = (T)max_xor16(max_xor1(m));
                     }
                 store_tile_rows<T>(o, pdst + po, writer && valid[i], (nb * NT + j) * 32, half, p.Cd);
@@ -519,80 +536,88 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         }
     }
 
-    // ---- fused conv_final (1x1x1) + softmax + uint8 ------------------------------------------------------------
-    // the lane pair (l, l^32) holds all channels of a voxel of EACH tile: both lanes form partial dot products for
-    // both tiles, one half-wave swap per class leaves the lower lane with the full logits of tile 0's voxel and the
-    // upper lane with those of tile 1's voxel -> every lane finishes (softmax, store) exactly one voxel.
-    if (p.final_w) {
+    // ---- fused conv_final (1x1x1) + softmax + uint8, on the matrix core --------------------------------------------
+    // logits[class][voxel] = W[class][channel] . act[channel][voxel]: the B fragment of k-step s is exactly the pair
+    // of packed output quads (2s, 2s+1) this lane already holds (the k order of an MFMA is free, the weight fragment
+    // is packed in the same channel order); the fp32 weights enter as bf16/f16 hi + lo parts (two MFMAs), which
+    // keeps the product sum at fp32 accuracy.  Result rows = classes: lower lanes hold classes 0-3 of their voxel
+    // in registers 0-3, upper lanes classes 4-7; one half-wave swap per register then gives the lower lane all 8
+    // logits of tile tp's voxel and the upper lane those of tile tp+1's voxel.
+    if (p.final_wfrag) {
         const long nvox = (long)p.D * p.H * p.W;
 #pragma unroll
         for (int tp = 0; tp < MT; tp += 2) {
-        float lg[2][8];
+            f32x16 lgt[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i) {
 #pragma unroll
-            for (int co = 0; co < 8; ++co) lg[i][co] = 0.f;
+                for (int r = 0; r < 16; ++r) lgt[i][r] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {       // one tile at a time: with both chains in one loop hipcc (ROCm 7.2, -O3) SLP-packs
-                                            // them into dependent v_pk_fma_f32 whose results were sporadically wrong at scale
-                                            // (tools/debug_final.py); the library is also built with -fno-slp-vectorize
+                for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        v8 bfrag;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = j * 32 + 4 * half + 8 * q;
-                    if (n < p.Cd) {
-#pragma unroll
-                        for (int co = 0; co < 8; ++co) {
-                            if (co < p.final_cout) {
-                                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wl + co * p.Cd + n);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) lg[i][co] = fmaf(acc[tp + i][j][4 * q + e], w4[e], lg[i][co]);
-                            }
+                        for (int e = 0; e < 4; ++e) {
+                            bfrag[e] = oq[tp + i][j][2 * s2][e];
+                            bfrag[4 + e] = oq[tp + i][j][2 * s2 + 1][e];
                         }
+                        lgt[i] = Act<T>::mfma(fw[j][s2][0], bfrag, lgt[i]);
+                        lgt[i] = Act<T>::mfma(fw[j][s2][1], bfrag, lgt[i]);
                     }
+            }
+            float l[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // the class bias is added BEFORE the swap by a compiler-visible VALU op: an asm statement must not be
+                // the first reader of an MFMA result (hipcc pads no MFMA -> VALU hazard for inline asm consumers)
+                const float bmine = half ? fb[4 + e] : fb[e];
+                unsigned a = __builtin_bit_cast(unsigned, lgt[0][e] + bmine);
+                unsigned b2 = __builtin_bit_cast(unsigned, lgt[1][e] + bmine);
+                swap32(a, b2);      // lower: a = own tile-tp classes 0-3, b2 = tile-tp classes 4-7 (from the upper lane)
+                l[e] = __builtin_bit_cast(float, a);
+                l[4 + e] = __builtin_bit_cast(float, b2);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int co = 0; co < 8; ++co)
+                if (co < p.final_cout) mx = fmaxf(mx, l[co]);
+            if (p.final_kind != SD_OUT_LOGITS_F32) {
+                float sum = 0.f;
+#pragma unroll
+                for (int co = 0; co < 8; ++co) {
+                    l[co] = co < p.final_cout ? __expf(l[co] - mx) : 0.f;
+                    sum += l[co];
+                }
+                const float inv = 1.0f / sum;
+#pragma unroll
+                for (int co = 0; co < 8; ++co) l[co] *= inv;
+            }
+            const bool vmine = half ? valid[tp + 1] : valid[tp];
+            const size_t v = (half ? voxoff[tp + 1] : voxoff[tp]) / p.Cd;
+            if (vmine) {
+                if (p.final_kind == SD_OUT_PROBS_U8) {
+                    uint8_t* out = reinterpret_cast<uint8_t*>(p.final_out);
+#pragma unroll
+                    for (int co = 0; co < 8; ++co)
+                        if (co < p.final_cout) out[(size_t)co * nvox + v] = (uint8_t)(l[co] * 255.f);
+                } else {
+                    float* out = reinterpret_cast<float*>(p.final_out);
+#pragma unroll
+                    for (int co = 0; co < 8; ++co)
+                        if (co < p.final_cout) out[(size_t)co * nvox + v] = l[co];
                 }
             }
         }
-        float l[8];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int co = 0; co < 8; ++co) {
-            l[co] = 0.f;
-            if (co < p.final_cout) {
-                unsigned a = __builtin_bit_cast(unsigned, lg[0][co]), b2 = __builtin_bit_cast(unsigned, lg[1][co]);
-                swap32(a, b2);          // a: [tile0.lower, tile1.lower], b2: [tile0.upper, tile1.upper]
-                l[co] = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b2) + wl[8 * p.Cd + co];
-                mx = fmaxf(mx, l[co]);
-            }
-        }
-        if (p.final_kind != SD_OUT_LOGITS_F32) {
-            float sum = 0.f;
-#pragma unroll
-            for (int co = 0; co < 8; ++co)
-                if (co < p.final_cout) { l[co] = __expf(l[co] - mx); sum += l[co]; }
-            const float inv = 1.0f / sum;
-#pragma unroll
-            for (int co = 0; co < 8; ++co) l[co] *= inv;
-        }
-        const bool vmine = half ? valid[tp + 1] : valid[tp];
-        const size_t v = (half ? voxoff[tp + 1] : voxoff[tp]) / p.Cd;
-        if (vmine) {
-            if (p.final_kind == SD_OUT_PROBS_U8) {
-                uint8_t* out = reinterpret_cast<uint8_t*>(p.final_out);
-#pragma unroll
-                for (int co = 0; co < 8; ++co)
-                    if (co < p.final_cout) out[(size_t)co * nvox + v] = (uint8_t)(l[co] * 255.f);
-            } else {
-                float* out = reinterpret_cast<float*>(p.final_out);
-#pragma unroll
-                for (int co = 0; co < 8; ++co)
-                    if (co < p.final_cout) out[(size_t)co * nvox + v] = l[co];
-            }
-        }
-        }
     }
 
+        SD_T(6);   // epilogue done
+#ifdef SD_TIMING
+        if (tcount == 2 && lane == 0 && p.dbg) {
+            long long* o = p.dbg + ((size_t)blockIdx.x * WAVES + wave) * 8;
+            for (int i = 0; i < 7; ++i) o[i] = tstamp[i];
+        }
+#endif
         lb = nlb; z0 = nz0; y0 = ny0; x0 = nx0;
     }
 }
