@@ -90,14 +90,36 @@ def broadcast_weights(model: torch.nn.Module, src: int = 0, device: Optional[tor
     unflatten_state(model, flat.cpu())
 
 
-def gather_to_root(local: torch.Tensor, dst: int = 0) -> Optional[List[torch.Tensor]]:
-    """Gather equally-shaped uint8 result tensors on `dst` (Coll-3).  Returns the list on `dst`, None elsewhere."""
+_GATHER_MODE = {'mode': 'gather'}     # 'gather' (root-centric send/recv) or 'all_gather' (fallback)
+
+
+def gather_to_root(local: torch.Tensor, dst: int = 0, async_op: bool = False, out: Optional[torch.Tensor] = None):
+    """Gather equally-shaped uint8 result tensors on `dst` (Coll-3).
+
+    Returns ``(buffers, work)``: `buffers` is the list of per-rank tensors on `dst` (None elsewhere; with the
+    all_gather fallback every rank holds them), `work` the async handle (None when synchronous or world size 1).
+    `out` optionally provides the (world, *local.shape) receive buffer so that steady-state steps allocate nothing.
+    If the backend rejects ``dist.gather`` (it is emulated with grouped send/recv on RCCL) the first failure
+    switches this process group to ``all_gather_into_tensor`` for the rest of the run."""
     rank, world = world_info()
     if world == 1:
-        return [local]
-    bufs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
-    dist.gather(local, gather_list=bufs, dst=dst)
-    return bufs
+        return [local], None
+    if _GATHER_MODE['mode'] == 'gather':
+        try:
+            bufs = None
+            if rank == dst:
+                if out is None:
+                    out = torch.empty((world, *local.shape), dtype=local.dtype, device=local.device)
+                bufs = list(out.unbind(0))
+            work = dist.gather(local, gather_list=bufs, dst=dst, async_op=async_op)
+            return bufs, (work if async_op else None)
+        except (RuntimeError, ValueError, NotImplementedError):
+            _GATHER_MODE['mode'] = 'all_gather'
+    if out is None:
+        out = torch.empty((world, *local.shape), dtype=local.dtype, device=local.device)
+    work = dist.all_gather_into_tensor(out.view(-1, *local.shape[1:]) if local.dim() > 0 else out, local.contiguous(),
+                                       async_op=async_op)
+    return list(out.unbind(0)), (work if async_op else None)
 
 
 def barrier():

@@ -43,7 +43,12 @@ def _worker(rank, world, port, n_units, q):
     local = torch.zeros((share, 4, 4, 4), dtype=torch.uint8)
     for k, u in enumerate(mine):
         local[k] = u + 1
-    got = par.gather_to_root(local, dst=0)
+    got, _ = par.gather_to_root(local, dst=0)
+    got_async, work = par.gather_to_root(local, dst=0, async_op=True)
+    if work is not None:
+        work.wait()
+    if rank == 0:
+        assert all(torch.equal(a, b) for a, b in zip(got, got_async))
     t = par.max_over_ranks(float(rank + 1))
     par.barrier()
     if rank == 0:
