@@ -289,7 +289,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
 #ifdef SD_TIMING
     long long tstamp[8];
     int tcount = 0;
-#define SD_T(i) do { if (tcount == 2) tstamp[i] = __builtin_readcyclecounter(); } while (0)
+#define SD_T(i) do { if (tcount == (NSLOT > 0 ? 2 : 1)) tstamp[i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define SD_T(i) do {} while (0)
 #endif
@@ -445,6 +445,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                 } else if (kz == 0) {
                     dma_stream(gc + NA - 1);     // (a hand-specialised NA == 2 form without the stream arithmetic
                 }                                //  measured 15 % SLOWER: hipcc allocates it worse)
+                if (s == 0) SD_T(1);     // after the DMA issue of the first stage
                 const char* const bcur = ldsB + (WRES ? s : (gs & 1)) * B_BYTES + lane * 16;
                 const char* const acur = abuf + kz * SLICE;
                 // software-pipelined over the 9 taps: the fragments of tap t+1 are in flight while tap t's MFMAs run
@@ -613,7 +614,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
 
         SD_T(6);   // epilogue done
 #ifdef SD_TIMING
-        if (tcount == 2 && lane == 0 && p.dbg) {
+        if (tcount == (NSLOT > 0 ? 2 : 1) && lane == 0 && p.dbg) {
             long long* o = p.dbg + ((size_t)blockIdx.x * WAVES + wave) * 8;
             for (int i = 0; i < 7; ++i) o[i] = tstamp[i];
         }

@@ -15,7 +15,7 @@ torch.cuda.synchronize()
 raw = dm._ws[65536:65536 + nwg * waves * 64].view(torch.int64).cpu().numpy().reshape(nwg, waves, 8)
 d = np.diff(raw[:, :, :7], axis=2).astype(np.float64)
 names = ['dma issue', 'stage-0 MFMA loop', 'stage-0 wait+barrier', 'remaining stages', 'main store', 'pool+final']
-ok = (d > 0).all(axis=2) & (d < 1e7).all(axis=2)
+ok = (d >= 0).all(axis=2) & (d < 1e7).all(axis=2)
 print('valid waves', ok.sum(), 'of', ok.size)
 for i, n in enumerate(names):
     v = d[:, :, i][ok]
