@@ -273,3 +273,46 @@ def test_predict_cellorganelles_labels_end_to_end(gpu, tmp_path):
     assert not (mism & safe).any() and safe.mean() > 0.5
     assert len(np.unique(ref)) >= 2
     global_params.wd = None
+
+
+def test_config3_volume_in_overlapping_chunks(gpu):
+    """BASELINE config 3 at reduced scale: a volume cut into overlapping chunks (useful region + halo = one model
+    input tile, zeros outside the volume), predicted chunk by chunk through parallel.predict_volume_distributed
+    (world size 1 here; the 2-rank scatter/gather logic is covered by tests/test_distributed_cpu.py) and compared
+    with the oracle run in the same geometry."""
+    from syconn_amd import parallel as par
+    from syconn_amd.handler.prediction import Predictor
+    model = build_unet('semseg_axon', seed=31, start_filts=16, final_scale=4.0)
+    vol_shape, chunk, halo = (60, 100, 90), (28, 48, 48), (4, 8, 8)
+    vol = _em_like(vol_shape, 9)
+    tile = tuple(c + 2 * h for c, h in zip(chunk, halo))
+    p = Predictor(model, apply_softmax=True, device=gpu)
+
+    def predict_fn(ch):
+        pr = p.predict_proba_u8_device(ch)
+        return pr[:, halo[0]:-halo[0], halo[1]:-halo[1], halo[2]:-halo[2]].contiguous()
+    out = par.predict_volume_distributed(torch.from_numpy(vol), vol_shape, chunk, halo, predict_fn, n_out=6,
+                                         device=gpu).cpu().numpy()
+    assert out.shape == (6, *vol_shape)
+    # oracle, same chunk grid / zero padding
+    grid = [-(-vol_shape[i] // chunk[i]) for i in range(3)]
+    pad = np.zeros([g * c + 2 * h for g, c, h in zip(grid, chunk, halo)], np.uint8)
+    pad[halo[0]:halo[0] + vol_shape[0], halo[1]:halo[1] + vol_shape[1], halo[2]:halo[2] + vol_shape[2]] = vol
+    ref = np.zeros((6, *[g * c for g, c in zip(grid, chunk)]), np.uint8)
+    pr = PredictorRef(model, tile_shape=tile, overlap_shape=(0, 0, 0), out_shape=(6, *tile), strict_shapes=True)
+    for iz in range(grid[0]):
+        for iy in range(grid[1]):
+            for ix in range(grid[2]):
+                z, y, x = iz * chunk[0], iy * chunk[1], ix * chunk[2]
+                raw = pad[z:z + tile[0], y:y + tile[1], x:x + tile[2]]
+                u8 = dense_predicton_helper_ref(raw.astype(np.float32) / 255., pr, True, True)
+                ref[:, z:z + chunk[0], y:y + chunk[1], x:x + chunk[2]] = \
+                    u8[:, halo[0]:-halo[0], halo[1]:-halo[1], halo[2]:-halo[2]]
+    ref = ref[:, :vol_shape[0], :vol_shape[1], :vol_shape[2]]
+    d = np.abs(out.astype(np.int16) - ref.astype(np.int16))
+    print('config-3 style volume: uint8 prob diff max', d.max(), 'mean', d.mean())
+    assert d.max() <= TOL_U8
+    lab, _ = label_rule_ref(out, (1, 2, 3, 4, 5), [None] * 6)
+    lab_ref, _ = label_rule_ref(ref, (1, 2, 3, 4, 5), [None] * 6)
+    safe = np.all(np.abs(ref[1:].astype(np.int16) - 127.5) > TOL_U8, axis=0)
+    assert not ((lab != lab_ref) & safe).any()
