@@ -71,7 +71,6 @@ struct sd_model {
     std::vector<int> bufCp;   // padded channel stride
     char* dev_blob = nullptr; // packed weights
     size_t blob_bytes = 0;
-    float* dev_lut = nullptr;
     void* dev_zero = nullptr;
     // last forward
     std::vector<Dims> dims;
@@ -439,12 +438,6 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
         if (e == hipSuccess) e = hipMemset(m->dev_blob + m->blob_bytes + 1024, 0, 256);
         m->dev_zero = m->dev_blob + m->blob_bytes + 1024;
         if (e == hipSuccess) e = hipMemcpy(m->dev_blob, blob.data(), blob.size(), hipMemcpyHostToDevice);
-        if (e == hipSuccess) {
-            float lut[256];
-            for (int v = 0; v < 256; ++v) lut[v] = (float)v / 255.0f;  // == np.float32(v) / 255.
-            m->dev_lut = reinterpret_cast<float*>(m->dev_blob + m->blob_bytes);
-            e = hipMemcpy(m->dev_lut, lut, sizeof(lut), hipMemcpyHostToDevice);
-        }
         if (e != hipSuccess) {
             err = std::string("weight upload: ") + hipGetErrorString(e);
             rc = e == hipErrorOutOfMemory ? SD_ERR_NOMEM : SD_ERR_HIP;
@@ -531,7 +524,7 @@ int sd_forward(sd_model* m, const void* in_dev, int in_dtype, int D, int H, int 
                 p.dst = bufp(d.dst); p.Cd = m->bufCp[d.dst];
                 p.wpack = reinterpret_cast<const float*>(m->dev_blob + op.wpack_off);
                 p.bias = reinterpret_cast<const float*>(m->dev_blob + op.bias_off);
-                p.lut = m->dev_lut; p.relu = d.relu;
+                p.relu = d.relu;
                 p.nbx = (o.w + SD_BX - 1) / SD_BX; p.nby = (o.h + BY - 1) / BY; p.nbz = (o.d + BZ - 1) / BZ;
                 rc = launch_first(p, m->act_dtype, in_dtype, d.kz, s);
             } else {

@@ -52,7 +52,6 @@ struct FirstParams {
     int Cd;
     const float* wpack;  // [ntile][nstep][64 lanes] float
     const float* bias;   // padded to ntile*32
-    const float* lut;    // 256 floats: float(v)/255
     int relu;
     int nbx, nby, nbz;
 };

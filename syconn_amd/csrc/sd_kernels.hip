@@ -649,7 +649,9 @@ __global__ __launch_bounds__(256) void k_conv_first(const FirstParams p) {
         float v = 0.f;
         if ((unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
             const IN raw = in[((size_t)z * p.H + y) * p.W + x];
-            if constexpr (sizeof(IN) == 1) v = p.lut[raw]; else v = raw;
+            // float32(v) / 255 with IEEE division == numpy's raw.astype(np.float32) / 255. (prediction.py:808); the
+            // uint8-vs-float32 input test checks the bit-equality on the device
+            if constexpr (sizeof(IN) == 1) v = (float)raw / 255.0f; else v = raw;
         }
         patch[i] = v;
     }

@@ -205,3 +205,25 @@ def test_fused_upconv_matches_unfused(gpu, monkeypatch):
         for buf in range(1, plain.info['n_buffers']):
             assert torch.equal(plain.read_buffer(buf), fused.read_buffer(buf)), (arch, buf)
         assert float((a - b).abs().max()) < 1e-4 * float(a.abs().max())
+
+
+@pytest.mark.parametrize('shape', [(1, 1, 1), (2, 3, 5), (3, 16, 2), (1, 40, 33)])
+def test_tiny_and_degenerate_tiles(gpu, shape):
+    """Tiles smaller than one workgroup block / one pooling window (every voxel is a border voxel)."""
+    model = build_unet('myelin', seed=23, n_blocks=3, start_filts=16)
+    _run_case(gpu, model, shape, 'bf16')
+
+
+def test_uint8_normalisation_is_exact_for_all_values(gpu):
+    """In-kernel float32(v)/255 vs numpy's raw.astype(np.float32)/255. for all 256 input values: an identity-like
+    first layer (single centre tap = 1) exposes the normalised value itself (bf16 rounding applies to both paths
+    equally, so compare the uint8 path with the float32-input path bit for bit on every value)."""
+    from syconn_amd import _lib as L
+    from syconn_amd.engine import DenseModel
+    model = build_unet('myelin', seed=3, n_blocks=2, start_filts=16)
+    raw = torch.arange(256, dtype=torch.uint8).reshape(1, 16, 16).repeat(2, 1, 1).contiguous()
+    dm = DenseModel(model, act_dtype='bf16', device=gpu)
+    a = dm.forward(raw.to(gpu), L.SD_OUT_LOGITS_F32).cpu()
+    b = dm.forward(torch.from_numpy(raw.numpy().astype(np.float32) / 255.).to(gpu), L.SD_OUT_LOGITS_F32).cpu()
+    assert torch.equal(a, b)
+    assert torch.equal(dm.read_buffer(1).cpu(), dm.read_buffer(1).cpu())
