@@ -278,12 +278,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         }
     };
     // chunk number f of this workgroup's stream (f = round * nchunks + c) -> ring slot f % NA
-    auto dma_stream = [&](int f) {
-        const int rf = f / nchunks, cf = f - rf * nchunks;
-        const int lbf = block_of(rf);
-        int fz = 0, fy = 0, fx = 0;
-        if (lbf >= 0) coords(lbf, fz, fy, fx);
-        dma_halo(cf, f % NA, fz, fy, fx, lbf >= 0);
+    // The stream position is carried incrementally (chunk within block, block coordinates) so that the integer
+    // divisions of block_of / coords run once per BLOCK, not once per chunk.
+    int sf_c = 0, sf_round = 0, sf_slot = 0, sf_z = 0, sf_y = 0, sf_x = 0;
+    bool sf_ok = false;
+    auto stream_block = [&]() {
+        const int lbf = block_of(sf_round);
+        sf_ok = lbf >= 0;
+        if (sf_ok) coords(lbf, sf_z, sf_y, sf_x);
+    };
+    auto dma_stream_next = [&]() {
+        if (sf_c == 0) stream_block();
+        dma_halo(sf_c, sf_slot, sf_z, sf_y, sf_x, sf_ok);
+        if (++sf_c == nchunks) { sf_c = 0; ++sf_round; }
+        if (++sf_slot == NA) sf_slot = 0;
     };
 
 #ifdef SD_TIMING
@@ -408,7 +416,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     constexpr bool fuse_up = FUP && !WRES;      // compile-time: the producer phase costs ~50 VGPRs
     if (WRES) {
         for (int s = 0; s < nstages; ++s) dma_weights(s, s);
-        for (int f = 0; f < NA - 1; ++f) dma_stream(f);
+        for (int f = 0; f < NA - 1; ++f) dma_stream_next();
     } else {
         dma_weights(0, 0);
         if (!fuse_up) dma_halo(0, 0, z0, y0, x0, true);
@@ -443,8 +451,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                     if (kz == 0 && c + 1 < nchunks && !(fuse_up && c + 1 < p.nchunk0))
                         dma_halo(c + 1, (gc + 1) & 1, z0, y0, x0, true);
                 } else if (kz == 0) {
-                    dma_stream(gc + NA - 1);     // (a hand-specialised NA == 2 form without the stream arithmetic
-                }                                //  measured 15 % SLOWER: hipcc allocates it worse)
+                    dma_stream_next();           // chunk gc + NA - 1 of this workgroup's stream
+                }
                 if (s == 0) SD_T(1);     // after the DMA issue of the first stage
                 const char* const bcur = ldsB + (WRES ? s : (gs & 1)) * B_BYTES + lane * 16;
                 const char* const acur = abuf + kz * SLICE;

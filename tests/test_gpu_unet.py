@@ -227,3 +227,23 @@ def test_uint8_normalisation_is_exact_for_all_values(gpu):
     b = dm.forward(torch.from_numpy(raw.numpy().astype(np.float32) / 255.).to(gpu), L.SD_OUT_LOGITS_F32).cpu()
     assert torch.equal(a, b)
     assert torch.equal(dm.read_buffer(1).cpu(), dm.read_buffer(1).cpu())
+
+
+@pytest.mark.parametrize('arch,shape', [('er', (20, 150, 170)), ('syntype', (18, 140, 150)), ('mivcsj', (16, 100, 120))])
+def test_full_architectures_many_workgroups(gpu, arch, shape):
+    """Full-size production architectures on tiles with thousands of workgroups per layer (multi-round persistent
+    scheduling, 48/28-channel padding, GroupNorm statistics over large tensors) against the fp32 oracle."""
+    from syconn_amd import _lib as L
+    from syconn_amd.engine import DenseModel
+    model = build_unet(arch, seed=41)
+    raw = _input(shape, 19)
+    with torch.no_grad():
+        ref = model((raw.float() / 255.)[None, None])[0]
+    dm = DenseModel(model, act_dtype='bf16', device=gpu)
+    out = dm.forward(raw.to(gpu), L.SD_OUT_LOGITS_F32).cpu()
+    out2 = dm.forward(raw.to(gpu), L.SD_OUT_LOGITS_F32).cpu()
+    assert torch.equal(out, out2), 'forward is not deterministic'
+    err = float((out - ref).abs().max()) / float(ref.abs().max())
+    rms = float((out - ref).pow(2).mean().sqrt()) / float(ref.pow(2).mean().sqrt())
+    print(f'{arch} {shape}: rel err max {err:.2e} rms {rms:.2e}')
+    assert err < TOL_FP32['bf16'] and rms < TOL_FP32_RMS['bf16']
