@@ -353,7 +353,8 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
             Op& c = m->ops[i];
             Op& nx = m->ops[i + 1];
             if (c.d.kind != SD_OP_CONV || c.first) continue;
-            if (nx.d.kind == SD_OP_POOL && nx.d.src0 == c.d.dst && (c.d.kz == 3) == (nx.d.kz == 2)) {
+            // (the fused pooling maximum works on the packed, rounded outputs as integers: exact behind a ReLU only)
+            if (nx.d.kind == SD_OP_POOL && nx.d.src0 == c.d.dst && (c.d.kz == 3) == (nx.d.kz == 2) && c.d.relu) {
                 c.fuse_pool = (int)(i + 1);
                 nx.skipped = true;
             } else if (nx.d.kind == SD_OP_FINAL && nx.d.src0 == c.d.dst && c.NB == 1 && i + 2 == m->ops.size()) {

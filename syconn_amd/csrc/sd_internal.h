@@ -7,6 +7,7 @@
 // Activation tensors are voxel-major / channel-minor: element (z,y,x,c) at ((z*H + y)*W + x)*C + c, with C the
 // padded channel stride (multiple of 16).  A "chunk" is 16 consecutive channels = one MFMA k-step.
 constexpr int SD_CHUNK = 16;
+constexpr int SD_CONV_PARAM_BYTES = 512;     // k_conv_mfma LDS constants: folded bias (<= 96 floats) + 8 class biases
 
 // geometry of one workgroup of the first-layer convolution: 256 output voxels = 8 MFMA column tiles of
 // (2 y-rows x 16 x); 3x3x3: 2x8x16 voxels, 1x3x3: 1x16x16 voxels.  (The generic conv picks its own, ConvGeo.)

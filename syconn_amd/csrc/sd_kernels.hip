@@ -10,6 +10,8 @@
 #include "../../include/syconn_dense.h"
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 typedef __bf16 bf16_t;
 typedef _Float16 f16_t;
@@ -27,6 +29,11 @@ template <> struct Act<bf16_t> {
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
+    static __device__ __forceinline__ unsigned pack2(float a, float b) {     // RNE, one v_cvt_pk_bf16_f32
+        typedef __attribute__((ext_vector_type(2))) float f2;
+        typedef __attribute__((ext_vector_type(2))) __bf16 t2;
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a, b}, t2));
+    }
 };
 template <> struct Act<f16_t> {
     using v8 = f16x8;
@@ -34,11 +41,41 @@ template <> struct Act<f16_t> {
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     }
+    static __device__ __forceinline__ unsigned pack2(float a, float b) {     // RNE, one v_cvt_pk_f16_f32
+        typedef __attribute__((ext_vector_type(2))) float f2;
+        typedef __attribute__((ext_vector_type(2))) _Float16 t2;
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a, b}, t2));
+    }
 };
+// max of two packed pairs of NON-NEGATIVE-or-any 16-bit floats against each other as signed 16-bit integers: for
+// sign-magnitude floats this is the float max whenever at most one operand is negative (ReLU: max(x, +0) is exact
+// for every x incl. -0; pooling: all operands are >= 0 after the ReLU).  One v_pk_max_i16 for two channels.
+__device__ __forceinline__ unsigned pk_max16(unsigned a, unsigned b) {
+    typedef __attribute__((ext_vector_type(2))) short s2;
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, a), __builtin_bit_cast(s2, b)));
+}
 
 // Hardware places workgroup b on XCD b % 8 (observed; used for L2 locality only).  Map it to a logical block id
 // such that each XCD owns a contiguous run of logical ids (neighbouring blocks share halo voxels in that L2).
 // Bijective for any grid size.
+// ---- explicit LDS reads (see the tap loop of k_conv_mfma) --------------------------------------------------------
+template <int OFF, typename V>
+__device__ __forceinline__ void ds_read16(V& r, uint32_t addr) {     // 16 bytes per lane; completion via lgkmcnt
+    static_assert(sizeof(V) == 16 && OFF >= 0 && OFF < 65536, "ds_read_b128 offset");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+}
+template <typename V> __device__ __forceinline__ void tie(V& r) { asm volatile("" : "+v"(r)); }
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {        // LDS byte offset of a pointer into shared memory
+    return (uint32_t)(uintptr_t)p;
+}
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 __device__ __forceinline__ int xcd_remap(int b, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
@@ -55,6 +92,30 @@ __device__ __forceinline__ void swap32(unsigned& a, unsigned& b) {
 }
 __device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap32x4(unsigned& a0, unsigned& b0, unsigned& a1, unsigned& b1, unsigned& a2, unsigned& b2,
+                                         unsigned& a3, unsigned& b3) {     // four independent swaps, one hazard pad
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\t"
+                 "v_permlane32_swap_b32 %4, %5\n\tv_permlane32_swap_b32 %6, %7\n\ts_nop 1"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3));
+}
+// packed-pair max over the 2x2 (y,x) pooling window: lane^1 by DPP, lane^16 by one batched v_permlane16_swap of
+// the eight registers of an accumulator tile; result valid in all four lanes
+__device__ __forceinline__ void pool_xy_pk8(unsigned (&m)[8]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        m[k] = pk_max16(m[k], (unsigned)__builtin_amdgcn_update_dpp(0, (int)m[k], 0xB1, 0xF, 0xF, true));
+    unsigned b[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) b[k] = m[k];
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %8\n\tv_permlane16_swap_b32 %1, %9\n\t"
+                 "v_permlane16_swap_b32 %2, %10\n\tv_permlane16_swap_b32 %3, %11\n\t"
+                 "v_permlane16_swap_b32 %4, %12\n\tv_permlane16_swap_b32 %5, %13\n\t"
+                 "v_permlane16_swap_b32 %6, %14\n\tv_permlane16_swap_b32 %7, %15\n\ts_nop 1"
+                 : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7]),
+                   "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[k] = pk_max16(m[k], b[k]);
 }
 __device__ __forceinline__ float max_xor1(float m) {       // max with lane^1 (DPP quad_perm [1,0,3,2])
     return fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xF,
@@ -83,8 +144,27 @@ __device__ __forceinline__ void store_tile_rows(typename Act<T>::v4 (&o)[4], T* 
     x = a1.x; { unsigned y = a3.x; swap32(x, y); a1.x = x; a3.x = y; }
     x = a1.y; { unsigned y = a3.y; swap32(x, y); a1.y = x; a3.y = y; }
     const int n0 = cbase + half * 16;
+#if defined(SD_EXP_NOSTORE)
+    if (valid && n0 < Cd && a0.x == 0x12345678u) { u4 v = {a0.x, a0.y, a2.x, a2.y}; *reinterpret_cast<u4*>(vox + n0) = v; }
+    if (valid && n0 + 8 < Cd && a1.x == 0x12345678u) { u4 v = {a1.x, a1.y, a3.x, a3.y}; *reinterpret_cast<u4*>(vox + n0 + 8) = v; }
+#elif defined(SD_EXP_NT)
+    if (valid && n0 < Cd) { u4 v = {a0.x, a0.y, a2.x, a2.y}; __builtin_nontemporal_store(v, reinterpret_cast<u4*>(vox + n0)); }
+    if (valid && n0 + 8 < Cd) { u4 v = {a1.x, a1.y, a3.x, a3.y}; __builtin_nontemporal_store(v, reinterpret_cast<u4*>(vox + n0 + 8)); }
+#else
     if (valid && n0 < Cd) { u4 v = {a0.x, a0.y, a2.x, a2.y}; *reinterpret_cast<u4*>(vox + n0) = v; }
     if (valid && n0 + 8 < Cd) { u4 v = {a1.x, a1.y, a3.x, a3.y}; *reinterpret_cast<u4*>(vox + n0 + 8) = v; }
+#endif
+}
+
+// Same, from the packed form pk[2q + h] = channels (cbase + 8q + 4*(lane>>5) + 2h, +1) of voxel (lane&31).
+template <typename T>
+__device__ __forceinline__ void store_tile_rows_pk(const unsigned (&pk)[8], T* vox, bool valid, int cbase, int half, int Cd) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u4;
+    unsigned a0x = pk[0], a0y = pk[1], a1x = pk[2], a1y = pk[3], a2x = pk[4], a2y = pk[5], a3x = pk[6], a3y = pk[7];
+    swap32x4(a0x, a2x, a0y, a2y, a1x, a3x, a1y, a3y);
+    const int n0 = cbase + half * 16;
+    if (valid && n0 < Cd) { u4 v = {a0x, a0y, a2x, a2y}; *reinterpret_cast<u4*>(vox + n0) = v; }
+    if (valid && n0 + 8 < Cd) { u4 v = {a1x, a1y, a3x, a3y}; *reinterpret_cast<u4*>(vox + n0 + 8) = v; }
 }
 
 // + bias, ReLU, round to the storage type and store one accumulator tile (lane owns voxel column lane&31 and
@@ -139,7 +219,8 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 // one-stage double buffer.  Every wave issues exactly AJ DMA instructions per chunk (padding ones go to a dummy
 // slot) so that the stage-end wait is the compile-time counted `s_waitcnt vmcnt((NSLOT-2)*AJ)`; nothing inside the
 // loop issues an ordinary VGPR load (bias and final-layer weights are preloaded), which would drain the ring.
-// NSLOT == 0: weight groups are streamed (double-buffered) and each workgroup computes one block.
+// NSLOT == 0: weight groups are streamed (double-buffered); the workgroups are persistent as well, and the first
+// weight group and halo chunk of a workgroup's next block are requested during the last stage of the current one.
 template <typename T, int KZ, int NT, int WAVES, int NSLOT, int MT, bool FUP>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(const ConvParams p) {
     using v8 = typename Act<T>::v8;
@@ -163,8 +244,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     const int nstages = nchunks * KZ;
     char* const ldsA = smem;
     char* const ldsB = smem + NA * A_BYTES;
-    float* const wl = reinterpret_cast<float*>(ldsB + (WRES ? nstages : 2) * B_BYTES);   // fused conv_final w + b
-    char* const ldsDummy = reinterpret_cast<char*>(wl) + 2048 + 64;
+    // per-workgroup constants kept in LDS instead of registers (they would be live across the whole stage loop):
+    // the folded bias of the NT*32 output channels (+ 8 class biases) and, with a fused final layer, its weight
+    // fragments (NT*4 KiB, one 16-byte entry per lane and k-step)
+    float* const wl = reinterpret_cast<float*>(ldsB + (WRES ? nstages : 2) * B_BYTES);
+    char* const fwl = reinterpret_cast<char*>(wl) + SD_CONV_PARAM_BYTES;
+    char* const ldsDummy = fwl + (p.final_wfrag ? NT * 4096 : 0);
     // fused up-convolution (see up_phase below): low-resolution region + one 32-channel weight group, double-buffered
     constexpr int UDZ = KZ == 3 ? BZ / 2 + 2 : 1, UDY = BY / 2 + 2, UDX = BX / 2 + 2;
     constexpr int UND = UDZ * UDY * UDX;
@@ -195,34 +280,18 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         xoffO[i] = hv * 32 + ((half ^ (dy & 1) ^ 1) << 4);
     }
 
-    // everything that needs an ordinary (VGPR-destination) global load happens BEFORE the first DMA is issued:
-    // the folded bias of this lane's output channels (it becomes the accumulators' initial value) and, for a fused
-    // final layer, the hi/lo halves of the 1x1x1 weights in MFMA A-fragment order plus the class biases
-    f32x4 breg[NT][4];
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int n = (nb * NT + j) * 32 + 4 * half + 8 * q;
-            breg[j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (n < p.Cd) breg[j][q] = *reinterpret_cast<const f32x4*>(p.bias + n);
-        }
-    v8 fw[NT][2][2];
-    float fb[8];
-#pragma unroll
-    for (int co = 0; co < 8; ++co) fb[co] = 0.f;
-    if (p.final_wfrag) {
-        const T* const fwp = reinterpret_cast<const T*>(p.final_wfrag);
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int hl = 0; hl < 2; ++hl)
-                    fw[j][s2][hl] = *reinterpret_cast<const v8*>(fwp + ((size_t)((j * 2 + s2) * 2 + hl) * 64 + lane) * 8);
-#pragma unroll
-        for (int co = 0; co < 8; ++co) fb[co] = co < p.final_cout ? p.final_b[co] : 0.f;
+    // ordinary (VGPR-destination) global loads happen only here, before the first DMA is issued
+    for (int idx = tid; idx < NT * 32; idx += WAVES * 64) {
+        const int n = nb * NT * 32 + idx;
+        wl[idx] = n < p.Cd ? p.bias[n] : 0.f;
     }
+    if (p.final_wfrag) {
+        if (tid < 8) wl[NT * 32 + tid] = tid < p.final_cout ? p.final_b[tid] : 0.f;
+        const T* const fwp = reinterpret_cast<const T*>(p.final_wfrag);
+        for (int k = wave; k < NT * 4; k += WAVES)
+            *reinterpret_cast<v8*>(fwl + (k * 64 + lane) * 16) = *reinterpret_cast<const v8*>(fwp + ((size_t)k * 64 + lane) * 8);
+    }
+    __syncthreads();
 
     const char* const wbase = reinterpret_cast<const char*>(p.wpack) + (size_t)nb * nstages * B_BYTES;
 
@@ -272,7 +341,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                 const bool ok = inst && hp >= 0 && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H &&
                                 (unsigned)x < (unsigned)p.W;
                 const char* src = reinterpret_cast<const char*>(p.zero);
+#ifdef SD_EXP_BLOCKED
+                if (ok) src = (c < p.nchunk0 ? (const char*)p.src0 : (const char*)p.src1) +
+                              (((size_t)cc * p.D * Hs * Ws + (size_t)(z * Hs + y) * Ws + x) * 32 + (hp & 1) * 16);
+#else
                 if (ok) src = sbase + (((size_t)(z * Hs + y) * Ws + x) * Cs + (hp & 1) * 8) * sizeof(T);
+#endif
                 glds16(src, inst ? dst + j * (WAVES * 1024) : ldsDummy);
             }
         }
@@ -297,9 +371,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
 #ifdef SD_TIMING
     long long tstamp[8];
     int tcount = 0;
-#define SD_T(i) do { if (tcount == (NSLOT > 0 ? 2 : 1)) tstamp[i] = __builtin_readcyclecounter(); } while (0)
+#define SD_T(i) do { if (tcount == SD_TB) tstamp[i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define SD_T(i) do {} while (0)
+#endif
+#ifndef SD_TS
+#define SD_TS 0
+#endif
+#ifndef SD_TB
+#define SD_TB 2      // probed block of the workgroup (1 = first)
 #endif
     int lb = block_of(0);
     if (lb < 0) return;
@@ -425,7 +505,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
 
     int gc = 0, gs = 0;   // chunk / stage counters across blocks (slot parity)
     for (int round = 0; lb >= 0; ++round) {
-        const int nlb = WRES ? block_of(round + 1) : -1;   // streamed-weight layers: one block per workgroup
+        const int nlb = fuse_up ? -1 : block_of(round + 1);   // (the fused up-conv variant computes one block)
         int nz0 = 0, ny0 = 0, nx0 = 0;
         if (nlb >= 0) coords(nlb, nz0, ny0, nx0);
 
@@ -435,60 +515,89 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = breg[j][r >> 2][r & 3];
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = wl[j * 32 + 4 * half + 8 * (r >> 2) + (r & 3)];
 #ifdef SD_TIMING
         ++tcount;
 #endif
         SD_T(0);
+#ifdef SD_RT
+        const long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
         int s = 0;
         for (int c = 0; c < nchunks; ++c, ++gc) {
             if constexpr (fuse_up) { if (c < p.nchunk0 && (c & 1) == 0) up_phase(c >> 1); }
             const char* const abuf = ldsA + (gc % NA) * A_BYTES;
 #pragma unroll 1
             for (int kz = 0; kz < KZ; ++kz, ++s, ++gs) {
+                if (s == SD_TS) SD_T(7);     // start of the probed stage
                 if (!WRES) {
+                    // next weight group / next halo chunk into the other buffer; at the end of a block these are
+                    // the first group and chunk of the workgroup's NEXT block, so its prologue hides behind the
+                    // last stage and the epilogue of this one
                     if (s + 1 < nstages) dma_weights(s + 1, (gs + 1) & 1);
-                    if (kz == 0 && c + 1 < nchunks && !(fuse_up && c + 1 < p.nchunk0))
-                        dma_halo(c + 1, (gc + 1) & 1, z0, y0, x0, true);
+                    else if (nlb >= 0) dma_weights(0, (gs + 1) & 1);
+                    if (kz == 0) {
+                        if (c + 1 < nchunks) {
+                            if (!(fuse_up && c + 1 < p.nchunk0)) dma_halo(c + 1, (gc + 1) & 1, z0, y0, x0, true);
+                        } else if (nlb >= 0) {
+                            dma_halo(0, (gc + 1) & 1, nz0, ny0, nx0, true);
+                        }
+                    }
                 } else if (kz == 0) {
                     dma_stream_next();           // chunk gc + NA - 1 of this workgroup's stream
                 }
-                if (s == 0) SD_T(1);     // after the DMA issue of the first stage
+                if (s == SD_TS) SD_T(1);     // after the DMA issue of the probed stage
                 const char* const bcur = ldsB + (WRES ? s : (gs & 1)) * B_BYTES + lane * 16;
                 const char* const acur = abuf + kz * SLICE;
-                // software-pipelined over the 9 taps: the fragments of tap t+1 are in flight while tap t's MFMAs run
+                // software-pipelined over the 9 taps: the fragments of tap t+1 are in flight while tap t's MFMAs run.
+                // The LDS reads and their counted waits are inline asm: left to the compiler the reads are sunk next
+                // to their use behind an lgkmcnt(0) (it prefers reusing the fragment registers), which idles the
+                // matrix pipe for one LDS latency per tap.  LDS returns in order, so lgkmcnt(MT + NT) after issuing
+                // tap t+1 means tap t has landed; `tie` makes the MFMAs depend on the post-wait values.
                 v8 xf[2][MT], wf[2][NT];
-                auto load_tap = [&](int t9, int buf) {
-                    const int ky = t9 / 3, kx = t9 % 3;
-                    const int tapoff = (ky * HX + kx) * 32;
+                const uint32_t aE = lds_addr(acur), bA = lds_addr(bcur);
+                uint32_t xaE[MT], xaO[MT];
 #pragma unroll
-                    for (int i = 0; i < MT; ++i)
-                        xf[buf][i] = *reinterpret_cast<const v8*>(acur + ((ky & 1) ? xoffO[i] : xoffE[i]) + tapoff);
+                for (int i = 0; i < MT; ++i) { xaE[i] = aE + xoffE[i]; xaO[i] = aE + xoffO[i]; }
+                auto load_tap = [&](auto tc) {
+                    constexpr int t9 = decltype(tc)::value, ky = t9 / 3, kx = t9 % 3, buf = t9 & 1;
+                    constexpr int tapoff = (ky * HX + kx) * 32;
 #pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        wf[buf][j] = *reinterpret_cast<const v8*>(bcur + (t9 * NT + j) * 1024);
+                    for (int i = 0; i < MT; ++i) ds_read16<tapoff>(xf[buf][i], (ky & 1) ? xaO[i] : xaE[i]);
+                    static_for<NT>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        ds_read16<(t9 * NT + j) * 1024>(wf[buf][j], bA);
+                    });
                 };
-                load_tap(0, 0);
+                load_tap(std::integral_constant<int, 0>{});
+                static_for<9>([&](auto tc) {
+                    constexpr int t9 = decltype(tc)::value, buf = t9 & 1;
+                    if constexpr (t9 + 1 < 9) {
+                        load_tap(std::integral_constant<int, t9 + 1>{});
+                        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT + NT));
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)");
+                    }
 #pragma unroll
-                for (int t9 = 0; t9 < 9; ++t9) {
-                    if (t9 + 1 < 9) load_tap(t9 + 1, (t9 + 1) & 1);
+                    for (int i = 0; i < MT; ++i) tie(xf[buf][i]);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) tie(wf[buf][j]);
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
                         for (int j = 0; j < NT; ++j)
-                            acc[i][j] = Act<T>::mfma(wf[t9 & 1][j], xf[t9 & 1][i], acc[i][j]);
-                }
-                if (s == 0) SD_T(2);     // after the MFMAs of the first stage
+                            acc[i][j] = Act<T>::mfma(wf[buf][j], xf[buf][i], acc[i][j]);
+                });
+                if (s == SD_TS) SD_T(2);     // after the MFMAs of the probed stage
                 // all of this wave's LDS reads done + the next chunk's DMA landed, then the workgroup barrier (raw
                 // s_barrier: __syncthreads() would drain every DMA in flight with a vmcnt(0))
                 asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WAITN) : "memory");
-                if (s == 0) SD_T(3);     // after the barrier of the first stage
+                if (s == SD_TS) SD_T(3);     // after the barrier of the probed stage
             }
         }
 
     SD_T(4);   // all stages done
     // ---- epilogue: + bias, ReLU, round to the storage type (kept in `acc` as the rounded value) ----------
-    using v4 = typename Act<T>::v4;
     bool valid[MT];
     size_t voxoff[MT];
 #pragma unroll
@@ -498,29 +607,62 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         voxoff[i] = ((size_t)(vz * p.H + vy) * p.W + vx) * p.Cd;
     }
     T* const dst = reinterpret_cast<T*>(p.dst);
-    v4 oq[MT][NT][4];          // rounded outputs as packed quads: channels cbase + 8q + 4*half + 0..3
+    // rounded outputs, packed two channels per register: pk[i][j][2q + h] = channels cbase + 8q + 4*half + 2h, +1.
+    // (VALU work is 4 cycles per wave64 instruction and the whole workgroup sits in this epilogue at once, so it is
+    // kept to one convert and one packed max per PAIR of values.)
+    unsigned pk[MT][NT][8];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int cbase = (nb * NT + j) * 32;
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int k = 0; k < 8; ++k)     // bias is already inside (accumulator init)
+                pk[i][j][k] = Act<T>::pack2(acc[i][j][2 * k], acc[i][j][2 * k + 1]);
+    if (p.relu) {                           // relu(round(x)) == round(relu(x)); uniform branch
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = acc[i][j][4 * q + e];             // bias is already inside (accumulator init)
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    oq[i][j][q][e] = (T)v;
-                }
-            if (p.store_main) {
-                v4 o[4] = {oq[i][j][0], oq[i][j][1], oq[i][j][2], oq[i][j][3]};
-                store_tile_rows<T>(o, dst + voxoff[i], valid[i], cbase, half, p.Cd);
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pk[i][j][k] = pk_max16(pk[i][j][k], 0u);
+    }
+#ifdef SD_T5_EARLY
+    SD_T(5);
+#endif
+    if (p.store_main) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#ifdef SD_EXP_DUMPSTORE
+            {   // (experiment) same bytes, fully coalesced WG-private destination
+                typedef __attribute__((ext_vector_type(4))) unsigned u4;
+                char* b = reinterpret_cast<char*>(p.dst) + (size_t)lb * (WAVES * 8192) + wave * 8192 + (i * NT + j) * 2048 + lane * 16;
+                *reinterpret_cast<u4*>(b) = u4{pk[i][j][0], pk[i][j][1], pk[i][j][2], pk[i][j][3]};
+                *reinterpret_cast<u4*>(b + 1024) = u4{pk[i][j][4], pk[i][j][5], pk[i][j][6], pk[i][j][7]};
             }
-        }
+#elif defined(SD_EXP_BLOCKED)
+            {   // (experiment, timing only) channel-blocked destination [C/16][vox][16]
+                typedef __attribute__((ext_vector_type(4))) unsigned u4;
+                unsigned a0x = pk[i][j][0], a0y = pk[i][j][1], a1x = pk[i][j][2], a1y = pk[i][j][3], a2x = pk[i][j][4], a2y = pk[i][j][5], a3x = pk[i][j][6], a3y = pk[i][j][7];
+                swap32x4(a0x, a2x, a0y, a2y, a1x, a3x, a1y, a3y);
+                const size_t nvox = (size_t)p.D * p.H * p.W;
+                char* b = reinterpret_cast<char*>(p.dst) + ((size_t)(((nb * NT + j) * 2 + half)) * nvox + voxoff[i] / p.Cd) * 32;
+                if (valid[i]) { *reinterpret_cast<u4*>(b) = u4{a0x, a0y, a2x, a2y}; *reinterpret_cast<u4*>(b + 16) = u4{a1x, a1y, a3x, a3y}; }
+            }
+#elif defined(SD_EXP_NOSTORE)
+                store_tile_rows_pk<T>(pk[i][j], dst + voxoff[i], valid[i] && pk[i][j][0] == 0x12345678u, (nb * NT + j) * 32, half, p.Cd);
+#else
+                store_tile_rows_pk<T>(pk[i][j], dst + voxoff[i], valid[i], (nb * NT + j) * 32, half, p.Cd);
+#endif
     }
 
+#ifndef SD_T5_EARLY
     SD_T(5);   // main store done
+#endif
     // ---- fused MaxPool(ceil_mode): (kz,2,2) window = {the wave's two tiles (3D)} x {lane^16 (y)} x {lane^1 (x)} ----
+    // Only planned behind a ReLU (sd_api.hip): all values are >= 0, so the packed integer max is the float max and
+    // voxels beyond the volume contribute 0.
     if (p.pool_dst) {
         T* const pdst = reinterpret_cast<T*>(p.pool_dst);
         const bool writer = (dy == 0) && ((dxl & 1) == 0);
@@ -531,16 +673,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
             const size_t po = ((size_t)(pz * p.pH + py) * p.pW + px) * p.Cd;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                v4 o[4];
+                unsigned m[8];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float m = valid[i] ? (float)oq[i][j][q][e] : -INFINITY;
-                        if (KZ == 3) m = fmaxf(m, valid[i | 1] ? (float)oq[i | 1][j][q][e] : -INFINITY);
-                        o[q][e] = (T)max_xor16(max_xor1(m));
-                    }
-                store_tile_rows<T>(o, pdst + po, writer && valid[i], (nb * NT + j) * 32, half, p.Cd);
+                for (int k = 0; k < 8; ++k) {
+                    m[k] = valid[i] ? pk[i][j][k] : 0u;
+                    if (KZ == 3) m[k] = pk_max16(m[k], valid[i | 1] ? pk[i | 1][j][k] : 0u);
+                }
+                pool_xy_pk8(m);
+                store_tile_rows_pk<T>(m, pdst + po, writer && valid[i], (nb * NT + j) * 32, half, p.Cd);
             }
         }
     }
@@ -565,14 +705,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                 for (int j = 0; j < NT; ++j)
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2) {
-                        v8 bfrag;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            bfrag[e] = oq[tp + i][j][2 * s2][e];
-                            bfrag[4 + e] = oq[tp + i][j][2 * s2 + 1][e];
-                        }
-                        lgt[i] = Act<T>::mfma(fw[j][s2][0], bfrag, lgt[i]);
-                        lgt[i] = Act<T>::mfma(fw[j][s2][1], bfrag, lgt[i]);
+                        typedef __attribute__((ext_vector_type(4))) unsigned u4;
+                        const unsigned* q4 = &pk[tp + i][j][4 * s2];          // quads 2*s2, 2*s2 + 1
+                        const v8 bfrag = __builtin_bit_cast(v8, u4{q4[0], q4[1], q4[2], q4[3]});
+                        const v8 fw0 = *reinterpret_cast<const v8*>(fwl + (((j * 2 + s2) * 2 + 0) * 64 + lane) * 16);
+                        const v8 fw1 = *reinterpret_cast<const v8*>(fwl + (((j * 2 + s2) * 2 + 1) * 64 + lane) * 16);
+                        lgt[i] = Act<T>::mfma(fw0, bfrag, lgt[i]);
+                        lgt[i] = Act<T>::mfma(fw1, bfrag, lgt[i]);
                     }
             }
             float l[8];
@@ -580,7 +719,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
             for (int e = 0; e < 4; ++e) {
                 // the class bias is added BEFORE the swap by a compiler-visible VALU op: an asm statement must not be
                 // the first reader of an MFMA result (hipcc pads no MFMA -> VALU hazard for inline asm consumers)
-                const float bmine = half ? fb[4 + e] : fb[e];
+                const float bmine = wl[NT * 32 + 4 * half + e];
                 unsigned a = __builtin_bit_cast(unsigned, lgt[0][e] + bmine);
                 unsigned b2 = __builtin_bit_cast(unsigned, lgt[1][e] + bmine);
                 swap32(a, b2);      // lower: a = own tile-tp classes 0-3, b2 = tile-tp classes 4-7 (from the upper lane)
@@ -622,9 +761,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
 
         SD_T(6);   // epilogue done
 #ifdef SD_TIMING
-        if (tcount == (NSLOT > 0 ? 2 : 1) && lane == 0 && p.dbg) {
+        if (tcount == SD_TB && lane == 0 && p.dbg) {
             long long* o = p.dbg + ((size_t)blockIdx.x * WAVES + wave) * 8;
-            for (int i = 0; i < 7; ++i) o[i] = tstamp[i];
+            for (int i = 0; i < 8; ++i) o[i] = tstamp[i];
+#ifdef SD_RT
+            o[4] = rt0; o[5] = __builtin_amdgcn_s_memrealtime();          // (probe) absolute 100 MHz ticks
+            o[6] = ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
         }
 #endif
         lb = nlb; z0 = nz0; y0 = ny0; x0 = nx0;
@@ -1100,20 +1243,22 @@ static inline int grid_for(long total, int per_block = 256, int cap = 256 * 16) 
 constexpr int SD_LDS_BYTES = 160 * 1024;
 constexpr int SD_NUM_CU = 256;
 
-template <int KZ, int NT, int WAVES, int MT, int NSLOT> static size_t conv_lds_bytes(int nstages, bool fuse_up = false) {
+template <int KZ, int NT, int WAVES, int MT, int NSLOT>
+static size_t conv_lds_bytes(int nstages, bool fuse_up = false, bool fuse_final = false) {
     using G = ConvGeo<KZ, WAVES, MT>;
     constexpr int NH = (G::BZ + KZ - 1) * (G::BY + 2) * (G::BX + 2);
     constexpr int A_BYTES = (NH * 2 + 63) / 64 * 1024;
     constexpr int UND = (KZ == 3 ? G::BZ / 2 + 2 : 1) * (G::BY / 2 + 2) * (G::BX / 2 + 2);
     constexpr int UBUF = (UND * 2 + 63) / 64 * 1024 + (KZ == 3 ? 8 : 4) * 1024;
-    return (size_t)(NSLOT > 0 ? NSLOT : 2) * A_BYTES + (size_t)(NSLOT > 0 ? nstages : 2) * 9 * NT * 1024 + 2048 + 64 +
-           1024 + (fuse_up ? 2 * UBUF : 0);
+    return (size_t)(NSLOT > 0 ? NSLOT : 2) * A_BYTES + (size_t)(NSLOT > 0 ? nstages : 2) * 9 * NT * 1024 +
+           SD_CONV_PARAM_BYTES + (fuse_final ? NT * 4096 : 0) + 1024 + (fuse_up ? 2 * UBUF : 0);
 }
 
 template <typename T, int KZ, int NT, int WAVES, int NSLOT, int MT = 2, bool FUP = false>
 static int launch_conv_k(ConvParams p, int NB, hipStream_t s) {
     using G = ConvGeo<KZ, WAVES, MT>;
-    const size_t lds = conv_lds_bytes<KZ, NT, WAVES, MT, NSLOT>((p.nchunk0 + p.nchunk1) * KZ, p.up_src != nullptr);
+    const size_t lds = conv_lds_bytes<KZ, NT, WAVES, MT, NSLOT>((p.nchunk0 + p.nchunk1) * KZ, p.up_src != nullptr,
+                                                                 p.final_wfrag != nullptr);
     p.nbx = (p.W + G::BX - 1) / G::BX; p.nby = (p.H + G::BY - 1) / G::BY; p.nbz = (p.D + G::BZ - 1) / G::BZ;
     static size_t attr_set = 0, occ_lds = 0;
     static int occ = 1;
@@ -1134,7 +1279,7 @@ static int launch_conv_k(ConvParams p, int NB, hipStream_t s) {
     const int wg_per_cu = std::min(occ, (int)(SD_LDS_BYTES / lds));
     const int cap = std::max(8, SD_NUM_CU * wg_per_cu / NB / 8 * 8);
     static const bool no_persist = getenv("SD_NO_PERSIST") != nullptr;   // debugging aid
-    dim3 grid((NSLOT > 0 && !no_persist) ? std::min(nsb, cap) : nsb, NB), block(WAVES * 64);
+    dim3 grid((!FUP && !no_persist) ? std::min(nsb, cap) : nsb, NB), block(WAVES * 64);
     hipLaunchKernelGGL(kern, grid, block, lds, s, p);
     return SD_LAUNCH_CHECK();
 }
@@ -1153,10 +1298,10 @@ static int launch_conv_knt(const ConvParams& p, int NB, hipStream_t s) {
     if (p.up_src)    // fused up-convolution producer: streamed-weight form only
         return big ? launch_conv_k<T, KZ, NT, 8, 0, 2, true>(p, NB, s) : launch_conv_k<T, KZ, NT, 4, 0, 2, true>(p, NB, s);
     if (big) {
-        if (conv_lds_bytes<KZ, NT, 8, 2, 2>(nstages) <= 96 * 1024) return launch_conv_k<T, KZ, NT, 8, 2>(p, NB, s);
+        if (conv_lds_bytes<KZ, NT, 8, 2, 2>(nstages, false, p.final_wfrag != nullptr) <= 96 * 1024) return launch_conv_k<T, KZ, NT, 8, 2>(p, NB, s);
         return launch_conv_k<T, KZ, NT, 8, 0>(p, NB, s);
     }
-    if (conv_lds_bytes<KZ, NT, 4, 2, 2>(nstages) <= 80 * 1024) return launch_conv_k<T, KZ, NT, 4, 2>(p, NB, s);
+    if (conv_lds_bytes<KZ, NT, 4, 2, 2>(nstages, false, p.final_wfrag != nullptr) <= 80 * 1024) return launch_conv_k<T, KZ, NT, 4, 2>(p, NB, s);
     return launch_conv_k<T, KZ, NT, 4, 0>(p, NB, s);
 }
 template <typename T>
