@@ -102,12 +102,14 @@ def main():
     ap.add_argument('--tile', type=int, default=128)
     ap.add_argument('--arch', default='semseg_spine')
     ap.add_argument('--act', default='bf16', choices=['bf16', 'f16'])
+    ap.add_argument('--batch', type=int, default=0, help='tiles per sd_forward_batch launch set (0 = all tiles of a step)')
+    ap.add_argument('--streams', type=int, default=1, help='HIP streams the batches of a step alternate over')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
     from syconn_amd import _lib as L
     from syconn_amd import parallel as par
-    from syconn_amd.engine import DenseModel, postproc_labels
+    from syconn_amd.engine import DenseModel, StreamRing, postproc_labels
     from oracle.unet_ref import build_unet   # architecture definition + seeded random init (no trained weights exist)
 
     rank, world, local_rank = par.init_distributed()
@@ -128,7 +130,10 @@ def main():
 
     S, T = args.tile, args.tiles
     tiles = torch.from_numpy(synthetic_em_tiles(T, S, seed=1 + rank)).to(dev)
-    probs = torch.empty((ncls, S, S, S), dtype=torch.uint8, device=dev)
+    B = T if args.batch <= 0 else min(args.batch, T)
+    ring = StreamRing(dev, args.streams)         # batch i runs on stream i % n with its own workspace / probability buffer
+    probs_k = [torch.empty((B, ncls, S, S, S), dtype=torch.uint8, device=dev) for _ in range(ring.n)]
+    probs = probs_k[0][0]
     # label volumes are double-buffered so that the gather of step k (RCCL, asynchronous) overlaps step k+1's compute
     labels = [torch.empty((T, S, S, S), dtype=torch.uint8, device=dev) for _ in range(2)]
     recv = [torch.empty((world, T, S, S, S), dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
@@ -142,9 +147,14 @@ def main():
         if pending[k] is not None:
             pending[k].wait()
             pending[k] = None
-        for t in range(T):
-            dm.forward(tiles[t], L.SD_OUT_PROBS_U8, probs)
-            postproc_labels(probs, ids, thr, out=labels[k][t])
+        with ring:
+            for i, t0 in enumerate(range(0, T, B)):
+                n = min(B, T - t0)
+                with ring.stream(i):
+                    pk = probs_k[ring.slot(i)]
+                    dm.forward_batch(tiles[t0:t0 + n], L.SD_OUT_PROBS_U8, pk[:n], slot=ring.slot(i))
+                    for j in range(n):
+                        postproc_labels(pk[j], ids, thr, out=labels[k][t0 + j])
         if world > 1:
             _, pending[k] = par.gather_to_root(labels[k], dst=0, async_op=True, out=recv[k])
 
@@ -157,7 +167,8 @@ def main():
     for _ in range(args.warmup):
         step()
     drain()
-    dm.profile(T * args.steps)                   # event ring: every forward of the timed region keeps its own slot
+    nbatch = (T + B - 1) // B                    # launch sets per step (the last one may hold fewer tiles)
+    dm.profile(nbatch * args.steps)              # event ring: every launch set of the timed region keeps its own slot
     torch.cuda.synchronize(dev)
     par.barrier()
     torch.cuda.synchronize(dev)
@@ -175,12 +186,13 @@ def main():
 
     # ---- per-kernel timings from the HIP events recorded inside the timed region (rank 0) ----------------------
     per_op = np.zeros(dm.n_ops)
-    n_fw = T * args.steps
+    n_fw = nbatch * args.steps
     for k in range(n_fw):
         per_op += dm.profile_read(k)
     per_op /= n_fw                                # ms per launch, averaged over the timed region
+    tiles_per_launch = T / nbatch                 # average tiles one launch processes
     dm.profile(0)
-    rows = layer_accounting(dm.ops, L, S, S, S)
+    rows = [(n, f * tiles_per_launch, b * tiles_per_launch) for n, f, b in layer_accounting(dm.ops, L, S, S, S)]
     groups = {}
     for (name, fl, by), ms in zip(rows, per_op):
         g = groups.setdefault(name, [0.0, 0.0, 0.0, 0])
@@ -195,7 +207,8 @@ def main():
     else:
         roof = {'kernel': dom, 'bound': 'hbm', 'achieved': by / (ms * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s'}
     roof['frac'] = roof['achieved'] / roof['peak']
-    roof['launches_per_tile'] = nlaunch
+    roof['launches_per_forward'] = nlaunch
+    roof['tiles_per_launch'] = tiles_per_launch
     roof['avg_launch_us'] = ms / nlaunch * 1e3
     roof['algorithmic_per_launch'] = (fl if roof['bound'] == 'mfma' else by) / nlaunch
     roof['traffic'] = None
@@ -203,13 +216,17 @@ def main():
     if os.path.isfile(tr_file):
         tr = json.load(open(tr_file))
         if tr.get('arch') == args.arch and tr.get('tile') == S and tr.get('act') == args.act:
-            roof['traffic'] = tr.get('hbm_bytes_per_launch', {}).get(dom)
+            t1 = tr.get('hbm_bytes_per_launch', {}).get(dom)      # measured with tr['tiles_per_launch'] tiles per launch
+            roof['traffic'] = None if t1 is None else t1 * tiles_per_launch / float(tr.get('tiles_per_launch', 1))
             roof['traffic_note'] = tr.get('note')
     # whole-network view the north star asks for: algorithmic bytes of one tile / device time of one tile / 8 TB/s
+    b_alg /= tiles_per_launch
+    kern_ms /= tiles_per_launch
+    rows = [(n, f / tiles_per_launch, b / tiles_per_launch) for n, f, b in rows]
     net = {'b_alg_bytes_per_tile': b_alg, 'gflop_per_tile': sum(r[1] for r in rows) / 1e9,
            'kernel_ms_per_tile': kern_ms, 'hbm_roofline_frac': b_alg / (kern_ms * 1e-3) / (PEAK_HBM_GBS * 1e9),
            'effective_tflops': sum(r[1] for r in rows) / (kern_ms * 1e-3) / 1e12,
-           'per_kernel_ms': {k: round(v[2], 4) for k, v in groups.items()}}
+           'per_kernel_ms_per_tile': {k: round(v[2] / tiles_per_launch, 4) for k, v in groups.items()}}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -235,9 +252,11 @@ def main():
                 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
                 'vs_baseline': None, 'dtype': args.act, 'data': 'synthetic',
-                'config': {'workload': f'BASELINE configs[1]: {args.arch} 3D U-Net, one {S}^3 uint8 tile per forward, '
-                                       f'{T} tiles per GPU per step, random-init weights',
+                'config': {'workload': f'BASELINE configs[1]: {args.arch} 3D U-Net on {S}^3 uint8 tiles, {T} tiles per GPU '
+                                       f'per step in launch sets of {B} (sd_forward_batch), random-init weights',
+                           'tiles_per_launch_set': B,
                            'tiles_per_gpu_per_step': T, 'tile': [S, S, S], 'parallelism': f'tile-sharded x{world}',
+                           'hip_streams_per_gpu': ring.n,
                            'collective': 'gather of uint8 labels to rank 0' if world > 1 else 'none'},
                 'roofline': roof, 'network': net, 'cpu_baseline': cpu}
         print(json.dumps(line))

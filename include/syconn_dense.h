@@ -86,7 +86,8 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* weights, size
                     sd_model** out);
 void sd_model_destroy(sd_model* m);
 
-/* Workspace bytes sd_forward needs for a (D,H,W) input tile; 0 on error. */
+/* Workspace bytes sd_forward needs for a (D,H,W) input tile (a multiple of 256); 0 on error.  sd_forward_batch needs
+ * N times this value. */
 size_t sd_workspace_bytes(const sd_model* m, int D, int H, int W);
 
 /* One forward pass of the network on one tile = Predictor._predict (row P4: model(inp) [+ softmax(1)]).
@@ -94,6 +95,13 @@ size_t sd_workspace_bytes(const sd_model* m, int D, int H, int W);
  * out_dev: (cout_final, D, H, W) planar, float32 or uint8 according to out_kind. */
 int sd_forward(sd_model* m, const void* in_dev, int in_dtype, int D, int H, int W, void* out_dev, int out_kind,
                void* workspace_dev, size_t ws_bytes, void* stream);
+
+/* The same for N independent tiles of one shape in ONE set of launches = Predictor.predict's batch split
+ * (`batch_size`, row P2): in_dev (N,D,H,W), out_dev (N,cout_final,D,H,W), both dense; workspace N *
+ * sd_workspace_bytes(D,H,W).  Every kernel simply sees N times as many blocks, which fills the 256 CUs in the deep,
+ * small layers of the network and amortises launch gaps; results are identical to N sd_forward calls. */
+int sd_forward_batch(sd_model* m, const void* in_dev, int in_dtype, int N, int D, int H, int W, void* out_dev,
+                     int out_kind, void* workspace_dev, size_t ws_bytes, void* stream);
 
 /* tiled_apply helpers (row P3).  Gather: copy the (TD,TH,TW) box starting at (oz,oy,ox) -- which may lie partly
  * outside the (VD,VH,VW) volume -- into a dense tile, zeros outside (zero-padded tile extraction).

@@ -467,7 +467,7 @@ size_t sd_workspace_bytes(const sd_model* m, int D, int H, int W) {
     std::vector<Dims> dims;
     std::vector<size_t> off;
     if (infer_shapes(m, D, H, W, dims) != SD_OK) return 0;
-    return plan_workspace(m, dims, off);
+    return (plan_workspace(m, dims, off) + 255) & ~(size_t)255;
 }
 
 int sd_profile_enable(sd_model* m, int n_slots) {
@@ -494,14 +494,24 @@ int sd_profile_read(sd_model* m, int slot, float* ms, int n_ops) {
 
 int sd_forward(sd_model* m, const void* in_dev, int in_dtype, int D, int H, int W, void* out_dev, int out_kind,
                void* ws, size_t ws_bytes, void* stream) {
+    return sd_forward_batch(m, in_dev, in_dtype, 1, D, H, W, out_dev, out_kind, ws, ws_bytes, stream);
+}
+
+int sd_forward_batch(sd_model* m, const void* in_dev, int in_dtype, int N, int D, int H, int W, void* out_dev,
+                     int out_kind, void* ws, size_t ws_bytes, void* stream) {
     if (!m || !in_dev || !out_dev || !ws) return fail(SD_ERR_INVALID, "null argument");
+    if (N <= 0 || N > 65535) return fail(SD_ERR_INVALID, "bad batch size");
     if (in_dtype != SD_U8 && in_dtype != SD_F32) return fail(SD_ERR_INVALID, "in_dtype must be SD_U8 or SD_F32");
     if (out_kind < 0 || out_kind > 2) return fail(SD_ERR_INVALID, "bad out_kind");
     if (D <= 0 || H <= 0 || W <= 0) return fail(SD_ERR_INVALID, "bad tile shape");
     int rc = infer_shapes(m, D, H, W, m->dims);
     if (rc != SD_OK) return rc;
     const size_t need = plan_workspace(m, m->dims, m->buf_off);
-    if (need > ws_bytes) return fail(SD_ERR_NOMEM, "workspace too small");
+    // tile t of a batch uses [t*tstride, t*tstride + need) of the workspace, its input / output follow tile 0's
+    const size_t tstride = (need + 255) & ~(size_t)255;
+    if ((size_t)N * tstride > ws_bytes) return fail(SD_ERR_NOMEM, "workspace too small");
+    const size_t in_tstride = (size_t)D * H * W * (in_dtype == SD_U8 ? 1 : 4);
+    const size_t out_tstride = (size_t)m->final_cout * D * H * W * (out_kind == SD_OUT_PROBS_U8 ? 1 : 4);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     char* const wsb = reinterpret_cast<char*>(ws);
     auto bufp = [&](int b) -> void* { return wsb + m->buf_off[b]; };
@@ -526,6 +536,7 @@ int sd_forward(sd_model* m, const void* in_dev, int in_dtype, int D, int H, int 
                 p.wpack = reinterpret_cast<const float*>(m->dev_blob + op.wpack_off);
                 p.bias = reinterpret_cast<const float*>(m->dev_blob + op.bias_off);
                 p.relu = d.relu;
+                p.batch = N; p.tstride = tstride; p.in_tstride = in_tstride;
                 p.nbx = (o.w + SD_BX - 1) / SD_BX; p.nby = (o.h + BY - 1) / BY; p.nbz = (o.d + BZ - 1) / BZ;
                 rc = launch_first(p, m->act_dtype, in_dtype, d.kz, s);
             } else {
@@ -544,6 +555,7 @@ int sd_forward(sd_model* m, const void* in_dev, int in_dtype, int D, int H, int 
                 p.bias = reinterpret_cast<const float*>(m->dev_blob + op.bias_off);
                 p.relu = d.relu; p.zero = m->dev_zero;
                 p.store_main = 1;
+                p.batch = N; p.tstride = tstride; p.out_tstride = out_tstride;
 #ifdef SD_TIMING
                 p.dbg = (getenv("SD_TIMING_OP") && atoi(getenv("SD_TIMING_OP")) == (int)i) ? reinterpret_cast<long long*>(wsb + m->buf_off[1]) : nullptr;
 #endif
@@ -578,6 +590,7 @@ int sd_forward(sd_model* m, const void* in_dev, int in_dtype, int D, int H, int 
             const Dims a = m->dims[d.src0], o = m->dims[d.dst];
             p.src = bufp(d.src0); p.dst = bufp(d.dst); p.C = m->bufCp[d.src0];
             p.D = a.d; p.H = a.h; p.W = a.w; p.Do = o.d; p.Ho = o.h; p.Wo = o.w; p.kz = d.kz;
+            p.batch = N; p.tstride = tstride;
             rc = launch_pool(p, m->act_dtype, s);
             break;
         }
@@ -590,6 +603,7 @@ int sd_forward(sd_model* m, const void* in_dev, int in_dtype, int D, int H, int 
             p.wpack = m->dev_blob + op.wpack_off;
             p.bias = reinterpret_cast<const float*>(m->dev_blob + op.bias_off);
             p.relu = d.relu; p.ntot = d.kz * 4 * p.Cd;
+            p.batch = N; p.tstride = tstride;
             rc = launch_upconv(p, m->act_dtype, op.NB, s);
             break;
         }
@@ -605,6 +619,7 @@ int sd_forward(sd_model* m, const void* in_dev, int in_dtype, int D, int H, int 
             p.sums = reinterpret_cast<double*>(wsb);
             p.scale_shift = reinterpret_cast<float*>(wsb + (size_t)2 * p.C * 8);
             p.relu = d.relu;
+            p.batch = N; p.tstride = tstride;
             rc = launch_groupnorm(p, m->act_dtype, s);
             break;
         }
@@ -616,6 +631,7 @@ int sd_forward(sd_model* m, const void* in_dev, int in_dtype, int D, int H, int 
             p.bias = reinterpret_cast<const float*>(m->dev_blob + op.bias_off);
             p.cout = d.cout; p.out = out_dev; p.out_kind = out_kind;
             p.nvox = (long)a.d * a.h * a.w;
+            p.batch = N; p.tstride = tstride; p.out_tstride = out_tstride;
             if (a.d != D || a.h != H || a.w != W) return fail(SD_ERR_INVALID, "final layer shape != input shape");
             rc = launch_final(p, m->act_dtype, s);
             break;

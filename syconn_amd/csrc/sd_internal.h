@@ -6,6 +6,10 @@
 
 // Activation tensors are voxel-major / channel-minor: element (z,y,x,c) at ((z*H + y)*W + x)*C + c, with C the
 // padded channel stride (multiple of 16).  A "chunk" is 16 consecutive channels = one MFMA k-step.
+// Batched launches: every kernel can process `batch` independent tiles in ONE launch.  Tile t uses the workspace at
+// byte offset t*tstride (all tiles share one workspace layout, so the same offset applies to every activation
+// buffer and scratch pointer of a launch); the network input / final output of tile t sit t*in_tstride /
+// t*out_tstride bytes after tile 0's.
 constexpr int SD_CHUNK = 16;
 constexpr int SD_CONV_PARAM_BYTES = 512;     // k_conv_mfma LDS constants: folded bias (<= 96 floats) + 8 class biases
 
@@ -44,6 +48,7 @@ struct ConvParams {
     const float* up_bias;   // folded bias per up channel, padded to ceil(nchunk0/2)*32
     int up_relu;
     long long* dbg;         // SD_TIMING builds: per-wave cycle stamps
+    int batch; size_t tstride, out_tstride;
 };
 
 struct FirstParams {
@@ -55,6 +60,7 @@ struct FirstParams {
     const float* bias;   // padded to ntile*32
     int relu;
     int nbx, nby, nbz;
+    int batch; size_t tstride, in_tstride;
 };
 
 struct UpconvParams {
@@ -68,6 +74,7 @@ struct UpconvParams {
     const float* bias; // per n = tap*Cd + co, padded to NB*64
     int relu;
     int ntot;          // ntaps*Cd
+    int batch; size_t tstride;
 };
 
 struct PoolParams {
@@ -76,6 +83,7 @@ struct PoolParams {
     int D, H, W;       // src dims
     int Do, Ho, Wo;    // dst dims
     int kz;            // 1 or 2
+    int batch; size_t tstride;
 };
 
 struct FinalParams {
@@ -86,6 +94,7 @@ struct FinalParams {
     void* out;         // planar (cout, nvox)
     int out_kind;
     long nvox;
+    int batch; size_t tstride, out_tstride;
 };
 
 struct GnParams {
@@ -98,6 +107,7 @@ struct GnParams {
     double* sums;              // [2*C] workspace (sum, sumsq)
     float* scale_shift;        // [2*C]
     int relu;
+    int batch; size_t tstride;
 };
 
 int launch_conv(const ConvParams& p, int act_dtype, int KZ, int NT, int NB, hipStream_t s);

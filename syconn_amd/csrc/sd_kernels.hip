@@ -144,16 +144,8 @@ __device__ __forceinline__ void store_tile_rows(typename Act<T>::v4 (&o)[4], T* 
     x = a1.x; { unsigned y = a3.x; swap32(x, y); a1.x = x; a3.x = y; }
     x = a1.y; { unsigned y = a3.y; swap32(x, y); a1.y = x; a3.y = y; }
     const int n0 = cbase + half * 16;
-#if defined(SD_EXP_NOSTORE)
-    if (valid && n0 < Cd && a0.x == 0x12345678u) { u4 v = {a0.x, a0.y, a2.x, a2.y}; *reinterpret_cast<u4*>(vox + n0) = v; }
-    if (valid && n0 + 8 < Cd && a1.x == 0x12345678u) { u4 v = {a1.x, a1.y, a3.x, a3.y}; *reinterpret_cast<u4*>(vox + n0 + 8) = v; }
-#elif defined(SD_EXP_NT)
-    if (valid && n0 < Cd) { u4 v = {a0.x, a0.y, a2.x, a2.y}; __builtin_nontemporal_store(v, reinterpret_cast<u4*>(vox + n0)); }
-    if (valid && n0 + 8 < Cd) { u4 v = {a1.x, a1.y, a3.x, a3.y}; __builtin_nontemporal_store(v, reinterpret_cast<u4*>(vox + n0 + 8)); }
-#else
     if (valid && n0 < Cd) { u4 v = {a0.x, a0.y, a2.x, a2.y}; *reinterpret_cast<u4*>(vox + n0) = v; }
     if (valid && n0 + 8 < Cd) { u4 v = {a1.x, a1.y, a3.x, a3.y}; *reinterpret_cast<u4*>(vox + n0 + 8) = v; }
-#endif
 }
 
 // Same, from the packed form pk[2q + h] = channels (cbase + 8q + 4*(lane>>5) + 2h, +1) of voxel (lane&31).
@@ -315,22 +307,25 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         hpack[j] = (idx < NH * 2) ? ((hz << 20) | (hy << 10) | (hx << 1) | ((idx & 1) ^ (hy & 1))) : -1;
     }
     // logical block of (round, this workgroup); -1 when the round has no block for it
+    const int nsb_all = nsb * p.batch;      // the tiles of a batched launch are simply more blocks
     auto block_of = [&](int round) -> int {
         const int base = round * gsz;
-        const int n = min(gsz, nsb - base);
+        const int n = min(gsz, nsb_all - base);
         return ((int)blockIdx.x < n) ? base + xcd_remap(blockIdx.x, n) : -1;
     };
-    auto coords = [&](int lb, int& z0, int& y0, int& x0) {
+    auto coords = [&](int lb, int& z0, int& y0, int& x0, int& tile) {
+        tile = lb / nsb;
+        lb -= tile * nsb;
         x0 = (lb % p.nbx) * BX; y0 = ((lb / p.nbx) % p.nby) * BY; z0 = (lb / (p.nbx * p.nby)) * BZ;
     };
     // DMA chunk c of the block at (z0,y0,x0) into halo slot `slot`; real == false issues the same number of
     // instructions against the dummy slot (keeps the per-wave DMA count per chunk constant for the counted waits)
-    auto dma_halo = [&](int c, int slot, int z0, int y0, int x0, bool real) {
+    auto dma_halo = [&](int c, int slot, int z0, int y0, int x0, int tile, bool real) {
         const char* sbase;
         int Cs, Hs, Ws, cc;
         if (c < p.nchunk0) { sbase = (const char*)p.src0; Cs = p.C0; Hs = p.H0; Ws = p.W0; cc = c; }
         else { sbase = (const char*)p.src1; Cs = p.C1; Hs = p.H1; Ws = p.W1; cc = c - p.nchunk0; }
-        sbase += (size_t)cc * SD_CHUNK * sizeof(T);
+        sbase += (size_t)cc * SD_CHUNK * sizeof(T) + (size_t)tile * p.tstride;
         char* dst = ldsA + slot * A_BYTES + wave * 1024;
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
@@ -341,12 +336,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                 const bool ok = inst && hp >= 0 && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H &&
                                 (unsigned)x < (unsigned)p.W;
                 const char* src = reinterpret_cast<const char*>(p.zero);
-#ifdef SD_EXP_BLOCKED
-                if (ok) src = (c < p.nchunk0 ? (const char*)p.src0 : (const char*)p.src1) +
-                              (((size_t)cc * p.D * Hs * Ws + (size_t)(z * Hs + y) * Ws + x) * 32 + (hp & 1) * 16);
-#else
                 if (ok) src = sbase + (((size_t)(z * Hs + y) * Ws + x) * Cs + (hp & 1) * 8) * sizeof(T);
-#endif
                 glds16(src, inst ? dst + j * (WAVES * 1024) : ldsDummy);
             }
         }
@@ -354,16 +344,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     // chunk number f of this workgroup's stream (f = round * nchunks + c) -> ring slot f % NA
     // The stream position is carried incrementally (chunk within block, block coordinates) so that the integer
     // divisions of block_of / coords run once per BLOCK, not once per chunk.
-    int sf_c = 0, sf_round = 0, sf_slot = 0, sf_z = 0, sf_y = 0, sf_x = 0;
+    int sf_c = 0, sf_round = 0, sf_slot = 0, sf_z = 0, sf_y = 0, sf_x = 0, sf_t = 0;
     bool sf_ok = false;
     auto stream_block = [&]() {
         const int lbf = block_of(sf_round);
         sf_ok = lbf >= 0;
-        if (sf_ok) coords(lbf, sf_z, sf_y, sf_x);
+        if (sf_ok) coords(lbf, sf_z, sf_y, sf_x, sf_t);
     };
     auto dma_stream_next = [&]() {
         if (sf_c == 0) stream_block();
-        dma_halo(sf_c, sf_slot, sf_z, sf_y, sf_x, sf_ok);
+        dma_halo(sf_c, sf_slot, sf_z, sf_y, sf_x, sf_t, sf_ok);
         if (++sf_c == nchunks) { sf_c = 0; ++sf_round; }
         if (++sf_slot == NA) sf_slot = 0;
     };
@@ -383,8 +373,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
 #endif
     int lb = block_of(0);
     if (lb < 0) return;
-    int z0, y0, x0;
-    coords(lb, z0, y0, x0);
+    int z0, y0, x0, tn;
+    coords(lb, z0, y0, x0, tn);
 
     // ---- fused ConvTranspose3d(k = s = (kz,2,2)) producer --------------------------------------------------------
     // Up-voxel (z,y,x) = W[:, :, z&1, y&1, x&1]^T . dec[z>>1, y>>1, x>>1]: one dense GEMM per tap.  The halo voxels of
@@ -399,7 +389,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     constexpr int UPT = 3;                                 // tiles accumulated per pass (register budget)
     constexpr int UNPASS = (UTPW + UPT - 1) / UPT;
     auto up_phase = [&](int k) {
-        const char* const dsrc = reinterpret_cast<const char*>(p.up_src);
+        const char* const dsrc = reinterpret_cast<const char*>(p.up_src) + (size_t)tn * p.tstride;
         const int zd0 = (KZ == 3) ? (z0 >> 1) - 1 : z0, yd0 = (y0 >> 1) - 1, xd0 = (x0 >> 1) - 1;
         auto dma_up = [&](int kd, int buf) {
             char* const base = ldsU + buf * UBUF;
@@ -499,15 +489,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         for (int f = 0; f < NA - 1; ++f) dma_stream_next();
     } else {
         dma_weights(0, 0);
-        if (!fuse_up) dma_halo(0, 0, z0, y0, x0, true);
+        if (!fuse_up) dma_halo(0, 0, z0, y0, x0, tn, true);
     }
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WAITN) : "memory");
 
     int gc = 0, gs = 0;   // chunk / stage counters across blocks (slot parity)
     for (int round = 0; lb >= 0; ++round) {
         const int nlb = fuse_up ? -1 : block_of(round + 1);   // (the fused up-conv variant computes one block)
-        int nz0 = 0, ny0 = 0, nx0 = 0;
-        if (nlb >= 0) coords(nlb, nz0, ny0, nx0);
+        int nz0 = 0, ny0 = 0, nx0 = 0, ntn = 0;
+        if (nlb >= 0) coords(nlb, nz0, ny0, nx0, ntn);
 
         f32x16 acc[MT][NT];
 #pragma unroll
@@ -538,9 +528,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                     else if (nlb >= 0) dma_weights(0, (gs + 1) & 1);
                     if (kz == 0) {
                         if (c + 1 < nchunks) {
-                            if (!(fuse_up && c + 1 < p.nchunk0)) dma_halo(c + 1, (gc + 1) & 1, z0, y0, x0, true);
+                            if (!(fuse_up && c + 1 < p.nchunk0)) dma_halo(c + 1, (gc + 1) & 1, z0, y0, x0, tn, true);
                         } else if (nlb >= 0) {
-                            dma_halo(0, (gc + 1) & 1, nz0, ny0, nx0, true);
+                            dma_halo(0, (gc + 1) & 1, nz0, ny0, nx0, ntn, true);
                         }
                     }
                 } else if (kz == 0) {
@@ -606,7 +596,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         valid[i] = vz < p.D && vy < p.H && vx < p.W;
         voxoff[i] = ((size_t)(vz * p.H + vy) * p.W + vx) * p.Cd;
     }
-    T* const dst = reinterpret_cast<T*>(p.dst);
+    T* const dst = reinterpret_cast<T*>(reinterpret_cast<char*>(p.dst) + (size_t)tn * p.tstride);
     // rounded outputs, packed two channels per register: pk[i][j][2q + h] = channels cbase + 8q + 4*half + 2h, +1.
     // (VALU work is 4 cycles per wave64 instruction and the whole workgroup sits in this epilogue at once, so it is
     // kept to one convert and one packed max per PAIR of values.)
@@ -634,27 +624,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
-#ifdef SD_EXP_DUMPSTORE
-            {   // (experiment) same bytes, fully coalesced WG-private destination
-                typedef __attribute__((ext_vector_type(4))) unsigned u4;
-                char* b = reinterpret_cast<char*>(p.dst) + (size_t)lb * (WAVES * 8192) + wave * 8192 + (i * NT + j) * 2048 + lane * 16;
-                *reinterpret_cast<u4*>(b) = u4{pk[i][j][0], pk[i][j][1], pk[i][j][2], pk[i][j][3]};
-                *reinterpret_cast<u4*>(b + 1024) = u4{pk[i][j][4], pk[i][j][5], pk[i][j][6], pk[i][j][7]};
-            }
-#elif defined(SD_EXP_BLOCKED)
-            {   // (experiment, timing only) channel-blocked destination [C/16][vox][16]
-                typedef __attribute__((ext_vector_type(4))) unsigned u4;
-                unsigned a0x = pk[i][j][0], a0y = pk[i][j][1], a1x = pk[i][j][2], a1y = pk[i][j][3], a2x = pk[i][j][4], a2y = pk[i][j][5], a3x = pk[i][j][6], a3y = pk[i][j][7];
-                swap32x4(a0x, a2x, a0y, a2y, a1x, a3x, a1y, a3y);
-                const size_t nvox = (size_t)p.D * p.H * p.W;
-                char* b = reinterpret_cast<char*>(p.dst) + ((size_t)(((nb * NT + j) * 2 + half)) * nvox + voxoff[i] / p.Cd) * 32;
-                if (valid[i]) { *reinterpret_cast<u4*>(b) = u4{a0x, a0y, a2x, a2y}; *reinterpret_cast<u4*>(b + 16) = u4{a1x, a1y, a3x, a3y}; }
-            }
-#elif defined(SD_EXP_NOSTORE)
-                store_tile_rows_pk<T>(pk[i][j], dst + voxoff[i], valid[i] && pk[i][j][0] == 0x12345678u, (nb * NT + j) * 32, half, p.Cd);
-#else
                 store_tile_rows_pk<T>(pk[i][j], dst + voxoff[i], valid[i], (nb * NT + j) * 32, half, p.Cd);
-#endif
     }
 
 #ifndef SD_T5_EARLY
@@ -664,7 +634,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     // Only planned behind a ReLU (sd_api.hip): all values are >= 0, so the packed integer max is the float max and
     // voxels beyond the volume contribute 0.
     if (p.pool_dst) {
-        T* const pdst = reinterpret_cast<T*>(p.pool_dst);
+        T* const pdst = reinterpret_cast<T*>(reinterpret_cast<char*>(p.pool_dst) + (size_t)tn * p.tstride);
         const bool writer = (dy == 0) && ((dxl & 1) == 0);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -745,12 +715,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
             const size_t v = (half ? voxoff[tp + 1] : voxoff[tp]) / p.Cd;
             if (vmine) {
                 if (p.final_kind == SD_OUT_PROBS_U8) {
-                    uint8_t* out = reinterpret_cast<uint8_t*>(p.final_out);
+                    uint8_t* out = reinterpret_cast<uint8_t*>(p.final_out) + (size_t)tn * p.out_tstride;
 #pragma unroll
                     for (int co = 0; co < 8; ++co)
                         if (co < p.final_cout) out[(size_t)co * nvox + v] = (uint8_t)(l[co] * 255.f);
                 } else {
-                    float* out = reinterpret_cast<float*>(p.final_out);
+                    float* out = reinterpret_cast<float*>(reinterpret_cast<char*>(p.final_out) + (size_t)tn * p.out_tstride);
 #pragma unroll
                     for (int co = 0; co < 8; ++co)
                         if (co < p.final_cout) out[(size_t)co * nvox + v] = l[co];
@@ -770,7 +740,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
 #endif
         }
 #endif
-        lb = nlb; z0 = nz0; y0 = ny0; x0 = nx0;
+        lb = nlb; z0 = nz0; y0 = ny0; x0 = nx0; tn = ntn;
     }
 }
 
@@ -792,7 +762,7 @@ __global__ __launch_bounds__(256) void k_conv_first(const FirstParams p) {
     const int lb = xcd_remap(blockIdx.x, nsb);
     const int bx = lb % p.nbx, by = (lb / p.nbx) % p.nby, bz = lb / (p.nbx * p.nby);
     const int x0 = bx * BX, y0 = by * BY, z0 = bz * BZ;
-    const IN* const in = reinterpret_cast<const IN*>(p.in);
+    const IN* const in = reinterpret_cast<const IN*>(reinterpret_cast<const char*>(p.in) + blockIdx.z * p.in_tstride);
 
     for (int i = tid; i < NH; i += 256) {
         const int hx = i % HX, hy = (i / HX) % HY, hz = i / (HX * HY);
@@ -817,7 +787,7 @@ __global__ __launch_bounds__(256) void k_conv_first(const FirstParams p) {
         const int kz = tap / 9, ky = (tap % 9) / 3, kx = tap % 3;
         toff[s] = (kz * HY + ky) * HX + kx;
     }
-    T* const dst = reinterpret_cast<T*>(p.dst);
+    T* const dst = reinterpret_cast<T*>(reinterpret_cast<char*>(p.dst) + blockIdx.z * p.tstride);
     const int ntiles = (p.Cd + 31) / 32;
     for (int nt = 0; nt < ntiles; ++nt) {
         float wf[NSTEP];
@@ -854,7 +824,7 @@ __global__ __launch_bounds__(256) void k_upconv_mfma(const UpconvParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long M = (long)p.D * p.H * p.W;
     const int nb = blockIdx.y;
-    const T* const src = reinterpret_cast<const T*>(p.src);
+    const T* const src = reinterpret_cast<const T*>(reinterpret_cast<const char*>(p.src) + blockIdx.z * p.tstride);
     const T* const wp = reinterpret_cast<const T*>(p.wpack) + (size_t)nb * p.nchunk * (2 * 64 * 8);
 
     long m[2];
@@ -890,7 +860,7 @@ __global__ __launch_bounds__(256) void k_upconv_mfma(const UpconvParams p) {
     }
 
     using v4 = typename Act<T>::v4;
-    T* const dst = reinterpret_cast<T*>(p.dst);
+    T* const dst = reinterpret_cast<T*>(reinterpret_cast<char*>(p.dst) + blockIdx.z * p.tstride);
     const int H2 = 2 * p.H, W2 = 2 * p.W;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -940,9 +910,9 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, vl = lane & 31;
     char* const tile = smem + wave * (32 * ROW);
     const long M = (long)p.D * p.H * p.W;
-    const T* const src = reinterpret_cast<const T*>(p.src);
+    const T* const src = reinterpret_cast<const T*>(reinterpret_cast<const char*>(p.src) + blockIdx.z * p.tstride);
     const T* const wp = reinterpret_cast<const T*>(p.wpack);
-    char* const dst = reinterpret_cast<char*>(p.dst);
+    char* const dst = reinterpret_cast<char*>(p.dst) + blockIdx.z * p.tstride;
     const int H2 = 2 * p.H, W2 = 2 * p.W;
 
     const long m0 = ((long)blockIdx.x * 4 + wave) * 32;
@@ -1016,8 +986,8 @@ __global__ __launch_bounds__(256) void k_maxpool(const PoolParams p) {
     using v8 = typename Act<T>::v8;
     const int ng = p.C / 8;
     const long total = (long)p.Do * p.Ho * p.Wo * ng;
-    const T* const src = reinterpret_cast<const T*>(p.src);
-    T* const dst = reinterpret_cast<T*>(p.dst);
+    const T* const src = reinterpret_cast<const T*>(reinterpret_cast<const char*>(p.src) + blockIdx.z * p.tstride);
+    T* const dst = reinterpret_cast<T*>(reinterpret_cast<char*>(p.dst) + blockIdx.z * p.tstride);
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int cg = (int)(idx % ng);
         const long v = idx / ng;
@@ -1055,7 +1025,7 @@ __global__ __launch_bounds__(256) void k_maxpool(const PoolParams p) {
 template <typename T>
 __global__ __launch_bounds__(256) void k_final(const FinalParams p) {
     using v8 = typename Act<T>::v8;
-    const T* const src = reinterpret_cast<const T*>(p.src);
+    const T* const src = reinterpret_cast<const T*>(reinterpret_cast<const char*>(p.src) + blockIdx.z * p.tstride);
     const float* __restrict__ w = p.w;
     for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < p.nvox; v += (long)gridDim.x * 256) {
         float acc[8];
@@ -1084,12 +1054,12 @@ __global__ __launch_bounds__(256) void k_final(const FinalParams p) {
             for (int co = 0; co < 8; ++co) acc[co] = acc[co] / sum;
         }
         if (p.out_kind == SD_OUT_PROBS_U8) {
-            uint8_t* out = reinterpret_cast<uint8_t*>(p.out);
+            uint8_t* out = reinterpret_cast<uint8_t*>(p.out) + blockIdx.z * p.out_tstride;
 #pragma unroll
             for (int co = 0; co < 8; ++co)
                 if (co < p.cout) out[(size_t)co * p.nvox + v] = (uint8_t)(acc[co] * 255.f);
         } else {
-            float* out = reinterpret_cast<float*>(p.out);
+            float* out = reinterpret_cast<float*>(reinterpret_cast<char*>(p.out) + blockIdx.z * p.out_tstride);
 #pragma unroll
             for (int co = 0; co < 8; ++co)
                 if (co < p.cout) out[(size_t)co * p.nvox + v] = acc[co];
@@ -1109,7 +1079,8 @@ __global__ __launch_bounds__(192) void k_gn_stats(const GnParams p) {
     const int tid = threadIdx.x;
     const int cg = tid % ng, vl = tid / ng, vper = 192 / ng;
     const long nvox = (long)p.D * p.H * p.W;
-    const T* const buf = reinterpret_cast<const T*>(p.buf);
+    const T* const buf = reinterpret_cast<const T*>(reinterpret_cast<const char*>(p.buf) + blockIdx.z * p.tstride);
+    double* const sums = reinterpret_cast<double*>(reinterpret_cast<char*>(p.sums) + blockIdx.z * p.tstride);
     float s[8], ss[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
@@ -1127,11 +1098,13 @@ __global__ __launch_bounds__(192) void k_gn_stats(const GnParams p) {
         double t = 0.0;
         for (int k = 0; k < vper; ++k) t += (double)red[k * ng + g][e];
         const int ch = g * 8 + (e & 7);
-        atomicAdd(&p.sums[(e >> 3) * p.C + ch], t);
+        atomicAdd(&sums[(e >> 3) * p.C + ch], t);
     }
 }
 
 __global__ void k_gn_finalize(const GnParams p) {
+    const double* const sums = reinterpret_cast<const double*>(reinterpret_cast<const char*>(p.sums) + blockIdx.z * p.tstride);
+    float* const scale_shift = reinterpret_cast<float*>(reinterpret_cast<char*>(p.scale_shift) + blockIdx.z * p.tstride);
     const int cpg = p.cout / p.groups;
     const double n = (double)p.D * p.H * p.W * cpg;
     for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
@@ -1139,7 +1112,7 @@ __global__ void k_gn_finalize(const GnParams p) {
         if (c < p.cout) {
             const int g = c / cpg;
             double s = 0.0, ss = 0.0;
-            for (int k = g * cpg; k < (g + 1) * cpg; ++k) { s += p.sums[k]; ss += p.sums[p.C + k]; }
+            for (int k = g * cpg; k < (g + 1) * cpg; ++k) { s += sums[k]; ss += sums[p.C + k]; }
             const double mean = s / n;
             double var = ss / n - mean * mean;
             if (var < 0.0) var = 0.0;
@@ -1147,8 +1120,8 @@ __global__ void k_gn_finalize(const GnParams p) {
             sc = (float)(rstd * (double)p.gamma[c]);
             sh = (float)((double)p.beta[c] - mean * rstd * (double)p.gamma[c]);
         }
-        p.scale_shift[c] = sc;
-        p.scale_shift[p.C + c] = sh;
+        scale_shift[c] = sc;
+        scale_shift[p.C + c] = sh;
     }
 }
 
@@ -1157,7 +1130,8 @@ __global__ __launch_bounds__(256) void k_gn_apply(const GnParams p) {
     using v8 = typename Act<T>::v8;
     const int ng = p.C / 8;
     const long total = (long)p.D * p.H * p.W * ng;
-    T* const buf = reinterpret_cast<T*>(p.buf);
+    T* const buf = reinterpret_cast<T*>(reinterpret_cast<char*>(p.buf) + blockIdx.z * p.tstride);
+    const float* const scale_shift = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.scale_shift) + blockIdx.z * p.tstride);
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int cg = (int)(idx % ng);
         const long v = idx / ng;
@@ -1166,7 +1140,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const GnParams p) {
         v8 val = *reinterpret_cast<const v8*>(ptr);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float f = fmaf((float)val[e], p.scale_shift[cg * 8 + e], p.scale_shift[p.C + cg * 8 + e]);
+            float f = fmaf((float)val[e], scale_shift[cg * 8 + e], scale_shift[p.C + cg * 8 + e]);
             if (p.relu) f = fmaxf(f, 0.f);
             val[e] = (T)f;
         }
@@ -1275,7 +1249,7 @@ static int launch_conv_k(ConvParams p, int NB, hipStream_t s) {
         occ = std::max(1, n);
         occ_lds = lds;
     }
-    const int nsb = p.nbx * p.nby * p.nbz;
+    const int nsb = p.nbx * p.nby * p.nbz * p.batch;
     const int wg_per_cu = std::min(occ, (int)(SD_LDS_BYTES / lds));
     const int cap = std::max(8, SD_NUM_CU * wg_per_cu / NB / 8 * 8);
     static const bool no_persist = getenv("SD_NO_PERSIST") != nullptr;   // debugging aid
@@ -1286,7 +1260,7 @@ static int launch_conv_k(ConvParams p, int NB, hipStream_t s) {
 
 template <typename T, int KZ, int NT>
 static int launch_conv_knt(const ConvParams& p, int NB, hipStream_t s) {
-    const long vox = (long)p.D * p.H * p.W;
+    const long vox = (long)p.D * p.H * p.W * p.batch;      // all tiles of a batched launch
     const int nstages = (p.nchunk0 + p.nchunk1) * KZ;
     constexpr size_t LIM = SD_LDS_BYTES - 512;
     // 512-voxel workgroups when they still give every CU work, else 256-voxel workgroups
@@ -1318,7 +1292,7 @@ int launch_conv(const ConvParams& p, int act_dtype, int KZ, int NT, int NB, hipS
 
 template <typename T, typename IN>
 static int launch_first_t(const FirstParams& p, int KZ, hipStream_t s) {
-    dim3 grid(p.nbx * p.nby * p.nbz), block(256);
+    dim3 grid(p.nbx * p.nby * p.nbz, 1, p.batch), block(256);
     if (KZ == 3) hipLaunchKernelGGL((k_conv_first<T, 3, IN>), grid, block, 0, s, p);
     else if (KZ == 1) hipLaunchKernelGGL((k_conv_first<T, 1, IN>), grid, block, 0, s, p);
     else return SD_ERR_INVALID;
@@ -1333,7 +1307,7 @@ int launch_first(const FirstParams& p, int act_dtype, int in_dtype, int KZ, hipS
 template <typename T, int NCH, int NTAB>
 static int launch_upconv_rows(const UpconvParams& p, hipStream_t s) {
     const long M = (long)p.D * p.H * p.W;
-    dim3 grid((unsigned)((M + 127) / 128)), block(256);
+    dim3 grid((unsigned)((M + 127) / 128), 1, p.batch), block(256);
     hipLaunchKernelGGL((k_upconv_rows<T, NCH, NTAB>), grid, block, 4 * 32 * 64 * NTAB, s, p);
     return SD_LAUNCH_CHECK();
 }
@@ -1345,7 +1319,7 @@ static int launch_upconv_t(const UpconvParams& p, int NB, hipStream_t s) {
     if (p.nchunk == 3 && p.Cd == 32) return launch_upconv_rows<T, 3, 2>(p, s);
     if (p.nchunk == 2 && p.Cd == 16) return launch_upconv_rows<T, 2, 1>(p, s);
     const long M = (long)p.D * p.H * p.W;
-    dim3 grid((unsigned)((M + 255) / 256), NB), block(256);
+    dim3 grid((unsigned)((M + 255) / 256), NB, p.batch), block(256);
     hipLaunchKernelGGL((k_upconv_mfma<T>), grid, block, 0, s, p);
     return SD_LAUNCH_CHECK();
 }
@@ -1353,7 +1327,7 @@ int launch_upconv(const UpconvParams& p, int act_dtype, int NB, hipStream_t s) {
     if (!getenv("SD_UPCONV_OLD"))
         return act_dtype == SD_BF16 ? launch_upconv_t<bf16_t>(p, NB, s) : launch_upconv_t<f16_t>(p, NB, s);
     const long M = (long)p.D * p.H * p.W;
-    dim3 grid((unsigned)((M + 255) / 256), NB), block(256);
+    dim3 grid((unsigned)((M + 255) / 256), NB, p.batch), block(256);
     if (act_dtype == SD_BF16) hipLaunchKernelGGL((k_upconv_mfma<bf16_t>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((k_upconv_mfma<f16_t>), grid, block, 0, s, p);
     return SD_LAUNCH_CHECK();
@@ -1361,14 +1335,14 @@ int launch_upconv(const UpconvParams& p, int act_dtype, int NB, hipStream_t s) {
 
 int launch_pool(const PoolParams& p, int act_dtype, hipStream_t s) {
     const long total = (long)p.Do * p.Ho * p.Wo * (p.C / 8);
-    dim3 grid(grid_for(total)), block(256);
+    dim3 grid(grid_for(total), 1, p.batch), block(256);
     if (act_dtype == SD_BF16) hipLaunchKernelGGL((k_maxpool<bf16_t>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((k_maxpool<f16_t>), grid, block, 0, s, p);
     return SD_LAUNCH_CHECK();
 }
 
 int launch_final(const FinalParams& p, int act_dtype, hipStream_t s) {
-    dim3 grid(grid_for(p.nvox)), block(256);
+    dim3 grid(grid_for(p.nvox), 1, p.batch), block(256);
     if (act_dtype == SD_BF16) hipLaunchKernelGGL((k_final<bf16_t>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((k_final<f16_t>), grid, block, 0, s, p);
     return SD_LAUNCH_CHECK();
@@ -1377,18 +1351,20 @@ int launch_final(const FinalParams& p, int act_dtype, hipStream_t s) {
 int launch_groupnorm(const GnParams& p, int act_dtype, hipStream_t s) {
     const int ng = p.C / 8;
     if (192 % ng != 0) return SD_ERR_INVALID;
-    if (hipMemsetAsync(p.sums, 0, sizeof(double) * 2 * p.C, s) != hipSuccess) return SD_ERR_HIP;
+    for (int t = 0; t < p.batch; ++t)
+        if (hipMemsetAsync(reinterpret_cast<char*>(p.sums) + t * p.tstride, 0, sizeof(double) * 2 * p.C, s) != hipSuccess)
+            return SD_ERR_HIP;
     const long nvox = (long)p.D * p.H * p.W;
     const int vper = 192 / ng;
-    dim3 g1(grid_for(nvox, vper * 8, 2048)), b1(192);
-    dim3 g3(grid_for(nvox * ng)), b3(256);
+    dim3 g1(grid_for(nvox, vper * 8, 2048), 1, p.batch), b1(192);
+    dim3 g3(grid_for(nvox * ng), 1, p.batch), b3(256);
     if (act_dtype == SD_BF16) {
         hipLaunchKernelGGL((k_gn_stats<bf16_t>), g1, b1, 0, s, p);
-        hipLaunchKernelGGL(k_gn_finalize, dim3(1), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(k_gn_finalize, dim3(1, 1, p.batch), dim3(256), 0, s, p);
         hipLaunchKernelGGL((k_gn_apply<bf16_t>), g3, b3, 0, s, p);
     } else {
         hipLaunchKernelGGL((k_gn_stats<f16_t>), g1, b1, 0, s, p);
-        hipLaunchKernelGGL(k_gn_finalize, dim3(1), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(k_gn_finalize, dim3(1, 1, p.batch), dim3(256), 0, s, p);
         hipLaunchKernelGGL((k_gn_apply<f16_t>), g3, b3, 0, s, p);
     }
     return SD_LAUNCH_CHECK();

@@ -59,7 +59,7 @@ class DenseModel:
         L.check(self.lib.sd_model_create(arr, len(ops), blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size,
                                          _ACT[act_dtype], C.byref(handle)), 'sd_model_create')
         self._h = handle
-        self._ws: Optional[torch.Tensor] = None
+        self._ws_slots = {}            # workspace per slot: forwards on different HIP streams use different slots
         self._profile = False
 
     def __del__(self):
@@ -75,27 +75,51 @@ class DenseModel:
             raise ValueError('sd_workspace_bytes: ' + self.lib.sd_last_error().decode())
         return int(n)
 
-    def _workspace(self, shape) -> torch.Tensor:
-        need = self.workspace_bytes(shape)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = None
+    @property
+    def _ws(self) -> Optional[torch.Tensor]:
+        return self._ws_slots.get(0)
+
+    def _workspace(self, shape, slot: int = 0, batch: int = 1) -> torch.Tensor:
+        need = self.workspace_bytes(shape) * batch
+        ws = self._ws_slots.get(slot)
+        if ws is None or ws.numel() < need:
+            self._ws_slots.pop(slot, None)
+            ws = None
             # torch.cuda.OutOfMemoryError is a RuntimeError -> the reference's tile-halving loop keeps working
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._ws
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws_slots[slot] = ws
+        return ws
 
     # -- forward --------------------------------------------------------------------------------------
-    def forward(self, inp: torch.Tensor, out_kind: int = L.SD_OUT_PROBS_F32, out: Optional[torch.Tensor] = None):
+    def forward(self, inp: torch.Tensor, out_kind: int = L.SD_OUT_PROBS_F32, out: Optional[torch.Tensor] = None,
+                slot: int = 0):
         """inp: (D,H,W) uint8 (normalised in-kernel as float32(v)/255) or float32, on this device.
-        Returns (C,D,H,W) float32 (logits / probabilities) or uint8 (floor(255*p))."""
+        Returns (C,D,H,W) float32 (logits / probabilities) or uint8 (floor(255*p)).  Launches on the CURRENT torch
+        stream; forwards that may overlap (different streams) must use different workspace `slot`s."""
         assert inp.is_cuda and inp.dim() == 3 and inp.is_contiguous()
         D, H, W = inp.shape
-        ws = self._workspace((D, H, W))
+        ws = self._workspace((D, H, W), slot)
         odt = torch.uint8 if out_kind == L.SD_OUT_PROBS_U8 else torch.float32
         if out is None:
             out = torch.empty((self.out_channels, D, H, W), dtype=odt, device=self.device)
         assert out.dtype == odt and out.is_contiguous() and out.numel() == self.out_channels * D * H * W
         L.check(self.lib.sd_forward(self._h, inp.data_ptr(), _dtype_code(inp), D, H, W, out.data_ptr(), out_kind,
                                     ws.data_ptr(), ws.numel(), _stream()), 'sd_forward')
+        return out
+
+    def forward_batch(self, inp: torch.Tensor, out_kind: int = L.SD_OUT_PROBS_F32, out: Optional[torch.Tensor] = None,
+                      slot: int = 0):
+        """N independent tiles in one set of launches: inp (N,D,H,W) uint8 / float32 -> (N,C,D,H,W).  Identical
+        results to N `forward` calls; every kernel sees N times as many blocks (fills the GPU in the small layers)."""
+        assert inp.is_cuda and inp.dim() == 4 and inp.is_contiguous()
+        N, D, H, W = inp.shape
+        ws = self._workspace((D, H, W), slot, N)
+        odt = torch.uint8 if out_kind == L.SD_OUT_PROBS_U8 else torch.float32
+        if out is None:
+            out = torch.empty((N, self.out_channels, D, H, W), dtype=odt, device=self.device)
+        assert out.dtype == odt and out.is_contiguous() and out.numel() == N * self.out_channels * D * H * W
+        L.check(self.lib.sd_forward_batch(self._h, inp.data_ptr(), _dtype_code(inp), N, D, H, W, out.data_ptr(),
+                                          out_kind, ws.data_ptr(), ws.numel(), _stream()), 'sd_forward_batch')
         return out
 
     def read_buffer(self, buf: int) -> torch.Tensor:
@@ -117,6 +141,38 @@ class DenseModel:
         ms = (C.c_float * self.n_ops)()
         L.check(self.lib.sd_profile_read(self._h, int(slot), ms, self.n_ops), 'sd_profile_read')
         return np.asarray(list(ms), dtype=np.float64)
+
+
+class StreamRing:
+    """`n` side streams for independent tiles: tile i runs on stream i % n with workspace slot i % n, so the small
+    deep-level layers and the launch tails of one tile overlap with the big layers of the next (one tile alone
+    cannot fill 256 CUs in every layer).  ``with ring: ... for i: with ring.stream(i): ...`` orders the side
+    streams after the caller's stream on entry and the caller's stream after them on exit."""
+
+    def __init__(self, device: torch.device, n: int = 2):
+        self.device = device
+        self.n = max(1, int(n))
+        self._streams = [torch.cuda.Stream(device=device) for _ in range(self.n)] if self.n > 1 else []
+
+    def slot(self, i: int) -> int:
+        return i % self.n
+
+    def stream(self, i: int):
+        if self.n == 1:
+            return torch.cuda.stream(torch.cuda.current_stream(self.device))
+        return torch.cuda.stream(self._streams[i % self.n])
+
+    def __enter__(self):
+        cur = torch.cuda.current_stream(self.device)
+        for s in self._streams:
+            s.wait_stream(cur)
+        return self
+
+    def __exit__(self, *exc):
+        cur = torch.cuda.current_stream(self.device)
+        for s in self._streams:
+            cur.wait_stream(s)
+        return False
 
 
 # -- tiled_apply helpers on the device (SURVEY.md row P3 / kernels K1, K12, K11) ----------------------------

@@ -48,7 +48,9 @@ class Predictor:
     (C,z,y,x), `strict_shapes`, `apply_softmax`, `apply_argmax`, `float16`, `batch_size`, `verbose`.
     `transform`, `augmentations`, `offset` (valid convolutions) and `argmax_with_threshold` are unused by SyConn
     and rejected.  Extra keyword `act_dtype` ('bf16' default, 'f16'; `float16=True` selects 'f16') names the storage
-    type of activations on the device; accumulation is fp32.
+    type of activations on the device; accumulation is fp32.  `batch_size`: tiles per launch set (default: automatic,
+    see `_batch_for`).  `n_streams` (default 1, env SYCONN_AMD_STREAMS): batches alternate over that many HIP
+    streams, each with its own workspace.
 
     ``predict(inp)`` takes an ``np.ndarray`` / ``Tensor`` of shape (N,1,D,H,W) and any float dtype and returns a
     float32 CPU tensor (N,C,D,H,W).  Device-memory exhaustion raises ``RuntimeError`` (the reference's
@@ -59,8 +61,8 @@ class Predictor:
                  overlap_shape=None, offset=None, out_shape=None, out_dtype=None, float16=False,
                  apply_softmax=True, transform=None, augmentations=None, strict_shapes=False, apply_argmax=False,
                  argmax_with_threshold=None, verbose=False, report_inf_speed=False, act_dtype=None,
-                 group_norm_groups=None):
-        from ..engine import DenseModel
+                 group_norm_groups=None, n_streams=None):
+        from ..engine import DenseModel, StreamRing
         if transform is not None or augmentations is not None or argmax_with_threshold is not None:
             raise NotImplementedError('transform / augmentations / argmax_with_threshold are not used by SyConn\'s '
                                       'dense path and not implemented')
@@ -107,6 +109,9 @@ class Predictor:
         self.act_dtype = act_dtype
         self._dm = DenseModel(model, act_dtype=act_dtype, device=self.device, group_norm_groups=group_norm_groups)
         self.out_channels = self._dm.out_channels
+        if n_streams is None:
+            n_streams = int(os.environ.get('SYCONN_AMD_STREAMS', '1'))
+        self._ring = StreamRing(self.device, n_streams)
 
     # -- geometry --------------------------------------------------------------------------------------
     def _geometry(self, spatial: np.ndarray):
@@ -140,15 +145,37 @@ class Predictor:
         if single:
             self._dm.forward(vol, out_kind, out)
             return
-        tbuf = torch.empty(tuple(int(t) for t in tin), dtype=vol.dtype, device=self.device)
-        obuf = torch.empty((self.out_channels, *[int(t) for t in tin]), dtype=out.dtype, device=self.device)
-        for pos in itertools.product(*[range(int(n)) for n in ntiles]):   # z-major, like itertools.product upstream
-            pos = np.asarray(pos, dtype=np.int64)
-            lo = tile * pos
-            keep = np.minimum(tile, spatial - lo)
-            tile_gather(vol, lo - ol, tin, tbuf)
-            self._dm.forward(tbuf, out_kind, obuf)
-            tile_scatter(obuf, ol, keep, out, lo)
+        # independent tiles go through the network `nb` at a time (sd_forward_batch: one set of launches, every
+        # kernel sees nb times as many blocks); batches alternate over `n_streams` HIP streams
+        pos_list = list(itertools.product(*[range(int(n)) for n in ntiles]))   # z-major, like upstream
+        nb = self._batch_for(tin, len(pos_list))
+        ring = self._ring
+        tbuf = [torch.empty((nb, *[int(t) for t in tin]), dtype=vol.dtype, device=self.device) for _ in range(ring.n)]
+        obuf = [torch.empty((nb, self.out_channels, *[int(t) for t in tin]), dtype=out.dtype, device=self.device)
+                for _ in range(ring.n)]
+        with ring:
+            for i, b0 in enumerate(range(0, len(pos_list), nb)):
+                group = pos_list[b0:b0 + nb]
+                k = ring.slot(i)
+                with ring.stream(i):
+                    for j, pos in enumerate(group):
+                        lo = tile * np.asarray(pos, dtype=np.int64)
+                        tile_gather(vol, lo - ol, tin, tbuf[k][j])
+                    n = len(group)
+                    self._dm.forward_batch(tbuf[k][:n], out_kind, obuf[k][:n], slot=k)
+                    for j, pos in enumerate(group):
+                        lo = tile * np.asarray(pos, dtype=np.int64)
+                        keep = np.minimum(tile, spatial - lo)
+                        tile_scatter(obuf[k][j], ol, keep, out, lo)
+
+    def _batch_for(self, tin, ntiles: int) -> int:
+        """Tiles per launch set: `batch_size` if given (elektronn3's Predictor argument), else as many as keep the
+        workspaces of one batch under ~8 GiB (at most 8): 128^3 tiles run 8 at a time, the reference's
+        178x243x331 tiles (7.4 GiB of activations each) one at a time."""
+        if self.batch_size is not None:
+            return max(1, min(int(self.batch_size), ntiles))
+        per_tile = self._dm.workspace_bytes(tuple(int(t) for t in tin))
+        return int(max(1, min(8, ntiles, (8 << 30) // max(per_tile, 1))))
 
     # -- public API ------------------------------------------------------------------------------------
     @torch.no_grad()

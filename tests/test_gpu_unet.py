@@ -247,3 +247,20 @@ def test_full_architectures_many_workgroups(gpu, arch, shape):
     rms = float((out - ref).pow(2).mean().sqrt()) / float(ref.pow(2).mean().sqrt())
     print(f'{arch} {shape}: rel err max {err:.2e} rms {rms:.2e}')
     assert err < TOL_FP32['bf16'] and rms < TOL_FP32_RMS['bf16']
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('arch,shape', [('semseg_spine', (24, 40, 48)), ('mivcsj', (16, 32, 48)), ('syntype', (13, 27, 29))])
+def test_forward_batch_equals_single_forwards(gpu, arch, shape):
+    """sd_forward_batch (N tiles, one set of launches) is bit-identical to N sd_forward calls."""
+    from syconn_amd import _lib as L
+    from syconn_amd.engine import DenseModel
+    net = build_unet(arch, seed=5, final_scale=4.0)
+    dm = DenseModel(net, 'bf16', gpu)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randint(0, 256, (3, *shape), dtype=torch.uint8, generator=g).to(gpu)
+    for kind in (L.SD_OUT_PROBS_U8, L.SD_OUT_LOGITS_F32):
+        single = torch.stack([dm.forward(x[i], kind).clone() for i in range(3)])
+        batched = dm.forward_batch(x, kind, slot=1)
+        assert batched.shape == single.shape
+        assert torch.equal(batched, single)
