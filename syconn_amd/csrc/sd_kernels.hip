@@ -360,6 +360,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
 
 #ifdef SD_TIMING
     long long tstamp[8];
+    long long sstamp[16];      // SD_STAGES: end of every stage of the probed block, [14] block start, [15] epilogue end
     int tcount = 0;
 #define SD_T(i) do { if (tcount == SD_TB) tstamp[i] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -583,6 +584,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                 // s_barrier: __syncthreads() would drain every DMA in flight with a vmcnt(0))
                 asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WAITN) : "memory");
                 if (s == SD_TS) SD_T(3);     // after the barrier of the probed stage
+#ifdef SD_STAGES
+                if (tcount == SD_TB && s < 14) sstamp[s] = __builtin_readcyclecounter();
+#endif
             }
         }
 
@@ -734,6 +738,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         if (tcount == SD_TB && lane == 0 && p.dbg) {
             long long* o = p.dbg + ((size_t)blockIdx.x * WAVES + wave) * 8;
             for (int i = 0; i < 8; ++i) o[i] = tstamp[i];
+#ifdef SD_STAGES
+            sstamp[14] = tstamp[0]; sstamp[15] = tstamp[6];
+            long long* o2 = p.dbg + (1 << 20) + ((size_t)blockIdx.x * WAVES + wave) * 16;
+            for (int i = 0; i < 16; ++i) o2[i] = sstamp[i];
+#endif
 #ifdef SD_RT
             o[4] = rt0; o[5] = __builtin_amdgcn_s_memrealtime();          // (probe) absolute 100 MHz ticks
             o[6] = ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
