@@ -43,14 +43,14 @@ def synthetic_em_tiles(n, size, seed):
     return out
 
 
-def layer_accounting(ops, L, D, H, W, act_bytes=2, out_bytes_per_class=1):
+def layer_accounting(ops, L, D, H, W, act_bytes=2, out_bytes_per_class=1, batch=1):
     """Algorithmic FLOPs and bytes of every plan op for a (D,H,W) tile.  Bytes follow SURVEY.md section 8(d):
     activation read + write per fused conv(+norm+act) layer, a pooled tensor counts its write only (it belongs in
     the producing conv's epilogue), concat = two read pointers, weights ignored (L2/MALL resident)."""
     dims = {0: (D, H, W)}
     chans = {0: 1}
     rows = []
-    for o in ops:
+    for io, o in enumerate(ops):
         if o.kind == L.SD_OP_CONV:
             d = dims[o.src1] if o.src1 >= 0 else dims[o.src0]
             vox = d[0] * d[1] * d[2]
@@ -65,8 +65,15 @@ def layer_accounting(ops, L, D, H, W, act_bytes=2, out_bytes_per_class=1):
                 ntile = (o.cout + 31) // 32
                 nt = 2 if ntile >= 2 else 1
                 nbk = (ntile + nt - 1) // nt
-                waves = 8 if (vox // 512) * nbk >= 512 else 4
-                name = 'k_conv_mfma<%dx3x3,NT=%d,%d waves>' % (o.kz, nt, waves)
+                waves = 8 if ((vox * batch) // 512) * nbk >= 512 else 4
+                # LDS-resident weights (NSLOT=2) when the layer's weight groups fit beside a 2-slot halo ring
+                bz, by = ((waves // 4) * 2, 8) if o.kz == 3 else (1, waves * 4)
+                a_bytes = -(-((bz + o.kz - 1) * (by + 2) * 18 * 2) // 64) * 1024
+                nstages = (-(-o.cin0 // 16) + (-(-o.cin1 // 16) if o.cin1 > 0 else 0)) * o.kz
+                fused_final = io + 1 < len(ops) and ops[io + 1].kind == L.SD_OP_FINAL and nbk == 1
+                lds = 2 * a_bytes + nstages * 9 * nt * 1024 + 512 + (nt * 4096 if fused_final else 0) + 1024
+                resident = lds <= (96 if waves == 8 else 80) * 1024
+                name = 'k_conv_mfma<%dx3x3,NT=%d,%d waves,%s>' % (o.kz, nt, waves, 'NSLOT=2' if resident else 'NSLOT=0')
             rows.append((name, flops, inb + vox * o.cout * act_bytes))
             dims[o.dst], chans[o.dst] = d, o.cout
         elif o.kind == L.SD_OP_POOL:
@@ -192,7 +199,8 @@ def main():
     per_op /= n_fw                                # ms per launch, averaged over the timed region
     tiles_per_launch = T / nbatch                 # average tiles one launch processes
     dm.profile(0)
-    rows = [(n, f * tiles_per_launch, b * tiles_per_launch) for n, f, b in layer_accounting(dm.ops, L, S, S, S)]
+    rows = [(n, f * tiles_per_launch, b * tiles_per_launch)
+            for n, f, b in layer_accounting(dm.ops, L, S, S, S, batch=B)]
     groups = {}
     for (name, fl, by), ms in zip(rows, per_op):
         g = groups.setdefault(name, [0.0, 0.0, 0.0, 0])
