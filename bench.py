@@ -63,7 +63,7 @@ def layer_accounting(ops, L, D, H, W, act_bytes=2, out_bytes_per_class=1, batch=
                 name = 'k_conv_first<%dx3x3>' % o.kz
             else:
                 ntile = (o.cout + 31) // 32
-                nt = 2 if ntile >= 2 else 1
+                nt = 3 if ntile % 3 == 0 else (2 if ntile >= 2 else 1)
                 nbk = (ntile + nt - 1) // nt
                 waves = 8 if ((vox * batch) // 512) * nbk >= 512 else 4
                 # LDS-resident weights (NSLOT=2) when the layer's weight groups fit beside a 2-slot halo ring

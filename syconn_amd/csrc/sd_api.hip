@@ -238,7 +238,11 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
                 if (d.src1 >= 0 && m->bufC[d.src1] != d.cin1) MODEL_FAIL("conv: cin1 does not match producer of src1");
                 const int nch0 = m->bufCp[d.src0] / SD_CHUNK, nch1 = d.src1 >= 0 ? m->bufCp[d.src1] / SD_CHUNK : 0;
                 const int ntile = (d.cout + 31) / 32;
-                op.NT = ntile >= 2 ? 2 : 1;
+                // output channels per workgroup: 64 (NT=2); 96 (NT=3) where that divides the layer without padding tiles
+                // (the 48-filter family: 96/192/384/768 channels) -- a 64-wide split would spend 25 % of the MFMAs of a
+                // 96-channel layer on zero columns; NT=3 also needs fewer LDS fragment reads per MFMA (5 per 6)
+                static const bool no_nt3 = getenv("SD_NO_NT3") != nullptr;
+                op.NT = (ntile % 3 == 0 && !no_nt3) ? 3 : (ntile >= 2 ? 2 : 1);
                 op.NB = (ntile + op.NT - 1) / op.NT;
                 const int nchunks = nch0 + nch1;
                 const size_t gbytes = (size_t)9 * op.NT * 1024;

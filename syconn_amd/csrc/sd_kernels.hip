@@ -1289,6 +1289,8 @@ static int launch_conv_knt(const ConvParams& p, int NB, hipStream_t s) {
 }
 template <typename T>
 static int launch_conv2_t(const ConvParams& p, int KZ, int NT, int NB, hipStream_t s) {
+    if (KZ == 3 && NT == 3) return launch_conv_knt<T, 3, 3>(p, NB, s);
+    if (KZ == 1 && NT == 3) return launch_conv_knt<T, 1, 3>(p, NB, s);
     if (KZ == 3 && NT == 2) return launch_conv_knt<T, 3, 2>(p, NB, s);
     if (KZ == 3 && NT == 1) return launch_conv_knt<T, 3, 1>(p, NB, s);
     if (KZ == 1 && NT == 2) return launch_conv_knt<T, 1, 2>(p, NB, s);
