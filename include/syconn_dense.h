@@ -136,6 +136,22 @@ int sd_model_num_ops(const sd_model* m);
 const char* sd_last_error(void);
 const char* sd_version(void);
 
+/* ---- KNOSSOS overlay cubes (host side, no GPU needed) -------------------------------
+ * Snappy raw-format codec for "*.seg.sz.zip": knossos_utils (third-party, called at
+ * /root/reference/syconn/handler/prediction.py:700-702, 835-843) stores each 128^3 uint64 cube as
+ * python-snappy compress(cube.tobytes()) inside a zip member.  Restates google/snappy format_description.txt (pinned
+ * upstream: snappy 1.1.8 / python-snappy 0.6.0); any conforming stream decodes, the encoder's output is decodable by
+ * any conforming decoder.  All return SD_OK or SD_ERR_INVALID (corrupt / truncated stream, capacity too small). */
+size_t sd_snappy_max_compressed_length(size_t n);
+int sd_snappy_compress(const void* src, size_t n, void* dst, size_t dst_capacity, size_t* dst_len);
+int sd_snappy_uncompressed_length(const void* src, size_t n, size_t* result);
+int sd_snappy_uncompress(const void* src, size_t n, void* dst, size_t dst_capacity, size_t* dst_len);
+
+/* Order-0 down-sampling by 2 per axis on the device = one level of the mag pyramid KnossosDataset.save_raw /
+ * save_seg(..., mags=[m, 2m, 4m], fast_resampling=True) writes (prediction.py:834-843): dst[z,y,x] = src[2z,2y,2x],
+ * dst dims = ceil(src dims / 2).  dtype: SD_U8 or SD_U64. */
+int sd_downsample2(const void* src_dev, int dtype, int D, int H, int W, void* dst_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

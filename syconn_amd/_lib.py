@@ -17,7 +17,8 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.g
 # every symbol include/syconn_dense.h declares (checked by tests/test_abi.py)
 EXPORTS = ['sd_init', 'sd_device_count', 'sd_model_create', 'sd_model_destroy', 'sd_workspace_bytes', 'sd_forward', 'sd_forward_batch',
            'sd_tile_gather', 'sd_tile_scatter', 'sd_postproc_labels', 'sd_profile_enable', 'sd_profile_read',
-           'sd_debug_read_buffer', 'sd_model_num_ops', 'sd_last_error', 'sd_version']
+           'sd_debug_read_buffer', 'sd_model_num_ops', 'sd_last_error', 'sd_version', 'sd_snappy_max_compressed_length',
+           'sd_snappy_compress', 'sd_snappy_uncompressed_length', 'sd_snappy_uncompress', 'sd_downsample2']
 
 
 class OpDesc(C.Structure):
@@ -63,6 +64,11 @@ def load():
     lib.sd_model_num_ops.argtypes = [vp]; lib.sd_model_num_ops.restype = i32
     lib.sd_last_error.argtypes = []; lib.sd_last_error.restype = C.c_char_p
     lib.sd_version.argtypes = []; lib.sd_version.restype = C.c_char_p
+    lib.sd_snappy_max_compressed_length.argtypes = [sz]; lib.sd_snappy_max_compressed_length.restype = sz
+    lib.sd_snappy_compress.argtypes = [vp, sz, vp, sz, C.POINTER(sz)]; lib.sd_snappy_compress.restype = i32
+    lib.sd_snappy_uncompressed_length.argtypes = [vp, sz, C.POINTER(sz)]; lib.sd_snappy_uncompressed_length.restype = i32
+    lib.sd_snappy_uncompress.argtypes = [vp, sz, vp, sz, C.POINTER(sz)]; lib.sd_snappy_uncompress.restype = i32
+    lib.sd_downsample2.argtypes = [vp, i32, i32, i32, i32, vp, vp]; lib.sd_downsample2.restype = i32
     _lib = lib
     return lib
 
@@ -77,3 +83,35 @@ def check(rc: int, what: str = ''):
     if rc == SD_ERR_INVALID:
         raise ValueError(text)
     raise RuntimeError(text)
+
+
+# -- snappy raw format (host side; the codec of the KNOSSOS ``*.seg.sz.zip`` overlay cubes) ---------------------------
+def snappy_compress(data) -> bytes:
+    """``snappy.compress(data)`` of python-snappy (raw format), computed by the C codec of the library."""
+    lib = load()
+    buf = bytes(data) if not isinstance(data, (bytes, bytearray)) else data
+    n = len(buf)
+    cap = lib.sd_snappy_max_compressed_length(n)
+    out = C.create_string_buffer(cap)
+    out_len = C.c_size_t(0)
+    src = (C.c_char * n).from_buffer_copy(buf) if n else None
+    rc = lib.sd_snappy_compress(src, n, out, cap, C.byref(out_len))
+    if rc != SD_OK:
+        raise ValueError('snappy_compress: invalid argument')
+    return out.raw[:out_len.value]
+
+
+def snappy_decompress(data) -> bytes:
+    """``snappy.decompress(data)``; raises ValueError on a corrupt or truncated stream."""
+    lib = load()
+    buf = bytes(data)
+    n = len(buf)
+    src = (C.c_char * n).from_buffer_copy(buf) if n else None
+    ulen = C.c_size_t(0)
+    if lib.sd_snappy_uncompressed_length(src, n, C.byref(ulen)) != SD_OK:
+        raise ValueError('snappy_decompress: corrupt input (length preamble)')
+    out = C.create_string_buffer(max(ulen.value, 1))
+    out_len = C.c_size_t(0)
+    if lib.sd_snappy_uncompress(src, n, out, ulen.value, C.byref(out_len)) != SD_OK:
+        raise ValueError('snappy_decompress: corrupt input')
+    return out.raw[:out_len.value]

@@ -671,6 +671,13 @@ int sd_tile_scatter(const void* tile, int dtype, int C, int TD, int TH, int TW, 
     return rc == SD_OK ? rc : fail(rc, "sd_tile_scatter launch failed");
 }
 
+int sd_downsample2(const void* src, int dtype, int D, int H, int W, void* dst, void* stream) {
+    if (!src || !dst || D <= 0 || H <= 0 || W <= 0 || (dtype != SD_U8 && dtype != SD_U64))
+        return fail(SD_ERR_INVALID, "sd_downsample2: bad argument");
+    int rc = launch_downsample2(src, dtype == SD_U8 ? 1 : 8, D, H, W, dst, reinterpret_cast<hipStream_t>(stream));
+    return rc == SD_OK ? rc : fail(rc, "sd_downsample2 launch failed");
+}
+
 int sd_postproc_labels(const uint8_t* probs, int C, size_t nvox, const int32_t* ids, const double* thresholds, int n_ids,
                        void* out, int out_dtype, void* stream) {
     if (!probs || !ids || !thresholds || !out || n_ids <= 0 || n_ids > 16)

@@ -1405,6 +1405,25 @@ int launch_tile_scatter(const void* tile, int esize, int C, int TD, int TH, int 
     return SD_LAUNCH_CHECK();
 }
 
+// Order-0 down-sampling by 2 (one mag-pyramid level of KnossosDataset.save_raw/save_seg, fast_resampling=True):
+// dst[z,y,x] = src[2z,2y,2x].  HBM-bound strided pick; one thread per output voxel, x fastest.
+template <typename E>
+__global__ __launch_bounds__(256) void k_downsample2(const E* src, int H, int W, E* dst, int Do, int Ho, int Wo) {
+    const long total = (long)Do * Ho * Wo;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int x = (int)(i % Wo), y = (int)((i / Wo) % Ho), z = (int)(i / ((long)Wo * Ho));
+        dst[i] = src[((size_t)(2 * z) * H + 2 * y) * W + 2 * x];
+    }
+}
+int launch_downsample2(const void* src, int esize, int D, int H, int W, void* dst, hipStream_t s) {
+    const int Do = (D + 1) / 2, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    dim3 grid(grid_for((long)Do * Ho * Wo)), block(256);
+    if (esize == 1) hipLaunchKernelGGL((k_downsample2<uint8_t>), grid, block, 0, s, (const uint8_t*)src, H, W, (uint8_t*)dst, Do, Ho, Wo);
+    else if (esize == 8) hipLaunchKernelGGL((k_downsample2<uint64_t>), grid, block, 0, s, (const uint64_t*)src, H, W, (uint64_t*)dst, Do, Ho, Wo);
+    else return SD_ERR_INVALID;
+    return SD_LAUNCH_CHECK();
+}
+
 int launch_labels(const uint8_t* probs, size_t nvox, const LabelArgs& a, void* out, int out_u64, hipStream_t s) {
     dim3 grid(grid_for((long)nvox)), block(256);
     if (out_u64) hipLaunchKernelGGL((k_labels<uint64_t>), grid, block, 0, s, probs, nvox, a, (uint64_t*)out);

@@ -223,3 +223,29 @@ def postproc_labels(probs_u8: torch.Tensor, ids: Sequence[int], thresholds: Sequ
     L.check(lib.sd_postproc_labels(probs_u8.data_ptr(), Cn, nvox, ids_a, thr_a, n, out.data_ptr(), code, _stream()),
             'sd_postproc_labels')
     return out
+
+
+def downsample2(t: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One mag-pyramid level on the device: ``t[::2, ::2, ::2]`` of a contiguous (D,H,W) uint8 (or 8-byte integer)
+    tensor -- the order-0 resampling of ``save_raw/save_seg(..., fast_resampling=True)`` (prediction.py:834-843)."""
+    lib = L.load()
+    assert t.is_cuda and t.dim() == 3 and t.is_contiguous()
+    if t.dtype == torch.uint8:
+        code = L.SD_U8
+    elif t.element_size() == 8 and not t.dtype.is_floating_point:
+        code = L.SD_U64
+    else:
+        raise ValueError(f'downsample2: unsupported dtype {t.dtype}')
+    D, H, W = (int(v) for v in t.shape)
+    if out is None:
+        out = torch.empty(((D + 1) // 2, (H + 1) // 2, (W + 1) // 2), dtype=t.dtype, device=t.device)
+    L.check(lib.sd_downsample2(t.data_ptr(), code, D, H, W, out.data_ptr(), _stream()), 'sd_downsample2')
+    return out
+
+
+def mag_pyramid(t: torch.Tensor, levels: int = 3):
+    """[t, t[::2,::2,::2], t[::4,::4,::4], ...] computed on the device."""
+    out = [t.contiguous()]
+    for _ in range(levels - 1):
+        out.append(downsample2(out[-1]))
+    return out

@@ -248,7 +248,7 @@ def dense_predictor(args):
     Differences to the reference are confined to WHERE the arithmetic runs: the uint8 chunk goes to the GPU once,
     normalisation, tiling, U-Net, softmax, uint8 cast, halo crop and the label rule run there, and only uint8
     results come back (the reference moves fp32 tiles over PCIe in both directions)."""
-    from ..engine import postproc_labels, tile_scatter
+    from ..engine import mag_pyramid, postproc_labels, tile_scatter
     chunk_ids, kd_p, target_p, model_p, overlap_shape, overlap_shape_tiles, tile_shape, chunk_size, n_channel, \
         target_channels, target_kd_path_list, channel_thresholds, mag, cube_of_interest = args
 
@@ -307,16 +307,21 @@ def dense_predictor(args):
             ids = target_channels[j]
             path = target_kd_path_list[j]
             save_as_raw = not (len(ids) > 1)
+            # the mag pyramid [mag, 2*mag, 4*mag] (order-0, fast_resampling=True) is built on the device; each level is
+            # written with its own data_mag, which is what one save_*(mags=[mag, 2*mag, 4*mag]) call produces
             if save_as_raw:
                 # no thresholding and only one label in the target KnossosDataset -> store probability map
-                data = crop[ids[-1]].cpu().numpy()
-                target_kd_dict[path].save_raw(offset=ch.coordinates * mag, data=data.astype(np.uint8), data_mag=mag,
-                                              mags=[mag, mag * 2, mag * 4], fast_resampling=True, upsample=False)
+                for k, lvl in enumerate(mag_pyramid(crop[ids[-1]], 3)):
+                    target_kd_dict[path].save_raw(offset=ch.coordinates * mag, data=lvl.cpu().numpy(),
+                                                  data_mag=mag * 2 ** k, mags=[mag * 2 ** k], fast_resampling=True,
+                                                  upsample=False)
             else:
                 thr = [_resolve_threshold(channel_thresholds[label]) for label in ids]
-                lab = postproc_labels(crop, ids, thr, out_dtype=torch.uint8).cpu().numpy()
-                target_kd_dict[path].save_seg(offset=ch.coordinates * mag, data=lab.astype(np.uint64), data_mag=mag,
-                                              mags=[mag, mag * 2, mag * 4], fast_resampling=True, upsample=False)
+                lab = postproc_labels(crop, ids, thr, out_dtype=torch.uint8)
+                for k, lvl in enumerate(mag_pyramid(lab, 3)):      # uint8 on the device and over PCIe, widened here
+                    target_kd_dict[path].save_seg(offset=ch.coordinates * mag, data=lvl.cpu().numpy().astype(np.uint64),
+                                                  data_mag=mag * 2 ** k, mags=[mag * 2 ** k], fast_resampling=True,
+                                                  upsample=False)
 
 
 def _wd_set() -> bool:

@@ -13,12 +13,15 @@ against source" there):
 * ``save_raw / save_seg(offset, mags, data, data_mag, fast_resampling, upsample)``: `data` is (z,y,x) at `data_mag`;
   written to every mag in `mags` >= data_mag by order-0 (strided) down-sampling.
 
-Deviation (documented in DESIGN.md): the overlay channel is stored as raw little-endian uint64 cubes
-(``*.seg.raw``) instead of snappy-compressed ``*.seg.sz.zip`` -- no snappy codec exists in this image.  The real
-on-disk overlay format is row 1 of SURVEY.md section 8(f) ("next").
+Overlay (segmentation) cubes use the KNOSSOS on-disk format: one zip archive
+``<cube>.seg.sz.zip`` per cube whose single member ``<cube>.seg.sz`` is the Snappy raw-format compression of the
+little-endian uint64 cube (z,y,x with x fastest).  The codec is the library's C implementation
+(``include/syconn_dense.h: sd_snappy_*``; python-snappy is not installed here).  Cubes written as raw uint64
+(``*.seg.raw``) by earlier versions of this file are still read.
 """
 import os
 import re
+import zipfile
 from typing import Dict, Iterable, List, Optional, Sequence
 
 import numpy as np
@@ -136,6 +139,35 @@ class KnossosDataset:
         return (f'{self._knossos_path}mag{mag}/x{cx:04d}/y{cy:04d}/z{cz:04d}/'
                 f'{self._experiment_name}_mag{mag}_x{cx:04d}_y{cy:04d}_z{cz:04d}.{ext}')
 
+    # one cube <-> one file.  ext 'raw': plain uint8; ext 'seg.sz': zip archive <file>.zip with the snappy stream
+    def _read_cube(self, fn: str, ext: str, dtype, shape) -> Optional[np.ndarray]:
+        if ext == 'seg.sz':
+            if os.path.isfile(fn + '.zip'):
+                from . import _lib
+                with zipfile.ZipFile(fn + '.zip', 'r') as zf:
+                    blob = zf.read(os.path.basename(fn))
+                return np.frombuffer(_lib.snappy_decompress(blob), dtype=dtype).reshape(shape).copy()
+            legacy = fn[:-len('seg.sz')] + 'seg.raw'
+            if os.path.isfile(legacy):
+                return np.fromfile(legacy, dtype=dtype).reshape(shape)
+            return None
+        if not os.path.isfile(fn):
+            return None
+        return np.fromfile(fn, dtype=dtype).reshape(shape)
+
+    def _write_cube(self, fn: str, ext: str, cube: np.ndarray):
+        os.makedirs(os.path.dirname(fn), exist_ok=True)
+        if ext == 'seg.sz':
+            from . import _lib
+            tmp = fn + f'.zip.tmp{os.getpid()}'
+            with zipfile.ZipFile(tmp, 'w', zipfile.ZIP_DEFLATED) as zf:
+                zf.writestr(os.path.basename(fn), _lib.snappy_compress(np.ascontiguousarray(cube).tobytes()))
+            os.replace(tmp, fn + '.zip')
+            return
+        tmp = fn + f'.tmp{os.getpid()}'
+        cube.tofile(tmp)
+        os.replace(tmp, fn)
+
     def _load(self, size, offset, mag: int, ext: str, dtype) -> np.ndarray:
         size = np.asarray(size, dtype=np.int64) // mag
         off = np.asarray(offset, dtype=np.int64) // mag
@@ -150,10 +182,9 @@ class KnossosDataset:
         for cx in range(c_lo[0], c_hi[0] + 1):
             for cy in range(c_lo[1], c_hi[1] + 1):
                 for cz in range(c_lo[2], c_hi[2] + 1):
-                    fn = self._cube_file(mag, cx, cy, cz, ext)
-                    if not os.path.isfile(fn):
+                    cube = self._read_cube(self._cube_file(mag, cx, cy, cz, ext), ext, dtype, tuple(cs[::-1]))
+                    if cube is None:
                         continue
-                    cube = np.fromfile(fn, dtype=dtype).reshape(tuple(cs[::-1]))
                     c0 = np.array([cx, cy, cz]) * cs
                     a = np.maximum(lo, c0)
                     b = np.minimum(hi, c0 + cs)
@@ -166,7 +197,7 @@ class KnossosDataset:
         return self._load(size, offset, mag, 'raw', np.uint8)
 
     def load_seg(self, size, offset, mag: int = 1, **_) -> np.ndarray:
-        return self._load(size, offset, mag, 'seg.raw', np.uint64)
+        return self._load(size, offset, mag, 'seg.sz', np.uint64)
 
     def _save(self, offset, mags: Sequence[int], data: np.ndarray, data_mag: int, ext: str, dtype,
               fast_resampling: bool = True, upsample: bool = False):
@@ -194,17 +225,13 @@ class KnossosDataset:
                         c0 = np.array([cx, cy, cz]) * cs
                         a, b = np.maximum(lo, c0), np.minimum(hi, c0 + cs)
                         whole = np.all(a == c0) and np.all(b == c0 + cs)
-                        if os.path.isfile(fn) and not whole:
-                            cube = np.fromfile(fn, dtype=dtype).reshape(tuple(cs[::-1]))
-                        else:
+                        cube = None if whole else self._read_cube(fn, ext, dtype, tuple(cs[::-1]))
+                        if cube is None:
                             cube = np.zeros(tuple(cs[::-1]), dtype=dtype)
-                            os.makedirs(os.path.dirname(fn), exist_ok=True)
                         dst = tuple(slice(int(a[i] - c0[i]), int(b[i] - c0[i])) for i in (2, 1, 0))
                         src = tuple(slice(int(a[i] - off[i]), int(b[i] - off[i])) for i in (2, 1, 0))
                         cube[dst] = d[src]
-                        tmp = fn + f'.tmp{os.getpid()}'
-                        cube.tofile(tmp)
-                        os.replace(tmp, fn)
+                        self._write_cube(fn, ext, cube)
 
     def save_raw(self, offset, mags, data, data_mag: int = 1, fast_resampling: bool = True, upsample: bool = True,
                  **_):
@@ -212,7 +239,7 @@ class KnossosDataset:
 
     def save_seg(self, offset, mags, data, data_mag: int = 1, fast_resampling: bool = True, upsample: bool = True,
                  **_):
-        self._save(offset, mags, data, data_mag, 'seg.raw', np.uint64, fast_resampling, upsample)
+        self._save(offset, mags, data, data_mag, 'seg.sz', np.uint64, fast_resampling, upsample)
 
 
 class Chunk:

@@ -272,7 +272,26 @@ def test_predict_cellorganelles_labels_end_to_end(gpu, tmp_path):
           f'unsafe {int((mism & ~safe).sum())}; label hist {np.bincount(ref.ravel().astype(np.int64), minlength=4)}')
     assert not (mism & safe).any() and safe.mean() > 0.5
     assert len(np.unique(ref)) >= 2
+    # on-disk overlay format: snappy-in-zip cubes, pyramid [1, 2, 4] by order-0 resampling
+    import glob
+    assert glob.glob(f'{wd}/knossosdatasets/mivcsj/mag1/x0000/y0000/z0000/*_mag1_x0000_y0000_z0000.seg.sz.zip')
+    got2 = kd_out.load_seg(size=shape_xyz, offset=(0, 0, 0), mag=2)
+    assert np.array_equal(got2, got[::2, ::2, ::2][:got2.shape[0], :got2.shape[1], :got2.shape[2]])
     global_params.wd = None
+
+
+def test_downsample2_is_strided_pick(gpu):
+    """sd_downsample2 == data[::2, ::2, ::2] (the order-0 mag pyramid), uint8 and 8-byte labels, odd extents."""
+    from syconn_amd.engine import downsample2, mag_pyramid
+    g = torch.Generator().manual_seed(3)
+    for shape in ((7, 9, 11), (64, 48, 130), (1, 1, 1), (33, 2, 65)):
+        a = torch.randint(0, 256, shape, dtype=torch.uint8, generator=g)
+        assert torch.equal(downsample2(a.to(gpu)).cpu(), a[::2, ::2, ::2])
+        b = torch.randint(0, 2 ** 62, shape, dtype=torch.int64, generator=g)
+        assert torch.equal(downsample2(b.to(gpu)).cpu(), b[::2, ::2, ::2])
+    a = torch.randint(0, 256, (41, 63, 65), dtype=torch.uint8, generator=g)
+    lv = mag_pyramid(a.to(gpu), 3)
+    assert torch.equal(lv[1].cpu(), a[::2, ::2, ::2]) and torch.equal(lv[2].cpu(), a[::4, ::4, ::4])
 
 
 def test_config3_volume_in_overlapping_chunks(gpu):
