@@ -264,3 +264,31 @@ def test_forward_batch_equals_single_forwards(gpu, arch, shape):
         batched = dm.forward_batch(x, kind, slot=1)
         assert batched.shape == single.shape
         assert torch.equal(batched, single)
+
+
+def test_full_size_tile_properties(gpu):
+    """BASELINE configs[1] at full size (semseg_spine, 128^3, bf16), checked through size-independent properties:
+    bit-identical repeat runs, batched == single launches, probabilities of a voxel sum to 255 up to the truncation
+    (each of the C classes loses < 1), and translation consistency: the centre of a tile does not depend on what lies
+    beyond the network's receptive field."""
+    from syconn_amd import _lib as L
+    from syconn_amd.engine import DenseModel
+    net = build_unet('semseg_spine', seed=2, final_scale=6.0)
+    dm = DenseModel(net, 'bf16', gpu)
+    x = _input((2, 128, 128, 128), 5).to(gpu)
+    a = dm.forward(x[0], L.SD_OUT_PROBS_U8).clone()
+    b = dm.forward(x[0], L.SD_OUT_PROBS_U8).clone()
+    assert torch.equal(a, b)
+    both = dm.forward_batch(x, L.SD_OUT_PROBS_U8, slot=1)
+    assert torch.equal(both[0], a) and torch.equal(both[1], dm.forward(x[1], L.SD_OUT_PROBS_U8))
+    s = a.to(torch.int32).sum(0)
+    assert int(s.max()) <= 255 and int(s.min()) > 255 - a.shape[0]
+    # same data, but everything further than 48 voxels (> receptive field 44 of this net along y/x; planar levels do
+    # not look along z at all levels, 3D ones reach 20) from the central 16^3 block replaced: the block must not change
+    y = x[0].clone()
+    y[:8] = 255 - y[:8]
+    y[-8:] = 255 - y[-8:]
+    y[:, :8] = 0
+    y[:, :, -8:] = 17
+    c = dm.forward(y, L.SD_OUT_PROBS_U8)
+    assert torch.equal(c[:, 56:72, 56:72, 56:72], a[:, 56:72, 56:72, 56:72])
