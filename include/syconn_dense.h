@@ -152,6 +152,14 @@ int sd_snappy_uncompress(const void* src, size_t n, void* dst, size_t dst_capaci
  * dst dims = ceil(src dims / 2).  dtype: SD_U8 or SD_U64. */
 int sd_downsample2(const void* src_dev, int dtype, int D, int H, int W, void* dst_dev, void* stream);
 
+/* ---- first consumer of the myelin probability map -----------------------------------
+ * map_myelin2coords (/root/reference/syconn/reps/super_segmentation_helper.py:550-615): for each of n boxes with
+ * origin origins_zyx[3i..3i+2] (voxels of `vol`, may lie partly outside = zeros, like kd.load_raw) and extent
+ * (ez,ey,ex): out[i] = (count(vol > thresh_proba) / (ez*ey*ex) > thresh_majority), the division in float64 as in
+ * the reference (:611-612).  vol: (D,H,W) uint8 on the device; origins int32 and out uint8 on the device. */
+int sd_box_majority(const uint8_t* vol_dev, int D, int H, int W, const int32_t* origins_zyx_dev, size_t n, int ez, int ey,
+                    int ex, double thresh_proba, double thresh_majority, uint8_t* out_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

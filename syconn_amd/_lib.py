@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.g
 EXPORTS = ['sd_init', 'sd_device_count', 'sd_model_create', 'sd_model_destroy', 'sd_workspace_bytes', 'sd_forward', 'sd_forward_batch',
            'sd_tile_gather', 'sd_tile_scatter', 'sd_postproc_labels', 'sd_profile_enable', 'sd_profile_read',
            'sd_debug_read_buffer', 'sd_model_num_ops', 'sd_last_error', 'sd_version', 'sd_snappy_max_compressed_length',
-           'sd_snappy_compress', 'sd_snappy_uncompressed_length', 'sd_snappy_uncompress', 'sd_downsample2']
+           'sd_snappy_compress', 'sd_snappy_uncompressed_length', 'sd_snappy_uncompress', 'sd_downsample2', 'sd_box_majority']
 
 
 class OpDesc(C.Structure):
@@ -69,6 +69,8 @@ def load():
     lib.sd_snappy_uncompressed_length.argtypes = [vp, sz, C.POINTER(sz)]; lib.sd_snappy_uncompressed_length.restype = i32
     lib.sd_snappy_uncompress.argtypes = [vp, sz, vp, sz, C.POINTER(sz)]; lib.sd_snappy_uncompress.restype = i32
     lib.sd_downsample2.argtypes = [vp, i32, i32, i32, i32, vp, vp]; lib.sd_downsample2.restype = i32
+    lib.sd_box_majority.argtypes = [vp, i32, i32, i32, vp, sz, i32, i32, i32, C.c_double, C.c_double, vp, vp]
+    lib.sd_box_majority.restype = i32
     _lib = lib
     return lib
 

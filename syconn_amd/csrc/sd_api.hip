@@ -678,6 +678,19 @@ int sd_downsample2(const void* src, int dtype, int D, int H, int W, void* dst, v
     return rc == SD_OK ? rc : fail(rc, "sd_downsample2 launch failed");
 }
 
+int sd_box_majority(const uint8_t* vol, int D, int H, int W, const int32_t* origins_zyx, size_t n, int ez, int ey, int ex,
+                    double thresh_proba, double thresh_majority, uint8_t* out, void* stream) {
+    if (!vol || (!origins_zyx && n) || (!out && n) || D <= 0 || H <= 0 || W <= 0 || ez <= 0 || ey <= 0 || ex <= 0)
+        return fail(SD_ERR_INVALID, "sd_box_majority: bad argument");
+    if (thresh_proba != thresh_proba) return fail(SD_ERR_INVALID, "sd_box_majority: NaN threshold");
+    // (uint8 p > t) <=> p >= floor(t) + 1, exact for any real t
+    const double c = std::floor(thresh_proba) + 1.0;
+    const int cut = c < 0.0 ? 0 : (c > 256.0 ? 256 : (int)c);
+    int rc = launch_box_majority(vol, D, H, W, origins_zyx, (long)n, ez, ey, ex, cut, thresh_majority, out,
+                                 reinterpret_cast<hipStream_t>(stream));
+    return rc == SD_OK ? rc : fail(rc, "sd_box_majority launch failed");
+}
+
 int sd_postproc_labels(const uint8_t* probs, int C, size_t nvox, const int32_t* ids, const double* thresholds, int n_ids,
                        void* out, int out_dtype, void* stream) {
     if (!probs || !ids || !thresholds || !out || n_ids <= 0 || n_ids > 16)

@@ -121,6 +121,8 @@ int launch_tile_gather(const void* vol, int esize, int VD, int VH, int VW, int o
 int launch_tile_scatter(const void* tile, int esize, int C, int TD, int TH, int TW, int cz, int cy, int cx, int KD,
                         int KH, int KW, void* vol, int VD, int VH, int VW, int oz, int oy, int ox, hipStream_t s);
 int launch_downsample2(const void* src, int esize, int D, int H, int W, void* dst, hipStream_t s);
+int launch_box_majority(const uint8_t* vol, int D, int H, int W, const int32_t* origins, long n, int ez, int ey, int ex,
+                        int cut, double thresh_majority, uint8_t* out, hipStream_t s);
 struct LabelArgs { int n; int ids[16]; int cuts[16]; };
 int launch_labels(const uint8_t* probs, size_t nvox, const LabelArgs& a, void* out, int out_u64, hipStream_t s);
 int launch_read_buffer(const void* buf, int act_dtype, int C, int Cs, int D, int H, int W, float* out, hipStream_t s);

@@ -1424,6 +1424,35 @@ int launch_downsample2(const void* src, int esize, int D, int H, int W, void* ds
     return SD_LAUNCH_CHECK();
 }
 
+// Box majority vote (map_myelin2coords, /root/reference/syconn/reps/super_segmentation_helper.py:550-615): for every
+// box origin (z,y,x; may lie partly outside the volume = zeros) count the voxels >= cut inside an (ez,ey,ex) box and
+// emit (double)count / n_box > thresh_majority.  One wave per box; lanes stride over the box voxels, x fastest.
+__global__ __launch_bounds__(256) void k_box_majority(const uint8_t* vol, int D, int H, int W, const int32_t* origins,
+                                                      long n, int ez, int ey, int ex, int cut, double thresh_majority,
+                                                      uint8_t* out) {
+    const int lane = threadIdx.x & 63;
+    const long box = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (box >= n) return;
+    const int oz = origins[3 * box], oy = origins[3 * box + 1], ox = origins[3 * box + 2];
+    const int nvox = ez * ey * ex;
+    int cnt = 0;
+    for (int i = lane; i < nvox; i += 64) {
+        const int x = ox + i % ex, y = oy + (i / ex) % ey, z = oz + i / (ex * ey);
+        if ((unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+            cnt += (int)vol[((size_t)z * H + y) * W + x] >= cut;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) cnt += __shfl_xor(cnt, m, 64);
+    if (lane == 0) out[box] = ((double)cnt / (double)nvox > thresh_majority) ? 1 : 0;
+}
+int launch_box_majority(const uint8_t* vol, int D, int H, int W, const int32_t* origins, long n, int ez, int ey, int ex,
+                        int cut, double thresh_majority, uint8_t* out, hipStream_t s) {
+    if (n <= 0) return SD_OK;
+    dim3 grid((unsigned)((n + 3) / 4)), block(256);
+    hipLaunchKernelGGL(k_box_majority, grid, block, 0, s, vol, D, H, W, origins, n, ez, ey, ex, cut, thresh_majority, out);
+    return SD_LAUNCH_CHECK();
+}
+
 int launch_labels(const uint8_t* probs, size_t nvox, const LabelArgs& a, void* out, int out_u64, hipStream_t s) {
     dim3 grid(grid_for((long)nvox)), block(256);
     if (out_u64) hipLaunchKernelGGL((k_labels<uint64_t>), grid, block, 0, s, probs, nvox, a, (uint64_t*)out);

@@ -109,3 +109,18 @@ def test_g6_config1_end_to_end():
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3     # floor() may flip on a 1-ulp softmax difference
     if diff.max() == 0:
         assert hashlib.sha256(out.tobytes()).digest() == g['sha256'].tobytes()
+
+
+def test_g7_map_myelin2coords_restatement_matches_reference_outputs():
+    """oracle/myelin_ref.py vs the outputs of the reference's own map_myelin2coords (lifted and executed by
+    tests/golden/make_golden_myelin.py): this row of the oracle is PINNED."""
+    from oracle.myelin_ref import box_majority_ref
+    g = np.load(os.path.join(G, 'g7_myelin2coords.npz'))
+    vol4, coords, mag = g['vol4'], g['coords'], int(g['mag'])
+    assert np.array_equal(box_majority_ref(vol4, coords, mag=mag), g['default'])
+    assert np.array_equal(box_majority_ref(vol4, coords, cube_edge_avg=(5, 7, 3), mag=mag), g['edge_5_7_3'])
+    assert np.array_equal(box_majority_ref(vol4, coords, thresh_proba=100, thresh_majority=0.3, mag=mag),
+                          g['thresh_100_maj_0p3'])
+    assert np.array_equal(box_majority_ref(vol4, coords, thresh_proba=140.5, thresh_majority=0.1, mag=mag),
+                          g['thresh_frac_maj_0p1'])
+    assert 0 < g['default'].sum() < len(coords)          # both classes occur
