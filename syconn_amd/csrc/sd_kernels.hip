@@ -906,7 +906,10 @@ __global__ __launch_bounds__(256) void k_upconv_mfma(const UpconvParams p) {
 // two x-taps (= the two adjacent output voxels of every input voxel), rounds them, transposes them through a
 // wave-private LDS tile (XOR-swizzled 16-byte pieces) and writes them out as fully coalesced 16-byte pieces: every
 // input voxel yields one contiguous run of 2*C_out*sizeof(T) bytes per (a,b).
-template <typename T, int NCH, int NTAB>
+// WL: the weight fragments of the workgroup's taps live in LDS (loaded once) and the workgroup is persistent over
+// voxel groups; blockIdx.y selects the (z-tap, y-tap) pair, so a workgroup needs NTAB*NCH KiB of weights.  Without
+// WL every wave re-reads all its weights from L2 for each 32 voxels, which bounds the 128 -> 64 channel up-convolution.
+template <typename T, int NCH, int NTAB, bool WL>
 __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
     using v8 = typename Act<T>::v8;
     using v4 = typename Act<T>::v4;
@@ -914,7 +917,7 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
     constexpr int CD = NTAB * 16;            // channel stride of the output
     constexpr int ROW = 4 * CD;              // bytes per input voxel per (a,b): 2 taps * CD * 2 B
     constexpr int PPV = ROW / 16;            // 16-byte pieces per voxel
-    constexpr int SWM = PPV >= 8 ? 7 : PPV - 1;
+    constexpr int SWM = (PPV % 8 == 0) ? 7 : (PPV % 4 == 0) ? 3 : (PPV % 2 == 0) ? 1 : 0;   // XOR mask must divide the row
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, vl = lane & 31;
     char* const tile = smem + wave * (32 * ROW);
@@ -924,8 +927,17 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
     char* const dst = reinterpret_cast<char*>(p.dst) + blockIdx.z * p.tstride;
     const int H2 = 2 * p.H, W2 = 2 * p.W;
 
-    const long m0 = ((long)blockIdx.x * 4 + wave) * 32;
-    if (m0 >= M) return;                     // wave-uniform; no workgroup barrier is used in this kernel
+    static_assert(!WL || NTAB % 2 == 0, "one (a,b) tap pair = NTAB/2 weight blocks");
+    constexpr int WBYTES = NTAB * NCH * 1024;                 // weight fragments of one (z-tap, y-tap) pair
+    const char* const wlds = smem + 4 * 32 * ROW;
+    const int a_wg = WL ? (int)blockIdx.y : 0;
+    if constexpr (WL) {
+        const char* const wsrc = reinterpret_cast<const char*>(wp) + (size_t)a_wg * WBYTES;
+        for (int o = tid * 16; o < WBYTES; o += 256 * 16)
+            *reinterpret_cast<u4*>(smem + 4 * 32 * ROW + o) = *reinterpret_cast<const u4*>(wsrc + o);
+        __syncthreads();
+    }
+    for (long m0 = ((long)blockIdx.x * 4 + wave) * 32; m0 < M; m0 += WL ? (long)gridDim.x * 128 : M) {
     const long m = m0 + vl;
     const bool mv = m < M;
     v8 xf[NCH];
@@ -935,9 +947,9 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
         if (mv) val = *reinterpret_cast<const v8*>(src + m * p.Cs + c * SD_CHUNK + half * 8);
         xf[c] = val;
     }
-    const int nab = p.kz * 2;
+    const int ab0 = WL ? a_wg : 0, nab = WL ? ab0 + 1 : p.kz * 2;
 #pragma unroll 1
-    for (int ab = 0; ab < nab; ++ab) {
+    for (int ab = ab0; ab < nab; ++ab) {
         f32x16 acc[NTAB];
 #pragma unroll
         for (int j = 0; j < NTAB; ++j)
@@ -948,8 +960,13 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
 #pragma unroll
             for (int j = 0; j < NTAB; ++j) {
                 const int tl = ab * NTAB + j;             // global 32-column tile (n = tap*CD + co ordering)
-                const v8 wf = *reinterpret_cast<const v8*>(
-                    wp + ((((size_t)(tl >> 1) * NCH + c) * 2 + (tl & 1)) * 64 + lane) * 8);
+                v8 wf;
+                if constexpr (WL) {
+                    const int tloc = (ab - ab0) * NTAB + j;
+                    wf = *reinterpret_cast<const v8*>(wlds + ((((tloc >> 1) * NCH + c) * 2 + (tloc & 1)) * 64 + lane) * 16);
+                } else {
+                    wf = *reinterpret_cast<const v8*>(wp + ((((size_t)(tl >> 1) * NCH + c) * 2 + (tl & 1)) * 64 + lane) * 8);
+                }
                 acc[j] = Act<T>::mfma(wf, xf[c], acc[j]);
             }
         }
@@ -985,6 +1002,7 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
                 *reinterpret_cast<u4*>(dst + ov * (size_t)(CD * sizeof(T)) + piece * 16) = val;
             }
         }
+    }
     }
 }
 
@@ -1319,16 +1337,38 @@ template <typename T, int NCH, int NTAB>
 static int launch_upconv_rows(const UpconvParams& p, hipStream_t s) {
     const long M = (long)p.D * p.H * p.W;
     dim3 grid((unsigned)((M + 127) / 128), 1, p.batch), block(256);
-    hipLaunchKernelGGL((k_upconv_rows<T, NCH, NTAB>), grid, block, 4 * 32 * 64 * NTAB, s, p);
+    hipLaunchKernelGGL((k_upconv_rows<T, NCH, NTAB, false>), grid, block, 4 * 32 * 64 * NTAB, s, p);
+    return SD_LAUNCH_CHECK();
+}
+template <typename T, int NCH, int NTAB>
+static int launch_upconv_rows_wl(const UpconvParams& p, hipStream_t s) {      // LDS-resident weights, persistent
+    const long M = (long)p.D * p.H * p.W;
+    const size_t lds = 4 * 32 * 64 * NTAB + (size_t)NTAB * NCH * 1024;
+    auto kern = k_upconv_rows<T, NCH, NTAB, true>;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess) return SD_ERR_HIP;
+        attr = true;
+    }
+    const int per_cu = std::max(1, (int)(SD_LDS_BYTES / lds));
+    const long want = std::max(1L, (long)SD_NUM_CU * per_cu * 2 / (2 * p.kz * p.batch));     // ~2 rounds of workgroups
+    dim3 grid((unsigned)std::min((M + 127) / 128, want), 2 * p.kz, p.batch), block(256);
+    hipLaunchKernelGGL(kern, grid, block, lds, s, p);
     return SD_LAUNCH_CHECK();
 }
 template <typename T>
 static int launch_upconv_t(const UpconvParams& p, int NB, hipStream_t s) {
-    // the store-bound full-resolution shape gets the row-coalescing kernel (64 -> 32 channels: 77 -> 52 us at 128^3);
-    // at 128 -> 64 channels it measured slower than the plain kernel (85 vs 63 us: 32 L2 weight loads per row pair)
+    // the store-bound full-resolution shapes get the row-coalescing kernel (64 -> 32 channels: 77 -> 52 us at 128^3);
+    // at 128 -> 64 channels it needs its weights in LDS (plain rows kernel 85 us, k_upconv_mfma 63 us, LDS weights with
+    // one tap pair per workgroup and two workgroups per CU 51 us; 48 -> 33 us per tile at 8 tiles per launch)
     if (p.nchunk == 4 && p.Cd == 32) return launch_upconv_rows<T, 4, 2>(p, s);
     if (p.nchunk == 3 && p.Cd == 32) return launch_upconv_rows<T, 3, 2>(p, s);
     if (p.nchunk == 2 && p.Cd == 16) return launch_upconv_rows<T, 2, 1>(p, s);
+    static const bool no_wl = getenv("SD_NO_UPCONV_WL") != nullptr;
+    if (p.nchunk == 8 && p.Cd == 64 && !no_wl) return launch_upconv_rows_wl<T, 8, 4>(p, s);
+    if (p.nchunk == 12 && p.Cd == 96 && !no_wl) return launch_upconv_rows_wl<T, 12, 6>(p, s);     // 48-filter family
+    if (p.nchunk == 6 && p.Cd == 48) return launch_upconv_rows<T, 6, 3>(p, s);                    // (150 -> 93 us at 128^3)
     const long M = (long)p.D * p.H * p.W;
     dim3 grid((unsigned)((M + 255) / 256), NB, p.batch), block(256);
     hipLaunchKernelGGL((k_upconv_mfma<T>), grid, block, 0, s, p);
