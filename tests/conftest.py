@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # a fresh checkout has no built library (it is git-ignored): build it once, in-tree, before any test imports it
+    lib = os.path.join(ROOT, 'syconn_amd', 'libsyconn_dense_hip.so')
+    if not os.path.isfile(lib) and os.path.isfile('/opt/rocm/bin/hipcc'):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope='session')
