@@ -55,6 +55,8 @@ struct Op {
     int fuse_pool = -1;    // index of the MaxPool op computed in this conv's epilogue
     int fuse_final = -1;   // index of the final 1x1x1 op computed in this conv's epilogue
     int fuse_up = -1;      // index of the ConvTranspose op whose output (this conv's src0) is produced on the fly
+    int fuse_gn = -1;      // conv: index of the GroupNorm op whose statistics this conv's epilogue accumulates
+    bool stats_done = false;   // groupnorm: statistics come from the producing conv
     size_t upw_off = 0, upb_off = 0;   // fused up-conv weights / bias (byte offsets)
     size_t fwfrag_off = 0;             // fused final 1x1x1: hi/lo MFMA weight fragments
     bool skipped = false;  // op is executed inside its producer
@@ -357,6 +359,12 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
             Op& c = m->ops[i];
             Op& nx = m->ops[i + 1];
             if (c.d.kind != SD_OP_CONV || c.first) continue;
+            // GroupNorm right behind a conv over the conv's whole output: statistics in the conv epilogue
+            if (nx.d.kind == SD_OP_GROUPNORM && nx.d.src0 == c.d.dst && nx.d.src1 < 0 && !getenv("SD_NO_GN_FUSE")) {
+                c.fuse_gn = (int)(i + 1);
+                nx.stats_done = true;
+                continue;
+            }
             // (the fused pooling maximum works on the packed, rounded outputs as integers: exact behind a ReLU only)
             if (nx.d.kind == SD_OP_POOL && nx.d.src0 == c.d.dst && (c.d.kz == 3) == (nx.d.kz == 2) && c.d.relu) {
                 c.fuse_pool = (int)(i + 1);
@@ -584,6 +592,11 @@ int sd_forward_batch(sd_model* m, const void* in_dev, int in_dtype, int N, int D
                     p.final_cout = fo.d.cout; p.final_kind = out_kind; p.final_out = out_dev;
                     p.store_main = m->keep_all ? 1 : 0;
                 }
+                if (op.fuse_gn >= 0) {
+                    p.gn_sums = reinterpret_cast<double*>(wsb); p.gn_C = p.Cd;
+                    for (int t = 0; t < N; ++t)
+                        HIP_TRY(hipMemsetAsync(wsb + (size_t)t * tstride, 0, sizeof(double) * 2 * p.Cd, s));
+                }
                 p.nbx = (o.w + SD_BX - 1) / SD_BX; p.nby = (o.h + BY - 1) / BY; p.nbz = (o.d + BZ - 1) / BZ;
                 rc = launch_conv(p, m->act_dtype, d.kz, op.NT, op.NB, s);
             }
@@ -623,7 +636,7 @@ int sd_forward_batch(sd_model* m, const void* in_dev, int in_dtype, int N, int D
             p.sums = reinterpret_cast<double*>(wsb);
             p.scale_shift = reinterpret_cast<float*>(wsb + (size_t)2 * p.C * 8);
             p.relu = d.relu;
-            p.batch = N; p.tstride = tstride;
+            p.batch = N; p.tstride = tstride; p.skip_stats = op.stats_done ? 1 : 0;
             rc = launch_groupnorm(p, m->act_dtype, s);
             break;
         }

@@ -49,6 +49,9 @@ struct ConvParams {
     int up_relu;
     long long* dbg;         // SD_TIMING builds: per-wave cycle stamps
     int batch; size_t tstride, out_tstride;
+    // fused GroupNorm statistics: per-channel sum / sum of squares of the stored outputs are added to
+    // gn_sums[0..gn_C) / gn_sums[gn_C..2*gn_C) of the block's tile (doubles, zeroed by the host), or nullptr
+    double* gn_sums; int gn_C;
 };
 
 struct FirstParams {
@@ -108,6 +111,7 @@ struct GnParams {
     float* scale_shift;        // [2*C]
     int relu;
     int batch; size_t tstride;
+    int skip_stats;            // the producing convolution already accumulated `sums` (ConvParams::gn_sums)
 };
 
 int launch_conv(const ConvParams& p, int act_dtype, int KZ, int NT, int NB, hipStream_t s);

@@ -620,6 +620,55 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
 #pragma unroll
                 for (int k = 0; k < 8; ++k) pk[i][j][k] = pk_max16(pk[i][j][k], 0u);
     }
+    // ---- fused GroupNorm statistics ---------------------------------------------------------------------------------
+    // sum and sum of squares per output channel over the block's valid voxels, from the ROUNDED values (what the
+    // separate statistics pass would read back).  The cross-lane reduction over voxels is done by the matrix core: with
+    // the packed tile as A operand (rows = voxels, k = 16 channels) and a 0/1 selector as B, D[voxel][channel] is the
+    // transposed tile -- lane = channel, 16 voxels in its registers, exact in fp32 -- so each lane just sums its
+    // registers.  Waves and half-waves are combined in a fixed order through LDS (deterministic), then one double
+    // atomicAdd per channel and statistic per block.
+    if (p.gn_sums) {
+        typedef __attribute__((ext_vector_type(4))) unsigned u4;
+        float* const part = reinterpret_cast<float*>(ldsA + ((gc - 1) % NA) * A_BYTES);   // free: last chunk's halo slot
+        const int n32 = lane & 31;
+        v8 s1, s2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = 8 * (e >> 2) + 4 * half + (e & 3);     // channel of k-slot (half, e) within a 16-channel group
+            s1[e] = (T)((c == n32) ? 1.0f : 0.0f);
+            s2[e] = (T)((c + 16 == n32) ? 1.0f : 0.0f);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float sj = 0.f, ssj = 0.f;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                u4 lo = {pk[i][j][0], pk[i][j][1], pk[i][j][2], pk[i][j][3]};
+                u4 hi = {pk[i][j][4], pk[i][j][5], pk[i][j][6], pk[i][j][7]};
+                if (!valid[i]) { lo = u4{0u, 0u, 0u, 0u}; hi = lo; }
+                f32x16 d;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d[r] = 0.f;
+                d = Act<T>::mfma(__builtin_bit_cast(v8, lo), s1, d);
+                d = Act<T>::mfma(__builtin_bit_cast(v8, hi), s2, d);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sj += d[r]; ssj = fmaf(d[r], d[r], ssj); }
+            }
+            float* const q = part + ((size_t)(wave * 2 + half) * (NT * 32) + j * 32 + n32) * 2;
+            q[0] = sj; q[1] = ssj;
+        }
+        __syncthreads();
+        if (tid < NT * 64) {
+            const int stat = tid / (NT * 32), cw = tid % (NT * 32);
+            double t = 0.0;
+            for (int w = 0; w < WAVES * 2; ++w) t += (double)part[((size_t)w * (NT * 32) + cw) * 2 + stat];
+            const int ch = nb * NT * 32 + cw;
+            if (ch < p.Cd)
+                atomicAdd(reinterpret_cast<double*>(reinterpret_cast<char*>(p.gn_sums) + (size_t)tn * p.tstride) +
+                              (size_t)stat * p.gn_C + ch, t);
+        }
+        __syncthreads();         // the slot is a DMA target again in the next block
+    }
 #ifdef SD_T5_EARLY
     SD_T(5);
 #endif
@@ -1402,19 +1451,20 @@ int launch_final(const FinalParams& p, int act_dtype, hipStream_t s) {
 int launch_groupnorm(const GnParams& p, int act_dtype, hipStream_t s) {
     const int ng = p.C / 8;
     if (192 % ng != 0) return SD_ERR_INVALID;
-    for (int t = 0; t < p.batch; ++t)
-        if (hipMemsetAsync(reinterpret_cast<char*>(p.sums) + t * p.tstride, 0, sizeof(double) * 2 * p.C, s) != hipSuccess)
-            return SD_ERR_HIP;
+    if (!p.skip_stats)
+        for (int t = 0; t < p.batch; ++t)
+            if (hipMemsetAsync(reinterpret_cast<char*>(p.sums) + t * p.tstride, 0, sizeof(double) * 2 * p.C, s) != hipSuccess)
+                return SD_ERR_HIP;
     const long nvox = (long)p.D * p.H * p.W;
     const int vper = 192 / ng;
     dim3 g1(grid_for(nvox, vper * 8, 2048), 1, p.batch), b1(192);
     dim3 g3(grid_for(nvox * ng), 1, p.batch), b3(256);
     if (act_dtype == SD_BF16) {
-        hipLaunchKernelGGL((k_gn_stats<bf16_t>), g1, b1, 0, s, p);
+        if (!p.skip_stats) hipLaunchKernelGGL((k_gn_stats<bf16_t>), g1, b1, 0, s, p);
         hipLaunchKernelGGL(k_gn_finalize, dim3(1, 1, p.batch), dim3(256), 0, s, p);
         hipLaunchKernelGGL((k_gn_apply<bf16_t>), g3, b3, 0, s, p);
     } else {
-        hipLaunchKernelGGL((k_gn_stats<f16_t>), g1, b1, 0, s, p);
+        if (!p.skip_stats) hipLaunchKernelGGL((k_gn_stats<f16_t>), g1, b1, 0, s, p);
         hipLaunchKernelGGL(k_gn_finalize, dim3(1, 1, p.batch), dim3(256), 0, s, p);
         hipLaunchKernelGGL((k_gn_apply<f16_t>), g3, b3, 0, s, p);
     }
