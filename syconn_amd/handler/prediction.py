@@ -290,38 +290,79 @@ def dense_predictor(args):
             log_main.warning(f'Changed tile shape from {tile_sh_orig} to {tile_shape} to reduce memory requirements.')
             ix = (ix + 1) % 3
 
+    # Host I/O is pipelined around the GPU: one thread reads chunk k+1 from the KnossosDataset while chunk k is
+    # predicted, one thread writes the results of chunk k-1 (cube files of neighbouring chunks overlap, so writes stay
+    # sequential and in chunk order).  The reference does read -> predict -> write strictly in sequence.
+    from concurrent.futures import ThreadPoolExecutor
     dev = predictor.device
-    for ch_id in chunk_ids:
+
+    def read_chunk(ch_id):
         ch = cd.chunk_dict[ch_id]
         ol = ch.overlap
         size = np.array(np.array(ch.size) + 2 * np.array(ol), dtype=np.int32)
         coords = np.array(np.array(ch.coordinates) - np.array(ol), dtype=np.int32)
-        raw = kd.load_raw(size=size * mag, offset=coords * mag, mag=mag)          # uint8, ZYX
-        raw_dev = torch.from_numpy(np.ascontiguousarray(raw)).to(dev)
-        pred_dev = predictor.predict_proba_u8_device(raw_dev)                     # (C, Z, Y, X) uint8
-        # slice out the original input volume along ZYX (prediction.py:812)
-        zyx = tuple(int(s) for s in np.asarray(ch.size)[::-1])
-        crop = torch.empty((pred_dev.shape[0], *zyx), dtype=torch.uint8, device=dev)
-        tile_scatter(pred_dev, (int(ol[2]), int(ol[1]), int(ol[0])), zyx, crop, (0, 0, 0))
-        for j in range(len(target_channels)):
-            ids = target_channels[j]
-            path = target_kd_path_list[j]
-            save_as_raw = not (len(ids) > 1)
-            # the mag pyramid [mag, 2*mag, 4*mag] (order-0, fast_resampling=True) is built on the device; each level is
-            # written with its own data_mag, which is what one save_*(mags=[mag, 2*mag, 4*mag]) call produces
-            if save_as_raw:
-                # no thresholding and only one label in the target KnossosDataset -> store probability map
-                for k, lvl in enumerate(mag_pyramid(crop[ids[-1]], 3)):
-                    target_kd_dict[path].save_raw(offset=ch.coordinates * mag, data=lvl.cpu().numpy(),
-                                                  data_mag=mag * 2 ** k, mags=[mag * 2 ** k], fast_resampling=True,
-                                                  upsample=False)
-            else:
-                thr = [_resolve_threshold(channel_thresholds[label]) for label in ids]
-                lab = postproc_labels(crop, ids, thr, out_dtype=torch.uint8)
-                for k, lvl in enumerate(mag_pyramid(lab, 3)):      # uint8 on the device and over PCIe, widened here
-                    target_kd_dict[path].save_seg(offset=ch.coordinates * mag, data=lvl.cpu().numpy().astype(np.uint64),
-                                                  data_mag=mag * 2 ** k, mags=[mag * 2 ** k], fast_resampling=True,
-                                                  upsample=False)
+        return np.ascontiguousarray(kd.load_raw(size=size * mag, offset=coords * mag, mag=mag))     # uint8, ZYX
+
+    def write_chunk(jobs):
+        for save, kwargs in jobs:
+            save(**kwargs)
+
+    class _Inline:                       # SYCONN_AMD_SEQ_IO=1: no overlap, everything in the caller's thread (debugging / A-B)
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            return False
+
+        def submit(self, fn, *a):
+            from concurrent.futures import Future
+            f = Future()
+            f.set_result(fn(*a))
+            return f
+
+    seq_io = bool(os.environ.get('SYCONN_AMD_SEQ_IO'))
+    chunk_ids = list(chunk_ids)
+    with (_Inline() if seq_io else ThreadPoolExecutor(max_workers=1)) as reader, \
+            (_Inline() if seq_io else ThreadPoolExecutor(max_workers=1)) as writer:
+        nxt = reader.submit(read_chunk, chunk_ids[0]) if chunk_ids else None
+        writes = []
+        for n, ch_id in enumerate(chunk_ids):
+            ch = cd.chunk_dict[ch_id]
+            ol = ch.overlap
+            raw = nxt.result()
+            nxt = reader.submit(read_chunk, chunk_ids[n + 1]) if n + 1 < len(chunk_ids) else None
+            raw_dev = torch.from_numpy(raw).to(dev)
+            pred_dev = predictor.predict_proba_u8_device(raw_dev)                     # (C, Z, Y, X) uint8
+            # slice out the original input volume along ZYX (prediction.py:812)
+            zyx = tuple(int(s) for s in np.asarray(ch.size)[::-1])
+            crop = torch.empty((pred_dev.shape[0], *zyx), dtype=torch.uint8, device=dev)
+            tile_scatter(pred_dev, (int(ol[2]), int(ol[1]), int(ol[0])), zyx, crop, (0, 0, 0))
+            jobs = []
+            for j in range(len(target_channels)):
+                ids = target_channels[j]
+                path = target_kd_path_list[j]
+                save_as_raw = not (len(ids) > 1)
+                # the mag pyramid [mag, 2*mag, 4*mag] (order-0, fast_resampling=True) is built on the device; each level
+                # is written with its own data_mag, which is what one save_*(mags=[mag, 2*mag, 4*mag]) call produces
+                if save_as_raw:
+                    # no thresholding and only one label in the target KnossosDataset -> store probability map
+                    for k, lvl in enumerate(mag_pyramid(crop[ids[-1]], 3)):
+                        jobs.append((target_kd_dict[path].save_raw,
+                                     dict(offset=ch.coordinates * mag, data=lvl.cpu().numpy(), data_mag=mag * 2 ** k,
+                                          mags=[mag * 2 ** k], fast_resampling=True, upsample=False)))
+                else:
+                    thr = [_resolve_threshold(channel_thresholds[label]) for label in ids]
+                    lab = postproc_labels(crop, ids, thr, out_dtype=torch.uint8)
+                    for k, lvl in enumerate(mag_pyramid(lab, 3)):  # uint8 on the device and over PCIe, widened here
+                        jobs.append((target_kd_dict[path].save_seg,
+                                     dict(offset=ch.coordinates * mag, data=lvl.cpu().numpy().astype(np.uint64),
+                                          data_mag=mag * 2 ** k, mags=[mag * 2 ** k], fast_resampling=True,
+                                          upsample=False)))
+            writes.append(writer.submit(write_chunk, jobs))
+            while len(writes) > 2:                   # bound the host memory held by queued results
+                writes.pop(0).result()
+        for w in writes:
+            w.result()
 
 
 def _wd_set() -> bool:

@@ -19,12 +19,33 @@ little-endian uint64 cube (z,y,x with x fastest).  The codec is the library's C 
 (``include/syconn_dense.h: sd_snappy_*``; python-snappy is not installed here).  Cubes written as raw uint64
 (``*.seg.raw``) by earlier versions of this file are still read.
 """
+import itertools
 import os
 import re
 import zipfile
+from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, Iterable, List, Optional, Sequence
 
 import numpy as np
+
+
+# cube files are independent: a box is read / written with one task per cube (file I/O, numpy copies and the C snappy
+# codec all release the GIL)
+_IO_THREADS = max(1, min(16, int(os.environ.get('SYCONN_AMD_IO_THREADS', '8'))))
+_pool = None
+
+
+def _map_cubes(fn, items):
+    global _pool
+    items = list(items)
+    if _IO_THREADS == 1 or len(items) < 2:
+        for it in items:
+            fn(*it)
+        return
+    if _pool is None:
+        _pool = ThreadPoolExecutor(max_workers=_IO_THREADS)
+    for f in [_pool.submit(fn, *it) for it in items]:
+        f.result()
 
 
 class KnossosDataset:
@@ -179,18 +200,19 @@ class KnossosDataset:
         if np.any(hi <= lo):
             return out
         c_lo, c_hi = lo // cs, (hi - 1) // cs
-        for cx in range(c_lo[0], c_hi[0] + 1):
-            for cy in range(c_lo[1], c_hi[1] + 1):
-                for cz in range(c_lo[2], c_hi[2] + 1):
-                    cube = self._read_cube(self._cube_file(mag, cx, cy, cz, ext), ext, dtype, tuple(cs[::-1]))
-                    if cube is None:
-                        continue
-                    c0 = np.array([cx, cy, cz]) * cs
-                    a = np.maximum(lo, c0)
-                    b = np.minimum(hi, c0 + cs)
-                    src = tuple(slice(int(a[i] - c0[i]), int(b[i] - c0[i])) for i in (2, 1, 0))
-                    dst = tuple(slice(int(a[i] - off[i]), int(b[i] - off[i])) for i in (2, 1, 0))
-                    out[dst] = cube[src]
+        def one(cx, cy, cz):
+            cube = self._read_cube(self._cube_file(mag, cx, cy, cz, ext), ext, dtype, tuple(cs[::-1]))
+            if cube is None:
+                return
+            c0 = np.array([cx, cy, cz]) * cs
+            a = np.maximum(lo, c0)
+            b = np.minimum(hi, c0 + cs)
+            src = tuple(slice(int(a[i] - c0[i]), int(b[i] - c0[i])) for i in (2, 1, 0))
+            dst = tuple(slice(int(a[i] - off[i]), int(b[i] - off[i])) for i in (2, 1, 0))
+            out[dst] = cube[src]                      # disjoint destination boxes
+
+        _map_cubes(one, itertools.product(range(c_lo[0], c_hi[0] + 1), range(c_lo[1], c_hi[1] + 1),
+                                          range(c_lo[2], c_hi[2] + 1)))
         return out
 
     def load_raw(self, size, offset, mag: int = 1, **_) -> np.ndarray:
@@ -218,20 +240,21 @@ class KnossosDataset:
             if np.any(hi <= lo):
                 continue
             c_lo, c_hi = lo // cs, (hi - 1) // cs
-            for cx in range(c_lo[0], c_hi[0] + 1):
-                for cy in range(c_lo[1], c_hi[1] + 1):
-                    for cz in range(c_lo[2], c_hi[2] + 1):
-                        fn = self._cube_file(mag, cx, cy, cz, ext)
-                        c0 = np.array([cx, cy, cz]) * cs
-                        a, b = np.maximum(lo, c0), np.minimum(hi, c0 + cs)
-                        whole = np.all(a == c0) and np.all(b == c0 + cs)
-                        cube = None if whole else self._read_cube(fn, ext, dtype, tuple(cs[::-1]))
-                        if cube is None:
-                            cube = np.zeros(tuple(cs[::-1]), dtype=dtype)
-                        dst = tuple(slice(int(a[i] - c0[i]), int(b[i] - c0[i])) for i in (2, 1, 0))
-                        src = tuple(slice(int(a[i] - off[i]), int(b[i] - off[i])) for i in (2, 1, 0))
-                        cube[dst] = d[src]
-                        self._write_cube(fn, ext, cube)
+            def one(cx, cy, cz, mag=mag, d=d, off=off, lo=lo, hi=hi):
+                fn = self._cube_file(mag, cx, cy, cz, ext)
+                c0 = np.array([cx, cy, cz]) * cs
+                a, b = np.maximum(lo, c0), np.minimum(hi, c0 + cs)
+                whole = np.all(a == c0) and np.all(b == c0 + cs)
+                cube = None if whole else self._read_cube(fn, ext, dtype, tuple(cs[::-1]))
+                if cube is None:
+                    cube = np.zeros(tuple(cs[::-1]), dtype=dtype)
+                dst = tuple(slice(int(a[i] - c0[i]), int(b[i] - c0[i])) for i in (2, 1, 0))
+                src = tuple(slice(int(a[i] - off[i]), int(b[i] - off[i])) for i in (2, 1, 0))
+                cube[dst] = d[src]
+                self._write_cube(fn, ext, cube)
+
+            _map_cubes(one, itertools.product(range(c_lo[0], c_hi[0] + 1), range(c_lo[1], c_hi[1] + 1),
+                                              range(c_lo[2], c_hi[2] + 1)))
 
     def save_raw(self, offset, mags, data, data_mag: int = 1, fast_resampling: bool = True, upsample: bool = True,
                  **_):
