@@ -119,7 +119,12 @@ def main():
     from syconn_amd.engine import DenseModel, StreamRing, postproc_labels
     from oracle.unet_ref import build_unet   # architecture definition + seeded random init (no trained weights exist)
 
-    rank, world, local_rank = par.init_distributed()
+    # SD_BENCH_ONE_GPU_DEBUG=1: exercise the N > 1 code path on a box with ONE GPU (all ranks on cuda:0, gloo) -- a
+    # functional check of the sharding / gather / timing logic only, never a measurement
+    one_gpu_debug = bool(os.environ.get('SD_BENCH_ONE_GPU_DEBUG'))
+    rank, world, local_rank = par.init_distributed('gloo' if one_gpu_debug else None)
+    if one_gpu_debug:
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
     if not torch.cuda.is_available():
