@@ -308,11 +308,25 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     }
     // logical block of (round, this workgroup); -1 when the round has no block for it
     const int nsb_all = nsb * p.batch;      // the tiles of a batched launch are simply more blocks
+#ifdef SD_XCD_ROUNDS
     auto block_of = [&](int round) -> int {
         const int base = round * gsz;
         const int n = min(gsz, nsb_all - base);
         return ((int)blockIdx.x < n) ? base + xcd_remap(blockIdx.x, n) : -1;
     };
+#else
+    // Every XCD (workgroup b runs on XCD b % 8) owns ONE contiguous range of the block list and walks it round by
+    // round: consecutive rounds of an XCD are neighbouring rows / z-slabs, whose shared halo planes are then still in
+    // that XCD's L2 (with the blocks of a round spread over the whole list they were fetched from HBM again).
+    const int xk = blockIdx.x & 7, xj = blockIdx.x >> 3;
+    const int xw = gsz / 8 + (xk < gsz % 8);                             // workgroups of this XCD
+    const int xsize = nsb_all / 8 + (xk < nsb_all % 8);                  // blocks of this XCD
+    const int xstart = xk * (nsb_all / 8) + min(xk, nsb_all % 8);
+    auto block_of = [&](int round) -> int {
+        const int idx = round * xw + xj;
+        return idx < xsize ? xstart + idx : -1;
+    };
+#endif
     auto coords = [&](int lb, int& z0, int& y0, int& x0, int& tile) {
         tile = lb / nsb;
         lb -= tile * nsb;
