@@ -330,7 +330,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     auto coords = [&](int lb, int& z0, int& y0, int& x0, int& tile) {
         tile = lb / nsb;
         lb -= tile * nsb;
-        x0 = (lb % p.nbx) * BX; y0 = ((lb / p.nbx) % p.nby) * BY; z0 = (lb / (p.nbx * p.nby)) * BZ;
+        // 3x3x3: z fastest -- the blocks an XCD works on at the same time are then z-neighbours of one (y,x) column,
+        // whose shared halo planes (2 of 6, the largest overlap of a 4x8x16 block) hit in L2 (-12 % HBM reads);
+        // 1x3x3 blocks share nothing along z: x fastest, then y
+        if (KZ == 3) { z0 = (lb % p.nbz) * BZ; x0 = ((lb / p.nbz) % p.nbx) * BX; y0 = (lb / (p.nbz * p.nbx)) * BY; }
+        else { x0 = (lb % p.nbx) * BX; y0 = ((lb / p.nbx) % p.nby) * BY; z0 = (lb / (p.nbx * p.nby)) * BZ; }
     };
     // DMA chunk c of the block at (z0,y0,x0) into halo slot `slot`; real == false issues the same number of
     // instructions against the dummy slot (keeps the per-wave DMA count per chunk constant for the counted waits)
