@@ -57,6 +57,7 @@ struct Op {
     int fuse_up = -1;      // index of the ConvTranspose op whose output (this conv's src0) is produced on the fly
     int fuse_gn = -1;      // conv: index of the GroupNorm op whose statistics this conv's epilogue accumulates
     bool stats_done = false;   // groupnorm: statistics come from the producing conv
+    int gn_pool = -1;          // groupnorm: index of the MaxPool op fused into the apply pass
     size_t upw_off = 0, upb_off = 0;   // fused up-conv weights / bias (byte offsets)
     size_t fwfrag_off = 0;             // fused final 1x1x1: hi/lo MFMA weight fragments
     bool skipped = false;  // op is executed inside its producer
@@ -355,6 +356,16 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
     if (m->ops.empty() || m->ops.back().d.kind != SD_OP_FINAL) MODEL_FAIL("the plan must end with SD_OP_FINAL");
     // epilogue fusions (SD_NO_FUSE=1 keeps every layer a separate launch, for layer-wise debugging)
     if (!getenv("SD_NO_FUSE")) {
+        // GroupNorm (whole buffer) directly followed by the pooling of its output: one pass
+        for (size_t i = 0; i + 1 < m->ops.size(); ++i) {
+            Op& g = m->ops[i];
+            Op& nx = m->ops[i + 1];
+            if (g.d.kind == SD_OP_GROUPNORM && g.d.src1 < 0 && nx.d.kind == SD_OP_POOL && nx.d.src0 == g.d.src0 &&
+                !getenv("SD_NO_GN_FUSE")) {
+                g.gn_pool = (int)(i + 1);
+                nx.skipped = true;
+            }
+        }
         for (size_t i = 0; i + 1 < m->ops.size(); ++i) {
             Op& c = m->ops[i];
             Op& nx = m->ops[i + 1];
@@ -637,6 +648,11 @@ int sd_forward_batch(sd_model* m, const void* in_dev, int in_dtype, int N, int D
             p.scale_shift = reinterpret_cast<float*>(wsb + (size_t)2 * p.C * 8);
             p.relu = d.relu;
             p.batch = N; p.tstride = tstride; p.skip_stats = op.stats_done ? 1 : 0;
+            if (op.gn_pool >= 0) {
+                const sd_op_desc& pd = m->ops[op.gn_pool].d;
+                const Dims po = m->dims[pd.dst];
+                p.pool_dst = bufp(pd.dst); p.pkz = pd.kz; p.pD = po.d; p.pH = po.h; p.pW = po.w;
+            }
             rc = launch_groupnorm(p, m->act_dtype, s);
             break;
         }

@@ -112,6 +112,8 @@ struct GnParams {
     int relu;
     int batch; size_t tstride;
     int skip_stats;            // the producing convolution already accumulated `sums` (ConvParams::gn_sums)
+    void* pool_dst;            // fused MaxPool3d(ceil_mode) of the normalised tensor ((pkz,2,2) windows), or nullptr
+    int pkz, pD, pH, pW;       // pooling kz (1 or 2) and pooled extents
 };
 
 int launch_conv(const ConvParams& p, int act_dtype, int KZ, int NT, int NB, hipStream_t s);

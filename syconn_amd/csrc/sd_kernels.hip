@@ -1196,6 +1196,55 @@ __global__ __launch_bounds__(192) void k_gn_stats(const GnParams p) {
     }
 }
 
+// GroupNorm apply + ReLU with the following MaxPool3d(ceil_mode) fused: one thread per POOLED voxel and 8-channel
+// group normalises the (pkz,2,2) window in place and writes the window maximum -- the separate pooling pass would
+// read the whole normalised tensor again.
+template <typename T>
+__global__ __launch_bounds__(256) void k_gn_apply_pool(const GnParams p) {
+    using v8 = typename Act<T>::v8;
+    const int ng = p.C / 8;
+    const long total = (long)p.pD * p.pH * p.pW * ng;
+    T* const buf = reinterpret_cast<T*>(reinterpret_cast<char*>(p.buf) + blockIdx.z * p.tstride);
+    T* const pdst = reinterpret_cast<T*>(reinterpret_cast<char*>(p.pool_dst) + blockIdx.z * p.tstride);
+    const float* const scale_shift = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.scale_shift) + blockIdx.z * p.tstride);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int cg = (int)(idx % ng);
+        const long v = idx / ng;
+        const int xo = (int)(v % p.pW), yo = (int)((v / p.pW) % p.pH), zo = (int)(v / ((long)p.pW * p.pH));
+        float sc[8], sh[8], mx[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = scale_shift[cg * 8 + e]; sh[e] = scale_shift[p.C + cg * 8 + e]; mx[e] = -INFINITY; }
+        for (int dz = 0; dz < p.pkz; ++dz) {
+            const int z = zo * p.pkz + dz;
+            if (z >= p.D) continue;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                const int y = yo * 2 + dy;
+                if (y >= p.H) continue;
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int x = xo * 2 + dx;
+                    if (x >= p.W) continue;
+                    T* ptr = buf + (((size_t)z * p.Hs + y) * p.Ws + x) * p.C + cg * 8;
+                    v8 val = *reinterpret_cast<const v8*>(ptr);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float f = fmaf((float)val[e], sc[e], sh[e]);
+                        if (p.relu) f = fmaxf(f, 0.f);
+                        val[e] = (T)f;
+                        mx[e] = fmaxf(mx[e], (float)val[e]);          // max of the ROUNDED values, like the pooling pass
+                    }
+                    *reinterpret_cast<v8*>(ptr) = val;
+                }
+            }
+        }
+        v8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (T)mx[e];
+        *reinterpret_cast<v8*>(pdst + (size_t)v * p.C + cg * 8) = o;
+    }
+}
+
 __global__ void k_gn_finalize(const GnParams p) {
     const double* const sums = reinterpret_cast<const double*>(reinterpret_cast<const char*>(p.sums) + blockIdx.z * p.tstride);
     float* const scale_shift = reinterpret_cast<float*>(reinterpret_cast<char*>(p.scale_shift) + blockIdx.z * p.tstride);
@@ -1477,14 +1526,17 @@ int launch_groupnorm(const GnParams& p, int act_dtype, hipStream_t s) {
     const int vper = 192 / ng;
     dim3 g1(grid_for(nvox, vper * 8, 2048), 1, p.batch), b1(192);
     dim3 g3(grid_for(nvox * ng), 1, p.batch), b3(256);
+    dim3 gp(grid_for((long)std::max(p.pD, 1) * std::max(p.pH, 1) * std::max(p.pW, 1) * ng), 1, p.batch);
     if (act_dtype == SD_BF16) {
         if (!p.skip_stats) hipLaunchKernelGGL((k_gn_stats<bf16_t>), g1, b1, 0, s, p);
         hipLaunchKernelGGL(k_gn_finalize, dim3(1, 1, p.batch), dim3(256), 0, s, p);
-        hipLaunchKernelGGL((k_gn_apply<bf16_t>), g3, b3, 0, s, p);
+        if (p.pool_dst) hipLaunchKernelGGL((k_gn_apply_pool<bf16_t>), gp, b3, 0, s, p);
+        else hipLaunchKernelGGL((k_gn_apply<bf16_t>), g3, b3, 0, s, p);
     } else {
         if (!p.skip_stats) hipLaunchKernelGGL((k_gn_stats<f16_t>), g1, b1, 0, s, p);
         hipLaunchKernelGGL(k_gn_finalize, dim3(1, 1, p.batch), dim3(256), 0, s, p);
-        hipLaunchKernelGGL((k_gn_apply<f16_t>), g3, b3, 0, s, p);
+        if (p.pool_dst) hipLaunchKernelGGL((k_gn_apply_pool<f16_t>), gp, b3, 0, s, p);
+        else hipLaunchKernelGGL((k_gn_apply<f16_t>), g3, b3, 0, s, p);
     }
     return SD_LAUNCH_CHECK();
 }
