@@ -335,3 +335,22 @@ def test_config3_volume_in_overlapping_chunks(gpu):
     lab_ref, _ = label_rule_ref(ref, (1, 2, 3, 4, 5), [None] * 6)
     safe = np.all(np.abs(ref[1:].astype(np.int16) - 127.5) > TOL_U8, axis=0)
     assert not ((lab != lab_ref) & safe).any()
+
+
+def test_config3_geometry_batching_and_streams_do_not_change_results(gpu):
+    """BASELINE config 3 geometry (model-input tile 128^3 = useful (112,96,96) + halo (8,16,16) per side, semseg_axon)
+    on a 336x288x288 volume = 27 tiles: tiles per launch set and HIP streams are scheduling choices only -- the uint8
+    probabilities must be bit-identical for batch 1 / automatic (8) / 5 (ragged last set) and 1 / 2 streams."""
+    from syconn_amd.handler.prediction import Predictor
+    model = build_unet('semseg_axon', seed=4, final_scale=6.0)
+    g = torch.Generator().manual_seed(9)
+    vol = torch.randint(0, 256, (336, 288, 288), dtype=torch.uint8, generator=g).to(gpu)
+    outs = []
+    for bs, ns in ((1, 1), (None, 1), (5, 2)):
+        p = Predictor(model, tile_shape=(112, 96, 96), overlap_shape=(8, 16, 16), out_shape=(6, 336, 288, 288),
+                      strict_shapes=True, apply_softmax=True, batch_size=bs, n_streams=ns)
+        outs.append(p.predict_proba_u8_device(vol).clone())
+        del p
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    s = outs[0].to(torch.int32).sum(0)
+    assert int(s.max()) <= 255 and int(s.min()) > 255 - 6
