@@ -163,10 +163,9 @@ def main():
             for i, t0 in enumerate(range(0, T, B)):
                 n = min(B, T - t0)
                 with ring.stream(i):
-                    pk = probs_k[ring.slot(i)]
-                    dm.forward_batch(tiles[t0:t0 + n], L.SD_OUT_PROBS_U8, pk[:n], slot=ring.slot(i))
-                    for j in range(n):
-                        postproc_labels(pk[j], ids, thr, out=labels[k][t0 + j])
+                    # U-Net + softmax + uint8 cast + label rule (prediction.py:813-833) in one launch set: the rule is
+                    # evaluated in the final layer's epilogue (== postproc_labels(forward_batch(PROBS_U8)), tested)
+                    dm.forward_labels_batch(tiles[t0:t0 + n], ids, thr, out=labels[k][t0:t0 + n], slot=ring.slot(i))
         if world > 1:
             _, pending[k] = par.gather_to_root(labels[k], dst=0, async_op=True, out=recv[k])
 

@@ -42,7 +42,8 @@ enum sd_dtype { SD_U8 = 0, SD_F32 = 1, SD_BF16 = 2, SD_F16 = 3, SD_U64 = 4 };
 
 /* what sd_forward writes: raw logits (model(inp)), softmax(1) (Predictor(apply_softmax=True), prediction.py:779),
  * or floor(255*softmax) as uint8 (dense_predicton_helper, prediction.py:864-865) */
-enum sd_out_kind { SD_OUT_LOGITS_F32 = 0, SD_OUT_PROBS_F32 = 1, SD_OUT_PROBS_U8 = 2 };
+enum sd_out_kind { SD_OUT_LOGITS_F32 = 0, SD_OUT_PROBS_F32 = 1, SD_OUT_PROBS_U8 = 2,
+                   SD_OUT_LABELS_U8 = 3 /* only through sd_forward_labels_batch */ };
 
 /* layer kinds of the network plan (the elektronn3 U-Net block structure) */
 enum sd_op_kind {
@@ -102,6 +103,14 @@ int sd_forward(sd_model* m, const void* in_dev, int in_dtype, int D, int H, int 
  * small layers of the network and amortises launch gaps; results are identical to N sd_forward calls. */
 int sd_forward_batch(sd_model* m, const void* in_dev, int in_dtype, int N, int D, int H, int W, void* out_dev,
                      int out_kind, void* workspace_dev, size_t ws_bytes, void* stream);
+
+/* Forward pass with the label rule of dense_predictor (prediction.py:813-833, row A7) applied in the final layer's
+ * epilogue: out_dev (N, D, H, W) uint8 = what sd_postproc_labels computes from the SD_OUT_PROBS_U8 result of
+ * sd_forward_batch -- label = 0; for i in order: if floor(255*p[ids[i]]) > thresholds[i] then label = ids[i] -- without
+ * writing and re-reading the probability maps.  ids in [0, cout_final), n_ids <= 16, thresholds in uint8 units. */
+int sd_forward_labels_batch(sd_model* m, const void* in_dev, int in_dtype, int N, int D, int H, int W,
+                            const int32_t* ids, const double* thresholds, int n_ids, uint8_t* out_dev,
+                            void* workspace_dev, size_t ws_bytes, void* stream);
 
 /* tiled_apply helpers (row P3).  Gather: copy the (TD,TH,TW) box starting at (oz,oy,ox) -- which may lie partly
  * outside the (VD,VH,VW) volume -- into a dense tile, zeros outside (zero-padded tile extraction).

@@ -15,7 +15,7 @@ LIB_NAME = 'libsyconn_dense_hip.so'
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get('SD_LIB_NAME', LIB_NAME))
 
 # every symbol include/syconn_dense.h declares (checked by tests/test_abi.py)
-EXPORTS = ['sd_init', 'sd_device_count', 'sd_model_create', 'sd_model_destroy', 'sd_workspace_bytes', 'sd_forward', 'sd_forward_batch',
+EXPORTS = ['sd_init', 'sd_device_count', 'sd_model_create', 'sd_model_destroy', 'sd_workspace_bytes', 'sd_forward', 'sd_forward_batch', 'sd_forward_labels_batch',
            'sd_tile_gather', 'sd_tile_scatter', 'sd_postproc_labels', 'sd_profile_enable', 'sd_profile_read',
            'sd_debug_read_buffer', 'sd_model_num_ops', 'sd_last_error', 'sd_version', 'sd_snappy_max_compressed_length',
            'sd_snappy_compress', 'sd_snappy_uncompressed_length', 'sd_snappy_uncompress', 'sd_downsample2', 'sd_box_majority']
@@ -53,6 +53,9 @@ def load():
     lib.sd_forward.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp, sz, vp]; lib.sd_forward.restype = i32
     lib.sd_forward_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, i32, vp, sz, vp]
     lib.sd_forward_batch.restype = i32
+    lib.sd_forward_labels_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, C.POINTER(C.c_int32), C.POINTER(C.c_double), i32,
+                                            vp, vp, sz, vp]
+    lib.sd_forward_labels_batch.restype = i32
     lib.sd_tile_gather.argtypes = [vp, i32] + [i32] * 6 + [vp] + [i32] * 3 + [vp]; lib.sd_tile_gather.restype = i32
     lib.sd_tile_scatter.argtypes = [vp, i32] + [i32] * 10 + [vp] + [i32] * 6 + [vp]; lib.sd_tile_scatter.restype = i32
     lib.sd_postproc_labels.argtypes = [vp, i32, sz, C.POINTER(C.c_int32), C.POINTER(C.c_double), i32, vp, i32, vp]

@@ -520,12 +520,45 @@ int sd_forward(sd_model* m, const void* in_dev, int in_dtype, int D, int H, int 
     return sd_forward_batch(m, in_dev, in_dtype, 1, D, H, W, out_dev, out_kind, ws, ws_bytes, stream);
 }
 
+static bool make_label_args(int C, const int32_t* ids, const double* thresholds, int n_ids, LabelArgs& a) {
+    if (!ids || !thresholds || n_ids <= 0 || n_ids > 16) return false;
+    a.n = n_ids;
+    for (int i = 0; i < n_ids; ++i) {
+        if (ids[i] < 0 || ids[i] >= C) return false;
+        a.ids[i] = ids[i];
+        const double t = thresholds[i];
+        if (t != t) return false;
+        // (uint8 p > t) <=> p >= floor(t) + 1, exact for any real t
+        const double c = std::floor(t) + 1.0;
+        a.cuts[i] = c < 0.0 ? 0 : (c > 256.0 ? 256 : (int)c);
+    }
+    return true;
+}
+
+static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, int D, int H, int W, void* out_dev,
+                        int out_kind, const LabelArgs* lab, void* ws, size_t ws_bytes, void* stream);
+
 int sd_forward_batch(sd_model* m, const void* in_dev, int in_dtype, int N, int D, int H, int W, void* out_dev,
                      int out_kind, void* ws, size_t ws_bytes, void* stream) {
+    if (out_kind < 0 || out_kind > 2) return fail(SD_ERR_INVALID, "bad out_kind");
+    return forward_impl(m, in_dev, in_dtype, N, D, H, W, out_dev, out_kind, nullptr, ws, ws_bytes, stream);
+}
+
+int sd_forward_labels_batch(sd_model* m, const void* in_dev, int in_dtype, int N, int D, int H, int W,
+                            const int32_t* ids, const double* thresholds, int n_ids, uint8_t* out_dev, void* ws,
+                            size_t ws_bytes, void* stream) {
+    if (!m) return fail(SD_ERR_INVALID, "null argument");
+    LabelArgs a{};
+    if (!make_label_args(m->final_cout, ids, thresholds, n_ids, a))
+        return fail(SD_ERR_INVALID, "sd_forward_labels_batch: bad label arguments");
+    return forward_impl(m, in_dev, in_dtype, N, D, H, W, out_dev, SD_OUT_LABELS_U8, &a, ws, ws_bytes, stream);
+}
+
+static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, int D, int H, int W, void* out_dev,
+                        int out_kind, const LabelArgs* lab, void* ws, size_t ws_bytes, void* stream) {
     if (!m || !in_dev || !out_dev || !ws) return fail(SD_ERR_INVALID, "null argument");
     if (N <= 0 || N > 65535) return fail(SD_ERR_INVALID, "bad batch size");
     if (in_dtype != SD_U8 && in_dtype != SD_F32) return fail(SD_ERR_INVALID, "in_dtype must be SD_U8 or SD_F32");
-    if (out_kind < 0 || out_kind > 2) return fail(SD_ERR_INVALID, "bad out_kind");
     if (D <= 0 || H <= 0 || W <= 0) return fail(SD_ERR_INVALID, "bad tile shape");
     int rc = infer_shapes(m, D, H, W, m->dims);
     if (rc != SD_OK) return rc;
@@ -534,7 +567,8 @@ int sd_forward_batch(sd_model* m, const void* in_dev, int in_dtype, int N, int D
     const size_t tstride = (need + 255) & ~(size_t)255;
     if ((size_t)N * tstride > ws_bytes) return fail(SD_ERR_NOMEM, "workspace too small");
     const size_t in_tstride = (size_t)D * H * W * (in_dtype == SD_U8 ? 1 : 4);
-    const size_t out_tstride = (size_t)m->final_cout * D * H * W * (out_kind == SD_OUT_PROBS_U8 ? 1 : 4);
+    const size_t out_tstride = out_kind == SD_OUT_LABELS_U8 ? (size_t)D * H * W
+                                                            : (size_t)m->final_cout * D * H * W * (out_kind == SD_OUT_PROBS_U8 ? 1 : 4);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     char* const wsb = reinterpret_cast<char*>(ws);
     auto bufp = [&](int b) -> void* { return wsb + m->buf_off[b]; };
@@ -601,6 +635,7 @@ int sd_forward_batch(sd_model* m, const void* in_dev, int in_dtype, int N, int D
                     p.final_wfrag = m->dev_blob + op.fwfrag_off;
                     p.final_b = reinterpret_cast<const float*>(m->dev_blob + fo.bias_off);
                     p.final_cout = fo.d.cout; p.final_kind = out_kind; p.final_out = out_dev;
+                    if (lab) p.lab = *lab;
                     p.store_main = m->keep_all ? 1 : 0;
                 }
                 if (op.fuse_gn >= 0) {
@@ -665,6 +700,7 @@ int sd_forward_batch(sd_model* m, const void* in_dev, int in_dtype, int N, int D
             p.cout = d.cout; p.out = out_dev; p.out_kind = out_kind;
             p.nvox = (long)a.d * a.h * a.w;
             p.batch = N; p.tstride = tstride; p.out_tstride = out_tstride;
+            if (lab) p.lab = *lab;
             if (a.d != D || a.h != H || a.w != W) return fail(SD_ERR_INVALID, "final layer shape != input shape");
             rc = launch_final(p, m->act_dtype, s);
             break;

@@ -19,6 +19,8 @@ constexpr int SD_BX = 16;
 __host__ __device__ constexpr int sd_bz(int KZ) { return KZ == 3 ? 2 : 1; }
 __host__ __device__ constexpr int sd_by(int KZ) { return KZ == 3 ? 8 : 16; }
 
+struct LabelArgs { int n; int ids[16]; int cuts[16]; };   // label rule: later entries override; p >= cut <=> p > t
+
 struct ConvParams {
     const void* src0;  // first input (for a merged conv: the up-convolved tensor, cropped by reading fewer voxels)
     const void* src1;  // second input or nullptr
@@ -52,6 +54,7 @@ struct ConvParams {
     // fused GroupNorm statistics: per-channel sum / sum of squares of the stored outputs are added to
     // gn_sums[0..gn_C) / gn_sums[gn_C..2*gn_C) of the block's tile (doubles, zeroed by the host), or nullptr
     double* gn_sums; int gn_C;
+    LabelArgs lab;     // final_kind == SD_OUT_LABELS_U8
 };
 
 struct FirstParams {
@@ -98,6 +101,7 @@ struct FinalParams {
     int out_kind;
     long nvox;
     int batch; size_t tstride, out_tstride;
+    LabelArgs lab;     // out_kind == SD_OUT_LABELS_U8
 };
 
 struct GnParams {
@@ -129,6 +133,5 @@ int launch_tile_scatter(const void* tile, int esize, int C, int TD, int TH, int 
 int launch_downsample2(const void* src, int esize, int D, int H, int W, void* dst, hipStream_t s);
 int launch_box_majority(const uint8_t* vol, int D, int H, int W, const int32_t* origins, long n, int ez, int ey, int ex,
                         int cut, double thresh_majority, uint8_t* out, hipStream_t s);
-struct LabelArgs { int n; int ids[16]; int cuts[16]; };
 int launch_labels(const uint8_t* probs, size_t nvox, const LabelArgs& a, void* out, int out_u64, hipStream_t s);
 int launch_read_buffer(const void* buf, int act_dtype, int C, int Cs, int D, int H, int W, float* out, hipStream_t s);

@@ -785,7 +785,17 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
             const bool vmine = half ? valid[tp + 1] : valid[tp];
             const size_t v = (half ? voxoff[tp + 1] : voxoff[tp]) / p.Cd;
             if (vmine) {
-                if (p.final_kind == SD_OUT_PROBS_U8) {
+                if (p.final_kind == SD_OUT_LABELS_U8) {
+                    uint8_t lab = 0;
+                    for (int k = 0; k < p.lab.n; ++k) {
+                        const int id = p.lab.ids[k];
+                        float pv = 0.f;
+#pragma unroll
+                        for (int co = 0; co < 8; ++co) pv = (co == id) ? l[co] : pv;
+                        if ((int)(uint8_t)(pv * 255.f) >= p.lab.cuts[k]) lab = (uint8_t)id;
+                    }
+                    (reinterpret_cast<uint8_t*>(p.final_out) + (size_t)tn * p.out_tstride)[v] = lab;
+                } else if (p.final_kind == SD_OUT_PROBS_U8) {
                     uint8_t* out = reinterpret_cast<uint8_t*>(p.final_out) + (size_t)tn * p.out_tstride;
 #pragma unroll
                     for (int co = 0; co < 8; ++co)
@@ -1147,7 +1157,17 @@ __global__ __launch_bounds__(256) void k_final(const FinalParams p) {
 #pragma unroll
             for (int co = 0; co < 8; ++co) acc[co] = acc[co] / sum;
         }
-        if (p.out_kind == SD_OUT_PROBS_U8) {
+        if (p.out_kind == SD_OUT_LABELS_U8) {
+            uint8_t lab = 0;
+            for (int k = 0; k < p.lab.n; ++k) {
+                const int id = p.lab.ids[k];
+                float pv = 0.f;
+#pragma unroll
+                for (int co = 0; co < 8; ++co) pv = (co == id) ? acc[co] : pv;
+                if ((int)(uint8_t)(pv * 255.f) >= p.lab.cuts[k]) lab = (uint8_t)id;
+            }
+            (reinterpret_cast<uint8_t*>(p.out) + blockIdx.z * p.out_tstride)[v] = lab;
+        } else if (p.out_kind == SD_OUT_PROBS_U8) {
             uint8_t* out = reinterpret_cast<uint8_t*>(p.out) + blockIdx.z * p.out_tstride;
 #pragma unroll
             for (int co = 0; co < 8; ++co)

@@ -122,6 +122,24 @@ class DenseModel:
                                           out_kind, ws.data_ptr(), ws.numel(), _stream()), 'sd_forward_batch')
         return out
 
+    def forward_labels_batch(self, inp: torch.Tensor, ids: Sequence[int], thresholds: Sequence[float],
+                             out: Optional[torch.Tensor] = None, slot: int = 0) -> torch.Tensor:
+        """N tiles -> (N,D,H,W) uint8 labels: the label rule of dense_predictor (prediction.py:813-833) evaluated in
+        the final layer's epilogue on floor(255*softmax); identical to ``postproc_labels(forward_batch(PROBS_U8))``."""
+        assert inp.is_cuda and inp.dim() == 4 and inp.is_contiguous()
+        N, D, H, W = inp.shape
+        ws = self._workspace((D, H, W), slot, N)
+        if out is None:
+            out = torch.empty((N, D, H, W), dtype=torch.uint8, device=self.device)
+        assert out.dtype == torch.uint8 and out.is_contiguous() and out.numel() == N * D * H * W
+        n = len(ids)
+        ids_a = (C.c_int32 * n)(*[int(i) for i in ids])
+        thr_a = (C.c_double * n)(*[float(t) for t in thresholds])
+        L.check(self.lib.sd_forward_labels_batch(self._h, inp.data_ptr(), _dtype_code(inp), N, D, H, W, ids_a, thr_a, n,
+                                                 out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+                'sd_forward_labels_batch')
+        return out
+
     def read_buffer(self, buf: int) -> torch.Tensor:
         """Activation buffer `buf` of the last forward as float32 (C,d,h,w) -- test support."""
         dims = (C.c_int32 * 4)()

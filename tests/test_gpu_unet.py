@@ -292,3 +292,22 @@ def test_full_size_tile_properties(gpu):
     y[:, :, -8:] = 17
     c = dm.forward(y, L.SD_OUT_PROBS_U8)
     assert torch.equal(c[:, 56:72, 56:72, 56:72], a[:, 56:72, 56:72, 56:72])
+
+
+@pytest.mark.parametrize('arch,shape,ids,thr', [('semseg_spine', (24, 40, 48), (1, 2, 3, 4), (60.5, 50.0, 55.5, 45.0)),
+                                                ('mivcsj', (16, 32, 48), (1, 2, 3), (90.5, 76.5, 60.0)),
+                                                ('syntype', (13, 27, 29), (2, 1), (0.0, 254.5))])
+def test_fused_label_rule_equals_probs_then_labels(gpu, arch, shape, ids, thr):
+    """sd_forward_labels_batch == sd_postproc_labels(sd_forward_batch(PROBS_U8)) bit for bit (fused and unfused final
+    layer, different id orders and thresholds)."""
+    from syconn_amd import _lib as L
+    from syconn_amd.engine import DenseModel, postproc_labels
+    net = build_unet(arch, seed=6, final_scale=5.0)
+    dm = DenseModel(net, 'bf16', gpu)
+    x = _input((2, *shape), 13).to(gpu)
+    probs = dm.forward_batch(x, L.SD_OUT_PROBS_U8)
+    want = torch.stack([postproc_labels(probs[i], list(ids), list(thr)) for i in range(2)])
+    got = dm.forward_labels_batch(x, ids, thr)
+    assert got.shape == want.shape and torch.equal(got, want)
+    if arch != 'syntype':
+        assert len(torch.unique(got)) >= 2       # the rule really selects between labels
