@@ -134,7 +134,7 @@ class Predictor:
         ntiles = np.ceil(spatial / tile).astype(np.int64)
         return tile, ol, ntiles
 
-    def _tiled(self, vol: torch.Tensor, out: torch.Tensor, out_kind: int):
+    def _tiled(self, vol: torch.Tensor, out: torch.Tensor, out_kind: int, label_args=None):
         """tiled_apply (elektronn3) on the device: zero-padded tile extraction, forward,
         crop of the overlap, write into `out` (C,D,H,W).  vol: (D,H,W) uint8 / float32 on the device."""
         from ..engine import tile_gather, tile_scatter
@@ -142,8 +142,16 @@ class Predictor:
         tile, ol, ntiles = self._geometry(spatial)
         tin = tile + 2 * ol
         single = bool(np.all(ntiles == 1) and np.all(ol == 0) and np.all(tile == spatial))
+        nch = 1 if label_args is not None else self.out_channels
+
+        def run(inp, outp, slot):           # inp (n,D,H,W) -> outp (n,nch,D,H,W)
+            if label_args is not None:
+                self._dm.forward_labels_batch(inp, label_args[0], label_args[1], out=outp[:, 0], slot=slot)
+            else:
+                self._dm.forward_batch(inp, out_kind, outp, slot=slot)
+
         if single:
-            self._dm.forward(vol, out_kind, out)
+            run(vol[None], out[None], 0)
             return
         # independent tiles go through the network `nb` at a time (sd_forward_batch: one set of launches, every
         # kernel sees nb times as many blocks); batches alternate over `n_streams` HIP streams
@@ -151,7 +159,7 @@ class Predictor:
         nb = self._batch_for(tin, len(pos_list))
         ring = self._ring
         tbuf = [torch.empty((nb, *[int(t) for t in tin]), dtype=vol.dtype, device=self.device) for _ in range(ring.n)]
-        obuf = [torch.empty((nb, self.out_channels, *[int(t) for t in tin]), dtype=out.dtype, device=self.device)
+        obuf = [torch.empty((nb, nch, *[int(t) for t in tin]), dtype=out.dtype, device=self.device)
                 for _ in range(ring.n)]
         with ring:
             for i, b0 in enumerate(range(0, len(pos_list), nb)):
@@ -162,7 +170,7 @@ class Predictor:
                         lo = tile * np.asarray(pos, dtype=np.int64)
                         tile_gather(vol, lo - ol, tin, tbuf[k][j])
                     n = len(group)
-                    self._dm.forward_batch(tbuf[k][:n], out_kind, obuf[k][:n], slot=k)
+                    run(tbuf[k][:n], obuf[k][:n], k)
                     for j, pos in enumerate(group):
                         lo = tile * np.asarray(pos, dtype=np.int64)
                         keep = np.minimum(tile, spatial - lo)
@@ -215,6 +223,21 @@ class Predictor:
         out = torch.empty((self.out_channels, *raw_u8.shape), dtype=torch.uint8, device=self.device)
         self._tiled(raw_u8, out, L.SD_OUT_PROBS_U8)
         return out
+
+
+    @torch.no_grad()
+    def predict_labels_u8_device(self, raw_u8: torch.Tensor, ids, thresholds) -> torch.Tensor:
+        """`predict_proba_u8_device` followed by the label rule of dense_predictor (prediction.py:813-833) for ONE
+        multi-id target, evaluated in the network's final epilogue: (D,H,W) uint8 labels on the device.  `thresholds`
+        are the resolved uint8-scale values, one per id."""
+        if not self.apply_softmax:
+            raise ValueError('labels need apply_softmax=True')
+        assert raw_u8.dtype == torch.uint8 and raw_u8.dim() == 3
+        torch.cuda.set_device(self.device)
+        raw_u8 = raw_u8.contiguous()
+        out = torch.empty((1, *raw_u8.shape), dtype=torch.uint8, device=self.device)
+        self._tiled(raw_u8, out, L.SD_OUT_PROBS_U8, label_args=([int(i) for i in ids], [float(t) for t in thresholds]))
+        return out[0]
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -332,7 +355,14 @@ def dense_predictor(args):
             raw = nxt.result()
             nxt = reader.submit(read_chunk, chunk_ids[n + 1]) if n + 1 < len(chunk_ids) else None
             raw_dev = torch.from_numpy(raw).to(dev)
-            pred_dev = predictor.predict_proba_u8_device(raw_dev)                     # (C, Z, Y, X) uint8
+            # one multi-id target (mivcsj, syntype): only its label volume is needed -> label rule in the final epilogue
+            only_labels = len(target_channels) == 1 and len(target_channels[0]) > 1
+            if only_labels:
+                ids0 = target_channels[0]
+                thr0 = [_resolve_threshold(channel_thresholds[label]) for label in ids0]
+                pred_dev = predictor.predict_labels_u8_device(raw_dev, ids0, thr0)[None]   # (1, Z, Y, X) uint8 labels
+            else:
+                pred_dev = predictor.predict_proba_u8_device(raw_dev)                 # (C, Z, Y, X) uint8
             # slice out the original input volume along ZYX (prediction.py:812)
             zyx = tuple(int(s) for s in np.asarray(ch.size)[::-1])
             crop = torch.empty((pred_dev.shape[0], *zyx), dtype=torch.uint8, device=dev)
@@ -352,7 +382,7 @@ def dense_predictor(args):
                                           mags=[mag * 2 ** k], fast_resampling=True, upsample=False)))
                 else:
                     thr = [_resolve_threshold(channel_thresholds[label]) for label in ids]
-                    lab = postproc_labels(crop, ids, thr, out_dtype=torch.uint8)
+                    lab = crop[0] if only_labels else postproc_labels(crop, ids, thr, out_dtype=torch.uint8)
                     for k, lvl in enumerate(mag_pyramid(lab, 3)):  # uint8 on the device and over PCIe, widened here
                         jobs.append((target_kd_dict[path].save_seg,
                                      dict(offset=ch.coordinates * mag, data=lvl.cpu().numpy().astype(np.uint64),

@@ -354,3 +354,19 @@ def test_config3_geometry_batching_and_streams_do_not_change_results(gpu):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     s = outs[0].to(torch.int32).sum(0)
     assert int(s.max()) <= 255 and int(s.min()) > 255 - 6
+
+
+def test_predict_labels_device_equals_probs_then_rule(gpu):
+    """Predictor.predict_labels_u8_device (label rule in the final epilogue, tiled) == label rule applied to
+    predict_proba_u8_device, incl. a ragged last launch set and a single-tile volume."""
+    from syconn_amd.engine import postproc_labels
+    from syconn_amd.handler.prediction import Predictor
+    model = build_unet('mivcsj', seed=8, n_blocks=3, start_filts=8, final_scale=6.0)
+    g = torch.Generator().manual_seed(2)
+    ids, thr = (1, 2, 3), (100.0, 90.5, 80.0)
+    for shape, tile, ol, bs in (((48, 60, 72), (16, 20, 24), (4, 6, 6), 5), ((16, 24, 24), None, None, None)):
+        vol = torch.randint(0, 256, shape, dtype=torch.uint8, generator=g).to(gpu)
+        p = Predictor(model, tile_shape=tile, overlap_shape=ol, apply_softmax=True, batch_size=bs)
+        want = postproc_labels(p.predict_proba_u8_device(vol), list(ids), list(thr))
+        got = p.predict_labels_u8_device(vol, ids, thr)
+        assert got.shape == want.shape and torch.equal(got, want)
