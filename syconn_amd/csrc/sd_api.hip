@@ -54,11 +54,9 @@ struct Op {
     bool first = false;    // conv reading the network input (cin = 1)
     int fuse_pool = -1;    // index of the MaxPool op computed in this conv's epilogue
     int fuse_final = -1;   // index of the final 1x1x1 op computed in this conv's epilogue
-    int fuse_up = -1;      // index of the ConvTranspose op whose output (this conv's src0) is produced on the fly
     int fuse_gn = -1;      // conv: index of the GroupNorm op whose statistics this conv's epilogue accumulates
     bool stats_done = false;   // groupnorm: statistics come from the producing conv
     int gn_pool = -1;          // groupnorm: index of the MaxPool op fused into the apply pass
-    size_t upw_off = 0, upb_off = 0;   // fused up-conv weights / bias (byte offsets)
     size_t fwfrag_off = 0;             // fused final 1x1x1: hi/lo MFMA weight fragments
     bool skipped = false;  // op is executed inside its producer
 };
@@ -405,55 +403,6 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
                             }
             }
         }
-        // ConvTranspose (BatchNorm folded) -> merge conv: compute the up-convolved halo on the fly inside the conv.
-        // Correct (tests/test_gpu_unet.py::test_fused_upconv_matches_unfused) but NOT faster yet: the producer phase
-        // is a chain of short barrier-separated steps (3 MFMAs per wave per step) and costs what the separate
-        // launch cost (op15 275 vs 200+63 us) -> opt-in with SD_FUSE_UP=1 until that phase is pipelined.
-        if (getenv("SD_FUSE_UP")) {
-            for (size_t i = 0; i + 1 < m->ops.size(); ++i) {
-                Op& u = m->ops[i];
-                Op& c = m->ops[i + 1];
-                if (u.d.kind != SD_OP_UPCONV || c.d.kind != SD_OP_CONV || c.first) continue;
-                if (c.d.src0 != u.d.dst || c.d.src1 < 0 || (c.d.kz == 3) != (u.d.kz == 2)) continue;
-                bool used_elsewhere = false;
-                for (size_t j = 0; j < m->ops.size(); ++j)
-                    if (j != i + 1 && (m->ops[j].d.src0 == u.d.dst || m->ops[j].d.src1 == u.d.dst) && j != i)
-                        used_elsewhere = true;
-                if (used_elsewhere || m->bufCp[u.d.src0] / SD_CHUNK > 64) continue;
-                // pack W[ci][co][tap] * scale[co] as [n-tile k][dec chunk kd][tap][lane][8] (A operand = weights)
-                const sd_op_desc& d = u.d;
-                const int taps = d.kz * 4, nkd = m->bufCp[d.src0] / SD_CHUNK;
-                const int nchunk0 = m->bufCp[d.dst] / SD_CHUNK, ntile = (nchunk0 + 1) / 2;
-                std::vector<float> sc(d.cout, 1.f), sh(d.cout, 0.f);
-                if (d.norm == 1) {
-                    for (int co = 0; co < d.cout; ++co) {
-                        const float sv = W[d.gamma_off + co] / std::sqrt(W[d.var_off + co] + d.eps);
-                        sc[co] = sv;
-                        sh[co] = W[d.beta_off + co] - W[d.mean_off + co] * sv;
-                    }
-                }
-                const size_t wo = blob_alloc((size_t)ntile * nkd * taps * 64 * 8 * 2);
-                const size_t bo = blob_alloc((size_t)ntile * 32 * 4 + 16);
-                uint16_t* wp = reinterpret_cast<uint16_t*>(blob.data() + wo);
-                float* bp = reinterpret_cast<float*>(blob.data() + bo);
-                const float* w = W + d.w_off;
-                for (int k = 0; k < ntile; ++k)
-                    for (int kd = 0; kd < nkd; ++kd)
-                        for (int t = 0; t < taps; ++t)
-                            for (int l = 0; l < 64; ++l)
-                                for (int e = 0; e < 8; ++e) {
-                                    const int co = k * 32 + (l & 31), ci = kd * SD_CHUNK + (l >> 5) * 8 + e;
-                                    float v = 0.f;
-                                    if (co < d.cout && ci < d.cin0) v = w[((size_t)ci * d.cout + co) * taps + t] * sc[co];
-                                    wp[((((size_t)k * nkd + kd) * taps + t) * 64 + l) * 8 + e] = cvt(v, act_dtype);
-                                }
-                for (int co = 0; co < d.cout; ++co) bp[co] = W[d.b_off + co] * sc[co] + sh[co];
-                c.fuse_up = (int)i;
-                c.upw_off = wo;
-                c.upb_off = bo;
-                u.skipped = true;
-            }
-        }
     }
 
     {
@@ -581,7 +530,7 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
         const Op& op = m->ops[i];
         const sd_op_desc& d = op.d;
         if (ev) HIP_TRY(hipEventRecord(ev[i], s));
-        if (op.skipped && !(m->keep_all && d.kind == SD_OP_UPCONV)) continue;   // SD_KEEP_ALL: also materialise fused up-convs
+        if (op.skipped) continue;
         switch (d.kind) {
         case SD_OP_CONV: {
             const Dims o = m->dims[d.dst];
@@ -616,15 +565,6 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
 #ifdef SD_TIMING
                 p.dbg = (getenv("SD_TIMING_OP") && atoi(getenv("SD_TIMING_OP")) == (int)i) ? reinterpret_cast<long long*>(wsb + m->buf_off[1]) : nullptr;
 #endif
-                if (op.fuse_up >= 0) {
-                    const Op& uo = m->ops[op.fuse_up];
-                    const Dims ud = m->dims[uo.d.src0];
-                    p.up_src = bufp(uo.d.src0); p.up_C = m->bufCp[uo.d.src0]; p.up_nchunk = p.up_C / SD_CHUNK;
-                    p.up_D = ud.d; p.up_H = ud.h; p.up_W = ud.w;
-                    p.up_w = m->dev_blob + op.upw_off;
-                    p.up_bias = reinterpret_cast<const float*>(m->dev_blob + op.upb_off);
-                    p.up_relu = uo.d.relu;
-                }
                 if (op.fuse_pool >= 0) {
                     const sd_op_desc& pd = m->ops[op.fuse_pool].d;
                     p.pool_dst = bufp(pd.dst); p.pH = m->dims[pd.dst].h; p.pW = m->dims[pd.dst].w;

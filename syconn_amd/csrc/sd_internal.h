@@ -42,13 +42,6 @@ struct ConvParams {
     const float* final_b;
     int final_cout, final_kind;
     void* final_out;   // planar (cout, D*H*W)
-    // fused ConvTranspose3d(k=s=(kz,2,2)) producer of the src0 chunks (merge convs): src0 is then NOT read; its
-    // nchunk0 chunks are computed on the fly from the low-resolution tensor up_src into the LDS halo slots
-    const void* up_src;     // (up_D, up_H, up_W, up_C) channels-last, or nullptr
-    int up_C, up_D, up_H, up_W, up_nchunk;
-    const void* up_w;       // [ceil(nchunk0/2)][up_nchunk][taps][64 lanes][8]
-    const float* up_bias;   // folded bias per up channel, padded to ceil(nchunk0/2)*32
-    int up_relu;
     long long* dbg;         // SD_TIMING builds: per-wave cycle stamps
     int batch; size_t tstride, out_tstride;
     // fused GroupNorm statistics: per-channel sum / sum of squares of the stored outputs are added to

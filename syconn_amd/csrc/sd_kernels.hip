@@ -213,7 +213,7 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 // loop issues an ordinary VGPR load (bias and final-layer weights are preloaded), which would drain the ring.
 // NSLOT == 0: weight groups are streamed (double-buffered); the workgroups are persistent as well, and the first
 // weight group and halo chunk of a workgroup's next block are requested during the last stage of the current one.
-template <typename T, int KZ, int NT, int WAVES, int NSLOT, int MT, bool FUP>
+template <typename T, int KZ, int NT, int WAVES, int NSLOT, int MT>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(const ConvParams p) {
     using v8 = typename Act<T>::v8;
     using G = ConvGeo<KZ, WAVES, MT>;
@@ -242,13 +242,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     float* const wl = reinterpret_cast<float*>(ldsB + (WRES ? nstages : 2) * B_BYTES);
     char* const fwl = reinterpret_cast<char*>(wl) + SD_CONV_PARAM_BYTES;
     char* const ldsDummy = fwl + (p.final_wfrag ? NT * 4096 : 0);
-    // fused up-convolution (see up_phase below): low-resolution region + one 32-channel weight group, double-buffered
-    constexpr int UDZ = KZ == 3 ? BZ / 2 + 2 : 1, UDY = BY / 2 + 2, UDX = BX / 2 + 2;
-    constexpr int UND = UDZ * UDY * UDX;
-    constexpr int UDEC_INSTR = (UND * 2 + 63) / 64, UDEC_BYTES = UDEC_INSTR * 1024;
-    constexpr int UTAPS = KZ == 3 ? 8 : 4, UPW_BYTES = UTAPS * 1024;
-    constexpr int UBUF = UDEC_BYTES + UPW_BYTES;
-    char* const ldsU = ldsDummy + 1024;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -395,126 +388,18 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     int z0, y0, x0, tn;
     coords(lb, z0, y0, x0, tn);
 
-    // ---- fused ConvTranspose3d(k = s = (kz,2,2)) producer --------------------------------------------------------
-    // Up-voxel (z,y,x) = W[:, :, z&1, y&1, x&1]^T . dec[z>>1, y>>1, x>>1]: one dense GEMM per tap.  The halo voxels of
-    // the block are grouped by tap (parity class), 32 per MFMA tile; k = dec channels in 16-channel steps, n = 32 up
-    // channels (= two halo slots) per call.  Results (+bias, ReLU, rounding; zero outside the volume = the conv's
-    // padding) are written straight into the LDS halo slots in the swizzled record format the tap loop reads.
-    constexpr int UNZ = KZ == 3 ? HZ / 2 : 1, UNY = HY / 2, UNX = HX / 2;
-    constexpr int UCNT = UNZ * UNY * UNX;                  // halo voxels per tap class
-    constexpr int UTPC = (UCNT + 31) / 32;                 // tiles per class
-    constexpr int UNT = UTAPS * UTPC;                      // tiles per call
-    constexpr int UTPW = (UNT + WAVES - 1) / WAVES;        // tiles per wave
-    constexpr int UPT = 3;                                 // tiles accumulated per pass (register budget)
-    constexpr int UNPASS = (UTPW + UPT - 1) / UPT;
-    auto up_phase = [&](int k) {
-        const char* const dsrc = reinterpret_cast<const char*>(p.up_src) + (size_t)tn * p.tstride;
-        const int zd0 = (KZ == 3) ? (z0 >> 1) - 1 : z0, yd0 = (y0 >> 1) - 1, xd0 = (x0 >> 1) - 1;
-        auto dma_up = [&](int kd, int buf) {
-            char* const base = ldsU + buf * UBUF;
-#pragma unroll
-            for (int j = 0; j < (UDEC_INSTR + WAVES - 1) / WAVES; ++j) {
-                const int kk = wave + j * WAVES;
-                if (kk < UDEC_INSTR) {
-                    const int idx = kk * 64 + lane;
-                    const int dv = idx >> 1;
-                    const int dx = dv % UDX, dyy = (dv / UDX) % UDY, dz = dv / (UDX * UDY);
-                    const int z = zd0 + dz, y = yd0 + dyy, x = xd0 + dx;
-                    const bool ok = dv < UND && (unsigned)z < (unsigned)p.up_D && (unsigned)y < (unsigned)p.up_H &&
-                                    (unsigned)x < (unsigned)p.up_W;
-                    const char* src = reinterpret_cast<const char*>(p.zero);
-                    if (ok) src = dsrc + (((size_t)(z * p.up_H + y) * p.up_W + x) * p.up_C + kd * SD_CHUNK +
-                                          (idx & 1) * 8) * sizeof(T);
-                    glds16(src, base + kk * 1024);
-                }
-            }
-            const char* wsrc = reinterpret_cast<const char*>(p.up_w) +
-                               ((size_t)k * p.up_nchunk + kd) * UPW_BYTES + lane * 16;
-#pragma unroll
-            for (int j = 0; j < (UTAPS + WAVES - 1) / WAVES; ++j) {
-                const int kk = wave + j * WAVES;
-                if (kk < UTAPS) glds16(wsrc + kk * 1024, base + UDEC_BYTES + kk * 1024);
-            }
-        };
-#pragma unroll 1
-        for (int pass = 0; pass < UNPASS; ++pass) {
-            // this lane's voxel in each of the pass's tiles
-            int xaddr[UPT], hrec[UPT], tapw[UPT];
-            bool slot_ok[UPT], invol[UPT];
-#pragma unroll
-            for (int tt = 0; tt < UPT; ++tt) {
-                const int t = wave + WAVES * (pass * UPT + tt);
-                const int cls = t / UTPC, v = (t - cls * UTPC) * 32 + (lane & 31);
-                const int a = (KZ == 3) ? (cls >> 2) : 0, b = (cls >> 1) & 1, c2 = cls & 1;
-                const int ix = v % UNX, iy = (v / UNX) % UNY, iz = v / (UNX * UNY);
-                const int hz = (KZ == 3) ? 2 * iz + ((a + 1) & 1) : 0, hy = 2 * iy + ((b + 1) & 1),
-                          hx = 2 * ix + ((c2 + 1) & 1);
-                slot_ok[tt] = t < UNT && v < UCNT;
-                const int dlz = (KZ == 3) ? (hz + 1) >> 1 : 0, dly = (hy + 1) >> 1, dlx = (hx + 1) >> 1;
-                xaddr[tt] = slot_ok[tt] ? ((dlz * UDY + dly) * UDX + dlx) * 32 + half * 16 : 0;
-                hrec[tt] = ((hz * HY + hy) * HX + hx) * 32 + ((hy & 1) << 4);   // record base, bit 4 = row parity
-                tapw[tt] = cls * 1024 + lane * 16;
-                const int z = z0 - PZ + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
-                invol[tt] = (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-            }
-            f32x16 au[UPT];
-#pragma unroll
-            for (int tt = 0; tt < UPT; ++tt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) au[tt][r] = 0.f;
-            dma_up(0, 0);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            for (int kd = 0; kd < p.up_nchunk; ++kd) {
-                if (kd + 1 < p.up_nchunk) dma_up(kd + 1, (kd + 1) & 1);
-                const char* const base = ldsU + (kd & 1) * UBUF;
-#pragma unroll
-                for (int tt = 0; tt < UPT; ++tt) {
-                    if (wave + WAVES * (pass * UPT + tt) < UNT) {      // wave-uniform
-                        const v8 xv = *reinterpret_cast<const v8*>(base + xaddr[tt]);
-                        const v8 wv = *reinterpret_cast<const v8*>(base + UDEC_BYTES + tapw[tt]);
-                        au[tt] = Act<T>::mfma(wv, xv, au[tt]);
-                    }
-                }
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            }
-            // + bias, ReLU, round, write the two 16-channel chunks (2k -> slot 0, 2k+1 -> slot 1)
-            using v4u = typename Act<T>::v4;
-#pragma unroll
-            for (int tt = 0; tt < UPT; ++tt) {
-                if (wave + WAVES * (pass * UPT + tt) < UNT) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int ch = k * 32 + 8 * q + 4 * half;
-                        const f32x4 bq = *reinterpret_cast<const f32x4*>(p.up_bias + ch);
-                        v4u o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float v = au[tt][4 * q + e] + bq[e];
-                            if (p.up_relu) v = fmaxf(v, 0.f);
-                            o[e] = (T)(invol[tt] ? v : 0.f);
-                        }
-                        const int chunk = 2 * k + (q >> 1);
-                        if (slot_ok[tt] && chunk < p.nchunk0)
-                            *reinterpret_cast<v4u*>(ldsA + (q >> 1) * A_BYTES + (hrec[tt] ^ ((q & 1) << 4)) + half * 8) = o;
-                    }
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    };
-    constexpr bool fuse_up = FUP && !WRES;      // compile-time: the producer phase costs ~50 VGPRs
     if (WRES) {
         for (int s = 0; s < nstages; ++s) dma_weights(s, s);
         for (int f = 0; f < NA - 1; ++f) dma_stream_next();
     } else {
         dma_weights(0, 0);
-        if (!fuse_up) dma_halo(0, 0, z0, y0, x0, tn, true);
+        dma_halo(0, 0, z0, y0, x0, tn, true);
     }
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WAITN) : "memory");
 
     int gc = 0, gs = 0;   // chunk / stage counters across blocks (slot parity)
     for (int round = 0; lb >= 0; ++round) {
-        const int nlb = fuse_up ? -1 : block_of(round + 1);   // (the fused up-conv variant computes one block)
+        const int nlb = block_of(round + 1);
         int nz0 = 0, ny0 = 0, nx0 = 0, ntn = 0;
         if (nlb >= 0) coords(nlb, nz0, ny0, nx0, ntn);
 
@@ -534,7 +419,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
 #endif
         int s = 0;
         for (int c = 0; c < nchunks; ++c, ++gc) {
-            if constexpr (fuse_up) { if (c < p.nchunk0 && (c & 1) == 0) up_phase(c >> 1); }
             const char* const abuf = ldsA + (gc % NA) * A_BYTES;
 #pragma unroll 1
             for (int kz = 0; kz < KZ; ++kz, ++s, ++gs) {
@@ -547,7 +431,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                     else if (nlb >= 0) dma_weights(0, (gs + 1) & 1);
                     if (kz == 0) {
                         if (c + 1 < nchunks) {
-                            if (!(fuse_up && c + 1 < p.nchunk0)) dma_halo(c + 1, (gc + 1) & 1, z0, y0, x0, tn, true);
+                            dma_halo(c + 1, (gc + 1) & 1, z0, y0, x0, tn, true);
                         } else if (nlb >= 0) {
                             dma_halo(0, (gc + 1) & 1, nz0, ny0, nx0, ntn, true);
                         }
@@ -1381,25 +1265,22 @@ constexpr int SD_LDS_BYTES = 160 * 1024;
 constexpr int SD_NUM_CU = 256;
 
 template <int KZ, int NT, int WAVES, int MT, int NSLOT>
-static size_t conv_lds_bytes(int nstages, bool fuse_up = false, bool fuse_final = false) {
+static size_t conv_lds_bytes(int nstages, bool fuse_final = false) {
     using G = ConvGeo<KZ, WAVES, MT>;
     constexpr int NH = (G::BZ + KZ - 1) * (G::BY + 2) * (G::BX + 2);
     constexpr int A_BYTES = (NH * 2 + 63) / 64 * 1024;
-    constexpr int UND = (KZ == 3 ? G::BZ / 2 + 2 : 1) * (G::BY / 2 + 2) * (G::BX / 2 + 2);
-    constexpr int UBUF = (UND * 2 + 63) / 64 * 1024 + (KZ == 3 ? 8 : 4) * 1024;
     return (size_t)(NSLOT > 0 ? NSLOT : 2) * A_BYTES + (size_t)(NSLOT > 0 ? nstages : 2) * 9 * NT * 1024 +
-           SD_CONV_PARAM_BYTES + (fuse_final ? NT * 4096 : 0) + 1024 + (fuse_up ? 2 * UBUF : 0);
+           SD_CONV_PARAM_BYTES + (fuse_final ? NT * 4096 : 0) + 1024;
 }
 
-template <typename T, int KZ, int NT, int WAVES, int NSLOT, int MT = 2, bool FUP = false>
+template <typename T, int KZ, int NT, int WAVES, int NSLOT, int MT = 2>
 static int launch_conv_k(ConvParams p, int NB, hipStream_t s) {
     using G = ConvGeo<KZ, WAVES, MT>;
-    const size_t lds = conv_lds_bytes<KZ, NT, WAVES, MT, NSLOT>((p.nchunk0 + p.nchunk1) * KZ, p.up_src != nullptr,
-                                                                 p.final_wfrag != nullptr);
+    const size_t lds = conv_lds_bytes<KZ, NT, WAVES, MT, NSLOT>((p.nchunk0 + p.nchunk1) * KZ, p.final_wfrag != nullptr);
     p.nbx = (p.W + G::BX - 1) / G::BX; p.nby = (p.H + G::BY - 1) / G::BY; p.nbz = (p.D + G::BZ - 1) / G::BZ;
     static size_t attr_set = 0, occ_lds = 0;
     static int occ = 1;
-    auto kern = k_conv_mfma<T, KZ, NT, WAVES, NSLOT, MT, FUP>;
+    auto kern = k_conv_mfma<T, KZ, NT, WAVES, NSLOT, MT>;
     if (lds > attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) return SD_ERR_HIP;
@@ -1416,7 +1297,7 @@ static int launch_conv_k(ConvParams p, int NB, hipStream_t s) {
     const int wg_per_cu = std::min(occ, (int)(SD_LDS_BYTES / lds));
     const int cap = std::max(8, SD_NUM_CU * wg_per_cu / NB / 8 * 8);
     static const bool no_persist = getenv("SD_NO_PERSIST") != nullptr;   // debugging aid
-    dim3 grid((!FUP && !no_persist) ? std::min(nsb, cap) : nsb, NB), block(WAVES * 64);
+    dim3 grid(!no_persist ? std::min(nsb, cap) : nsb, NB), block(WAVES * 64);
     hipLaunchKernelGGL(kern, grid, block, lds, s, p);
     return SD_LAUNCH_CHECK();
 }
@@ -1432,13 +1313,11 @@ static int launch_conv_knt(const ConvParams& p, int NB, hipStream_t s) {
     // workgroups still share a CU (level-0 layers); else streamed weights, one block per workgroup.  Deeper rings
     // (NSLOT 4/6, one workgroup per CU) were measured SLOWER on the level-0 layers (1.32 vs 1.23 ms per tile): those
     // layers are bound by per-wave instruction latency, not by bytes in flight, so resident waves win over ring depth.
-    if (p.up_src)    // fused up-convolution producer: streamed-weight form only
-        return big ? launch_conv_k<T, KZ, NT, 8, 0, 2, true>(p, NB, s) : launch_conv_k<T, KZ, NT, 4, 0, 2, true>(p, NB, s);
     if (big) {
-        if (conv_lds_bytes<KZ, NT, 8, 2, 2>(nstages, false, p.final_wfrag != nullptr) <= 96 * 1024) return launch_conv_k<T, KZ, NT, 8, 2>(p, NB, s);
+        if (conv_lds_bytes<KZ, NT, 8, 2, 2>(nstages, p.final_wfrag != nullptr) <= 96 * 1024) return launch_conv_k<T, KZ, NT, 8, 2>(p, NB, s);
         return launch_conv_k<T, KZ, NT, 8, 0>(p, NB, s);
     }
-    if (conv_lds_bytes<KZ, NT, 4, 2, 2>(nstages, false, p.final_wfrag != nullptr) <= 80 * 1024) return launch_conv_k<T, KZ, NT, 4, 2>(p, NB, s);
+    if (conv_lds_bytes<KZ, NT, 4, 2, 2>(nstages, p.final_wfrag != nullptr) <= 80 * 1024) return launch_conv_k<T, KZ, NT, 4, 2>(p, NB, s);
     return launch_conv_k<T, KZ, NT, 4, 0>(p, NB, s);
 }
 template <typename T>

@@ -183,30 +183,6 @@ def test_large_tile_many_workgroups(gpu):
     assert err < TOL_FP32['bf16']
 
 
-def test_fused_upconv_matches_unfused(gpu, monkeypatch):
-    """Opt-in fusion (SD_FUSE_UP=1): the merge convolution computes its up-convolved input halo on the fly from the
-    low-resolution tensor instead of reading a materialised ConvTranspose output.  Same rounded values -> the
-    conv outputs must be bit-identical to the separate-launch path (odd shapes exercise autocrop + zero padding)."""
-    from syconn_amd import _lib as L
-    from syconn_amd.engine import DenseModel
-    for arch, shape in (('semseg_spine', (9, 35, 37)), ('syntype', (6, 20, 36)), ('semseg_axon', (5, 18, 34))):
-        model = build_unet(arch, seed=21, final_scale=4.0)
-        raw = _input(shape, 6).to(gpu)
-        monkeypatch.setenv('SD_NO_FUSE', '1')
-        plain = DenseModel(model, act_dtype='bf16', device=gpu)
-        monkeypatch.delenv('SD_NO_FUSE')
-        monkeypatch.setenv('SD_FUSE_UP', '1')
-        monkeypatch.setenv('SD_KEEP_ALL', '1')
-        fused = DenseModel(model, act_dtype='bf16', device=gpu)
-        monkeypatch.delenv('SD_KEEP_ALL')
-        monkeypatch.delenv('SD_FUSE_UP')
-        a = plain.forward(raw, L.SD_OUT_LOGITS_F32).cpu()
-        b = fused.forward(raw, L.SD_OUT_LOGITS_F32).cpu()
-        for buf in range(1, plain.info['n_buffers']):
-            assert torch.equal(plain.read_buffer(buf), fused.read_buffer(buf)), (arch, buf)
-        assert float((a - b).abs().max()) < 1e-4 * float(a.abs().max())
-
-
 @pytest.mark.parametrize('shape', [(1, 1, 1), (2, 3, 5), (3, 16, 2), (1, 40, 33)])
 def test_tiny_and_degenerate_tiles(gpu, shape):
     """Tiles smaller than one workgroup block / one pooling window (every voxel is a border voxel)."""
