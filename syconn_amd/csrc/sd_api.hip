@@ -548,15 +548,15 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
             } else {
                 ConvParams p{};
                 const Dims a = m->dims[d.src0];
-                p.src0 = bufp(d.src0); p.C0 = m->bufCp[d.src0]; p.H0 = a.h; p.W0 = a.w;
+                p.src0 = bufp(d.src0); p.C0 = m->bufCp[d.src0]; p.H0 = a.h; p.W0 = a.w; p.P0 = (size_t)a.d * a.h * a.w;
                 p.nchunk0 = p.C0 / SD_CHUNK;
                 if (d.src1 >= 0) {
                     const Dims b = m->dims[d.src1];
-                    p.src1 = bufp(d.src1); p.C1 = m->bufCp[d.src1]; p.H1 = b.h; p.W1 = b.w;
+                    p.src1 = bufp(d.src1); p.C1 = m->bufCp[d.src1]; p.H1 = b.h; p.W1 = b.w; p.P1 = (size_t)b.d * b.h * b.w;
                     p.nchunk1 = p.C1 / SD_CHUNK;
                 }
                 p.dst = bufp(d.dst); p.Cd = m->bufCp[d.dst];
-                p.D = o.d; p.H = o.h; p.W = o.w;
+                p.D = o.d; p.H = o.h; p.W = o.w; p.Pd = (size_t)o.d * o.h * o.w;
                 p.wpack = m->dev_blob + op.wpack_off;
                 p.bias = reinterpret_cast<const float*>(m->dev_blob + op.bias_off);
                 p.relu = d.relu; p.zero = m->dev_zero;
@@ -568,6 +568,7 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
                 if (op.fuse_pool >= 0) {
                     const sd_op_desc& pd = m->ops[op.fuse_pool].d;
                     p.pool_dst = bufp(pd.dst); p.pH = m->dims[pd.dst].h; p.pW = m->dims[pd.dst].w;
+                    p.Pp = (size_t)m->dims[pd.dst].d * p.pH * p.pW;
                 }
                 if (op.fuse_final >= 0) {
                     const Op& fo = m->ops[op.fuse_final];
@@ -593,6 +594,7 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
             const Dims a = m->dims[d.src0], o = m->dims[d.dst];
             p.src = bufp(d.src0); p.dst = bufp(d.dst); p.C = m->bufCp[d.src0];
             p.D = a.d; p.H = a.h; p.W = a.w; p.Do = o.d; p.Ho = o.h; p.Wo = o.w; p.kz = d.kz;
+            p.Ps = (size_t)a.d * a.h * a.w; p.Pd = (size_t)o.d * o.h * o.w;
             p.batch = N; p.tstride = tstride;
             rc = launch_pool(p, m->act_dtype, s);
             break;
@@ -603,6 +605,7 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
             p.src = bufp(d.src0); p.Cs = m->bufCp[d.src0]; p.nchunk = p.Cs / SD_CHUNK;
             p.D = a.d; p.H = a.h; p.W = a.w;
             p.dst = bufp(d.dst); p.Cd = m->bufCp[d.dst]; p.kz = d.kz;
+            p.Pd = (size_t)m->dims[d.dst].d * m->dims[d.dst].h * m->dims[d.dst].w;
             p.wpack = m->dev_blob + op.wpack_off;
             p.bias = reinterpret_cast<const float*>(m->dev_blob + op.bias_off);
             p.relu = d.relu; p.ntot = d.kz * 4 * p.Cd;
@@ -615,7 +618,7 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
             const Dims a = m->dims[d.src0];
             const Dims r = d.src1 >= 0 ? m->dims[d.src1] : a;
             p.buf = bufp(d.src0); p.C = m->bufCp[d.src0];
-            p.D = r.d; p.H = r.h; p.W = r.w; p.Hs = a.h; p.Ws = a.w;
+            p.D = r.d; p.H = r.h; p.W = r.w; p.Hs = a.h; p.Ws = a.w; p.P = (size_t)a.d * a.h * a.w;
             p.groups = d.groups; p.cout = m->bufC[d.src0]; p.eps = d.eps;
             p.gamma = reinterpret_cast<const float*>(m->dev_blob + op.aux_off);
             p.beta = p.gamma + p.C;

@@ -4,8 +4,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// Activation tensors are voxel-major / channel-minor: element (z,y,x,c) at ((z*H + y)*W + x)*C + c, with C the
-// padded channel stride (multiple of 16).  A "chunk" is 16 consecutive channels = one MFMA k-step.
+// Activation tensors are CHANNEL-BLOCKED: a "chunk" is 16 consecutive channels = one MFMA k-step, and element
+// (chunk k, z, y, x, c) sits at ((k*P + (z*H + y)*W + x)*16 + c) with P = D*H*W the voxels of the buffer's own
+// extents ("plane").  Every 16-channel slab of an x-row is contiguous: a halo row of 18 voxels is one 576-byte run
+// for the LDS-DMA gathers (voxel-major records cost a 128-byte line per 32 useful bytes).  C / Cd / Cs below are
+// the padded channel COUNT (multiple of 16).
 // Batched launches: every kernel can process `batch` independent tiles in ONE launch.  Tile t uses the workspace at
 // byte offset t*tstride (all tiles share one workspace layout, so the same offset applies to every activation
 // buffer and scratch pointer of a launch); the network input / final output of tile t sit t*in_tstride /
@@ -24,7 +27,8 @@ struct LabelArgs { int n; int ids[16]; int cuts[16]; };   // label rule: later e
 struct ConvParams {
     const void* src0;  // first input (for a merged conv: the up-convolved tensor, cropped by reading fewer voxels)
     const void* src1;  // second input or nullptr
-    int C0, H0, W0;    // channel stride and y/x extents (strides) of src0
+    int C0, H0, W0;    // padded channels and y/x extents (strides) of src0
+    size_t P0, P1, Pd, Pp;  // voxels per chunk plane of src0 / src1 / dst / pool_dst
     int C1, H1, W1;
     int nchunk0, nchunk1;
     void* dst;
@@ -67,6 +71,7 @@ struct UpconvParams {
     int Cs, nchunk;
     int D, H, W;
     void* dst;         // (D*kz, 2H, 2W, Cd)
+    size_t Pd;         // voxels per chunk plane of dst
     int Cd;
     int kz;            // 1 or 2
     const void* wpack; // [nb][chunk][NT=2][64][8]
@@ -82,6 +87,7 @@ struct PoolParams {
     int D, H, W;       // src dims
     int Do, Ho, Wo;    // dst dims
     int kz;            // 1 or 2
+    size_t Ps, Pd;     // voxels per chunk plane
     int batch; size_t tstride;
 };
 
@@ -101,6 +107,7 @@ struct GnParams {
     void* buf; int C;          // channel stride
     int D, H, W;               // logical region
     int Hs, Ws;                // strides (buffer y/x extents)
+    size_t P;                  // voxels per chunk plane of the buffer
     int groups, cout;          // real channel count
     float eps;
     const float* gamma; const float* beta;   // padded to C

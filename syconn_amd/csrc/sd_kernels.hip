@@ -132,8 +132,8 @@ __device__ __forceinline__ float max_xor16(float m) {      // max with lane^16, 
 // quads so that each lane owns 16 CONSECUTIVE channels (32 contiguous bytes) -> two 16-byte stores per lane
 // instead of four 8-byte ones.  Must be called by all 64 lanes (stores are predicated, swaps are not).
 template <typename T>
-__device__ __forceinline__ void store_tile_rows(typename Act<T>::v4 (&o)[4], T* vox, bool valid, int cbase, int half,
-                                                int Cd) {
+__device__ __forceinline__ void store_tile_rows(typename Act<T>::v4 (&o)[4], T* base, size_t P, size_t vidx, bool valid,
+                                                int cbase, int half, int Cd) {
     typedef __attribute__((ext_vector_type(2))) unsigned u2;
     typedef __attribute__((ext_vector_type(4))) unsigned u4;
     u2 a0 = __builtin_bit_cast(u2, o[0]), a1 = __builtin_bit_cast(u2, o[1]);
@@ -143,26 +143,33 @@ __device__ __forceinline__ void store_tile_rows(typename Act<T>::v4 (&o)[4], T* 
     x = a0.y; { unsigned y = a2.y; swap32(x, y); a0.y = x; a2.y = y; }
     x = a1.x; { unsigned y = a3.x; swap32(x, y); a1.x = x; a3.x = y; }
     x = a1.y; { unsigned y = a3.y; swap32(x, y); a1.y = x; a3.y = y; }
-    const int n0 = cbase + half * 16;
-    if (valid && n0 < Cd) { u4 v = {a0.x, a0.y, a2.x, a2.y}; *reinterpret_cast<u4*>(vox + n0) = v; }
-    if (valid && n0 + 8 < Cd) { u4 v = {a1.x, a1.y, a3.x, a3.y}; *reinterpret_cast<u4*>(vox + n0 + 8) = v; }
+    const int n0 = cbase + half * 16;          // this lane now owns the whole 16-channel chunk n0/16 of its voxel
+    if (valid && n0 < Cd) {
+        T* const q = base + ((size_t)(n0 >> 4) * P + vidx) * SD_CHUNK;
+        { u4 v = {a0.x, a0.y, a2.x, a2.y}; *reinterpret_cast<u4*>(q) = v; }
+        { u4 v = {a1.x, a1.y, a3.x, a3.y}; *reinterpret_cast<u4*>(q + 8) = v; }
+    }
 }
 
 // Same, from the packed form pk[2q + h] = channels (cbase + 8q + 4*(lane>>5) + 2h, +1) of voxel (lane&31).
 template <typename T>
-__device__ __forceinline__ void store_tile_rows_pk(const unsigned (&pk)[8], T* vox, bool valid, int cbase, int half, int Cd) {
+__device__ __forceinline__ void store_tile_rows_pk(const unsigned (&pk)[8], T* base, size_t P, size_t vidx, bool valid,
+                                                   int cbase, int half, int Cd) {
     typedef __attribute__((ext_vector_type(4))) unsigned u4;
     unsigned a0x = pk[0], a0y = pk[1], a1x = pk[2], a1y = pk[3], a2x = pk[4], a2y = pk[5], a3x = pk[6], a3y = pk[7];
     swap32x4(a0x, a2x, a0y, a2y, a1x, a3x, a1y, a3y);
     const int n0 = cbase + half * 16;
-    if (valid && n0 < Cd) { u4 v = {a0x, a0y, a2x, a2y}; *reinterpret_cast<u4*>(vox + n0) = v; }
-    if (valid && n0 + 8 < Cd) { u4 v = {a1x, a1y, a3x, a3y}; *reinterpret_cast<u4*>(vox + n0 + 8) = v; }
+    if (valid && n0 < Cd) {
+        T* const q = base + ((size_t)(n0 >> 4) * P + vidx) * SD_CHUNK;
+        { u4 v = {a0x, a0y, a2x, a2y}; *reinterpret_cast<u4*>(q) = v; }
+        { u4 v = {a1x, a1y, a3x, a3y}; *reinterpret_cast<u4*>(q + 8) = v; }
+    }
 }
 
 // + bias, ReLU, round to the storage type and store one accumulator tile (lane owns voxel column lane&31 and
 // channel rows (r&3) + 8*(r>>2) + 4*(lane>>5)).
 template <typename T>
-__device__ __forceinline__ void store_acc_tile(const f32x16& acc, T* vox, bool valid, int cbase, int half,
+__device__ __forceinline__ void store_acc_tile(const f32x16& acc, T* base, size_t P, size_t vidx, bool valid, int cbase, int half,
                                                const float* __restrict__ bias, int relu, int Cd) {
     using v4 = typename Act<T>::v4;
     v4 o[4];
@@ -178,7 +185,7 @@ __device__ __forceinline__ void store_acc_tile(const f32x16& acc, T* vox, bool v
             o[q][e] = (T)v;
         }
     }
-    store_tile_rows<T>(o, vox, valid, cbase, half, Cd);
+    store_tile_rows<T>(o, base, P, vidx, valid, cbase, half, Cd);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -333,10 +340,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     // instructions against the dummy slot (keeps the per-wave DMA count per chunk constant for the counted waits)
     auto dma_halo = [&](int c, int slot, int z0, int y0, int x0, int tile, bool real) {
         const char* sbase;
-        int Cs, Hs, Ws, cc;
-        if (c < p.nchunk0) { sbase = (const char*)p.src0; Cs = p.C0; Hs = p.H0; Ws = p.W0; cc = c; }
-        else { sbase = (const char*)p.src1; Cs = p.C1; Hs = p.H1; Ws = p.W1; cc = c - p.nchunk0; }
-        sbase += (size_t)cc * SD_CHUNK * sizeof(T) + (size_t)tile * p.tstride;
+        int Hs, Ws, cc;
+        size_t Ps;
+        if (c < p.nchunk0) { sbase = (const char*)p.src0; Ps = p.P0; Hs = p.H0; Ws = p.W0; cc = c; }
+        else { sbase = (const char*)p.src1; Ps = p.P1; Hs = p.H1; Ws = p.W1; cc = c - p.nchunk0; }
+        sbase += (size_t)cc * Ps * (SD_CHUNK * sizeof(T)) + (size_t)tile * p.tstride;      // chunk plane of this tile
         char* dst = ldsA + slot * A_BYTES + wave * 1024;
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
@@ -347,7 +355,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                 const bool ok = inst && hp >= 0 && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H &&
                                 (unsigned)x < (unsigned)p.W;
                 const char* src = reinterpret_cast<const char*>(p.zero);
-                if (ok) src = sbase + (((size_t)(z * Hs + y) * Ws + x) * Cs + (hp & 1) * 8) * sizeof(T);
+                if (ok) src = sbase + (((size_t)(z * Hs + y) * Ws + x) * SD_CHUNK + (hp & 1) * 8) * sizeof(T);
                 glds16(src, inst ? dst + j * (WAVES * 1024) : ldsDummy);
             }
         }
@@ -500,7 +508,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     for (int i = 0; i < MT; ++i) {
         const int vz = z0 + tzs[i], vy = y0 + tys[i] + dy, vx = x0 + dxl;
         valid[i] = vz < p.D && vy < p.H && vx < p.W;
-        voxoff[i] = ((size_t)(vz * p.H + vy) * p.W + vx) * p.Cd;
+        voxoff[i] = (size_t)(vz * p.H + vy) * p.W + vx;          // voxel index inside the tile's tensor
     }
     T* const dst = reinterpret_cast<T*>(reinterpret_cast<char*>(p.dst) + (size_t)tn * p.tstride);
     // rounded outputs, packed two channels per register: pk[i][j][2q + h] = channels cbase + 8q + 4*half + 2h, +1.
@@ -579,7 +587,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
-                store_tile_rows_pk<T>(pk[i][j], dst + voxoff[i], valid[i], (nb * NT + j) * 32, half, p.Cd);
+                store_tile_rows_pk<T>(pk[i][j], dst, p.Pd, voxoff[i], valid[i], (nb * NT + j) * 32, half, p.Cd);
     }
 
 #ifndef SD_T5_EARLY
@@ -595,7 +603,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         for (int i = 0; i < MT; ++i) {
             if (KZ == 3 && (i & 1)) continue;   // 3D: tiles (i, i+1) form ONE pooled tile (z pair)
             const int pz = (KZ == 3) ? (z0 + tzs[i]) >> 1 : z0, py = (y0 + tys[i]) >> 1, px = (x0 + dxl) >> 1;
-            const size_t po = ((size_t)(pz * p.pH + py) * p.pW + px) * p.Cd;
+            const size_t po = (size_t)(pz * p.pH + py) * p.pW + px;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 unsigned m[8];
@@ -605,7 +613,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                     if (KZ == 3) m[k] = pk_max16(m[k], valid[i | 1] ? pk[i | 1][j][k] : 0u);
                 }
                 pool_xy_pk8(m);
-                store_tile_rows_pk<T>(m, pdst + po, writer && valid[i], (nb * NT + j) * 32, half, p.Cd);
+                store_tile_rows_pk<T>(m, pdst, p.Pp, po, writer && valid[i], (nb * NT + j) * 32, half, p.Cd);
             }
         }
     }
@@ -667,7 +675,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                 for (int co = 0; co < 8; ++co) l[co] *= inv;
             }
             const bool vmine = half ? valid[tp + 1] : valid[tp];
-            const size_t v = (half ? voxoff[tp + 1] : voxoff[tp]) / p.Cd;
+            const size_t v = half ? voxoff[tp + 1] : voxoff[tp];
             if (vmine) {
                 if (p.final_kind == SD_OUT_LABELS_U8) {
                     uint8_t lab = 0;
@@ -778,8 +786,8 @@ __global__ __launch_bounds__(256) void k_conv_first(const FirstParams p) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[s], patch[base + toff[s]], acc, 0, 0, 0);
             const int vz = z0 + tz, vy = y0 + ly, vx = x0 + lx;
             const bool valid = vz < p.D && vy < p.H && vx < p.W;
-            T* vox = dst + ((size_t)(vz * p.H + vy) * p.W + vx) * p.Cd;
-            store_acc_tile<T>(acc, vox, valid, nt * 32, lane >> 5, p.bias, p.relu, p.Cd);
+            store_acc_tile<T>(acc, dst, (size_t)p.D * p.H * p.W, (size_t)(vz * p.H + vy) * p.W + vx, valid, nt * 32, lane >> 5,
+                              p.bias, p.relu, p.Cd);
         }
     }
 }
@@ -818,7 +826,7 @@ __global__ __launch_bounds__(256) void k_upconv_mfma(const UpconvParams p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             v8 val = {};
-            if (mv[i]) val = *reinterpret_cast<const v8*>(src + m[i] * p.Cs + c * SD_CHUNK + (lane >> 5) * 8);
+            if (mv[i]) val = *reinterpret_cast<const v8*>(src + ((size_t)c * M + m[i]) * SD_CHUNK + (lane >> 5) * 8);
             xf[i] = val;
         }
 #pragma unroll
@@ -854,7 +862,7 @@ __global__ __launch_bounds__(256) void k_upconv_mfma(const UpconvParams p) {
                         o[e] = (T)v;
                     }
                     const size_t vo = ((size_t)(z * p.kz + a) * H2 + (2 * y + b)) * W2 + (2 * x + cx);
-                    *reinterpret_cast<v4*>(dst + vo * p.Cd + co) = o;
+                    *reinterpret_cast<v4*>(dst + ((size_t)(co >> 4) * p.Pd + vo) * SD_CHUNK + (co & 15)) = o;
                 }
             }
         }
@@ -905,7 +913,7 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         v8 val = {};
-        if (mv) val = *reinterpret_cast<const v8*>(src + m * p.Cs + c * SD_CHUNK + half * 8);
+        if (mv) val = *reinterpret_cast<const v8*>(src + ((size_t)c * M + m) * SD_CHUNK + half * 8);
         xf[c] = val;
     }
     const int ab0 = WL ? a_wg : 0, nab = WL ? ab0 + 1 : p.kz * 2;
@@ -949,18 +957,22 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
                 *reinterpret_cast<v4*>(tile + vl * ROW + pc * 16 + half * 8) = o;
             }
         }
-        // LDS -> global, 16 bytes per lane, consecutive lanes = consecutive pieces of consecutive voxels
+        // LDS -> global, 16 bytes per lane.  Channel-blocked destination: per 16-channel chunk an input voxel yields 64
+        // contiguous bytes (two x-taps x 16 channels) and consecutive input voxels of a row follow each other, so
+        // the pieces are walked chunk-major: consecutive lanes = (voxel, tap, half) of ONE chunk = contiguous memory
         const int a = (p.kz == 2) ? (ab >> 1) : 0, b = ab & 1;
 #pragma unroll
         for (int it = 0; it < (32 * PPV) / 64; ++it) {
             const int u = it * 64 + lane;
-            const int v = u / PPV, piece = u % PPV;
+            const int chunk = u >> 7, r = u & 127;            // 128 pieces per chunk: 32 voxels x 2 taps x 2 halves
+            const int v = r >> 2, tap = (r >> 1) & 1, hf = r & 1;
+            const int piece = tap * (CD / 8) + chunk * 2 + hf;
             const long mm = m0 + v;
             if (mm < M) {
                 const int x = (int)(mm % p.W), y = (int)((mm / p.W) % p.H), z = (int)(mm / ((long)p.W * p.H));
-                const size_t ov = ((size_t)(z * p.kz + a) * H2 + (2 * y + b)) * W2 + 2 * x;
+                const size_t ov = ((size_t)(z * p.kz + a) * H2 + (2 * y + b)) * W2 + 2 * x + tap;
                 const u4 val = *reinterpret_cast<const u4*>(tile + v * ROW + ((piece ^ (v & SWM)) * 16));
-                *reinterpret_cast<u4*>(dst + ov * (size_t)(CD * sizeof(T)) + piece * 16) = val;
+                *reinterpret_cast<u4*>(dst + (((size_t)chunk * p.Pd + ov) * SD_CHUNK + hf * 8) * sizeof(T)) = val;
             }
         }
     }
@@ -994,7 +1006,7 @@ __global__ __launch_bounds__(256) void k_maxpool(const PoolParams p) {
                 for (int dx = 0; dx < 2; ++dx) {
                     const int x = xo * 2 + dx;
                     if (x >= p.W) continue;
-                    const v8 val = *reinterpret_cast<const v8*>(src + (((size_t)z * p.H + y) * p.W + x) * p.C + cg * 8);
+                    const v8 val = *reinterpret_cast<const v8*>(src + ((size_t)(cg >> 1) * p.Ps + ((size_t)z * p.H + y) * p.W + x) * SD_CHUNK + (cg & 1) * 8);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) mx[e] = fmaxf(mx[e], (float)val[e]);
                 }
@@ -1003,7 +1015,7 @@ __global__ __launch_bounds__(256) void k_maxpool(const PoolParams p) {
         v8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (T)mx[e];
-        *reinterpret_cast<v8*>(dst + (size_t)v * p.C + cg * 8) = o;
+        *reinterpret_cast<v8*>(dst + ((size_t)(cg >> 1) * p.Pd + v) * SD_CHUNK + (cg & 1) * 8) = o;
     }
 }
 
@@ -1020,7 +1032,7 @@ __global__ __launch_bounds__(256) void k_final(const FinalParams p) {
 #pragma unroll
         for (int co = 0; co < 8; ++co) acc[co] = 0.f;
         for (int c8 = 0; c8 < p.Cs / 8; ++c8) {
-            const v8 xv = *reinterpret_cast<const v8*>(src + (size_t)v * p.Cs + c8 * 8);
+            const v8 xv = *reinterpret_cast<const v8*>(src + ((size_t)(c8 >> 1) * p.nvox + v) * SD_CHUNK + (c8 & 1) * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float xf = (float)xv[e];
@@ -1084,7 +1096,7 @@ __global__ __launch_bounds__(192) void k_gn_stats(const GnParams p) {
     for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
     for (long v = (long)blockIdx.x * vper + vl; v < nvox; v += (long)gridDim.x * vper) {
         const int x = (int)(v % p.W), y = (int)((v / p.W) % p.H), z = (int)(v / ((long)p.W * p.H));
-        const v8 val = *reinterpret_cast<const v8*>(buf + (((size_t)z * p.Hs + y) * p.Ws + x) * p.C + cg * 8);
+        const v8 val = *reinterpret_cast<const v8*>(buf + ((size_t)(cg >> 1) * p.P + ((size_t)z * p.Hs + y) * p.Ws + x) * SD_CHUNK + (cg & 1) * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const float f = (float)val[e]; s[e] += f; ss[e] = fmaf(f, f, ss[e]); }
     }
@@ -1129,7 +1141,7 @@ __global__ __launch_bounds__(256) void k_gn_apply_pool(const GnParams p) {
                 for (int dx = 0; dx < 2; ++dx) {
                     const int x = xo * 2 + dx;
                     if (x >= p.W) continue;
-                    T* ptr = buf + (((size_t)z * p.Hs + y) * p.Ws + x) * p.C + cg * 8;
+                    T* ptr = buf + ((size_t)(cg >> 1) * p.P + ((size_t)z * p.Hs + y) * p.Ws + x) * SD_CHUNK + (cg & 1) * 8;
                     v8 val = *reinterpret_cast<const v8*>(ptr);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
@@ -1145,7 +1157,7 @@ __global__ __launch_bounds__(256) void k_gn_apply_pool(const GnParams p) {
         v8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (T)mx[e];
-        *reinterpret_cast<v8*>(pdst + (size_t)v * p.C + cg * 8) = o;
+        *reinterpret_cast<v8*>(pdst + ((size_t)(cg >> 1) * ((size_t)p.pD * p.pH * p.pW) + v) * SD_CHUNK + (cg & 1) * 8) = o;
     }
 }
 
@@ -1183,7 +1195,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const GnParams p) {
         const int cg = (int)(idx % ng);
         const long v = idx / ng;
         const int x = (int)(v % p.W), y = (int)((v / p.W) % p.H), z = (int)(v / ((long)p.W * p.H));
-        T* ptr = buf + (((size_t)z * p.Hs + y) * p.Ws + x) * p.C + cg * 8;
+        T* ptr = buf + ((size_t)(cg >> 1) * p.P + ((size_t)z * p.Hs + y) * p.Ws + x) * SD_CHUNK + (cg & 1) * 8;
         v8 val = *reinterpret_cast<const v8*>(ptr);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -1247,7 +1259,7 @@ __global__ __launch_bounds__(256) void k_read_buffer(const T* buf, int C, int Cs
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int c = (int)(i / nvox);
         const long v = i - (long)c * nvox;
-        out[i] = (float)buf[(size_t)v * Cs + c];
+        out[i] = (float)buf[((size_t)(c >> 4) * nvox + v) * SD_CHUNK + (c & 15)];
     }
 }
 
