@@ -323,7 +323,6 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
             if (d.src0 <= 0 || d.groups <= 0) MODEL_FAIL("groupnorm: bad arguments");
             const int C = m->bufC[d.src0], Cp = m->bufCp[d.src0];
             if (C % d.groups) MODEL_FAIL("groupnorm: channels not divisible by groups");
-            if (192 % (Cp / 8)) MODEL_FAIL("groupnorm: unsupported channel count");
             if ((size_t)Cp * 24 > WS_SCRATCH) MODEL_FAIL("groupnorm: too many channels");
             if (!chk(d.gamma_off, C) || !chk(d.beta_off, C)) MODEL_FAIL("groupnorm: offsets");
             op.aux_off = blob_alloc((size_t)2 * Cp * 4);

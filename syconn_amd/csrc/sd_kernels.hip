@@ -988,9 +988,10 @@ __global__ __launch_bounds__(256) void k_maxpool(const PoolParams p) {
     const long total = (long)p.Do * p.Ho * p.Wo * ng;
     const T* const src = reinterpret_cast<const T*>(reinterpret_cast<const char*>(p.src) + blockIdx.z * p.tstride);
     T* const dst = reinterpret_cast<T*>(reinterpret_cast<char*>(p.dst) + blockIdx.z * p.tstride);
+    const long npv = (long)p.Do * p.Ho * p.Wo;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int cg = (int)(idx % ng);
-        const long v = idx / ng;
+        const long v = (idx >> 1) % npv;                                  // (chunk, pooled voxel, half)
+        const int cg = (int)((idx >> 1) / npv) * 2 + (int)(idx & 1);
         const int xo = (int)(v % p.Wo), yo = (int)((v / p.Wo) % p.Ho), zo = (int)(v / ((long)p.Wo * p.Ho));
         float mx[8];
 #pragma unroll
@@ -1082,33 +1083,37 @@ __global__ __launch_bounds__(256) void k_final(const FinalParams p) {
 // thread, double atomics per workgroup).  Phase 2: one small block turns them into per-channel scale / shift.
 // Phase 3: y = relu(x*scale + shift) in place.
 template <typename T>
-__global__ __launch_bounds__(192) void k_gn_stats(const GnParams p) {
+__global__ __launch_bounds__(256) void k_gn_stats(const GnParams p) {
+    // one 16-channel chunk plane per blockIdx.y: a thread reads the 32 contiguous bytes of a voxel, consecutive threads
+    // consecutive voxels; fp32 partials per thread, fixed-order block reduction, one double atomic per channel
     using v8 = typename Act<T>::v8;
-    __shared__ float red[192][17];
-    const int ng = p.C / 8;
-    const int tid = threadIdx.x;
-    const int cg = tid % ng, vl = tid / ng, vper = 192 / ng;
+    __shared__ float red[256][33];
+    const int tid = threadIdx.x, chunk = blockIdx.y;
     const long nvox = (long)p.D * p.H * p.W;
-    const T* const buf = reinterpret_cast<const T*>(reinterpret_cast<const char*>(p.buf) + blockIdx.z * p.tstride);
+    const T* const buf = reinterpret_cast<const T*>(reinterpret_cast<const char*>(p.buf) + blockIdx.z * p.tstride) +
+                         (size_t)chunk * p.P * SD_CHUNK;
     double* const sums = reinterpret_cast<double*>(reinterpret_cast<char*>(p.sums) + blockIdx.z * p.tstride);
-    float s[8], ss[8];
+    float s[16], ss[16];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
-    for (long v = (long)blockIdx.x * vper + vl; v < nvox; v += (long)gridDim.x * vper) {
+    for (int e = 0; e < 16; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+    for (long v = (long)blockIdx.x * 256 + tid; v < nvox; v += (long)gridDim.x * 256) {
         const int x = (int)(v % p.W), y = (int)((v / p.W) % p.H), z = (int)(v / ((long)p.W * p.H));
-        const v8 val = *reinterpret_cast<const v8*>(buf + ((size_t)(cg >> 1) * p.P + ((size_t)z * p.Hs + y) * p.Ws + x) * SD_CHUNK + (cg & 1) * 8);
+        const T* q = buf + (((size_t)z * p.Hs + y) * p.Ws + x) * SD_CHUNK;
+        const v8 lo = *reinterpret_cast<const v8*>(q), hi = *reinterpret_cast<const v8*>(q + 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float f = (float)val[e]; s[e] += f; ss[e] = fmaf(f, f, ss[e]); }
+        for (int e = 0; e < 8; ++e) {
+            const float f = (float)lo[e], g = (float)hi[e];
+            s[e] += f; ss[e] = fmaf(f, f, ss[e]);
+            s[8 + e] += g; ss[8 + e] = fmaf(g, g, ss[8 + e]);
+        }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { red[tid][e] = s[e]; red[tid][8 + e] = ss[e]; }
+    for (int e = 0; e < 16; ++e) { red[tid][e] = s[e]; red[tid][16 + e] = ss[e]; }
     __syncthreads();
-    for (int k0 = tid; k0 < ng * 16; k0 += 192) {
-        const int g = k0 / 16, e = k0 % 16;
+    if (tid < 32) {
         double t = 0.0;
-        for (int k = 0; k < vper; ++k) t += (double)red[k * ng + g][e];
-        const int ch = g * 8 + (e & 7);
-        atomicAdd(&sums[(e >> 3) * p.C + ch], t);
+        for (int k = 0; k < 256; ++k) t += (double)red[k][tid];
+        atomicAdd(&sums[(tid >> 4) * p.C + chunk * SD_CHUNK + (tid & 15)], t);
     }
 }
 
@@ -1123,9 +1128,10 @@ __global__ __launch_bounds__(256) void k_gn_apply_pool(const GnParams p) {
     T* const buf = reinterpret_cast<T*>(reinterpret_cast<char*>(p.buf) + blockIdx.z * p.tstride);
     T* const pdst = reinterpret_cast<T*>(reinterpret_cast<char*>(p.pool_dst) + blockIdx.z * p.tstride);
     const float* const scale_shift = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.scale_shift) + blockIdx.z * p.tstride);
+    const long npv = (long)p.pD * p.pH * p.pW;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int cg = (int)(idx % ng);
-        const long v = idx / ng;
+        const long v = (idx >> 1) % npv;                                  // (chunk, pooled voxel, half)
+        const int cg = (int)((idx >> 1) / npv) * 2 + (int)(idx & 1);
         const int xo = (int)(v % p.pW), yo = (int)((v / p.pW) % p.pH), zo = (int)(v / ((long)p.pW * p.pH));
         float sc[8], sh[8], mx[8];
 #pragma unroll
@@ -1191,9 +1197,11 @@ __global__ __launch_bounds__(256) void k_gn_apply(const GnParams p) {
     const long total = (long)p.D * p.H * p.W * ng;
     T* const buf = reinterpret_cast<T*>(reinterpret_cast<char*>(p.buf) + blockIdx.z * p.tstride);
     const float* const scale_shift = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.scale_shift) + blockIdx.z * p.tstride);
+    const long nvx = (long)p.D * p.H * p.W;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int cg = (int)(idx % ng);
-        const long v = idx / ng;
+        // (chunk, voxel, half): consecutive threads touch consecutive 16-byte pieces of one chunk plane
+        const long v = (idx >> 1) % nvx;
+        const int cg = (int)((idx >> 1) / nvx) * 2 + (int)(idx & 1);
         const int x = (int)(v % p.W), y = (int)((v / p.W) % p.H), z = (int)(v / ((long)p.W * p.H));
         T* ptr = buf + ((size_t)(cg >> 1) * p.P + ((size_t)z * p.Hs + y) * p.Ws + x) * SD_CHUNK + (cg & 1) * 8;
         v8 val = *reinterpret_cast<const v8*>(ptr);
@@ -1428,14 +1436,12 @@ int launch_final(const FinalParams& p, int act_dtype, hipStream_t s) {
 
 int launch_groupnorm(const GnParams& p, int act_dtype, hipStream_t s) {
     const int ng = p.C / 8;
-    if (192 % ng != 0) return SD_ERR_INVALID;
     if (!p.skip_stats)
         for (int t = 0; t < p.batch; ++t)
             if (hipMemsetAsync(reinterpret_cast<char*>(p.sums) + t * p.tstride, 0, sizeof(double) * 2 * p.C, s) != hipSuccess)
                 return SD_ERR_HIP;
     const long nvox = (long)p.D * p.H * p.W;
-    const int vper = 192 / ng;
-    dim3 g1(grid_for(nvox, vper * 8, 2048), 1, p.batch), b1(192);
+    dim3 g1(grid_for(nvox, 256 * 8, 1024), p.C / SD_CHUNK, p.batch), b1(256);
     dim3 g3(grid_for(nvox * ng), 1, p.batch), b3(256);
     dim3 gp(grid_for((long)std::max(p.pD, 1) * std::max(p.pH, 1) * std::max(p.pW, 1) * ng), 1, p.batch);
     if (act_dtype == SD_BF16) {
