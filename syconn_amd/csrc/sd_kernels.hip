@@ -767,10 +767,15 @@ __global__ __launch_bounds__(256) void k_conv_first(const FirstParams p) {
     }
     T* const dst = reinterpret_cast<T*>(reinterpret_cast<char*>(p.dst) + blockIdx.z * p.tstride);
     const int ntiles = (p.Cd + 31) / 32;
+    const int half = lane >> 5;
+    const size_t P = (size_t)p.D * p.H * p.W;
     for (int nt = 0; nt < ntiles; ++nt) {
         float wf[NSTEP];
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) wf[s] = p.wpack[(nt * NSTEP + s) * 64 + lane];
+        f32x4 bq[4];                  // folded bias of this lane's 16 channels (added AFTER the tap chain, like the oracle)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(p.bias + nt * 32 + 8 * q + 4 * half);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int t = wave * 2 + i;
@@ -786,8 +791,16 @@ __global__ __launch_bounds__(256) void k_conv_first(const FirstParams p) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[s], patch[base + toff[s]], acc, 0, 0, 0);
             const int vz = z0 + tz, vy = y0 + ly, vx = x0 + lx;
             const bool valid = vz < p.D && vy < p.H && vx < p.W;
-            store_acc_tile<T>(acc, dst, (size_t)p.D * p.H * p.W, (size_t)(vz * p.H + vy) * p.W + vx, valid, nt * 32, lane >> 5,
-                              p.bias, p.relu, p.Cd);
+            // packed epilogue: one convert and one integer max per pair (relu(round(x)) == round(relu(x)))
+            unsigned pk[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                pk[k] = Act<T>::pack2(acc[2 * k] + bq[k >> 1][(2 * k) & 3], acc[2 * k + 1] + bq[k >> 1][(2 * k + 1) & 3]);
+            if (p.relu) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pk[k] = pk_max16(pk[k], 0u);
+            }
+            store_tile_rows_pk<T>(pk, dst, P, (size_t)(vz * p.H + vy) * p.W + vx, valid, nt * 32, half, p.Cd);
         }
     }
 }
