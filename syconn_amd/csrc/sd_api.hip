@@ -54,6 +54,7 @@ struct Op {
     bool first = false;    // conv reading the network input (cin = 1)
     int fuse_pool = -1;    // index of the MaxPool op computed in this conv's epilogue
     int fuse_final = -1;   // index of the final 1x1x1 op computed in this conv's epilogue
+    int fuse_first = -1;   // conv: index of the first (cin = 1) convolution whose output (this conv's src0) it computes itself
     int fuse_gn = -1;      // conv: index of the GroupNorm op whose statistics this conv's epilogue accumulates
     bool stats_done = false;   // groupnorm: statistics come from the producing conv
     int gn_pool = -1;          // groupnorm: index of the MaxPool op fused into the apply pass
@@ -353,6 +354,20 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
     if (m->ops.empty() || m->ops.back().d.kind != SD_OP_FINAL) MODEL_FAIL("the plan must end with SD_OP_FINAL");
     // epilogue fusions (SD_NO_FUSE=1 keeps every layer a separate launch, for layer-wise debugging)
     if (!getenv("SD_NO_FUSE")) {
+        // first conv (1 -> 32, 1x3x3) -> conv (1x3x3) of one input: the second conv computes its halo of the first conv's
+        // output on the fly (decided per launch: only the resident-weight form of the kernel can do it)
+        for (size_t i = 0; i + 1 < m->ops.size(); ++i) {
+            Op& f = m->ops[i];
+            Op& c = m->ops[i + 1];
+            if (f.d.kind == SD_OP_CONV && f.first && f.d.kz == 1 && m->bufCp[f.d.dst] == 32 && f.d.cout == 32 &&
+                c.d.kind == SD_OP_CONV && !c.first && c.d.kz == 1 && c.d.src0 == f.d.dst && c.d.src1 < 0 &&
+                !getenv("SD_NO_FIRST_FUSE")) {
+                bool other_reader = false;
+                for (size_t k = i + 2; k < m->ops.size(); ++k)
+                    if (m->ops[k].d.src0 == f.d.dst || m->ops[k].d.src1 == f.d.dst) other_reader = true;
+                if (!other_reader) c.fuse_first = (int)i;
+            }
+        }
         // GroupNorm (whole buffer) directly followed by the pooling of its output: one pass
         for (size_t i = 0; i + 1 < m->ops.size(); ++i) {
             Op& g = m->ops[i];
@@ -534,7 +549,16 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
         case SD_OP_CONV: {
             const Dims o = m->dims[d.dst];
             const int BZ = sd_bz(d.kz), BY = sd_by(d.kz);
-            if (op.first) {
+            bool first_fused_into_next = false;
+            if (op.first && i + 1 < m->ops.size() && m->ops[i + 1].fuse_first == (int)i && !m->keep_all) {
+                const Op& c = m->ops[i + 1];
+                const int nst = (m->bufCp[c.d.src0] / SD_CHUNK) * c.d.kz;
+                first_fused_into_next = conv_can_fuse_first(c.d.kz, c.NT, c.NB, (long)o.d * o.h * o.w * N, nst,
+                                                            c.fuse_final >= 0);
+            }
+            if (first_fused_into_next) {
+                // computed inside the next convolution
+            } else if (op.first) {
                 FirstParams p{};
                 p.in = in_dev; p.D = o.d; p.H = o.h; p.W = o.w;
                 p.dst = bufp(d.dst); p.Cd = m->bufCp[d.dst];
@@ -577,6 +601,15 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
                     p.final_cout = fo.d.cout; p.final_kind = out_kind; p.final_out = out_dev;
                     if (lab) p.lab = *lab;
                     p.store_main = m->keep_all ? 1 : 0;
+                }
+                if (op.fuse_first >= 0 && !m->keep_all &&
+                    conv_can_fuse_first(d.kz, op.NT, op.NB, (long)o.d * o.h * o.w * N, (p.nchunk0 + p.nchunk1) * d.kz,
+                                        op.fuse_final >= 0)) {
+                    const Op& fo = m->ops[op.fuse_first];
+                    p.first_in = in_dev; p.first_in_tstride = in_tstride; p.first_in_f32 = in_dtype == SD_F32 ? 1 : 0;
+                    p.first_w = reinterpret_cast<const float*>(m->dev_blob + fo.wpack_off);
+                    p.first_bias = reinterpret_cast<const float*>(m->dev_blob + fo.bias_off);
+                    p.first_relu = fo.d.relu;
                 }
                 if (op.fuse_gn >= 0) {
                     p.gn_sums = reinterpret_cast<double*>(wsb); p.gn_C = p.Cd;

@@ -52,6 +52,12 @@ struct ConvParams {
     // gn_sums[0..gn_C) / gn_sums[gn_C..2*gn_C) of the block's tile (doubles, zeroed by the host), or nullptr
     double* gn_sums; int gn_C;
     LabelArgs lab;     // final_kind == SD_OUT_LABELS_U8
+    // fused FIRST convolution (1 -> 32 channels, 1x3x3): src0 is then NOT read, its two chunks are computed from the
+    // network input inside the kernel (k_conv_mfma<..., FF = true>)
+    const void* first_in; size_t first_in_tstride; int first_in_f32;
+    const float* first_w;      // [5 k-steps][64 lanes] exact-f32 MFMA A fragments of the 32 output channels
+    const float* first_bias;   // folded bias, 32 floats
+    int first_relu;
 };
 
 struct FirstParams {
@@ -121,6 +127,9 @@ struct GnParams {
 };
 
 int launch_conv(const ConvParams& p, int act_dtype, int KZ, int NT, int NB, hipStream_t s);
+// true when launch_conv would run this planar layer with LDS-resident weights and 512-voxel workgroups -- the form
+// that can compute a fused first convolution (ConvParams::first_in)
+bool conv_can_fuse_first(int KZ, int NT, int NB, long vox_all_tiles, int nstages, bool fused_final);
 int launch_first(const FirstParams& p, int act_dtype, int in_dtype, int KZ, hipStream_t s);
 int launch_upconv(const UpconvParams& p, int act_dtype, int NB, hipStream_t s);
 int launch_pool(const PoolParams& p, int act_dtype, hipStream_t s);

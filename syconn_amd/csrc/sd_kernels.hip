@@ -220,7 +220,7 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 // loop issues an ordinary VGPR load (bias and final-layer weights are preloaded), which would drain the ring.
 // NSLOT == 0: weight groups are streamed (double-buffered); the workgroups are persistent as well, and the first
 // weight group and halo chunk of a workgroup's next block are requested during the last stage of the current one.
-template <typename T, int KZ, int NT, int WAVES, int NSLOT, int MT>
+template <typename T, int KZ, int NT, int WAVES, int NSLOT, int MT, bool FF>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(const ConvParams p) {
     using v8 = typename Act<T>::v8;
     using G = ConvGeo<KZ, WAVES, MT>;
@@ -249,6 +249,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     float* const wl = reinterpret_cast<float*>(ldsB + (WRES ? nstages : 2) * B_BYTES);
     char* const fwl = reinterpret_cast<char*>(wl) + SD_CONV_PARAM_BYTES;
     char* const ldsDummy = fwl + (p.final_wfrag ? NT * 4096 : 0);
+    float* const fpatch = reinterpret_cast<float*>(ldsDummy + 1024);      // FF: normalised input patch (HY+2) x (HX+2)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
 
     if (WRES) {
         for (int s = 0; s < nstages; ++s) dma_weights(s, s);
-        for (int f = 0; f < NA - 1; ++f) dma_stream_next();
+        if (!FF) for (int f = 0; f < NA - 1; ++f) dma_stream_next();
     } else {
         dma_weights(0, 0);
         dma_halo(0, 0, z0, y0, x0, tn, true);
@@ -411,6 +412,66 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         int nz0 = 0, ny0 = 0, nx0 = 0, ntn = 0;
         if (nlb >= 0) coords(nlb, nz0, ny0, nx0, ntn);
 
+        if constexpr (FF) {
+            // ---- fused FIRST convolution (1 -> 32 channels, 1x3x3, + BN + ReLU): the two 16-channel halo chunks of this
+            // block are COMPUTED from the uint8 / float input tile instead of DMA'd from a materialised tensor (which
+            // is never written).  Same arithmetic as k_conv_first: float32(v)/255 by IEEE division, the 9 taps as the
+            // k dimension of exact-f32 32x32x2 MFMAs, bias after the chain, ReLU, rounding -- bit-identical values.
+            static_assert(!FF || (KZ == 1 && WRES && NA == 2), "fused first conv: planar, resident weights");
+            constexpr int PXW = HX + 2, PYH = HY + 2, NPATCH = PXW * PYH, NSTEP1 = 5;
+            for (int i = tid; i < NPATCH; i += WAVES * 64) {
+                const int px = i % PXW, py = i / PXW;
+                const int y = y0 - 2 + py, x = x0 - 2 + px;
+                float v = 0.f;
+                if ((unsigned)z0 < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
+                    const size_t idx = ((size_t)z0 * p.H + y) * p.W + x;
+                    const char* const in = reinterpret_cast<const char*>(p.first_in) + (size_t)tn * p.first_in_tstride;
+                    if (p.first_in_f32) v = reinterpret_cast<const float*>(in)[idx];
+                    else v = (float)reinterpret_cast<const uint8_t*>(in)[idx] / 255.0f;
+                }
+                fpatch[i] = v;
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            float w1[NSTEP1];
+            int toff1[NSTEP1];
+#pragma unroll
+            for (int st = 0; st < NSTEP1; ++st) {
+                w1[st] = p.first_w[st * 64 + lane];
+                int tap = 2 * st + half;
+                if (tap >= 9) tap = 0;                       // (its weight is zero)
+                toff1[st] = (tap / 3) * PXW + (tap % 3);
+            }
+            f32x4 b1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b1[q] = *reinterpret_cast<const f32x4*>(p.first_bias + 8 * q + 4 * half);
+            for (int t = wave; t * 32 < NH; t += WAVES) {
+                const int hv = t * 32 + (lane & 31);
+                const int hvc = hv < NH ? hv : NH - 1;
+                const int hy = hvc / HX, hx = hvc % HX;
+                const int base = hy * PXW + hx;
+                f32x16 a1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a1[r] = 0.f;
+#pragma unroll
+                for (int st = 0; st < NSTEP1; ++st)
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[st], fpatch[base + toff1[st]], a1, 0, 0, 0);
+                const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+                const bool invol = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;     // z0 < D always
+                if (hv < NH) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        unsigned lo = Act<T>::pack2(a1[4 * q] + b1[q][0], a1[4 * q + 1] + b1[q][1]);
+                        unsigned hi = Act<T>::pack2(a1[4 * q + 2] + b1[q][2], a1[4 * q + 3] + b1[q][3]);
+                        if (p.first_relu) { lo = pk_max16(lo, 0u); hi = pk_max16(hi, 0u); }
+                        if (!invol) { lo = 0u; hi = 0u; }      // the second conv's zero padding
+                        typedef __attribute__((ext_vector_type(2))) unsigned u2;
+                        char* const slot = ldsA + ((gc + (q >> 1)) % NA) * A_BYTES;
+                        *reinterpret_cast<u2*>(slot + hv * 32 + ((((q & 1) ^ (hy & 1))) << 4) + half * 8) = u2{lo, hi};
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
         f32x16 acc[MT][NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -444,7 +505,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                             dma_halo(0, (gc + 1) & 1, nz0, ny0, nx0, ntn, true);
                         }
                     }
-                } else if (kz == 0) {
+                } else if (kz == 0 && !FF) {
                     dma_stream_next();           // chunk gc + NA - 1 of this workgroup's stream
                 }
                 if (s == SD_TS) SD_T(1);     // after the DMA issue of the probed stage
@@ -1306,14 +1367,15 @@ static size_t conv_lds_bytes(int nstages, bool fuse_final = false) {
            SD_CONV_PARAM_BYTES + (fuse_final ? NT * 4096 : 0) + 1024;
 }
 
-template <typename T, int KZ, int NT, int WAVES, int NSLOT, int MT = 2>
+template <typename T, int KZ, int NT, int WAVES, int NSLOT, int MT = 2, bool FF = false>
 static int launch_conv_k(ConvParams p, int NB, hipStream_t s) {
     using G = ConvGeo<KZ, WAVES, MT>;
-    const size_t lds = conv_lds_bytes<KZ, NT, WAVES, MT, NSLOT>((p.nchunk0 + p.nchunk1) * KZ, p.final_wfrag != nullptr);
+    const size_t lds = conv_lds_bytes<KZ, NT, WAVES, MT, NSLOT>((p.nchunk0 + p.nchunk1) * KZ, p.final_wfrag != nullptr) +
+                       (FF ? (size_t)(G::BY + 4) * (G::BX + 4) * 4 : 0);
     p.nbx = (p.W + G::BX - 1) / G::BX; p.nby = (p.H + G::BY - 1) / G::BY; p.nbz = (p.D + G::BZ - 1) / G::BZ;
     static size_t attr_set = 0, occ_lds = 0;
     static int occ = 1;
-    auto kern = k_conv_mfma<T, KZ, NT, WAVES, NSLOT, MT>;
+    auto kern = k_conv_mfma<T, KZ, NT, WAVES, NSLOT, MT, FF>;
     if (lds > attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) return SD_ERR_HIP;
@@ -1335,6 +1397,13 @@ static int launch_conv_k(ConvParams p, int NB, hipStream_t s) {
     return SD_LAUNCH_CHECK();
 }
 
+bool conv_can_fuse_first(int KZ, int NT, int NB, long vox, int nstages, bool fused_final) {
+    if (KZ != 1 || NT > 2 || nstages != 2) return false;
+    if ((vox / 512) * NB < 512) return false;                                   // the `big` rule of launch_conv_knt
+    const size_t lds = NT == 1 ? conv_lds_bytes<1, 1, 8, 2, 2>(nstages, fused_final) : conv_lds_bytes<1, 2, 8, 2, 2>(nstages, fused_final);
+    return lds + 36 * 20 * 4 <= 96 * 1024;
+}
+
 template <typename T, int KZ, int NT>
 static int launch_conv_knt(const ConvParams& p, int NB, hipStream_t s) {
     const long vox = (long)p.D * p.H * p.W * p.batch;      // all tiles of a batched launch
@@ -1346,6 +1415,14 @@ static int launch_conv_knt(const ConvParams& p, int NB, hipStream_t s) {
     // workgroups still share a CU (level-0 layers); else streamed weights, one block per workgroup.  Deeper rings
     // (NSLOT 4/6, one workgroup per CU) were measured SLOWER on the level-0 layers (1.32 vs 1.23 ms per tile): those
     // layers are bound by per-wave instruction latency, not by bytes in flight, so resident waves win over ring depth.
+    if constexpr (KZ == 1 && NT <= 2) {
+        if (p.first_in) {
+            if (!conv_can_fuse_first(KZ, NT, NB, vox, nstages, p.final_wfrag != nullptr)) return SD_ERR_INVALID;
+            return launch_conv_k<T, KZ, NT, 8, 2, 2, true>(p, NB, s);
+        }
+    } else if (p.first_in) {
+        return SD_ERR_INVALID;
+    }
     if (big) {
         if (conv_lds_bytes<KZ, NT, 8, 2, 2>(nstages, p.final_wfrag != nullptr) <= 96 * 1024) return launch_conv_k<T, KZ, NT, 8, 2>(p, NB, s);
         return launch_conv_k<T, KZ, NT, 8, 0>(p, NB, s);

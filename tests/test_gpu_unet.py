@@ -287,3 +287,26 @@ def test_fused_label_rule_equals_probs_then_labels(gpu, arch, shape, ids, thr):
     assert got.shape == want.shape and torch.equal(got, want)
     if arch != 'syntype':
         assert len(torch.unique(got)) >= 2       # the rule really selects between labels
+
+
+def test_fused_first_conv_is_bit_identical(gpu, monkeypatch):
+    """Level-0 pair first conv (1->32, 1x3x3) -> conv (1x3x3): the second conv computes its input halo from the uint8 /
+    float tile itself (k_conv_mfma<FF>), the 32-channel tensor in between is never written.  Same arithmetic and rounding
+    points -> every later activation buffer and the output must be bit-identical to the separate launches; odd extents
+    exercise the zero padding of both convolutions, two tiles the batched path."""
+    from syconn_amd import _lib as L
+    from syconn_amd.engine import DenseModel
+    for arch, shape in (('semseg_spine', (12, 150, 170)), ('myelin', (9, 131, 77)), ('syntype', (16, 128, 144))):
+        model = build_unet(arch, seed=31, final_scale=4.0)
+        raw = _input((2, *shape), 8).to(gpu)
+        monkeypatch.setenv('SD_NO_FIRST_FUSE', '1')
+        plain = DenseModel(model, act_dtype='bf16', device=gpu)
+        monkeypatch.delenv('SD_NO_FIRST_FUSE')
+        fused = DenseModel(model, act_dtype='bf16', device=gpu)
+        for kind in (L.SD_OUT_LOGITS_F32, L.SD_OUT_PROBS_U8):
+            a = plain.forward_batch(raw, kind)
+            b = fused.forward_batch(raw, kind, slot=1)
+            assert torch.equal(a, b), (arch, kind)
+        af = plain.forward_batch(raw.float() / 255., L.SD_OUT_LOGITS_F32)          # float32 input path
+        bf = fused.forward_batch(raw.float() / 255., L.SD_OUT_LOGITS_F32, slot=1)
+        assert torch.equal(af, bf), arch
