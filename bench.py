@@ -50,6 +50,7 @@ def layer_accounting(ops, L, D, H, W, act_bytes=2, out_bytes_per_class=1, batch=
     dims = {0: (D, H, W)}
     chans = {0: 1}
     rows = []
+    fused_first = set()
     for io, o in enumerate(ops):
         if o.kind == L.SD_OP_CONV:
             d = dims[o.src1] if o.src1 >= 0 else dims[o.src0]
@@ -74,6 +75,13 @@ def layer_accounting(ops, L, D, H, W, act_bytes=2, out_bytes_per_class=1, batch=
                 lds = 2 * a_bytes + nstages * 9 * nt * 1024 + 512 + (nt * 4096 if fused_final else 0) + 1024
                 resident = lds <= (96 if waves == 8 else 80) * 1024
                 name = 'k_conv_mfma<%dx3x3,NT=%d,%d waves,%s>' % (o.kz, nt, waves, 'NSLOT=2' if resident else 'NSLOT=0')
+                # first conv computed inside this conv (conv_can_fuse_first in sd_kernels.hip)
+                prev = ops[io - 1] if io > 0 else None
+                if (prev is not None and prev.kind == L.SD_OP_CONV and prev.src0 == 0 and prev.kz == 1 and prev.cout == 32
+                        and o.kz == 1 and o.src0 == prev.dst and o.src1 < 0 and nt <= 2 and nstages == 2 and waves == 8
+                        and lds + 36 * 20 * 4 <= 96 * 1024):
+                    name = name[:-1] + ',FF>'
+                    fused_first.add(io - 1)
             rows.append((name, flops, inb + vox * o.cout * act_bytes))
             dims[o.dst], chans[o.dst] = d, o.cout
         elif o.kind == L.SD_OP_POOL:
@@ -97,6 +105,8 @@ def layer_accounting(ops, L, D, H, W, act_bytes=2, out_bytes_per_class=1, batch=
             d = dims[o.src0]
             vox = d[0] * d[1] * d[2]
             rows.append(('final', 2.0 * vox * o.cin0 * o.cout, vox * (o.cin0 * act_bytes + o.cout * out_bytes_per_class)))
+    for i in fused_first:             # the first conv's work is done inside its consumer: no launch of its own
+        rows[i] = ('k_conv_first(fused into next)',) + tuple(rows[i][1:])
     return rows
 
 
