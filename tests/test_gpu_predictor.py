@@ -370,3 +370,27 @@ def test_predict_labels_device_equals_probs_then_rule(gpu):
         want = postproc_labels(p.predict_proba_u8_device(vol), list(ids), list(thr))
         got = p.predict_labels_u8_device(vol, ids, thr)
         assert got.shape == want.shape and torch.equal(got, want)
+
+
+def test_reference_geometry_chunk_properties(gpu):
+    """One chunk in the reference's hard-coded geometry (prediction.py:672-677): chunk 482x481x236 + halo (30,31,20) =
+    (276,543,542) zyx, 12 tiles of 138x181x271 + overlap (20,31,30) = model input 178x243x331 (odd extents at every
+    level, 7.4 GiB of activations per tile), myelin U-Net.  Full size -> checked through properties: the result does
+    not depend on the launch-set size / stream count, probabilities of a voxel sum to 255 up to truncation, and an
+    interior tile equals the same region predicted on its own (tile + overlap read straight from the chunk)."""
+    from syconn_amd.handler.prediction import Predictor
+    model = build_unet('myelin', seed=3, final_scale=6.0)
+    g = torch.Generator().manual_seed(17)
+    raw = torch.randint(0, 256, (276, 543, 542), dtype=torch.uint8, generator=g).to(gpu)
+    kw = dict(strict_shapes=True, tile_shape=(138, 181, 271), out_shape=(2, 276, 543, 542), overlap_shape=(20, 31, 30),
+              apply_softmax=True)
+    a = Predictor(model, **kw).predict_proba_u8_device(raw)
+    b = Predictor(model, n_streams=2, batch_size=2, **kw).predict_proba_u8_device(raw)
+    assert torch.equal(a, b)
+    s = a.to(torch.int32).sum(0)
+    assert int(s.max()) <= 255 and int(s.min()) >= 253          # each of the 2 classes loses < 1, + float rounding
+    # tile (z,y,x) index (0,1,0): rows 181..362; its model input = the chunk region incl. overlap, zero-padded outside
+    sub = torch.zeros((178, 243, 331), dtype=torch.uint8, device=gpu)
+    sub[20:, :, 30:] = raw[0:158, 150:393, 0:301]
+    one = Predictor(model, apply_softmax=True).predict_proba_u8_device(sub)
+    assert torch.equal(one[:, 20:158, 31:212, 30:301], a[:, 0:138, 181:362, 0:271])
