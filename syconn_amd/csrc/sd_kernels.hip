@@ -970,13 +970,17 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
     char* const dst = reinterpret_cast<char*>(p.dst) + blockIdx.z * p.tstride;
     const int H2 = 2 * p.H, W2 = 2 * p.W;
 
-    static_assert(!WL || NTAB % 2 == 0, "one (a,b) tap pair = NTAB/2 weight blocks");
-    constexpr int WBYTES = NTAB * NCH * 1024;                 // weight fragments of one (z-tap, y-tap) pair
+    // weight fragments of one (z-tap, y-tap) pair: the NTAB column tiles [ab*NTAB, ab*NTAB + NTAB) live in blocks of two
+    // tiles (NCH * 2 KiB each); an odd NTAB straddles one block more
+    constexpr int WBLK = NTAB / 2 + (NTAB & 1);               // blocks kept in LDS (+1 below when the range is unaligned)
+    constexpr int WBYTES = (WBLK + (NTAB & 1)) * NCH * 2048;
     const char* const wlds = smem + 4 * 32 * ROW;
     const int a_wg = WL ? (int)blockIdx.y : 0;
     if constexpr (WL) {
-        const char* const wsrc = reinterpret_cast<const char*>(wp) + (size_t)a_wg * WBYTES;
-        for (int o = tid * 16; o < WBYTES; o += 256 * 16)
+        const int first_blk = (a_wg * NTAB) >> 1, last_blk = (a_wg * NTAB + NTAB - 1) >> 1;
+        const int nbytes = (last_blk - first_blk + 1) * NCH * 2048;
+        const char* const wsrc = reinterpret_cast<const char*>(wp) + (size_t)first_blk * NCH * 2048;
+        for (int o = tid * 16; o < nbytes; o += 256 * 16)
             *reinterpret_cast<u4*>(smem + 4 * 32 * ROW + o) = *reinterpret_cast<const u4*>(wsrc + o);
         __syncthreads();
     }
@@ -1005,7 +1009,7 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
                 const int tl = ab * NTAB + j;             // global 32-column tile (n = tap*CD + co ordering)
                 v8 wf;
                 if constexpr (WL) {
-                    const int tloc = (ab - ab0) * NTAB + j;
+                    const int tloc = ab * NTAB + j - 2 * ((ab0 * NTAB) >> 1);
                     wf = *reinterpret_cast<const v8*>(wlds + ((((tloc >> 1) * NCH + c) * 2 + (tloc & 1)) * 64 + lane) * 16);
                 } else {
                     wf = *reinterpret_cast<const v8*>(wp + ((((size_t)(tl >> 1) * NCH + c) * 2 + (tl & 1)) * 64 + lane) * 8);
@@ -1468,7 +1472,7 @@ static int launch_upconv_rows(const UpconvParams& p, hipStream_t s) {
 template <typename T, int NCH, int NTAB>
 static int launch_upconv_rows_wl(const UpconvParams& p, hipStream_t s) {      // LDS-resident weights, persistent
     const long M = (long)p.D * p.H * p.W;
-    const size_t lds = 4 * 32 * 64 * NTAB + (size_t)NTAB * NCH * 1024;
+    const size_t lds = 4 * 32 * 64 * NTAB + (size_t)(NTAB / 2 + 2 * (NTAB & 1)) * NCH * 2048;
     auto kern = k_upconv_rows<T, NCH, NTAB, true>;
     static bool attr = false;
     if (!attr) {
@@ -1492,8 +1496,8 @@ static int launch_upconv_t(const UpconvParams& p, int NB, hipStream_t s) {
     if (p.nchunk == 2 && p.Cd == 16) return launch_upconv_rows<T, 2, 1>(p, s);
     static const bool no_wl = getenv("SD_NO_UPCONV_WL") != nullptr;
     if (p.nchunk == 8 && p.Cd == 64 && !no_wl) return launch_upconv_rows_wl<T, 8, 4>(p, s);
-    if (p.nchunk == 12 && p.Cd == 96 && !no_wl) return launch_upconv_rows_wl<T, 12, 6>(p, s);     // 48-filter family
-    if (p.nchunk == 6 && p.Cd == 48) return launch_upconv_rows<T, 6, 3>(p, s);                    // (150 -> 93 us at 128^3)
+    // (192 -> 96 channels: k_upconv_mfma 76 us, LDS-weight rows kernel 83 us per tile in the channel-blocked layout)
+    if (p.nchunk == 6 && p.Cd == 48) return no_wl ? launch_upconv_rows<T, 6, 3>(p, s) : launch_upconv_rows_wl<T, 6, 3>(p, s);
     const long M = (long)p.D * p.H * p.W;
     dim3 grid((unsigned)((M + 255) / 256), NB, p.batch), block(256);
     hipLaunchKernelGGL((k_upconv_mfma<T>), grid, block, 0, s, p);
