@@ -971,9 +971,7 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
     const int H2 = 2 * p.H, W2 = 2 * p.W;
 
     // weight fragments of one (z-tap, y-tap) pair: the NTAB column tiles [ab*NTAB, ab*NTAB + NTAB) live in blocks of two
-    // tiles (NCH * 2 KiB each); an odd NTAB straddles one block more
-    constexpr int WBLK = NTAB / 2 + (NTAB & 1);               // blocks kept in LDS (+1 below when the range is unaligned)
-    constexpr int WBYTES = (WBLK + (NTAB & 1)) * NCH * 2048;
+    // tiles (NCH * 2 KiB each); an odd NTAB straddles one block more (the launcher sizes the LDS for NTAB/2 + 2 blocks)
     const char* const wlds = smem + 4 * 32 * ROW;
     const int a_wg = WL ? (int)blockIdx.y : 0;
     if constexpr (WL) {
@@ -1412,7 +1410,6 @@ template <typename T, int KZ, int NT>
 static int launch_conv_knt(const ConvParams& p, int NB, hipStream_t s) {
     const long vox = (long)p.D * p.H * p.W * p.batch;      // all tiles of a batched launch
     const int nstages = (p.nchunk0 + p.nchunk1) * KZ;
-    constexpr size_t LIM = SD_LDS_BYTES - 512;
     // 512-voxel workgroups when they still give every CU work, else 256-voxel workgroups
     const bool big = (vox / 512) * NB >= 512;
     // Resident weights + persistent blocks where the whole layer's weights fit beside a 2-slot halo ring and two
