@@ -310,3 +310,18 @@ def test_fused_first_conv_is_bit_identical(gpu, monkeypatch):
         af = plain.forward_batch(raw.float() / 255., L.SD_OUT_LOGITS_F32)          # float32 input path
         bf = fused.forward_batch(raw.float() / 255., L.SD_OUT_LOGITS_F32, slot=1)
         assert torch.equal(af, bf), arch
+
+
+def test_large_single_tile_locality(gpu):
+    """A 50-Mvoxel single tile (27 GiB of activations, > 2^31 bytes per chunk plane): deterministic, and an interior block
+    equals the same region predicted as its own tile once the margin exceeds the receptive field (44 voxels in y/x, 20 in
+    z for this network) -- pins 64-bit addressing of the channel-blocked planes and block-position independence."""
+    from syconn_amd import _lib as L
+    from syconn_amd.engine import DenseModel
+    dm = DenseModel(build_unet('myelin', seed=1, final_scale=6.0), 'bf16', gpu)
+    x = _input((192, 512, 512), 21).to(gpu)
+    a = dm.forward(x, L.SD_OUT_PROBS_U8).clone()
+    assert torch.equal(a, dm.forward(x, L.SD_OUT_PROBS_U8))
+    sub = x[32:160, 128:384, 128:384].contiguous()
+    c = dm.forward(sub, L.SD_OUT_PROBS_U8, slot=1)
+    assert torch.equal(c[:, 48:80, 48:208, 48:208], a[:, 80:112, 176:336, 176:336])
