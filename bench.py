@@ -6,14 +6,22 @@
 metric   : segmented Mvoxels/s (whole node) on synthetic 128^3 uint8 EM tiles  (BASELINE.json `metric`)
 workload : BASELINE.json configs[1] -- `semseg_spine` 3D U-Net (myelin trunk, 5 classes),
            bf16 activations / fp32 accumulate, whole 128^3 tile per forward.
-step     : one pass of the hot path over one batch of `--tiles` tiles per GPU, inputs resident in HBM as uint8:
-           uint8 tile -> [normalise, U-Net, softmax, floor(255 p)] -> uint8 probabilities -> label rule
-           (prediction.py:813-833) -> uint8 label volume; with N > 1 the label volumes are gathered on rank 0 (RCCL).
+step     : one pass of the hot path over one batch of `--tiles` tiles per GPU, HOST TO HOST (BASELINE.md section 2 /
+           SURVEY.md section 8d: "uint8 input in host memory to uint8 output in host memory"; the reference does one PCIe
+           round trip per tile, /root/reference/syconn/handler/prediction.py:806-809, 863):
+               pinned host uint8 tiles --H2D--> [normalise, U-Net, softmax, floor(255 p), label rule
+               (prediction.py:813-833)] --D2H--> pinned host uint8 label volume
+           on three HIP streams (copy-in / compute / copy-out) with two buffer sets, so the copies of steps k-1 and k+1
+           overlap the kernels of step k.  With N > 1 every rank feeds its own tiles over its own PCIe link, the label
+           volumes are gathered on rank 0 over RCCL / xGMI and leave through rank 0's link (one writer, as the north
+           star's "gather of per-chunk logits").
 value    = tiles * 128^3 * N * K / (max over ranks of the wall time of K steps), in Mvox/s.  Weak scaling.
+           `config.device_resident_value` is the same K steps with inputs and outputs left in HBM (kernel throughput).
 
 Extra objects on the JSON line: `roofline` for the dominant kernel (the 3x3x3 MFMA convolution; live HIP-event
-timings recorded on the launch stream inside the timed region) and `cpu_baseline` (the torch-CPU oracle on ONE tile
-on this box's host cores, rank 0, N = 1 only).
+timings recorded on the launch stream inside the timed region), `network` (whole-net HBM-roofline fraction) and
+`cpu_baseline` (the torch-CPU fp32 oracle on a bounded sample on this box's host cores, rank 0, N = 1 only, plus the
+margin-safe / margin-unsafe split of every label disagreement between the HIP path and that oracle).
 """
 import argparse
 import json
@@ -29,6 +37,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_MFMA_TFLOPS = 2500.0    # dense bf16/f16 MFMA
+BENCH_FINAL_SCALE = 8.0      # scale of the random final 1x1x1 weights (spreads the class logits)
 
 
 def synthetic_em_tiles(n, size, seed):
@@ -110,6 +119,78 @@ def layer_accounting(ops, L, D, H, W, act_bytes=2, out_bytes_per_class=1, batch=
     return rows
 
 
+class HostToHostPipeline:
+    """K steps of [pinned host tiles -> H2D -> sd_forward_labels_batch -> (RCCL gather on rank 0) -> D2H -> pinned host
+    labels] on three HIP streams with two buffer sets.  Step k uses set k % 2; the only host-side wait is for the copy-out
+    of step k-2 (its buffers are about to be reused), so two steps are in flight."""
+
+    def __init__(self, dm, tiles_host, ids, thr, batch, dev, par, rank, world):
+        self.dm, self.ids, self.thr, self.B, self.dev, self.par, self.rank, self.world = dm, ids, thr, batch, dev, par, rank, world
+        T, S = tiles_host.shape[0], tiles_host.shape[1]
+        self.T = T
+        self.in_host = tiles_host.pin_memory()
+        n_out = world if rank == 0 else 1
+        self.out_host = [torch.empty((n_out, T, S, S, S), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self.in_dev = [torch.empty((T, S, S, S), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.lab_dev = [torch.empty((T, S, S, S), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.recv = [torch.empty((world, T, S, S, S), dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
+                     for _ in range(2)]
+        self.s_in, self.s_comp, self.s_out = (torch.cuda.Stream(device=dev) for _ in range(3))
+        self.ev_in = [torch.cuda.Event() for _ in range(2)]       # H2D of the set finished
+        self.ev_comp = [torch.cuda.Event() for _ in range(2)]     # kernels of the set finished
+        self.ev_out = [torch.cuda.Event() for _ in range(2)]      # D2H (and gather) of the set finished
+        self.k = 0
+
+    def step(self):
+        s = self.k & 1
+        first_use = self.k < 2
+        self.k += 1
+        if not first_use:
+            self.ev_out[s].synchronize()              # host: the pinned output of step k-2 is complete (and reusable)
+        with torch.cuda.stream(self.s_in):
+            if not first_use:
+                self.s_in.wait_event(self.ev_comp[s])  # the kernels of step k-2 have consumed in_dev[s]
+            self.in_dev[s].copy_(self.in_host, non_blocking=True)
+            self.ev_in[s].record(self.s_in)
+        with torch.cuda.stream(self.s_comp):
+            self.s_comp.wait_event(self.ev_in[s])
+            if not first_use:
+                self.s_comp.wait_event(self.ev_out[s])  # lab_dev[s] of step k-2 has left the device
+            for t0 in range(0, self.T, self.B):
+                n = min(self.B, self.T - t0)
+                self.dm.forward_labels_batch(self.in_dev[s][t0:t0 + n], self.ids, self.thr, out=self.lab_dev[s][t0:t0 + n])
+            self.ev_comp[s].record(self.s_comp)
+        with torch.cuda.stream(self.s_out):
+            self.s_out.wait_event(self.ev_comp[s])
+            if self.world > 1:
+                _, work = self.par.gather_to_root(self.lab_dev[s], dst=0, async_op=True, out=self.recv[s])
+                work.wait()                             # stream-level dependency of s_out on the collective
+                if self.rank == 0:
+                    self.out_host[s].copy_(self.recv[s], non_blocking=True)
+            else:
+                self.out_host[s][0].copy_(self.lab_dev[s], non_blocking=True)
+            self.ev_out[s].record(self.s_out)
+
+    def drain(self):
+        for e in self.ev_out:
+            e.synchronize()
+        torch.cuda.synchronize(self.dev)
+
+
+def timed(fn_step, fn_drain, steps, par, dev):
+    torch.cuda.synchronize(dev)
+    par.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn_step()
+    fn_drain()
+    torch.cuda.synchronize(dev)
+    par.barrier()
+    torch.cuda.synchronize(dev)
+    return par.max_over_ranks(time.perf_counter() - t0, device=dev)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -120,14 +201,13 @@ def main():
     ap.add_argument('--arch', default='semseg_spine')
     ap.add_argument('--act', default='bf16', choices=['bf16', 'f16'])
     ap.add_argument('--batch', type=int, default=0, help='tiles per sd_forward_batch launch set (0 = all tiles of a step)')
-    ap.add_argument('--streams', type=int, default=1, help='HIP streams the batches of a step alternate over')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
     from syconn_amd import _lib as L
     from syconn_amd import parallel as par
-    from syconn_amd.engine import DenseModel, StreamRing, postproc_labels
-    from oracle.unet_ref import build_unet   # architecture definition + seeded random init (no trained weights exist)
+    from syconn_amd.cnn import random_state_dict    # architecture + seeded random init (no trained weights exist)
+    from syconn_amd.engine import DenseModel
 
     # SD_BENCH_ONE_GPU_DEBUG=1: exercise the N > 1 code path on a box with ONE GPU (all ranks on cuda:0, gloo) -- a
     # functional check of the sharding / gather / timing logic only, never a measurement
@@ -143,65 +223,25 @@ def main():
     torch.cuda.set_device(dev)
 
     # random-init weights: rank 0 is authoritative, everybody else receives them over RCCL (Coll-1)
-    model = build_unet(args.arch, seed=0 if rank == 0 else 1000 + rank, final_scale=8.0)
-    par.broadcast_weights(model, src=0, device=dev)
-    dm = DenseModel(model, act_dtype=args.act, device=dev)
+    sd = random_state_dict(args.arch, seed=0 if rank == 0 else 1000 + rank, final_scale=BENCH_FINAL_SCALE)
+    par.broadcast_weights(sd, src=0, device=dev)
+    dm = DenseModel(sd, act_dtype=args.act, device=dev)
     ncls = dm.out_channels
     ids = list(range(1, ncls))
     thr = [127.5] * len(ids)                     # channel_thresholds None -> 255/2 (prediction.py:824-825)
 
     S, T = args.tile, args.tiles
-    tiles = torch.from_numpy(synthetic_em_tiles(T, S, seed=1 + rank)).to(dev)
+    tiles_host = torch.from_numpy(synthetic_em_tiles(T, S, seed=1 + rank))
     B = T if args.batch <= 0 else min(args.batch, T)
-    ring = StreamRing(dev, args.streams)         # batch i runs on stream i % n with its own workspace / probability buffer
-    probs_k = [torch.empty((B, ncls, S, S, S), dtype=torch.uint8, device=dev) for _ in range(ring.n)]
-    probs = probs_k[0][0]
-    # label volumes are double-buffered so that the gather of step k (RCCL, asynchronous) overlaps step k+1's compute
-    labels = [torch.empty((T, S, S, S), dtype=torch.uint8, device=dev) for _ in range(2)]
-    recv = [torch.empty((world, T, S, S, S), dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
-            for _ in range(2)]
-    pending = [None, None]
-    step_no = [0]
-
-    def step():
-        k = step_no[0] & 1
-        step_no[0] += 1
-        if pending[k] is not None:
-            pending[k].wait()
-            pending[k] = None
-        with ring:
-            for i, t0 in enumerate(range(0, T, B)):
-                n = min(B, T - t0)
-                with ring.stream(i):
-                    # U-Net + softmax + uint8 cast + label rule (prediction.py:813-833) in one launch set: the rule is
-                    # evaluated in the final layer's epilogue (== postproc_labels(forward_batch(PROBS_U8)), tested)
-                    dm.forward_labels_batch(tiles[t0:t0 + n], ids, thr, out=labels[k][t0:t0 + n], slot=ring.slot(i))
-        if world > 1:
-            _, pending[k] = par.gather_to_root(labels[k], dst=0, async_op=True, out=recv[k])
-
-    def drain():
-        for k in range(2):
-            if pending[k] is not None:
-                pending[k].wait()
-                pending[k] = None
-
-    for _ in range(args.warmup):
-        step()
-    drain()
     nbatch = (T + B - 1) // B                    # launch sets per step (the last one may hold fewer tiles)
-    dm.profile(nbatch * args.steps)              # event ring: every launch set of the timed region keeps its own slot
-    torch.cuda.synchronize(dev)
-    par.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    drain()
-    torch.cuda.synchronize(dev)
-    par.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = par.max_over_ranks(time.perf_counter() - t0, device=dev)
+    pipe = HostToHostPipeline(dm, tiles_host, ids, thr, B, dev, par, rank, world)
 
+    # ---- timed region: host -> host ------------------------------------------------------------------------------
+    for _ in range(args.warmup):
+        pipe.step()
+    pipe.drain()
+    dm.profile(nbatch * args.steps)              # event ring: every launch set of the timed region keeps its own slot
+    elapsed = timed(pipe.step, pipe.drain, args.steps, par, dev)
     vox_total = float(T) * S ** 3 * world * args.steps
     value = vox_total / elapsed / 1e6
 
@@ -211,8 +251,25 @@ def main():
     for k in range(n_fw):
         per_op += dm.profile_read(k)
     per_op /= n_fw                                # ms per launch, averaged over the timed region
-    tiles_per_launch = T / nbatch                 # average tiles one launch processes
     dm.profile(0)
+
+    # ---- the same K steps with inputs / outputs resident in HBM (kernel throughput; NOT `value`) ------------------
+    tiles_dev = tiles_host.to(dev)
+    lab_res = torch.empty((T, S, S, S), dtype=torch.uint8, device=dev)
+
+    def resident_step():
+        for t0 in range(0, T, B):
+            n = min(B, T - t0)
+            dm.forward_labels_batch(tiles_dev[t0:t0 + n], ids, thr, out=lab_res[t0:t0 + n])
+
+    resident_step()
+    elapsed_res = timed(resident_step, lambda: None, args.steps, par, dev)
+    value_res = vox_total / elapsed_res / 1e6
+    # both legs compute the same labels
+    if world == 1:
+        assert torch.equal(lab_res.cpu(), pipe.out_host[(pipe.k - 1) & 1][0]), 'host-to-host labels differ from resident run'
+
+    tiles_per_launch = T / nbatch                 # average tiles one launch processes
     rows = [(n, f * tiles_per_launch, b * tiles_per_launch)
             for n, f, b in layer_accounting(dm.ops, L, S, S, S, batch=B)]
     groups = {}
@@ -252,27 +309,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle.predictor_ref import label_rule_ref
-        ncpu = min(3, T)                                           # bounded sample: ~15 s of CPU work
-        xs = tiles[:ncpu].cpu()
-        labs = []
-        with torch.no_grad():
-            model((xs[0, :16].float() / 255.)[None, None])          # warm the CPU kernels
-            t1 = time.perf_counter()
-            for i in range(ncpu):
-                p = model((xs[i].float() / 255.)[None, None]).softmax(1)[0].numpy()
-                u8 = (p * 255).astype(np.uint8)
-                labs.append(label_rule_ref(u8, ids, [None] * ncls)[0])
-            cpu_s = time.perf_counter() - t1
-        dm.forward_batch(tiles[:ncpu], L.SD_OUT_PROBS_U8, probs_k[0][:ncpu])
-        agree = 0.0
-        for i in range(ncpu):
-            postproc_labels(probs_k[0][i], ids, thr, out=labels[0][i])
-            agree += float((torch.from_numpy(labs[i].astype(np.uint8)) == labels[0][i].cpu()).float().mean()) / ncpu
-        cpu = {'value': ncpu * S ** 3 / cpu_s / 1e6, 'unit': 'Mvox/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-               'sample': f'{ncpu} {S}^3 tiles of the same workload through the torch-CPU fp32 oracle '
-                         f'(U-Net + softmax + uint8 + label rule), {cpu_s:.1f} s',
-               'label_agreement_with_gpu': agree}
+        cpu = cpu_baseline(args, sd, dm, tiles_host, ids, L)
 
     if rank == 0:
         line = {'metric': 'segmented Mvoxels/s (whole node), 128^3 EM tiles', 'value': value, 'unit': 'Mvox/s',
@@ -280,16 +317,57 @@ def main():
                 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
                 'vs_baseline': None, 'dtype': args.act, 'data': 'synthetic',
                 'config': {'workload': f'BASELINE configs[1]: {args.arch} 3D U-Net on {S}^3 uint8 tiles, {T} tiles per GPU '
-                                       f'per step in launch sets of {B} (sd_forward_batch), random-init weights',
+                                       f'per step in launch sets of {B} (sd_forward_labels_batch), random-init weights, '
+                                       f'HOST TO HOST: pinned host uint8 tiles -> H2D -> kernels -> D2H -> pinned host '
+                                       f'uint8 labels, 3 HIP streams, 2 buffer sets',
                            'tiles_per_launch_set': B,
                            'tiles_per_gpu_per_step': T, 'tile': [S, S, S], 'parallelism': f'tile-sharded x{world}',
-                           'hip_streams_per_gpu': ring.n,
-                           'collective': 'gather of uint8 labels to rank 0' if world > 1 else 'none'},
+                           'hip_streams_per_gpu': 3,
+                           'collective': 'RCCL gather of uint8 labels to rank 0, D2H there' if world > 1 else 'none',
+                           'device_resident_value': value_res,
+                           'device_resident_ms_per_step': elapsed_res / args.steps * 1e3,
+                           'pcie_bytes_per_step_each_way': T * S ** 3},
                 'roofline': roof, 'network': net, 'cpu_baseline': cpu}
         print(json.dumps(line))
     if world > 1:
         par.barrier()
         torch.distributed.destroy_process_group()
+
+
+def cpu_baseline(args, sd, dm, tiles_host, ids, L):
+    """The torch-CPU fp32 oracle (U-Net + softmax + uint8 + label rule) on a bounded sample of the same workload, timed
+    on this box's host cores, and the margin-safe / margin-unsafe split of every label disagreement with the HIP path."""
+    from oracle.label_margin import label_split, merge_splits
+    from oracle.predictor_ref import label_rule_ref
+    from oracle.unet_ref import ARCHS, UNet
+    ncls = dm.out_channels
+    model = UNet(in_channels=1, **ARCHS[args.arch]).eval()
+    model.load_state_dict(sd)
+    ncpu = min(3, tiles_host.shape[0])                         # bounded sample: ~15 s of CPU work
+    S = tiles_host.shape[1]
+    parts = []
+    with torch.no_grad():
+        model((tiles_host[0, :16].float() / 255.)[None, None])     # warm the CPU kernels
+        cpu_s = 0.0
+        for i in range(ncpu):
+            t1 = time.perf_counter()
+            lg = model((tiles_host[i].float() / 255.)[None, None])[0]
+            u8 = (lg.softmax(0).numpy() * 255).astype(np.uint8)
+            label_rule_ref(u8, ids, [None] * ncls)
+            cpu_s += time.perf_counter() - t1
+            x = tiles_host[i:i + 1].to(dm.device)
+            parts.append(label_split(lg, dm.forward_batch(x, L.SD_OUT_LOGITS_F32)[0].cpu(),
+                                     dm.forward_batch(x, L.SD_OUT_PROBS_F32)[0].cpu(),
+                                     dm.forward_labels_batch(x, ids, [127.5] * len(ids))[0].cpu(), ids, [None] * ncls))
+    sp = merge_splits(parts)
+    cpu = {'value': ncpu * S ** 3 / cpu_s / 1e6, 'unit': 'Mvox/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+           'sample': f'{ncpu} {S}^3 tiles of the same workload through the torch-CPU fp32 oracle '
+                     f'(U-Net + softmax + uint8 + label rule), {cpu_s:.1f} s'}
+    cpu.update({k: sp[k] for k in ('label_agreement', 'label_mismatch_safe', 'label_mismatch_unsafe', 'label_unsafe_frac',
+                                   'argmax_agreement', 'argmax_mismatch_safe', 'argmax_mismatch_unsafe',
+                                   'argmax_unsafe_frac', 'logit_err_max_rel', 'logit_err_rms',
+                                   'median_top2_margin_over_tol')})
+    return cpu
 
 
 if __name__ == '__main__':

@@ -18,8 +18,8 @@
  *   - every launch is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream); the caller
  *     synchronises.  A handle is bound to one device and is not thread-safe.
  *   - volumes are z,y,x (x fastest).  Network input is one channel, planar.  Network output is planar
- *     (C, D, H, W).  Activations inside the workspace are voxel-major / channel-minor ("channels-last") in the
- *     model's activation dtype; that layout is private to the library.
+ *     (C, D, H, W).  Activations inside the workspace are channel-blocked ([C/16][z][y][x][16]) in the model's
+ *     activation dtype; that layout is private to the library.
  */
 #ifndef SYCONN_DENSE_H
 #define SYCONN_DENSE_H

@@ -736,15 +736,9 @@ int sd_postproc_labels(const uint8_t* probs, int C, size_t nvox, const int32_t* 
     if (!probs || !ids || !thresholds || !out || n_ids <= 0 || n_ids > 16)
         return fail(SD_ERR_INVALID, "sd_postproc_labels: bad argument");
     if (out_dtype != SD_U8 && out_dtype != SD_U64) return fail(SD_ERR_INVALID, "sd_postproc_labels: out_dtype");
-    LabelArgs a{};
-    a.n = n_ids;
-    for (int i = 0; i < n_ids; ++i) {
-        if (ids[i] < 0 || ids[i] >= C) return fail(SD_ERR_INVALID, "sd_postproc_labels: id out of range");
-        a.ids[i] = ids[i];
-        const double t = thresholds[i];
-        // (uint8 p > t) <=> p >= floor(t) + 1, exact for any real t
-        a.cuts[i] = t < 0 ? 0 : (t >= 255.0 ? 256 : (int)std::floor(t) + 1);
-    }
+    LabelArgs a{};      // one threshold -> cut rule for the fused and the separate path (NaN rejected, cuts in [0, 256])
+    if (!make_label_args(C, ids, thresholds, n_ids, a))
+        return fail(SD_ERR_INVALID, "sd_postproc_labels: id out of range or NaN threshold");
     int rc = launch_labels(probs, nvox, a, out, out_dtype == SD_U64, reinterpret_cast<hipStream_t>(stream));
     return rc == SD_OK ? rc : fail(rc, "sd_postproc_labels launch failed");
 }

@@ -1,15 +1,17 @@
 // gfx950 (MI355X / CDNA4) kernels of the dense 3D-CNN prediction path.  Written for 64-wide wavefronts and the
 // 32x32 MFMA shapes; there is no other code path.
 //
-// Layout recap (private to the library): activations are voxel-major / channel-minor, 16-channel "chunks" are the
-// MFMA k-step.  Every conv is computed TRANSPOSED on the matrix core: the weight fragment is the A operand
-// (rows = output channels) and the activation fragment the B operand (columns = voxels), so that in the f32
-// accumulator a lane owns ONE voxel (column = lane&31) and 4 runs of 4 consecutive channels -- which are 8-byte
-// contiguous pieces of the channels-last output row.
+// Layout recap (private to the library, sd_internal.h): activations are CHANNEL-BLOCKED [C/16][z][y][x][16]; a
+// 16-channel "chunk" is one MFMA k-step and every chunk of an x-row is one contiguous run.  Every conv is computed
+// TRANSPOSED on the matrix core: the weight fragment is the A operand (rows = output channels) and the activation
+// fragment the B operand (columns = voxels), so that in the f32 accumulator a lane owns ONE voxel (column =
+// lane&31) and 4 runs of 4 consecutive channels; the lane pair (l, l^32) trades quads so that each lane stores the
+// 32 contiguous bytes of one (chunk, voxel) record.
 #include "sd_internal.h"
 #include "../../include/syconn_dense.h"
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 #include <utility>
 
@@ -1126,9 +1128,10 @@ __global__ __launch_bounds__(256) void k_final(const FinalParams p) {
             float sum = 0.f;
 #pragma unroll
             for (int co = 0; co < 8; ++co)
-                if (co < p.cout) { acc[co] = expf(acc[co] - mx); sum += acc[co]; }
+                if (co < p.cout) { acc[co] = __expf(acc[co] - mx); sum += acc[co]; }
+            const float inv = 1.0f / sum;     // same exp / reciprocal form as the fused epilogue of k_conv_mfma
 #pragma unroll
-            for (int co = 0; co < 8; ++co) acc[co] = acc[co] / sum;
+            for (int co = 0; co < 8; ++co) acc[co] *= inv;
         }
         if (p.out_kind == SD_OUT_LABELS_U8) {
             uint8_t lab = 0;
@@ -1359,6 +1362,8 @@ static inline int grid_for(long total, int per_block = 256, int cap = 256 * 16) 
 
 constexpr int SD_LDS_BYTES = 160 * 1024;
 constexpr int SD_NUM_CU = 256;
+constexpr int SD_MAX_DEVICES = 64;
+struct LaunchCache { size_t attr_set = 0, occ_lds = 0; int occ = 1; };
 
 template <int KZ, int NT, int WAVES, int MT, int NSLOT>
 static size_t conv_lds_bytes(int nstages, bool fuse_final = false) {
@@ -1375,20 +1380,31 @@ static int launch_conv_k(ConvParams p, int NB, hipStream_t s) {
     const size_t lds = conv_lds_bytes<KZ, NT, WAVES, MT, NSLOT>((p.nchunk0 + p.nchunk1) * KZ, p.final_wfrag != nullptr) +
                        (FF ? (size_t)(G::BY + 4) * (G::BX + 4) * 4 : 0);
     p.nbx = (p.W + G::BX - 1) / G::BX; p.nby = (p.H + G::BY - 1) / G::BY; p.nbz = (p.D + G::BZ - 1) / G::BZ;
-    static size_t attr_set = 0, occ_lds = 0;
-    static int occ = 1;
+    // per-DEVICE cache of the dynamic-LDS attribute and the occupancy answer of this instantiation (a function attribute
+    // set on one device does not carry over to a model created on another one in the same process); guarded, because
+    // two models may launch their first forward from different threads
     auto kern = k_conv_mfma<T, KZ, NT, WAVES, NSLOT, MT, FF>;
-    if (lds > attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess) return SD_ERR_HIP;
-        attr_set = lds;
-    }
-    if (lds != occ_lds) {   // resident workgroups per CU for this LDS footprint (registers + LDS), cached
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kern), WAVES * 64, lds) !=
-            hipSuccess) n = 1;
-        occ = std::max(1, n);
-        occ_lds = lds;
+    static std::mutex mu;
+    static LaunchCache cache[SD_MAX_DEVICES];
+    int occ = 1;
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SD_MAX_DEVICES) return SD_ERR_HIP;
+        std::lock_guard<std::mutex> lock(mu);
+        LaunchCache& c = cache[dev];
+        if (lds > c.attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess) return SD_ERR_HIP;
+            c.attr_set = lds;
+        }
+        if (lds != c.occ_lds) {   // resident workgroups per CU for this LDS footprint (registers + LDS)
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kern), WAVES * 64, lds) !=
+                hipSuccess) n = 1;
+            c.occ = std::max(1, n);
+            c.occ_lds = lds;
+        }
+        occ = c.occ;
     }
     const int nsb = p.nbx * p.nby * p.nbz * p.batch;
     const int wg_per_cu = std::min(occ, (int)(SD_LDS_BYTES / lds));
@@ -1471,11 +1487,17 @@ static int launch_upconv_rows_wl(const UpconvParams& p, hipStream_t s) {      //
     const long M = (long)p.D * p.H * p.W;
     const size_t lds = 4 * 32 * 64 * NTAB + (size_t)(NTAB / 2 + 2 * (NTAB & 1)) * NCH * 2048;
     auto kern = k_upconv_rows<T, NCH, NTAB, true>;
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-            hipSuccess) return SD_ERR_HIP;
-        attr = true;
+    {
+        static std::mutex mu;
+        static LaunchCache cache[SD_MAX_DEVICES];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SD_MAX_DEVICES) return SD_ERR_HIP;
+        std::lock_guard<std::mutex> lock(mu);
+        if (lds > cache[dev].attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+                hipSuccess) return SD_ERR_HIP;
+            cache[dev].attr_set = lds;
+        }
     }
     const int per_cu = std::max(1, (int)(SD_LDS_BYTES / lds));
     const long want = std::max(1L, (long)SD_NUM_CU * per_cu * 2 / (2 * p.kz * p.batch));     // ~2 rounds of workgroups

@@ -403,6 +403,53 @@ def _wd_set() -> bool:
         return False
 
 
+def _dense_targets(n_channel, target_names, target_channels, channel_thresholds):
+    """Defaults and validation of the per-target arguments (prediction.py:655-664): one target 'pred' holding every
+    channel, no thresholds; names and channel tuples must pair up."""
+    names = ['pred'] if target_names is None else list(target_names)
+    channels = [list(range(n_channel))] if target_channels is None else [list(c) for c in target_channels]
+    if len(names) != len(channels):
+        msg = 'For every target name the target channels have to be specified.'
+        log_reps.error(msg)
+        raise ValueError(msg)
+    thresholds = [None] * n_channel if channel_thresholds is None else list(channel_thresholds)
+    return names, channels, thresholds
+
+
+def _dense_geometry():
+    """(overlap, tile overlap, chunk size, tile shape) in x,y,z.  The reference hard-codes them and marks them as
+    future config parameters (prediction.py:671-677); here they are ``config['dense_prediction']`` with those values as
+    defaults.  Chunk halo == tile halo, as in the reference."""
+    geo = global_params.config['dense_prediction']
+    halo = np.array(geo['overlap_shape_tiles'])
+    return halo, halo, np.array(geo['chunk_size']), list(geo['tile_shape'])
+
+
+def _create_target_kds(paths, kd, cube_shape_kd, overwrite, log):
+    """One empty KnossosDataset per target with a 6-level mag list and a knossos.conf (prediction.py:685-706).
+    All existence checks run before anything is deleted or created, so a refused call leaves every target untouched."""
+    existing = [p for p in paths if os.path.isdir(p)]
+    if existing and not overwrite:
+        msg = f'Found existing KD at "{existing[0]}" but overwrite is set to False.'
+        log.error(msg)
+        raise ValueError(msg)
+    for p in existing:
+        log.debug('Found existing KD at {}. Removing it now.'.format(p))
+        shutil.rmtree(p)
+    scale = np.array(global_params.config['scaling'])
+    mags = [1 << k for k in range(6)]
+    for p in paths:
+        tkd = KnossosDataset()
+        tkd._cube_shape = cube_shape_kd
+        tkd.scales = [scale, ]
+        tkd.initialize_without_conf(p, kd.boundary, kd.scale, kd.experiment_name, mags, create_pyk_conf=False,
+                                    create_knossos_conf=True)
+        try:
+            basics.kd_factory(p)
+        except ValueError as e:
+            log.error(f'Could not initialize KnossosDataset at "{p}". {e}')
+
+
 def predict_dense_to_kd(kd_path: str, target_path: str, model_path: str, n_channel: int,
                         target_names: Optional[Iterable[str]] = None,
                         target_channels: Optional[Iterable[Iterable[int]]] = None,
@@ -418,68 +465,33 @@ def predict_dense_to_kd(kd_path: str, target_path: str, model_path: str, n_chann
     As in the reference the keyword `overlap_shape_tiles` is overridden by the configured geometry
     (prediction.py:671-677 hard-codes it; here it is ``config['dense_prediction']``, same defaults)."""
     from ..mp import batchjob_utils as qu
+    conf = global_params.config
     if log is None:
-        log = initialize_logging('dense_predictions', global_params.config.working_dir + '/logs/', overwrite=False)
-    if target_names is None:
-        target_names = ['pred']
-    if target_channels is None:
-        target_channels = [[ix for ix in range(n_channel)]]
-    if not len(target_names) == len(target_channels):
-        msg = 'For every target name the target channels have to be specified.'
-        log_reps.error(msg)
-        raise ValueError(msg)
-    if channel_thresholds is None:
-        channel_thresholds = [None for _ in range(n_channel)]
+        log = initialize_logging('dense_predictions', conf.working_dir + '/logs/', overwrite=False)
+    names, channels, thresholds = _dense_targets(n_channel, target_names, target_channels, channel_thresholds)
+    overlap_shape, overlap_shape_tiles, chunk_size, tile_shape = _dense_geometry()
 
     kd = basics.kd_factory(kd_path)
-    if cube_of_interest is None:
-        cube_of_interest = (np.zeros(3, ), kd.boundary // mag)
-    if cube_shape_kd is None:
-        cube_shape_kd = (256, 256, 256)
-    geo = global_params.config['dense_prediction']
-    overlap_shape_tiles = np.array(geo['overlap_shape_tiles'])
-    overlap_shape = overlap_shape_tiles
-    chunk_size = np.array(geo['chunk_size'])
-    tile_shape = list(geo['tile_shape'])
+    coi = (np.zeros(3, ), kd.boundary // mag) if cube_of_interest is None else cube_of_interest
+    grid = ChunkDataset()
+    grid.initialize(kd, coi[1], chunk_size, target_path + '/cd_tmp/', box_coords=coi[0], list_of_coords=[],
+                    fit_box_size=True, overlap=overlap_shape)
+    chunk_ids = list(grid.chunk_dict.keys())
 
-    cd = ChunkDataset()
-    cd.initialize(kd, cube_of_interest[1], chunk_size, target_path + '/cd_tmp/', box_coords=cube_of_interest[0],
-                  list_of_coords=[], fit_box_size=True, overlap=overlap_shape)
-    chunk_ids = list(cd.chunk_dict.keys())
-    # init target KnossosDatasets
-    target_kd_path_list = [target_path + '/{}/'.format(tn) for tn in target_names]
-    for path in target_kd_path_list:
-        if os.path.isdir(path):
-            if not overwrite:
-                msg = f'Found existing KD at "{path}" but overwrite is set to False.'
-                log.error(msg)
-                raise ValueError(msg)
-            log.debug('Found existing KD at {}. Removing it now.'.format(path))
-            shutil.rmtree(path)
-    for path in target_kd_path_list:
-        target_kd = KnossosDataset()
-        target_kd._cube_shape = cube_shape_kd
-        scale = np.array(global_params.config['scaling'])
-        target_kd.scales = [scale, ]
-        target_kd.initialize_without_conf(path, kd.boundary, kd.scale, kd.experiment_name,
-                                          [2 ** x for x in range(6)], create_pyk_conf=False,
-                                          create_knossos_conf=True)
-        try:  # make sure init works
-            basics.kd_factory(path)
-        except ValueError as e:
-            log.error(f'Could not initialize KnossosDataset at "{path}". {e}')
-    # init batchjob parameters
-    multi_params = chunk_ids
-    multi_params = chunkify(multi_params, global_params.config.ngpu_total)
-    multi_params = [(ch_ids, kd_path, target_path, model_path, overlap_shape, overlap_shape_tiles, tile_shape,
-                     chunk_size, n_channel, target_channels, target_kd_path_list, channel_thresholds, mag,
-                     cube_of_interest) for ch_ids in multi_params]
-    log.info('Started dense prediction of {} in {:d} chunk(s).'.format(", ".join(target_names), len(chunk_ids)))
-    n_cores_per_job = global_params.config['ncores_per_node'] // global_params.config['ngpus_per_node'] if \
-        qu.batchjob_enabled() else global_params.config['ncores_per_node']
-    qu.batchjob_script(multi_params, "predict_dense", n_cores=n_cores_per_job, suffix='_' + '_'.join(target_names),
-                       remove_jobfolder=True, log=log, additional_flags="--gres=gpu:1")
-    log.info('Finished dense prediction of {}'.format(", ".join(target_names)))
+    target_kds = [f'{target_path}/{name}/' for name in names]
+    _create_target_kds(target_kds, kd, (256, 256, 256) if cube_shape_kd is None else cube_shape_kd, overwrite, log)
+
+    # one 14-tuple per worker: its share of the chunk ids (static round-robin) + everything needed to rebuild the state
+    shared = (kd_path, target_path, model_path, overlap_shape, overlap_shape_tiles, tile_shape, chunk_size, n_channel,
+              channels, target_kds, thresholds, mag, coi)
+    jobs = [(share, *shared) for share in chunkify(chunk_ids, conf.ngpu_total)]
+    log.info('Started dense prediction of {} in {:d} chunk(s).'.format(", ".join(names), len(chunk_ids)))
+    cores = conf['ncores_per_node']
+    if qu.batchjob_enabled():
+        cores //= conf['ngpus_per_node']
+    qu.batchjob_script(jobs, "predict_dense", n_cores=cores, suffix='_' + '_'.join(names), remove_jobfolder=True,
+                       log=log, additional_flags="--gres=gpu:1")
+    log.info('Finished dense prediction of {}'.format(", ".join(names)))
 
 
 def get_myelin_cnn():

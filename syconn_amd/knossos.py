@@ -19,6 +19,8 @@ little-endian uint64 cube (z,y,x with x fastest).  The codec is the library's C 
 (``include/syconn_dense.h: sd_snappy_*``; python-snappy is not installed here).  Cubes written as raw uint64
 (``*.seg.raw``) by earlier versions of this file are still read.
 """
+import contextlib
+import fcntl
 import itertools
 import os
 import re
@@ -33,19 +35,40 @@ import numpy as np
 # codec all release the GIL)
 _IO_THREADS = max(1, min(16, int(os.environ.get('SYCONN_AMD_IO_THREADS', '8'))))
 _pool = None
+_pool_pid = None
 
 
 def _map_cubes(fn, items):
-    global _pool
+    global _pool, _pool_pid
     items = list(items)
     if _IO_THREADS == 1 or len(items) < 2:
         for it in items:
             fn(*it)
         return
-    if _pool is None:
+    if _pool is None or _pool_pid != os.getpid():      # a forked child inherits the pool object but not its threads
         _pool = ThreadPoolExecutor(max_workers=_IO_THREADS)
+        _pool_pid = os.getpid()
     for f in [_pool.submit(fn, *it) for it in items]:
         f.result()
+
+
+@contextlib.contextmanager
+def _cube_lock(fn: str):
+    """Exclusive inter-process lock on ONE cube file for a read-modify-write.  Workers of ``predict_dense_to_kd`` own
+    chunks (482x481x236 by default) that are not aligned to the 256^3 target cubes, so neighbouring chunks of DIFFERENT
+    worker processes update the same cube file at about the same time; ``os.replace`` only makes the file swap atomic,
+    not the read-modify-write (upstream knossos_utils serialises cube writes per cube as well).  ``flock`` on a sidecar
+    file: held per open file description, so it also serialises the I/O threads of one process."""
+    os.makedirs(os.path.dirname(fn), exist_ok=True)
+    fd = os.open(fn + '.lock', os.O_CREAT | os.O_RDWR, 0o666)
+    try:
+        fcntl.flock(fd, fcntl.LOCK_EX)
+        yield
+    finally:
+        try:
+            fcntl.flock(fd, fcntl.LOCK_UN)
+        finally:
+            os.close(fd)
 
 
 class KnossosDataset:
@@ -245,13 +268,14 @@ class KnossosDataset:
                 c0 = np.array([cx, cy, cz]) * cs
                 a, b = np.maximum(lo, c0), np.minimum(hi, c0 + cs)
                 whole = np.all(a == c0) and np.all(b == c0 + cs)
-                cube = None if whole else self._read_cube(fn, ext, dtype, tuple(cs[::-1]))
-                if cube is None:
-                    cube = np.zeros(tuple(cs[::-1]), dtype=dtype)
                 dst = tuple(slice(int(a[i] - c0[i]), int(b[i] - c0[i])) for i in (2, 1, 0))
                 src = tuple(slice(int(a[i] - off[i]), int(b[i] - off[i])) for i in (2, 1, 0))
-                cube[dst] = d[src]
-                self._write_cube(fn, ext, cube)
+                with _cube_lock(fn):                  # read-modify-write of a cube shared with other workers
+                    cube = None if whole else self._read_cube(fn, ext, dtype, tuple(cs[::-1]))
+                    if cube is None:
+                        cube = np.zeros(tuple(cs[::-1]), dtype=dtype)
+                    cube[dst] = d[src]
+                    self._write_cube(fn, ext, cube)
 
             _map_cubes(one, itertools.product(range(c_lo[0], c_hi[0] + 1), range(c_lo[1], c_hi[1] + 1),
                                               range(c_lo[2], c_hi[2] + 1)))

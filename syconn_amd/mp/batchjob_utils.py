@@ -9,8 +9,9 @@ local fallback ``batchjob_fallback`` :390-516) that ``predict_dense_to_kd`` reli
 
 The SLURM machinery (sbatch / sacct polling / requeue) is out of scope.  What replaces it is MI355X-specific: the
 reference's fallback does not pin devices (every local worker would land on GPU 0), here
-worker i is pinned to GPU ``i % ngpus_per_node`` through ``HIP_VISIBLE_DEVICES`` and at most one worker per GPU
-runs at a time.
+every visible GPU gets ONE dispatcher thread that runs its share of the jobs (``jobs[g::ngpu]``) one after the
+other with ``HIP_VISIBLE_DEVICES`` set to that GPU, so at most one worker process uses a GPU at any time -- also when
+there are more jobs than GPUs (``nnodes_total > 1`` on one node, or fewer visible GPUs than ``ngpus_per_node``).
 """
 import glob
 import os
@@ -72,7 +73,7 @@ def batchjob_script(params: list, name: str, n_cores: int = 1, suffix: str = "",
     n_workers = ngpu if use_gpu else max(1, min((os.cpu_count() or 1) // max(n_cores, 1), len(params)))
     n_workers = max(1, min(n_workers, len(params)))
     log_batchjob.info(f'Started batch job "{name}" with {len(params)} task(s) on {n_workers} worker(s)'
-                      + (f', pinned round-robin to {ngpu} GPU(s).' if use_gpu else '.'))
+                      + (f', one at a time on each of {ngpu} GPU(s).' if use_gpu else '.'))
     start = time.time()
     repo_root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -87,23 +88,38 @@ def batchjob_script(params: list, name: str, n_cores: int = 1, suffix: str = "",
             f.write(f'#!/bin/bash -l\nexport syconn_wd="{wd}"\n{python_path} {path_to_script} {storage} {out}')
         jobs.append((i_job, storage, out))
 
-    def run(job):
+    devs = []
+    if use_gpu:
+        base = os.environ.get('HIP_VISIBLE_DEVICES')
+        devs = [d for d in base.split(',') if d] if base else [str(k) for k in range(ngpu)]
+        devs = devs[:ngpu]
+
+    def run(job, device=None):
         i_job, storage, out = job
         env = dict(os.environ)
         env['syconn_wd'] = wd
         env['PYTHONPATH'] = repo_root + os.pathsep + env.get('PYTHONPATH', '')
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        if use_gpu:
-            base = os.environ.get('HIP_VISIBLE_DEVICES')
-            devs = [d for d in base.split(',') if d] if base else [str(k) for k in range(ngpu)]
-            env['HIP_VISIBLE_DEVICES'] = devs[i_job % len(devs)]
+        if device is not None:
+            env['HIP_VISIBLE_DEVICES'] = device
         with open(f'{dirs["log"]}job_{i_job}.log', 'w') as lo, open(f'{dirs["err"]}job_{i_job}.log', 'w') as le:
             rc = subprocess.call([python_path, path_to_script, storage, out], env=env, stdout=lo, stderr=le)
         err = open(f'{dirs["err"]}job_{i_job}.log').read()
         return rc, err
 
-    with ThreadPoolExecutor(max_workers=n_workers) as ex:
-        results = list(ex.map(run, jobs))
+    results = [None] * len(jobs)
+    if use_gpu:
+        # one dispatcher per GPU, each walking its own job list sequentially: a GPU never hosts two workers at once
+        def dispatcher(g):
+            for job in jobs[g::len(devs)]:
+                results[job[0]] = run(job, devs[g])
+
+        with ThreadPoolExecutor(max_workers=len(devs)) as ex:
+            for f in [ex.submit(dispatcher, g) for g in range(len(devs))]:
+                f.result()
+    else:
+        with ThreadPoolExecutor(max_workers=n_workers) as ex:
+            results = list(ex.map(run, jobs))
     out_files = glob.glob(dirs['out'] + '*.pkl')
     if len(out_files) < len(params):
         errs = '\n'.join(f'job {i}: rc={rc}\n{err[-2000:]}' for i, (rc, err) in enumerate(results) if rc != 0)

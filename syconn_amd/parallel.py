@@ -55,15 +55,19 @@ def shard_units(units: Sequence, rank: Optional[int] = None, world: Optional[int
     return list(parts[rank]) if rank < len(parts) else []
 
 
-def flatten_state(model: torch.nn.Module) -> torch.Tensor:
-    """All parameters and buffers that define the network as one float32 vector (deterministic key order)."""
-    sd = model.state_dict()
-    return torch.cat([v.detach().reshape(-1).to(torch.float32) for k, v in sd.items()
+def _state(model) -> dict:
+    return model if isinstance(model, dict) else model.state_dict()
+
+
+def flatten_state(model) -> torch.Tensor:
+    """All parameters and buffers that define the network (an ``nn.Module`` or a plain ``state_dict``) as one float32
+    vector (deterministic key order)."""
+    return torch.cat([v.detach().reshape(-1).to(torch.float32) for k, v in _state(model).items()
                       if not k.endswith('num_batches_tracked')])
 
 
-def unflatten_state(model: torch.nn.Module, flat: torch.Tensor) -> None:
-    sd = model.state_dict()
+def unflatten_state(model, flat: torch.Tensor) -> None:
+    sd = _state(model)
     off = 0
     new = {}
     for k, v in sd.items():
@@ -75,11 +79,14 @@ def unflatten_state(model: torch.nn.Module, flat: torch.Tensor) -> None:
         off += n
     if off != flat.numel():
         raise ValueError('flat parameter vector does not match the model')
-    model.load_state_dict(new)
+    if isinstance(model, dict):
+        model.update(new)
+    else:
+        model.load_state_dict(new)
 
 
-def broadcast_weights(model: torch.nn.Module, src: int = 0, device: Optional[torch.device] = None) -> None:
-    """Make every rank's `model` equal to rank `src`'s (Coll-1 of SURVEY.md section 2.2)."""
+def broadcast_weights(model, src: int = 0, device: Optional[torch.device] = None) -> None:
+    """Make every rank's `model` (``nn.Module`` or ``state_dict``) equal to rank `src`'s (Coll-1 of SURVEY.md 2.2)."""
     _, world = world_info()
     if world == 1:
         return
@@ -90,36 +97,23 @@ def broadcast_weights(model: torch.nn.Module, src: int = 0, device: Optional[tor
     unflatten_state(model, flat.cpu())
 
 
-_GATHER_MODE = {'mode': 'gather'}     # 'gather' (root-centric send/recv) or 'all_gather' (fallback)
-
-
 def gather_to_root(local: torch.Tensor, dst: int = 0, async_op: bool = False, out: Optional[torch.Tensor] = None):
-    """Gather equally-shaped uint8 result tensors on `dst` (Coll-3).
+    """Gather equally-shaped uint8 result tensors on `dst` (Coll-3): root-centric, every rank sends its payload once.
 
-    Returns ``(buffers, work)``: `buffers` is the list of per-rank tensors on `dst` (None elsewhere; with the
-    all_gather fallback every rank holds them), `work` the async handle (None when synchronous or world size 1).
-    `out` optionally provides the (world, *local.shape) receive buffer so that steady-state steps allocate nothing.
-    If the backend rejects ``dist.gather`` (it is emulated with grouped send/recv on RCCL) the first failure
-    switches this process group to ``all_gather_into_tensor`` for the rest of the run."""
+    Returns ``(buffers, work)``: `buffers` is the list of per-rank tensors on `dst` (None elsewhere), `work` the async
+    handle (None when synchronous or world size 1).  `out` optionally provides the (world, *local.shape) receive
+    buffer so that steady-state steps allocate nothing.  A failing collective propagates: there is no fallback to
+    another collective (a rank that switched alone would mismatch the others and hang the job)."""
     rank, world = world_info()
     if world == 1:
         return [local], None
-    if _GATHER_MODE['mode'] == 'gather':
-        try:
-            bufs = None
-            if rank == dst:
-                if out is None:
-                    out = torch.empty((world, *local.shape), dtype=local.dtype, device=local.device)
-                bufs = list(out.unbind(0))
-            work = dist.gather(local, gather_list=bufs, dst=dst, async_op=async_op)
-            return bufs, (work if async_op else None)
-        except (RuntimeError, ValueError, NotImplementedError):
-            _GATHER_MODE['mode'] = 'all_gather'
-    if out is None:
-        out = torch.empty((world, *local.shape), dtype=local.dtype, device=local.device)
-    work = dist.all_gather_into_tensor(out.view(-1, *local.shape[1:]) if local.dim() > 0 else out, local.contiguous(),
-                                       async_op=async_op)
-    return list(out.unbind(0)), (work if async_op else None)
+    bufs = None
+    if rank == dst:
+        if out is None:
+            out = torch.empty((world, *local.shape), dtype=local.dtype, device=local.device)
+        bufs = list(out.unbind(0))
+    work = dist.gather(local.contiguous(), gather_list=bufs, dst=dst, async_op=async_op)
+    return bufs, (work if async_op else None)
 
 
 def scatter_from_root(payloads: Optional[Sequence[torch.Tensor]], like: torch.Tensor, src: int = 0) -> torch.Tensor:

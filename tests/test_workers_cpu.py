@@ -1,0 +1,130 @@
+"""Multi-worker host logic of the dense path, no GPU needed:
+
+* two worker PROCESSES whose chunks share target cubes must produce the same KnossosDataset as one worker
+  (chunks of 482x481x236 are not aligned to the 256^3 target cubes, /root/reference/syconn/handler/prediction.py:672-677,
+  700-702: cube files on chunk borders are read-modify-written by different workers);
+* ``batchjob_script`` never runs two jobs on one GPU at the same time, also with more jobs than GPUs
+  (/root/reference/syconn/mp/batchjob_utils.py:390-516 does not pin devices at all).
+"""
+import multiprocessing as mp
+import os
+import pickle
+import sys
+import time
+
+import numpy as np
+
+from syconn_amd.knossos import KnossosDataset
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _vol(shape_zyx, seed):
+    return np.random.default_rng(seed).integers(1, 255, shape_zyx, dtype=np.uint8)
+
+
+def _writer(path, boxes, seed, ext, barrier):
+    kd = KnossosDataset().initialize_from_knossos_path(path)
+    barrier.wait()
+    for rep in range(3):                       # repeated passes widen the race window; the content is idempotent
+        for off_xyz, size_xyz in boxes:
+            z, y, x = off_xyz[2], off_xyz[1], off_xyz[0]
+            data = _vol((96, 96, 96), seed)[z:z + size_xyz[2], y:y + size_xyz[1], x:x + size_xyz[0]]
+            if ext == 'raw':
+                kd.save_raw(offset=np.array(off_xyz), mags=[1, 2], data=data, data_mag=1, fast_resampling=True,
+                            upsample=False)
+            else:
+                kd.save_seg(offset=np.array(off_xyz), mags=[1], data=data.astype(np.uint64), data_mag=1,
+                            fast_resampling=True, upsample=False)
+
+
+def _boxes():
+    # 24^3 chunks of a 96^3 volume stored in 64^3 cubes: every cube is shared by up to 27 chunks
+    out = []
+    for x in range(0, 96, 24):
+        for y in range(0, 96, 24):
+            for z in range(0, 96, 24):
+                out.append(((x, y, z), (24, 24, 24)))
+    return out
+
+
+def _make_kd(path):
+    kd = KnossosDataset()
+    kd._cube_shape = (64, 64, 64)
+    kd.initialize_without_conf(str(path), np.array([96, 96, 96]), np.array([10., 10., 20.]), 'race', mags=[1, 2])
+    return kd
+
+
+def test_two_processes_sharing_cubes_lose_no_update(tmp_path):
+    boxes = _boxes()
+    for ext in ('raw', 'seg'):
+        p = tmp_path / f'kd_{ext}'
+        _make_kd(p)
+        ctx = mp.get_context('fork')
+        barrier = ctx.Barrier(2)
+        procs = [ctx.Process(target=_writer, args=(str(p), boxes[i::2], 7, ext, barrier)) for i in range(2)]
+        for pr in procs:
+            pr.start()
+        for pr in procs:
+            pr.join(120)
+            assert pr.exitcode == 0
+        kd = KnossosDataset().initialize_from_knossos_path(str(p))
+        want = _vol((96, 96, 96), 7)
+        if ext == 'raw':
+            got = kd.load_raw(size=np.array([96, 96, 96]), offset=np.zeros(3, int), mag=1)
+            assert np.array_equal(got, want)
+            got2 = kd.load_raw(size=np.array([96, 96, 96]), offset=np.zeros(3, int), mag=2)
+            # every 24^3 chunk contributes its own order-0 pyramid level (chunk origins are even -> same sample grid)
+            assert np.array_equal(got2, want[::2, ::2, ::2])
+        else:
+            got = kd.load_seg(size=np.array([96, 96, 96]), offset=np.zeros(3, int), mag=1)
+            assert np.array_equal(got, want.astype(np.uint64))
+
+
+_JOB_SCRIPT = '''
+import os, pickle, sys, time
+args = []
+with open(sys.argv[1], 'rb') as f:
+    while True:
+        try:
+            args.append(pickle.load(f))
+        except EOFError:
+            break
+t0 = time.time()
+time.sleep(args[1])
+with open(os.path.join(args[0], 'span_%d.txt' % args[2]), 'w') as f:
+    f.write('%s %.6f %.6f' % (os.environ.get('HIP_VISIBLE_DEVICES'), t0, time.time()))
+with open(sys.argv[2], 'wb') as f:
+    pickle.dump(None, f)
+'''
+
+
+def test_batchjob_script_one_worker_per_gpu(tmp_path, monkeypatch):
+    from syconn_amd import global_params
+    from syconn_amd.handler.config import generate_default_conf
+    from syconn_amd.mp import batchjob_utils as qu
+    wd = tmp_path / 'wd'
+    generate_default_conf(str(wd), scaling=(10, 10, 20), key_value_pairs=[('ngpus_per_node', 2)])
+    global_params.wd = str(wd)
+    scripts = tmp_path / 'scripts'
+    scripts.mkdir()
+    (scripts / 'batchjob_sleepy.py').write_text(_JOB_SCRIPT)
+    spans = tmp_path / 'spans'
+    spans.mkdir()
+    monkeypatch.setattr(qu, '_visible_gpus', lambda: 2)
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '3,5')
+    # uneven durations: with dynamic hand-out the thread that finishes job 1 would start job 2 on GPU "3" while job 0
+    # still runs there
+    durs = [0.6, 0.1, 0.1, 0.1, 0.1]
+    params = [(str(spans), d, i) for i, d in enumerate(durs)]
+    qu.batchjob_script(params, 'sleepy', script_folder=str(scripts), additional_flags='--gres=gpu:1',
+                       remove_jobfolder=True)
+    rec = {}
+    for i in range(len(durs)):
+        dev, a, b = (spans / f'span_{i}.txt').read_text().split()
+        rec[i] = (dev, float(a), float(b))
+    assert [rec[i][0] for i in range(5)] == ['3', '5', '3', '5', '3']          # jobs[g::ngpu] on device g
+    for dev in ('3', '5'):
+        iv = sorted((a, b) for d, a, b in rec.values() if d == dev)
+        for (a0, b0), (a1, b1) in zip(iv, iv[1:]):
+            assert a1 >= b0 - 1e-3, f'two workers overlapped on GPU {dev}'
