@@ -38,7 +38,7 @@ extern "C" {
 #define SD_ERR_NODEVICE (-4)
 
 /* element types of caller-visible buffers */
-enum sd_dtype { SD_U8 = 0, SD_F32 = 1, SD_BF16 = 2, SD_F16 = 3, SD_U64 = 4 };
+enum sd_dtype { SD_U8 = 0, SD_F32 = 1, SD_BF16 = 2, SD_F16 = 3, SD_U64 = 4, SD_U32 = 5 };
 
 /* what sd_forward writes: raw logits (model(inp)), softmax(1) (Predictor(apply_softmax=True), prediction.py:779),
  * or floor(255*softmax) as uint8 (dense_predicton_helper, prediction.py:864-865) */
@@ -168,6 +168,35 @@ int sd_downsample2(const void* src_dev, int dtype, int D, int H, int W, void* ds
  * the reference (:611-612).  vol: (D,H,W) uint8 on the device; origins int32 and out uint8 on the device. */
 int sd_box_majority(const uint8_t* vol_dev, int D, int H, int W, const int32_t* origins_zyx_dev, size_t n, int ez, int ey,
                     int ex, double thresh_proba, double thresh_majority, uint8_t* out_dev, void* stream);
+
+/* ---- label-volume statistics ------------------------------------------------------------
+ * Device counterpart of the reference's Cython natives /root/reference/syconn/extraction/find_object_properties_C.pyx:
+ * find_object_properties (:24-49), map_subcell_C (:72-109), map_subcell_extract_props (:112-192).  Volumes are
+ * (X,Y,Z) with z fastest (the reference indexes chunk[x, y, z]), dtype SD_U32 or SD_U64, id 0 = background.
+ * One streaming pass fills open-addressing hash tables in CALLER-OWNED device memory:
+ *   object table  (sd_objtable_bytes(cap) bytes, cap a power of two <= 2^31): per non-zero id the smallest raster index
+ *                 (= the reference's representative coordinate, the first voxel its scan meets), the voxel count and the
+ *                 bounding box [min, max + 1);
+ *   pair table    (sd_pairtable_bytes(cap) bytes): per (subcell id, cell id) the number of voxels where both are set.
+ * sd_segstats_scan initialises the tables itself.  cell_dev may be NULL (properties of the `sub` volumes only); n_sub may
+ * be 0 (= find_object_properties(cell)); want_props = 0 computes the overlap counts only (= map_subcell_C).
+ * status_dev: int32[2], set to 1 when the object tables ([0]) / pair tables ([1]) were too small -- the caller retries
+ * with a larger capacity (results of an overflowed pass are incomplete and must be discarded). */
+size_t sd_objtable_bytes(size_t capacity);
+size_t sd_pairtable_bytes(size_t capacity);
+int sd_segstats_scan(const void* cell_dev, const void* const* sub_devs /* host array of device pointers */, int n_sub,
+                     int dtype, int X, int Y, int Z, void* cell_table, void* const* sub_tables, size_t cap_obj,
+                     void* const* pair_tables, size_t cap_pair, int want_props, int32_t* status_dev, void* stream);
+/* Turn a filled object table into dense arrays (any order): ids / first raster index / voxel count (uint64 each) and
+ * bbox int32[n][6] = (min x,y,z, max+1 x,y,z).  *count_dev = number of objects (may exceed max_out: then only max_out
+ * records were written). */
+int sd_segstats_compact_objects(const void* table, size_t cap_obj, uint64_t* ids_dev, uint64_t* first_dev,
+                                uint64_t* size_dev, int32_t* bbox_dev, size_t max_out, uint64_t* count_dev, void* stream);
+/* Dense (subcell id, cell id, overlap count) triples of one pair table; the ids are looked up in the two object tables
+ * the same sd_segstats_scan call filled. */
+int sd_segstats_compact_pairs(const void* pair_table, size_t cap_pair, const void* sub_table, const void* cell_table,
+                              size_t cap_obj, uint64_t* sub_ids_dev, uint64_t* cell_ids_dev, uint64_t* counts_dev,
+                              size_t max_out, uint64_t* count_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 SD_OK, SD_ERR_INVALID, SD_ERR_NOMEM, SD_ERR_HIP, SD_ERR_NODEVICE = 0, -1, -2, -3, -4
-SD_U8, SD_F32, SD_BF16, SD_F16, SD_U64 = 0, 1, 2, 3, 4
+SD_U8, SD_F32, SD_BF16, SD_F16, SD_U64, SD_U32 = 0, 1, 2, 3, 4, 5
 SD_OUT_LOGITS_F32, SD_OUT_PROBS_F32, SD_OUT_PROBS_U8 = 0, 1, 2
 SD_OP_CONV, SD_OP_POOL, SD_OP_UPCONV, SD_OP_GROUPNORM, SD_OP_FINAL = 1, 2, 3, 4, 5
 
@@ -18,7 +18,9 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.g
 EXPORTS = ['sd_init', 'sd_device_count', 'sd_model_create', 'sd_model_destroy', 'sd_workspace_bytes', 'sd_forward', 'sd_forward_batch', 'sd_forward_labels_batch',
            'sd_tile_gather', 'sd_tile_scatter', 'sd_postproc_labels', 'sd_profile_enable', 'sd_profile_read',
            'sd_debug_read_buffer', 'sd_model_num_ops', 'sd_last_error', 'sd_version', 'sd_snappy_max_compressed_length',
-           'sd_snappy_compress', 'sd_snappy_uncompressed_length', 'sd_snappy_uncompress', 'sd_downsample2', 'sd_box_majority']
+           'sd_snappy_compress', 'sd_snappy_uncompressed_length', 'sd_snappy_uncompress', 'sd_downsample2', 'sd_box_majority',
+           'sd_objtable_bytes', 'sd_pairtable_bytes', 'sd_segstats_scan', 'sd_segstats_compact_objects',
+           'sd_segstats_compact_pairs']
 
 
 class OpDesc(C.Structure):
@@ -74,6 +76,15 @@ def load():
     lib.sd_downsample2.argtypes = [vp, i32, i32, i32, i32, vp, vp]; lib.sd_downsample2.restype = i32
     lib.sd_box_majority.argtypes = [vp, i32, i32, i32, vp, sz, i32, i32, i32, C.c_double, C.c_double, vp, vp]
     lib.sd_box_majority.restype = i32
+    lib.sd_objtable_bytes.argtypes = [sz]; lib.sd_objtable_bytes.restype = sz
+    lib.sd_pairtable_bytes.argtypes = [sz]; lib.sd_pairtable_bytes.restype = sz
+    lib.sd_segstats_scan.argtypes = [vp, C.POINTER(vp), i32, i32, i32, i32, i32, vp, C.POINTER(vp), sz, C.POINTER(vp), sz,
+                                     i32, vp, vp]
+    lib.sd_segstats_scan.restype = i32
+    lib.sd_segstats_compact_objects.argtypes = [vp, sz, vp, vp, vp, vp, sz, vp, vp]
+    lib.sd_segstats_compact_objects.restype = i32
+    lib.sd_segstats_compact_pairs.argtypes = [vp, sz, vp, vp, sz, vp, vp, vp, sz, vp, vp]
+    lib.sd_segstats_compact_pairs.restype = i32
     _lib = lib
     return lib
 

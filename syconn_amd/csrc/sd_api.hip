@@ -64,6 +64,8 @@ struct Op {
 
 }  // namespace
 
+int sd_fail_msg(int code, const char* msg) { return fail(code, msg); }   // for the other translation units
+
 struct sd_model {
     int device = 0;
     int act_dtype = SD_BF16;

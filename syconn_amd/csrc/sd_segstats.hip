@@ -1,0 +1,262 @@
+// Label-volume statistics on the device: the gfx950 counterpart of the reference's only
+// native code, /root/reference/syconn/extraction/find_object_properties_C.pyx (find_object_properties :24-49,
+// map_subcell_C :72-109, map_subcell_extract_props :112-192).
+//
+// The reference scans the volume once on one core and keeps per-id properties in std::unordered_map.  Here the scan is one
+// HBM-bound streaming pass (8 B per voxel and volume, read exactly once) and the maps are open-addressing hash tables in
+// caller-owned device memory, updated with order-independent atomics (min / max / add), so the result is deterministic.
+// Label volumes are spatially coherent, so the atomics are issued per RUN of equal labels along the fastest axis (found
+// inside a wavefront with one ballot), not per voxel: a wave that sees one object in its 64 voxels issues one update.
+#include "../../include/syconn_dense.h"
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <algorithm>
+#include <string>
+
+extern int sd_fail_msg(int code, const char* msg);      // sd_api.hip: sets sd_last_error()
+
+namespace {
+
+typedef unsigned long long u64;
+constexpr u64 EMPTY = 0ull;                               // label 0 is background and never inserted
+
+// Object table of `cap` slots (power of two), structure of arrays in one buffer:
+//   keys u64[cap] | first u64[cap] (smallest raster index) | size u64[cap] | bbmin i32[3][cap] | bbmax i32[3][cap]
+struct ObjTable {
+    u64* keys; u64* first; u64* size; int* bbmin; int* bbmax; u64 cap;
+};
+__host__ __device__ inline ObjTable obj_table(void* base, u64 cap) {
+    ObjTable t;
+    char* p = reinterpret_cast<char*>(base);
+    t.keys = reinterpret_cast<u64*>(p);
+    t.first = t.keys + cap;
+    t.size = t.first + cap;
+    t.bbmin = reinterpret_cast<int*>(t.size + cap);
+    t.bbmax = t.bbmin + 3 * cap;
+    t.cap = cap;
+    return t;
+}
+constexpr size_t OBJ_SLOT_BYTES = 3 * 8 + 6 * 4;
+// Pair table: keys u64[cap] ((subcell slot << 32 | cell slot) + 1) | count u64[cap]
+constexpr size_t PAIR_SLOT_BYTES = 16;
+
+__device__ __forceinline__ u64 mix64(u64 k) {             // murmur3 finaliser
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return k;
+}
+
+// slot of `k` in an open-addressing table (linear probing), inserting it if absent; -1 when the table is full
+__device__ __forceinline__ long find_or_insert(u64* keys, u64 cap, u64 k) {
+    const u64 mask = cap - 1;
+    u64 h = mix64(k) & mask;
+    for (u64 probe = 0; probe < cap; ++probe, h = (h + 1) & mask) {
+        u64 cur = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == k) return (long)h;
+        if (cur == EMPTY) {
+            const u64 old = atomicCAS(&keys[h], EMPTY, k);
+            if (old == EMPTY || old == k) return (long)h;
+        }
+    }
+    return -1;
+}
+
+__global__ __launch_bounds__(256) void k_obj_init(ObjTable t) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < t.cap; i += (u64)gridDim.x * 256) {
+        t.keys[i] = EMPTY; t.first[i] = ~0ull; t.size[i] = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { t.bbmin[a * t.cap + i] = 0x7fffffff; t.bbmax[a * t.cap + i] = 0; }
+    }
+}
+__global__ __launch_bounds__(256) void k_zero64(u64* p, u64 n) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) p[i] = 0;
+}
+
+constexpr int MAX_SUB = 8;
+struct ScanParams {
+    const void* cell;                  // (X,Y,Z) labels, z fastest; may be nullptr (then only subcell properties)
+    const void* sub[MAX_SUB];
+    int n_sub;
+    int X, Y, Z;
+    ObjTable cell_t;
+    ObjTable sub_t[MAX_SUB];
+    u64* pair_keys[MAX_SUB]; u64* pair_cnt[MAX_SUB]; u64 pair_cap;
+    int want_props;                    // 0: overlap counts only (map_subcell_C)
+    int* status;                       // [0] object table overflow, [1] pair table overflow
+};
+
+template <typename L>
+__device__ __forceinline__ u64 load_label(const void* vol, u64 i) { return (u64)reinterpret_cast<const L*>(vol)[i]; }
+
+// run structure of a wave: `head` lanes start a run of equal values inside one z-row; returns the run length for head lanes
+__device__ __forceinline__ int run_length(bool head, int lane, int nvalid) {
+    const u64 m = __ballot(head);
+    const u64 later = (lane == 63) ? 0ull : (m >> (lane + 1));
+    int next = later ? (lane + 1 + __builtin_ctzll(later)) : 64;
+    if (next > nvalid) next = nvalid;
+    return next - lane;
+}
+
+__device__ __forceinline__ void obj_update(const ObjTable& t, u64 key, u64 lin, int x, int y, int z, int len, int* status) {
+    const long s = find_or_insert(t.keys, t.cap, key);
+    if (s < 0) { atomicExch(&status[0], 1); return; }
+    atomicMin(&t.first[s], lin);
+    atomicAdd(&t.size[s], (u64)len);
+    atomicMin(&t.bbmin[0 * t.cap + s], x); atomicMin(&t.bbmin[1 * t.cap + s], y); atomicMin(&t.bbmin[2 * t.cap + s], z);
+    atomicMax(&t.bbmax[0 * t.cap + s], x + 1); atomicMax(&t.bbmax[1 * t.cap + s], y + 1);
+    atomicMax(&t.bbmax[2 * t.cap + s], z + len);
+}
+
+// One wave = 64 consecutive voxels of the flattened volume.  Per volume a lane is a run head iff it is the wave's first
+// lane, the first voxel of a z-row, or its label differs from the previous voxel's.
+template <typename L>
+__global__ __launch_bounds__(256) void k_segstats_scan(const ScanParams p) {
+    const int lane = threadIdx.x & 63;
+    const u64 nvox = (u64)p.X * p.Y * p.Z;
+    const u64 nwaves = (nvox + 63) / 64;
+    for (u64 w = (u64)blockIdx.x * 4 + (threadIdx.x >> 6); w < nwaves; w += (u64)gridDim.x * 4) {
+        const u64 base = w * 64, lin = base + lane;
+        const int nvalid = (int)((nvox - base) < 64 ? (nvox - base) : 64);
+        const bool valid = lane < nvalid;
+        const u64 li = valid ? lin : (nvox - 1);
+        const int z = (int)(li % p.Z), y = (int)((li / p.Z) % p.Y), x = (int)(li / ((u64)p.Z * p.Y));
+        const bool row_start = (lane == 0) || (z == 0);
+        u64 ck = 0;
+        bool chead = false;
+        if (p.cell) {
+            ck = valid ? load_label<L>(p.cell, lin) : 0;
+            const u64 prev = __shfl_up(ck, 1, 64);
+            chead = valid && (row_start || ck != prev);
+            if (p.want_props) {
+                const int len = run_length(chead, lane, nvalid);
+                if (chead && ck != 0) obj_update(p.cell_t, ck, lin, x, y, z, len, p.status);
+            }
+        }
+        for (int ii = 0; ii < p.n_sub; ++ii) {
+            const u64 sk = valid ? load_label<L>(p.sub[ii], lin) : 0;
+            const u64 prev = __shfl_up(sk, 1, 64);
+            const bool shead = valid && (row_start || sk != prev);
+            if (p.want_props) {
+                const int len = run_length(shead, lane, nvalid);
+                if (shead && sk != 0) obj_update(p.sub_t[ii], sk, lin, x, y, z, len, p.status);
+            }
+            if (p.cell) {
+                // overlap counts: runs of a constant (subcell id, cell id) pair; both ids are inserted in their tables
+                // (by this very lane or an earlier head of the same run), their slots name the pair
+                const bool phead = chead || shead;
+                const int plen = run_length(phead, lane, nvalid);
+                if (phead && sk != 0 && ck != 0) {
+                    const long ss = find_or_insert(p.sub_t[ii].keys, p.sub_t[ii].cap, sk);
+                    const long cs = find_or_insert(p.cell_t.keys, p.cell_t.cap, ck);
+                    if (ss < 0 || cs < 0) { atomicExch(&p.status[0], 1); continue; }
+                    const long ps = find_or_insert(p.pair_keys[ii], p.pair_cap, (((u64)ss << 32) | (u64)cs) + 1);
+                    if (ps < 0) { atomicExch(&p.status[1], 1); continue; }
+                    atomicAdd(&p.pair_cnt[ii][ps], (u64)plen);
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_obj_compact(ObjTable t, u64* ids, u64* first, u64* size, int* bb, u64* count, u64 max_out) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < t.cap; i += (u64)gridDim.x * 256) {
+        const u64 k = t.keys[i];
+        if (k == EMPTY || t.size[i] == 0) continue;       // size 0: id only inserted for the overlap table
+        const u64 o = atomicAdd(count, 1ull);
+        if (o >= max_out) continue;
+        ids[o] = k; first[o] = t.first[i]; size[o] = t.size[i];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { bb[o * 6 + a] = t.bbmin[a * t.cap + i]; bb[o * 6 + 3 + a] = t.bbmax[a * t.cap + i]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pair_compact(const u64* pkeys, const u64* pcnt, u64 pcap, const u64* sub_keys,
+                                                      const u64* cell_keys, u64* out_sub, u64* out_cell, u64* out_cnt,
+                                                      u64* count, u64 max_out) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < pcap; i += (u64)gridDim.x * 256) {
+        const u64 k = pkeys[i];
+        if (k == EMPTY) continue;
+        const u64 o = atomicAdd(count, 1ull);
+        if (o >= max_out) continue;
+        out_sub[o] = sub_keys[(k - 1) >> 32];
+        out_cell[o] = cell_keys[(k - 1) & 0xffffffffull];
+        out_cnt[o] = pcnt[i];
+    }
+}
+
+inline bool pow2(u64 v) { return v && !(v & (v - 1)); }
+inline int grid_for(u64 n, int cap = 4096) { u64 g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > (u64)cap ? (u64)cap : g)); }
+
+}  // namespace
+
+extern "C" {
+
+size_t sd_objtable_bytes(size_t capacity) { return capacity * OBJ_SLOT_BYTES; }
+size_t sd_pairtable_bytes(size_t capacity) { return capacity * PAIR_SLOT_BYTES; }
+
+int sd_segstats_scan(const void* cell_dev, const void* const* sub_devs, int n_sub, int dtype, int X, int Y, int Z,
+                     void* cell_table, void* const* sub_tables, size_t cap_obj, void* const* pair_tables, size_t cap_pair,
+                     int want_props, int32_t* status_dev, void* stream) {
+    if ((!cell_dev && n_sub <= 0) || n_sub < 0 || n_sub > MAX_SUB || X <= 0 || Y <= 0 || Z <= 0 || !status_dev)
+        return sd_fail_msg(SD_ERR_INVALID, "sd_segstats_scan: bad argument");
+    if (dtype != SD_U32 && dtype != SD_U64) return sd_fail_msg(SD_ERR_INVALID, "sd_segstats_scan: dtype must be SD_U32 or SD_U64");
+    if (!pow2(cap_obj) || cap_obj > (1ull << 31) || (n_sub > 0 && cell_dev && (!pow2(cap_pair) || !pair_tables)))
+        return sd_fail_msg(SD_ERR_INVALID, "sd_segstats_scan: capacities must be powers of two (objects <= 2^31)");
+    if ((cell_dev && !cell_table) || (n_sub > 0 && (!sub_devs || !sub_tables)))
+        return sd_fail_msg(SD_ERR_INVALID, "sd_segstats_scan: null table");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ScanParams p{};
+    p.cell = cell_dev; p.n_sub = n_sub; p.X = X; p.Y = Y; p.Z = Z; p.want_props = want_props; p.status = status_dev;
+    p.pair_cap = cap_pair;
+    if (hipMemsetAsync(status_dev, 0, 2 * sizeof(int32_t), s) != hipSuccess) return sd_fail_msg(SD_ERR_HIP, "memset failed");
+    if (cell_dev) {
+        p.cell_t = obj_table(cell_table, cap_obj);
+        hipLaunchKernelGGL(k_obj_init, dim3(grid_for(cap_obj)), dim3(256), 0, s, p.cell_t);
+    }
+    for (int i = 0; i < n_sub; ++i) {
+        if (!sub_devs[i] || !sub_tables[i]) return sd_fail_msg(SD_ERR_INVALID, "sd_segstats_scan: null subcell volume / table");
+        p.sub[i] = sub_devs[i];
+        p.sub_t[i] = obj_table(sub_tables[i], cap_obj);
+        hipLaunchKernelGGL(k_obj_init, dim3(grid_for(cap_obj)), dim3(256), 0, s, p.sub_t[i]);
+        if (cell_dev) {
+            if (!pair_tables[i]) return sd_fail_msg(SD_ERR_INVALID, "sd_segstats_scan: null pair table");
+            p.pair_keys[i] = reinterpret_cast<u64*>(pair_tables[i]);
+            p.pair_cnt[i] = p.pair_keys[i] + cap_pair;
+            hipLaunchKernelGGL(k_zero64, dim3(grid_for(2 * cap_pair)), dim3(256), 0, s, p.pair_keys[i], (u64)2 * cap_pair);
+        }
+    }
+    const u64 nwaves = ((u64)X * Y * Z + 63) / 64;
+    const int grid = (int)std::min<u64>((nwaves + 3) / 4, 256 * 16);
+    if (dtype == SD_U64) hipLaunchKernelGGL(k_segstats_scan<uint64_t>, dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_segstats_scan<uint32_t>, dim3(grid), dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? SD_OK : sd_fail_msg(SD_ERR_HIP, "sd_segstats_scan: launch failed");
+}
+
+int sd_segstats_compact_objects(const void* table, size_t cap_obj, uint64_t* ids_dev, uint64_t* first_dev, uint64_t* size_dev,
+                                int32_t* bbox_dev, size_t max_out, uint64_t* count_dev, void* stream) {
+    if (!table || !pow2(cap_obj) || !ids_dev || !first_dev || !size_dev || !bbox_dev || !count_dev)
+        return sd_fail_msg(SD_ERR_INVALID, "sd_segstats_compact_objects: bad argument");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(count_dev, 0, sizeof(uint64_t), s) != hipSuccess) return sd_fail_msg(SD_ERR_HIP, "memset failed");
+    hipLaunchKernelGGL(k_obj_compact, dim3(grid_for(cap_obj)), dim3(256), 0, s, obj_table(const_cast<void*>(table), cap_obj),
+                       reinterpret_cast<u64*>(ids_dev), reinterpret_cast<u64*>(first_dev), reinterpret_cast<u64*>(size_dev),
+                       bbox_dev, reinterpret_cast<u64*>(count_dev), (u64)max_out);
+    return hipGetLastError() == hipSuccess ? SD_OK : sd_fail_msg(SD_ERR_HIP, "sd_segstats_compact_objects: launch failed");
+}
+
+int sd_segstats_compact_pairs(const void* pair_table, size_t cap_pair, const void* sub_table, const void* cell_table,
+                              size_t cap_obj, uint64_t* sub_ids_dev, uint64_t* cell_ids_dev, uint64_t* counts_dev,
+                              size_t max_out, uint64_t* count_dev, void* stream) {
+    if (!pair_table || !pow2(cap_pair) || !sub_table || !cell_table || !pow2(cap_obj) || !sub_ids_dev || !cell_ids_dev ||
+        !counts_dev || !count_dev)
+        return sd_fail_msg(SD_ERR_INVALID, "sd_segstats_compact_pairs: bad argument");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(count_dev, 0, sizeof(uint64_t), s) != hipSuccess) return sd_fail_msg(SD_ERR_HIP, "memset failed");
+    const u64* pk = reinterpret_cast<const u64*>(pair_table);
+    hipLaunchKernelGGL(k_pair_compact, dim3(grid_for(cap_pair)), dim3(256), 0, s, pk, pk + cap_pair, (u64)cap_pair,
+                       reinterpret_cast<const u64*>(sub_table), reinterpret_cast<const u64*>(cell_table),
+                       reinterpret_cast<u64*>(sub_ids_dev), reinterpret_cast<u64*>(cell_ids_dev),
+                       reinterpret_cast<u64*>(counts_dev), reinterpret_cast<u64*>(count_dev), (u64)max_out);
+    return hipGetLastError() == hipSuccess ? SD_OK : sd_fail_msg(SD_ERR_HIP, "sd_segstats_compact_pairs: launch failed");
+}
+
+}  // extern "C"

@@ -28,7 +28,7 @@ DEFAULTS = {
         'overlap_shape_tiles': [30, 31, 20],   # xyz, prediction.py:672
         'chunk_size': [482, 481, 236],         # prediction.py:674
         'tile_shape': [271, 181, 138],         # prediction.py:677
-        'act_dtype': 'bf16',
+        'act_dtype': 'f16',
     },
 }
 

@@ -47,8 +47,11 @@ class Predictor:
     pickled ``.pt`` file, `state_dict_src`, `device`, `tile_shape`/`overlap_shape` (z,y,x), `out_shape`
     (C,z,y,x), `strict_shapes`, `apply_softmax`, `apply_argmax`, `float16`, `batch_size`, `verbose`.
     `transform`, `augmentations`, `offset` (valid convolutions) and `argmax_with_threshold` are unused by SyConn
-    and rejected.  Extra keyword `act_dtype` ('bf16' default, 'f16'; `float16=True` selects 'f16') names the storage
-    type of activations on the device; accumulation is fp32.  `batch_size`: tiles per launch set (default: automatic,
+    and rejected.  Extra keyword `act_dtype` ('f16' default, 'bf16') names the storage type of activations on the
+    device; accumulation is fp32.  The reference computes in fp32 (`float16=False`, prediction.py:777-779); fp16 storage is
+    the closest the matrix cores offer at full rate: against the fp32 oracle at the 128^3 headline configuration it
+    changes 0.06 % of the threshold-rule labels (bf16: 0.45 %, max logit error 8.7e-4 vs 7.4e-3 of the logit range;
+    tests/test_gpu_labels_headline.py).  bf16 keeps fp32's exponent range and is ~3 % faster.  `batch_size`: tiles per launch set (default: automatic,
     see `_batch_for`).  `n_streams` (default 1, env SYCONN_AMD_STREAMS): batches alternate over that many HIP
     streams, each with its own workspace.
 
@@ -105,7 +108,7 @@ class Predictor:
         self.verbose = verbose
         self.report_inf_speed = report_inf_speed
         if act_dtype is None:
-            act_dtype = 'f16' if float16 else 'bf16'
+            act_dtype = 'f16'          # `float16=True` (elektronn3: model.half()) selects the same storage type
         self.act_dtype = act_dtype
         self._dm = DenseModel(model, act_dtype=act_dtype, device=self.device, group_norm_groups=group_norm_groups)
         self.out_channels = self._dm.out_channels
@@ -287,7 +290,7 @@ def dense_predictor(args):
     overlap_shape = np.asarray(overlap_shape)
     overlap_shape_tiles = np.asarray(overlap_shape_tiles)
     chunk_size = np.asarray(chunk_size)
-    act_dtype = global_params.config['dense_prediction']['act_dtype'] if _wd_set() else 'bf16'
+    act_dtype = global_params.config['dense_prediction']['act_dtype'] if _wd_set() else 'f16'
     while True:
         try:
             out_shape = (chunk_size + 2 * np.array(overlap_shape)).astype(np.int32)[::-1]  # ZYX

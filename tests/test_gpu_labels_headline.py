@@ -16,10 +16,15 @@ from oracle.unet_ref import ARCHS, UNet
 
 pytestmark = pytest.mark.gpu
 
-# stated tolerances of the full-size network (max |logit error| / max |logit|, measured values are printed):
-TOL_LOGIT_REL = {'bf16': 2.5e-2, 'f16': 4e-3}
-# bound on voxels whose oracle margin is inside the measured error (these may legitimately differ)
-MAX_UNSAFE_FRAC = {'bf16': 0.02, 'f16': 0.004}
+# stated tolerances of the full-size network: max |logit error| / max |logit| (measured on MI355X: 7.4e-3 / 8.7e-4)
+TOL_LOGIT_REL = {'bf16': 1e-2, 'f16': 1.3e-3}
+# bounds on the fraction of voxels whose oracle margin lies inside the MAXIMUM measured error (these may legitimately
+# differ; measured: threshold rule 5.3e-2 / 6.6e-3, argmax 1.2e-2 / 1.3e-3) and on the labels that really differ
+# (measured: 4.5e-3 / 5.8e-4 of the voxels for the threshold rule, 5e-4 / 6e-5 for argmax)
+MAX_UNSAFE_FRAC = {'bf16': (0.08, 0.02), 'f16': (0.012, 0.003)}
+MIN_AGREEMENT = {'bf16': (0.993, 0.999), 'f16': (0.999, 0.9998)}
+# median top-2 logit margin of the oracle / measured max error (scale-invariant for a ReLU network: measured 17 / 145)
+MIN_MARGIN_OVER_TOL = {'bf16': 12.0, 'f16': 90.0}
 
 
 @pytest.mark.parametrize('act', ['bf16', 'f16'])
@@ -45,7 +50,8 @@ def test_headline_tile_labels_vs_fp32_oracle(gpu, act):
     assert r['logit_err_max_rel'] <= TOL_LOGIT_REL[act], r
     assert r['label_mismatch_safe'] == 0, r          # threshold rule of the reference: exact wherever it can be
     assert r['argmax_mismatch_safe'] == 0, r         # argmax: exact wherever the fp32 margin exceeds the error
-    assert r['label_unsafe_frac'] <= MAX_UNSAFE_FRAC[act] and r['argmax_unsafe_frac'] <= 5 * MAX_UNSAFE_FRAC[act], r
+    assert r['label_unsafe_frac'] <= MAX_UNSAFE_FRAC[act][0] and r['argmax_unsafe_frac'] <= MAX_UNSAFE_FRAC[act][1], r
+    assert r['label_agreement'] >= MIN_AGREEMENT[act][0] and r['argmax_agreement'] >= MIN_AGREEMENT[act][1], r
     # the workload is meaningful: several classes are really predicted, and most voxels carry a decisive margin
     assert len(torch.unique(lab)) >= 3
-    assert r['median_top2_margin_over_tol'] >= 20.0, r
+    assert r['median_top2_margin_over_tol'] >= MIN_MARGIN_OVER_TOL[act], r
