@@ -198,6 +198,27 @@ int sd_segstats_compact_pairs(const void* pair_table, size_t cap_pair, const voi
                               size_t cap_obj, uint64_t* sub_ids_dev, uint64_t* cell_ids_dev, uint64_t* counts_dev,
                               size_t max_out, uint64_t* count_dev, void* stream);
 
+/* ---- probability map -> object segmentation, first stage ---------------------------------
+ * Non-watershed branches of _object_segmentation_thread (/root/reference/syconn/extraction/object_extraction_steps.py:
+ * 316-317 threshold, 354-358 morphology + scipy.ndimage.label) with the morphology semantics of
+ * /root/reference/syconn/proc/image.py:357-438, 485-507 (_multi_mop_findobjects / apply_morphological_operations) on a
+ * binary volume.  prob_dev: (X,Y,Z) uint8, z fastest (the reference's arrays are x,y,z here).
+ *   threshold   uint8 scale, mask = prob > threshold (0: prob already is a 0/1 mask, object_extraction_steps.py:316);
+ *   ops/iterations (HOST arrays, n_ops entries): the reference's operation list with runs of equal operations merged
+ *               into `iterations` (image.py:510-519).  SD_MOP_EROSION selects the reference's watershed branch
+ *               (:319-352, vigra + skimage) and is rejected with SD_ERR_INVALID: not implemented.
+ *   struct_host (sx,sy,sz) uint8 HOST array, odd extents: the structuring element (get_aniso_struct, image.py:522-539);
+ *   labels_dev  (X,Y,Z) int32: 6-connected components numbered 1..N in raster order of their first voxel, 0 = background
+ *               -- identical to scipy.ndimage.label; *max_label_dev = N;
+ *   mask_out_dev optional (X,Y,Z) uint8: the binary volume after the morphology.
+ * Workspace: sd_objseg_workspace_bytes(X, Y, Z, largest `iterations` of any closing / dilation). */
+enum sd_morph_op { SD_MOP_OPENING = 1, SD_MOP_CLOSING = 2, SD_MOP_DILATION = 3, SD_MOP_EROSION = 4 };
+size_t sd_objseg_workspace_bytes(int X, int Y, int Z, int max_iterations);
+int sd_object_segmentation(const uint8_t* prob_dev, int X, int Y, int Z, double threshold, const int32_t* ops,
+                           const int32_t* iterations, int n_ops, const uint8_t* struct_host, int sx, int sy, int sz,
+                           int32_t* labels_dev, int32_t* max_label_dev, uint8_t* mask_out_dev, void* workspace_dev,
+                           size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,7 @@ SD_OK, SD_ERR_INVALID, SD_ERR_NOMEM, SD_ERR_HIP, SD_ERR_NODEVICE = 0, -1, -2, -3
 SD_U8, SD_F32, SD_BF16, SD_F16, SD_U64, SD_U32 = 0, 1, 2, 3, 4, 5
 SD_OUT_LOGITS_F32, SD_OUT_PROBS_F32, SD_OUT_PROBS_U8 = 0, 1, 2
 SD_OP_CONV, SD_OP_POOL, SD_OP_UPCONV, SD_OP_GROUPNORM, SD_OP_FINAL = 1, 2, 3, 4, 5
+SD_MOP_OPENING, SD_MOP_CLOSING, SD_MOP_DILATION, SD_MOP_EROSION = 1, 2, 3, 4
 
 LIB_NAME = 'libsyconn_dense_hip.so'
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get('SD_LIB_NAME', LIB_NAME))
@@ -20,7 +21,7 @@ EXPORTS = ['sd_init', 'sd_device_count', 'sd_model_create', 'sd_model_destroy', 
            'sd_debug_read_buffer', 'sd_model_num_ops', 'sd_last_error', 'sd_version', 'sd_snappy_max_compressed_length',
            'sd_snappy_compress', 'sd_snappy_uncompressed_length', 'sd_snappy_uncompress', 'sd_downsample2', 'sd_box_majority',
            'sd_objtable_bytes', 'sd_pairtable_bytes', 'sd_segstats_scan', 'sd_segstats_compact_objects',
-           'sd_segstats_compact_pairs']
+           'sd_segstats_compact_pairs', 'sd_objseg_workspace_bytes', 'sd_object_segmentation']
 
 
 class OpDesc(C.Structure):
@@ -85,6 +86,10 @@ def load():
     lib.sd_segstats_compact_objects.restype = i32
     lib.sd_segstats_compact_pairs.argtypes = [vp, sz, vp, vp, sz, vp, vp, vp, sz, vp, vp]
     lib.sd_segstats_compact_pairs.restype = i32
+    lib.sd_objseg_workspace_bytes.argtypes = [i32, i32, i32, i32]; lib.sd_objseg_workspace_bytes.restype = sz
+    lib.sd_object_segmentation.argtypes = [vp, i32, i32, i32, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32), i32,
+                                           vp, i32, i32, i32, vp, vp, vp, vp, sz, vp]
+    lib.sd_object_segmentation.restype = i32
     _lib = lib
     return lib
 

@@ -1,0 +1,104 @@
+"""First stage of probability map -> object segmentation.
+
+CPU part: the oracle restatement against goldens produced by the REFERENCE'S OWN morphology helpers
+(/root/reference/syconn/proc/image.py:357-438, 485-539, lifted and executed by tests/golden/make_golden_objseg.py with the
+inline threshold / scipy.ndimage.label statements of object_extraction_steps.py:316-317, 354-358).
+GPU part (`-m gpu`): the HIP path through the C ABI -- binary volume after the morphology, label volume and label count
+bit-exact against those goldens and against the oracle on larger random volumes."""
+import os
+
+import numpy as np
+import pytest
+from scipy import ndimage
+
+from oracle.objseg_ref import (apply_morphological_operations_ref, count_subsequent_mops, get_aniso_struct_ref,
+                               object_segmentation_ref)
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g9_objseg.npz'))
+NAMES = [str(n) for n in G['names']]
+
+
+def _case(n):
+    return (G[f'{n}_prob'], float(G[f'{n}_thr']), [str(o) for o in G[f'{n}_ops']], G[f'{n}_scaling'], G[f'{n}_struct'],
+            G[f'{n}_mask'], G[f'{n}_labels'], int(G[f'{n}_max_label']))
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_oracle_matches_reference_goldens(name):
+    prob, thr, ops, scaling, struct, mask, labels, max_label = _case(name)
+    assert np.array_equal(get_aniso_struct_ref(scaling).astype(np.uint8), struct)
+    tmp = np.array(prob > thr, dtype=np.uint8)
+    got_mask = apply_morphological_operations_ref(tmp, ops, struct.astype(bool)) if ops else tmp
+    assert np.array_equal(got_mask, mask)
+    lab, mx = object_segmentation_ref(prob, thr, ops, scaling)
+    assert lab.dtype == np.int32 and np.array_equal(lab, labels) and mx == max_label
+
+
+def test_goldens_are_meaningful():
+    """the fixture exercises what it claims: morphology changes the mask, several components, the closing quirk (the
+    reference pads by `iterations` < reach of the element, so a closing can REMOVE voxels on the faces of the bounding box)"""
+    assert int(G['plain_big_max_label']) > 100 and int(G['open_close_max_label']) > 5
+    prob, thr = G['aniso3_prob'], float(G['aniso3_thr'])
+    assert int(G['aniso3_mask'].sum()) < int((prob > thr).sum())
+    assert count_subsequent_mops(['a', 'a', 'b', 'a']) == (['a', 'b', 'a'], [2, 1, 1])
+
+
+def _blobs(shape, seed, sigma, thr_q):
+    rng = np.random.default_rng(seed)
+    v = ndimage.gaussian_filter(rng.random(shape), sigma) + 0.02 * rng.random(shape)
+    v = (v - v.min()) / (v.max() - v.min())
+    return (v * 255).astype(np.uint8), float(np.quantile(v * 255, thr_q))
+
+
+# ---- HIP path ---------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', NAMES)
+def test_gpu_object_segmentation_matches_reference_goldens(gpu, name):
+    from syconn_amd.extraction.object_extraction_steps import get_aniso_struct, object_segmentation_first_stage
+    prob, thr, ops, scaling, struct, mask, labels, max_label = _case(name)
+    assert np.array_equal(get_aniso_struct(scaling).astype(np.uint8), struct)
+    lab, mx, m = object_segmentation_first_stage(prob, thr, ops, scaling, return_mask=True)
+    assert np.array_equal(m, mask), 'binary volume after the morphology differs'
+    assert mx == max_label and lab.dtype == np.int32 and np.array_equal(lab, labels)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape,sigma,q,ops,scaling', [
+    ((96, 80, 72), 1.5, 0.80, [], (10, 10, 20)),
+    ((70, 90, 50), 1.3, 0.75, ['binary_opening', 'binary_closing'], (10, 10, 20)),
+    ((64, 64, 33), 1.2, 0.85, ['binary_closing', 'binary_opening'], (10, 10, 20)),           # the 'sj' recipe of the docs
+    ((40, 37, 129), 2.0, 0.70, ['binary_closing', 'binary_closing', 'binary_opening'], (10, 10, 10)),
+    ((1, 1, 1), 1.0, 0.0, ['binary_closing'], (10, 10, 20)),
+    ((3, 200, 2), 1.0, 0.6, ['binary_opening'], (10, 10, 20))])
+def test_gpu_object_segmentation_equals_oracle(gpu, shape, sigma, q, ops, scaling):
+    from syconn_amd.extraction.object_extraction_steps import object_segmentation_first_stage
+    prob, thr = _blobs(shape, 5, sigma, q)
+    want, want_max = object_segmentation_ref(prob, thr, ops, scaling)
+    lab, mx = object_segmentation_first_stage(prob, thr, ops, scaling)
+    assert mx == want_max and np.array_equal(lab, want)
+
+
+@pytest.mark.gpu
+def test_gpu_object_segmentation_worst_case_components_and_errors(gpu):
+    from syconn_amd.extraction.object_extraction_steps import object_segmentation_first_stage
+    # 3D checkerboard: every foreground voxel its own component (no 6-neighbour), ids strictly in raster order
+    x, y, z = np.indices((32, 30, 34))
+    prob = (((x + y + z) & 1) * 255).astype(np.uint8)
+    lab, mx = object_segmentation_first_stage(prob, 127.5)
+    assert mx == int((prob > 0).sum())
+    assert np.array_equal(lab[prob > 0], np.arange(1, mx + 1, dtype=np.int32))
+    # one snake filling the volume: long union-find chains
+    full = np.full((16, 40, 64), 255, np.uint8)
+    full[:, 1::2, :-1] = 0
+    full[:, 1::4, :] = 0
+    full[:, 1::4, -1] = 255
+    full[:, 3::4, 0] = 255
+    lab, mx = object_segmentation_first_stage(full, 1.0)
+    want, want_max = ndimage.label(full > 1.0)
+    assert mx == want_max and np.array_equal(lab, want)
+    with pytest.raises(NotImplementedError):
+        object_segmentation_first_stage(prob, 100.0, ['binary_opening', 'binary_closing', 'binary_erosion'])
+    with pytest.raises(NotImplementedError):
+        object_segmentation_first_stage(prob, 100.0, ['binary_fill_holes'])
+    with pytest.raises(TypeError):
+        object_segmentation_first_stage(prob.astype(np.float32), 100.0)
