@@ -38,6 +38,7 @@ struct ConvParams {
     const float* bias; // padded to NB*NT*32
     int relu;
     int nbx, nby, nbz; // workgroup grid over the output volume
+    int block_order;   // 3x3x3: 0 = z-fastest block list, 1 = 4x4x2-brick order (L2 locality of the halo planes)
     const void* zero;  // >= 16 zero bytes (DMA source of out-of-volume halo voxels)
     int store_main;    // write dst (0 when only the fused final output is needed)
     void* pool_dst;    // fused MaxPool(ceil): pooled tensor (same channel stride), or nullptr

@@ -336,7 +336,26 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         // 3x3x3: z fastest -- the blocks an XCD works on at the same time are then z-neighbours of one (y,x) column,
         // whose shared halo planes (2 of 6, the largest overlap of a 4x8x16 block) hit in L2 (-12 % HBM reads);
         // 1x3x3 blocks share nothing along z: x fastest, then y
-        if (KZ == 3) { z0 = (lb % p.nbz) * BZ; x0 = ((lb / p.nbz) % p.nbx) * BX; y0 = (lb / (p.nbz * p.nbx)) * BY; }
+        if (KZ == 3 && p.block_order == 1) {
+            // brick order: y in slabs of 4 block rows, x in strips of 2 block columns, inside a (slab, strip) column z
+            // slowest.  32 consecutive list entries -- what the 32 workgroups of an XCD work on at the same time -- are then
+            // a compact 4 x 4 x 2 brick of blocks (16 x 32 x 32 voxels: each halo plane is shared with a block that is in
+            // the same L2 at the same time in all three directions, not only along z), and an XCD's next round is the
+            // brick above it.  Edge slabs / strips are simply narrower: a bijection for any grid.
+            constexpr int BYB = 4, BXB = 2;
+            const int slab_full = BYB * p.nbx * p.nbz;
+            const int sl = lb / slab_full;
+            int rem = lb - sl * slab_full;
+            const int h = min(BYB, p.nby - sl * BYB);
+            const int strip_full = BXB * h * p.nbz;
+            const int st = rem / strip_full;
+            rem -= st * strip_full;
+            const int w = min(BXB, p.nbx - st * BXB);
+            const int zi = rem / (h * w);
+            rem -= zi * h * w;
+            z0 = zi * BZ; y0 = (sl * BYB + rem / w) * BY; x0 = (st * BXB + rem % w) * BX;
+        }
+        else if (KZ == 3) { z0 = (lb % p.nbz) * BZ; x0 = ((lb / p.nbz) % p.nbx) * BX; y0 = (lb / (p.nbz * p.nbx)) * BY; }
         else { x0 = (lb % p.nbx) * BX; y0 = ((lb / p.nbx) % p.nby) * BY; z0 = (lb / (p.nbx * p.nby)) * BZ; }
     };
     // DMA chunk c of the block at (z0,y0,x0) into halo slot `slot`; real == false issues the same number of
@@ -1380,6 +1399,8 @@ static int launch_conv_k(ConvParams p, int NB, hipStream_t s) {
     const size_t lds = conv_lds_bytes<KZ, NT, WAVES, MT, NSLOT>((p.nchunk0 + p.nchunk1) * KZ, p.final_wfrag != nullptr) +
                        (FF ? (size_t)(G::BY + 4) * (G::BX + 4) * 4 : 0);
     p.nbx = (p.W + G::BX - 1) / G::BX; p.nby = (p.H + G::BY - 1) / G::BY; p.nbz = (p.D + G::BZ - 1) / G::BZ;
+    static const int order = getenv("SD_BLOCK_ORDER") ? atoi(getenv("SD_BLOCK_ORDER")) : 1;
+    p.block_order = order;
     // per-DEVICE cache of the dynamic-LDS attribute and the occupancy answer of this instantiation (a function attribute
     // set on one device does not carry over to a model created on another one in the same process); guarded, because
     // two models may launch their first forward from different threads
@@ -1432,16 +1453,31 @@ static int launch_conv_knt(const ConvParams& p, int NB, hipStream_t s) {
     // workgroups still share a CU (level-0 layers); else streamed weights, one block per workgroup.  Deeper rings
     // (NSLOT 4/6, one workgroup per CU) were measured SLOWER on the level-0 layers (1.32 vs 1.23 ms per tile): those
     // layers are bound by per-wave instruction latency, not by bytes in flight, so resident waves win over ring depth.
+    static const int l0_mode = getenv("SD_L0") ? atoi(getenv("SD_L0")) : 0;   // experiment: MT=4 tiles for NT=1 layers
     if constexpr (KZ == 1 && NT <= 2) {
         if (p.first_in) {
             if (!conv_can_fuse_first(KZ, NT, NB, vox, nstages, p.final_wfrag != nullptr)) return SD_ERR_INVALID;
+            if constexpr (NT == 1) {
+                if (l0_mode == 1) return launch_conv_k<T, KZ, NT, 8, 2, 4, true>(p, NB, s);
+                if (l0_mode == 2) return launch_conv_k<T, KZ, NT, 4, 2, 4, true>(p, NB, s);
+            }
             return launch_conv_k<T, KZ, NT, 8, 2, 2, true>(p, NB, s);
         }
     } else if (p.first_in) {
         return SD_ERR_INVALID;
     }
+    if constexpr (KZ == 1 && NT == 1) {
+        if (big && l0_mode == 1 && conv_lds_bytes<KZ, NT, 8, 4, 2>(nstages, p.final_wfrag != nullptr) <= 150 * 1024)
+            return launch_conv_k<T, KZ, NT, 8, 2, 4>(p, NB, s);
+        if (big && l0_mode == 2 && conv_lds_bytes<KZ, NT, 4, 4, 2>(nstages, p.final_wfrag != nullptr) <= 96 * 1024)
+            return launch_conv_k<T, KZ, NT, 4, 2, 4>(p, NB, s);
+    }
     if (big) {
         if (conv_lds_bytes<KZ, NT, 8, 2, 2>(nstages, p.final_wfrag != nullptr) <= 96 * 1024) return launch_conv_k<T, KZ, NT, 8, 2>(p, NB, s);
+        if constexpr (KZ == 3 && NT == 2) {
+            static const bool mt4 = getenv("SD_MT4") != nullptr;      // experiment: 8x8x16 blocks, 4 voxel tiles per wave
+            if (mt4 && !p.final_wfrag && (vox / 1024) * NB >= 256) return launch_conv_k<T, KZ, NT, 8, 0, 4>(p, NB, s);
+        }
         return launch_conv_k<T, KZ, NT, 8, 0>(p, NB, s);
     }
     if (conv_lds_bytes<KZ, NT, 4, 2, 2>(nstages, p.final_wfrag != nullptr) <= 80 * 1024) return launch_conv_k<T, KZ, NT, 4, 2>(p, NB, s);

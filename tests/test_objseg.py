@@ -46,8 +46,8 @@ def test_goldens_are_meaningful():
 def _blobs(shape, seed, sigma, thr_q):
     rng = np.random.default_rng(seed)
     v = ndimage.gaussian_filter(rng.random(shape), sigma) + 0.02 * rng.random(shape)
-    v = (v - v.min()) / (v.max() - v.min())
-    return (v * 255).astype(np.uint8), float(np.quantile(v * 255, thr_q))
+    v = (v - v.min()) / max(v.max() - v.min(), 1e-9) if v.size > 1 else np.ones(shape)
+    return (v * 255).astype(np.uint8), float(np.quantile(v * 255, thr_q)) - (1.0 if v.size == 1 else 0.0)
 
 
 # ---- HIP path ---------------------------------------------------------------------------------------------------------

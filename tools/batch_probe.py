@@ -1,12 +1,12 @@
 # dev probe: tile throughput of sd_forward_batch vs batch size (and optionally over 2 streams)
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle.unet_ref import build_unet
+from syconn_amd.cnn import random_state_dict
 from syconn_amd import _lib as L
 from syconn_amd.engine import DenseModel, StreamRing
 arch = sys.argv[1] if len(sys.argv) > 1 else 'semseg_spine'
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 128
-net = build_unet(arch, seed=0)
+net = random_state_dict(arch, seed=0)
 dm = DenseModel(net, 'bf16', torch.device('cuda', 0))
 for N in [int(v) for v in os.environ.get('SD_PROBE_BATCHES', '1,2,4,8').split(',')]:
     for ns in (1, 2):
