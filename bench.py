@@ -202,7 +202,14 @@ def main():
     ap.add_argument('--act', default='bf16', choices=['bf16', 'f16'])
     ap.add_argument('--batch', type=int, default=0, help='tiles per sd_forward_batch launch set (0 = all tiles of a step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', default='config2', choices=['config2', 'config3', 'config4', 'config5'],
+                    help='BASELINE.json configs[1..4]; the default (config2 = configs[1]) is the headline metric')
+    ap.add_argument('--geometry', default='tile128', choices=['tile128', 'reference'],
+                    help='volume workloads: 128^3 model tiles (SURVEY 8d) or the reference chunk / tile geometry')
+    ap.add_argument('--volume', type=int, nargs=3, default=None, help='volume workloads: z y x of the synthetic volume')
     args = ap.parse_args()
+    if args.workload != 'config2':
+        return volume_main(args)
 
     from syconn_amd import _lib as L
     from syconn_amd import parallel as par
@@ -332,6 +339,94 @@ def main():
     if world > 1:
         par.barrier()
         torch.distributed.destroy_process_group()
+
+
+# ---- BASELINE configs[2..4]: whole volumes, chunk-parallel ------------------------------------------------------------
+VOLUME_WORKLOADS = {
+    # name: (arch, act, default volume z,y,x, what BASELINE.json calls it)
+    'config3': ('semseg_axon', 'bf16', (512, 512, 512), 'configs[2]: semseg_axon 3D U-Net, 512^3 volume in overlapping 128^3 tiles'),
+    'config4': ('myelin', 'bf16', (512, 2048, 2048), 'configs[3]: 2048x2048x512 synthetic KnossosDataset volume, chunk-parallel, '
+                                                     'RCCL scatter / gather'),
+    'config5': ('mivcsj', 'f16', (512, 2048, 2048), 'configs[4]: 3-head mito/vesicle/synapse dense prediction, fp16, '
+                                                    'overlap-and-crop stitching'),
+}
+
+
+def synthetic_volume(shape, seed):
+    """(z,y,x) uint8 volume: a 128^3 block of structured synthetic EM repeated with flips (cheap for 2 GiB volumes)."""
+    blk = synthetic_em_tiles(1, 128, seed)[0]
+    reps = [-(-s // 128) for s in shape]
+    vol = np.tile(blk, reps)[:shape[0], :shape[1], :shape[2]]
+    return np.ascontiguousarray(vol)
+
+
+def volume_main(args):
+    """One step = the whole volume, host to host: rank 0 holds the uint8 volume in host memory, chunks (+ halo) are dealt
+    round-robin to the ranks (== chunkify, /root/reference/syconn/handler/prediction.py:708-709) over RCCL, every rank
+    predicts its chunks tile by tile, the uint8 results are gathered and stitched in rank 0's host memory
+    (syconn_amd.parallel.predict_volume_distributed, scatter / predict / gather overlapped).  Strong scaling."""
+    from syconn_amd import parallel as par
+    from syconn_amd.cnn import random_state_dict
+    from syconn_amd.handler.prediction import Predictor
+    arch, act, vol_default, what = VOLUME_WORKLOADS[args.workload]
+    vol_shape = tuple(args.volume) if args.volume else vol_default
+    one_gpu_debug = bool(os.environ.get('SD_BENCH_ONE_GPU_DEBUG'))
+    rank, world, local_rank = par.init_distributed('gloo' if one_gpu_debug else None)
+    if one_gpu_debug:
+        local_rank = 0
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+    sd = random_state_dict(arch, seed=0 if rank == 0 else 1000 + rank, final_scale=BENCH_FINAL_SCALE)
+    par.broadcast_weights(sd, src=0, device=dev)
+    if args.geometry == 'reference':      # prediction.py:672-677 (x,y,z) -> (z,y,x)
+        chunk, halo, tile = (236, 481, 482), (20, 31, 30), (138, 181, 271)
+    else:                                 # SURVEY.md 8d: model tile 128^3 = useful (112,96,96) + halo (8,16,16); 2x2x2 tiles per chunk
+        chunk, halo, tile = (224, 192, 192), (8, 16, 16), (112, 96, 96)
+    pred = Predictor(sd, device=dev, tile_shape=tile, overlap_shape=halo, apply_softmax=True, act_dtype=act)
+    ncls = pred.out_channels
+    ids, thr = list(range(1, ncls)), [127.5] * (ncls - 1)      # channel_thresholds None -> 255/2 (prediction.py:824-825)
+    in_halo = args.geometry != 'reference'
+
+    def predict_fn(ch):
+        """chunk + halo (uint8, device) -> (1, *chunk) uint8: a multi-id target gives the label volume (mivcsj: ids 1,2,3),
+        a two-class model the probability map of channel 1 (myelin), as exec_dense_prediction binds them.
+        tile128: the halo is real neighbouring data and the tile grid continues across chunks; reference: the chunk + halo
+        is zero-padded and tiled like /root/reference/syconn/handler/prediction.py:775-781, then the halo is cropped (:812)."""
+        if ncls > 2:
+            r = pred.predict_labels_u8_device(ch, ids, thr, halo_included=in_halo)[None]
+        else:
+            r = pred.predict_proba_u8_device(ch, halo_included=in_halo)[1:2]
+        return r if in_halo else _crop(r, halo)
+    vol = torch.from_numpy(synthetic_volume(vol_shape, seed=3)).pin_memory() if rank == 0 else None
+    steps, warm = (args.steps if args.steps != 20 else 2), min(args.warmup, 1)
+    for _ in range(warm):
+        par.predict_volume_distributed(vol, vol_shape, chunk, halo, predict_fn, n_out=1, device=dev)
+    out = [None]
+
+    def step():
+        out[0] = par.predict_volume_distributed(vol, vol_shape, chunk, halo, predict_fn, n_out=1, device=dev)
+    elapsed = timed(step, lambda: None, steps, par, dev)
+    nvox = float(np.prod(vol_shape))
+    if rank == 0:
+        nchunks = int(np.prod([-(-v // c) for v, c in zip(vol_shape, chunk)]))
+        line = {'metric': 'segmented Mvoxels/s (whole node), whole volume host to host', 'value': nvox * steps / elapsed / 1e6,
+                'unit': 'Mvox/s', 'n_gpus': world, 'steps': steps, 'warmup': warm, 'ms_per_step': elapsed / steps * 1e3,
+                'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': act, 'data': 'synthetic',
+                'config': {'workload': f'BASELINE {what}; {arch}, volume z,y,x = {vol_shape}, geometry {args.geometry}: chunks '
+                                       f'{chunk} + halo {halo}, model tiles {tuple(t + 2 * h for t, h in zip(tile, halo))}, '
+                                       f'{nchunks} chunks dealt round-robin over {world} rank(s)',
+                           'parallelism': f'chunk-sharded x{world}', 'output_classes_nonzero': int((out[0] > 0).float().mean() > 0),
+                           'collective': 'RCCL scatter of uint8 chunks / gather of uint8 results, rank 0 host memory' if world > 1 else 'none'}}
+        print(json.dumps(line))
+    if world > 1:
+        par.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def _crop(t, halo):
+    return t[:, halo[0]:t.shape[1] - halo[0], halo[1]:t.shape[2] - halo[1], halo[2]:t.shape[3] - halo[2]].contiguous()
 
 
 def cpu_baseline(args, sd, dm, tiles_host, ids, L):

@@ -219,6 +219,14 @@ int sd_object_segmentation(const uint8_t* prob_dev, int X, int Y, int Z, double 
                            int32_t* labels_dev, int32_t* max_label_dev, uint8_t* mask_out_dev, void* workspace_dev,
                            size_t ws_bytes, void* stream);
 
+/* ---- host-side helpers of the chunk pipeline (no GPU) -----------------------------------------------------------------
+ * Multi-threaded strided copy of an (nz, ny, nx)-byte box between two uint8 host arrays whose x-rows are contiguous
+ * (strides in bytes), and a multi-threaded memset: what numpy slicing does on one core when the reference cuts a chunk
+ * (+ halo) out of a volume and crops the result (/root/reference/syconn/handler/prediction.py:806-812). */
+int sd_host_box_copy(const uint8_t* src, int64_t src_stride_z, int64_t src_stride_y, uint8_t* dst, int64_t dst_stride_z,
+                     int64_t dst_stride_y, int64_t nz, int64_t ny, int64_t nx, int n_threads);
+int sd_host_zero(uint8_t* dst, int64_t nbytes, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif

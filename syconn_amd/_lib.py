@@ -21,7 +21,7 @@ EXPORTS = ['sd_init', 'sd_device_count', 'sd_model_create', 'sd_model_destroy', 
            'sd_debug_read_buffer', 'sd_model_num_ops', 'sd_last_error', 'sd_version', 'sd_snappy_max_compressed_length',
            'sd_snappy_compress', 'sd_snappy_uncompressed_length', 'sd_snappy_uncompress', 'sd_downsample2', 'sd_box_majority',
            'sd_objtable_bytes', 'sd_pairtable_bytes', 'sd_segstats_scan', 'sd_segstats_compact_objects',
-           'sd_segstats_compact_pairs', 'sd_objseg_workspace_bytes', 'sd_object_segmentation']
+           'sd_segstats_compact_pairs', 'sd_objseg_workspace_bytes', 'sd_object_segmentation', 'sd_host_box_copy', 'sd_host_zero']
 
 
 class OpDesc(C.Structure):
@@ -90,6 +90,9 @@ def load():
     lib.sd_object_segmentation.argtypes = [vp, i32, i32, i32, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32), i32,
                                            vp, i32, i32, i32, vp, vp, vp, vp, sz, vp]
     lib.sd_object_segmentation.restype = i32
+    i64 = C.c_int64
+    lib.sd_host_box_copy.argtypes = [vp, i64, i64, vp, i64, i64, i64, i64, i64, i32]; lib.sd_host_box_copy.restype = i32
+    lib.sd_host_zero.argtypes = [vp, i64, i32]; lib.sd_host_zero.restype = i32
     _lib = lib
     return lib
 
@@ -104,6 +107,25 @@ def check(rc: int, what: str = ''):
     if rc == SD_ERR_INVALID:
         raise ValueError(text)
     raise RuntimeError(text)
+
+
+def host_box_copy(dst, src, n_threads: int = 16):
+    """dst[...] = src for two 3D uint8 CPU tensors / arrays of equal shape whose last axis is contiguous (views into larger
+    volumes are the point), copied row by row on `n_threads` host threads by the C helper."""
+    import torch
+    d = dst if isinstance(dst, torch.Tensor) else torch.from_numpy(dst)
+    s = src if isinstance(src, torch.Tensor) else torch.from_numpy(src)
+    assert d.dtype == torch.uint8 and s.dtype == torch.uint8 and d.dim() == 3 and tuple(d.shape) == tuple(s.shape)
+    assert (d.stride(2) == 1 or d.shape[2] <= 1) and (s.stride(2) == 1 or s.shape[2] <= 1)
+    rc = load().sd_host_box_copy(s.data_ptr(), s.stride(0), s.stride(1), d.data_ptr(), d.stride(0), d.stride(1),
+                                 d.shape[0], d.shape[1], d.shape[2], int(n_threads))
+    if rc != SD_OK:
+        raise ValueError('sd_host_box_copy: bad argument')
+
+
+def host_zero(t, n_threads: int = 16):
+    assert t.is_contiguous() and t.dtype.itemsize == 1
+    load().sd_host_zero(t.data_ptr(), t.numel(), int(n_threads))
 
 
 # -- snappy raw format (host side; the codec of the KNOSSOS ``*.seg.sz.zip`` overlay cubes) ---------------------------

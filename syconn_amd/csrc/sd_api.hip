@@ -3,6 +3,7 @@
 #include "sd_internal.h"
 #include "../../include/syconn_dense.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
@@ -84,6 +85,7 @@ struct sd_model {
     std::vector<hipEvent_t> events;    // [slot][n_ops + 1]
     int final_cout = 0;
     bool keep_all = false;   // SD_KEEP_ALL=1: also store activations that only feed a fused consumer (tests)
+    bool ws_reuse = true;    // activation buffers with disjoint lifetimes share workspace memory
 };
 
 namespace {
@@ -126,15 +128,59 @@ int infer_shapes(const sd_model* m, int D, int H, int W, std::vector<Dims>& dims
     return SD_OK;
 }
 
+// Workspace layout for one tile.  Every activation buffer lives from the op that writes it to the last op that reads
+// it; buffers whose lifetimes do not overlap share memory (first-fit over the buffers in order of their first write).
+// A U-Net keeps only the encoder skip tensors alive across the bottleneck, so a 178x243x331 reference-geometry tile needs
+// about a third of the sum of all activations -- which is what lets several such tiles run in one launch set.
+// `reuse == false` (SD_KEEP_ALL / SD_NO_FUSE / SD_NO_WS_REUSE: layer-wise debugging reads buffers back after the
+// forward) gives every buffer its own range.
 size_t plan_workspace(const sd_model* m, const std::vector<Dims>& dims, std::vector<size_t>& off) {
-    off.assign(m->nbuf, 0);
-    size_t cur = WS_SCRATCH;
-    for (int b = 1; b < m->nbuf; ++b) {
-        off[b] = cur;
-        const size_t bytes = (size_t)dims[b].d * dims[b].h * dims[b].w * m->bufCp[b] * 2;
-        cur += rup_sz(bytes, 256);
+    const int nb = m->nbuf;
+    off.assign(nb, 0);
+    std::vector<size_t> bytes(nb, 0);
+    for (int b = 1; b < nb; ++b) bytes[b] = rup_sz((size_t)dims[b].d * dims[b].h * dims[b].w * m->bufCp[b] * 2, 256);
+    if (!m->ws_reuse) {
+        size_t cur = WS_SCRATCH;
+        for (int b = 1; b < nb; ++b) { off[b] = cur; cur += bytes[b]; }
+        return cur;
     }
-    return cur;
+    const int nops = (int)m->ops.size();
+    std::vector<int> first(nb, nops), last(nb, -1);
+    auto touch_w = [&](int b, int i) { if (b > 0) { first[b] = std::min(first[b], i); last[b] = std::max(last[b], i); } };
+    auto touch_r = [&](int b, int i) { if (b > 0) last[b] = std::max(last[b], i); };
+    for (int i = 0; i < nops; ++i) {
+        const Op& op = m->ops[i];
+        const sd_op_desc& d = op.d;
+        touch_r(d.src0, i);
+        touch_r(d.src1, i);
+        if (d.kind != SD_OP_FINAL) touch_w(d.dst, i);
+        // outputs of ops executed inside this op's launch are written NOW, not at their own position in the plan
+        if (op.fuse_pool >= 0) touch_w(m->ops[op.fuse_pool].d.dst, i);
+        if (op.gn_pool >= 0) touch_w(m->ops[op.gn_pool].d.dst, i);
+        // a first convolution computed inside its consumer may also run as its own launch (decided per launch)
+    }
+    std::vector<int> order;
+    for (int b = 1; b < nb; ++b)
+        if (last[b] >= 0 && bytes[b]) order.push_back(b);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return first[a] != first[b] ? first[a] < first[b] : a < b; });
+    std::vector<int> placed;
+    size_t top = WS_SCRATCH;
+    for (int b : order) {
+        // candidate offsets: scratch end and the end of every placed buffer that is alive at the same time
+        std::vector<std::pair<size_t, size_t>> busy;      // [begin, end) ranges this buffer must avoid
+        for (int q : placed)
+            if (first[q] <= last[b] && first[b] <= last[q]) busy.push_back({off[q], off[q] + bytes[q]});
+        std::sort(busy.begin(), busy.end());
+        size_t cur = WS_SCRATCH;
+        for (const auto& r : busy) {
+            if (cur + bytes[b] <= r.first) break;
+            cur = std::max(cur, r.second);
+        }
+        off[b] = cur;
+        top = std::max(top, cur + bytes[b]);
+        placed.push_back(b);
+    }
+    return top;
 }
 
 }  // namespace
@@ -168,6 +214,7 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
     sd_model* m = new sd_model();
     m->act_dtype = act_dtype;
     m->keep_all = getenv("SD_KEEP_ALL") != nullptr;
+    m->ws_reuse = !m->keep_all && !getenv("SD_NO_FUSE") && !getenv("SD_NO_WS_REUSE");
     if (hipGetDevice(&m->device) != hipSuccess) { delete m; return fail(SD_ERR_NODEVICE, "no current HIP device"); }
 
     auto chk = [&](int64_t off, size_t n) { return off >= 0 && (size_t)off + n <= n_floats; };

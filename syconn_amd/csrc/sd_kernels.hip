@@ -1453,24 +1453,15 @@ static int launch_conv_knt(const ConvParams& p, int NB, hipStream_t s) {
     // workgroups still share a CU (level-0 layers); else streamed weights, one block per workgroup.  Deeper rings
     // (NSLOT 4/6, one workgroup per CU) were measured SLOWER on the level-0 layers (1.32 vs 1.23 ms per tile): those
     // layers are bound by per-wave instruction latency, not by bytes in flight, so resident waves win over ring depth.
-    static const int l0_mode = getenv("SD_L0") ? atoi(getenv("SD_L0")) : 0;   // experiment: MT=4 tiles for NT=1 layers
+    // (NT = 1 layers with 4 voxel tiles per wave -- 8 waves x 1024 voxels or 4 waves x 512 voxels -- measured SLOWER than the
+    // 2-tile form, op19 54 -> 59 us per tile: these layers live on resident waves per CU, not on LDS reads per MFMA)
     if constexpr (KZ == 1 && NT <= 2) {
         if (p.first_in) {
             if (!conv_can_fuse_first(KZ, NT, NB, vox, nstages, p.final_wfrag != nullptr)) return SD_ERR_INVALID;
-            if constexpr (NT == 1) {
-                if (l0_mode == 1) return launch_conv_k<T, KZ, NT, 8, 2, 4, true>(p, NB, s);
-                if (l0_mode == 2) return launch_conv_k<T, KZ, NT, 4, 2, 4, true>(p, NB, s);
-            }
             return launch_conv_k<T, KZ, NT, 8, 2, 2, true>(p, NB, s);
         }
     } else if (p.first_in) {
         return SD_ERR_INVALID;
-    }
-    if constexpr (KZ == 1 && NT == 1) {
-        if (big && l0_mode == 1 && conv_lds_bytes<KZ, NT, 8, 4, 2>(nstages, p.final_wfrag != nullptr) <= 150 * 1024)
-            return launch_conv_k<T, KZ, NT, 8, 2, 4>(p, NB, s);
-        if (big && l0_mode == 2 && conv_lds_bytes<KZ, NT, 4, 4, 2>(nstages, p.final_wfrag != nullptr) <= 96 * 1024)
-            return launch_conv_k<T, KZ, NT, 4, 2, 4>(p, NB, s);
     }
     if (big) {
         if (conv_lds_bytes<KZ, NT, 8, 2, 2>(nstages, p.final_wfrag != nullptr) <= 96 * 1024) return launch_conv_k<T, KZ, NT, 8, 2>(p, NB, s);

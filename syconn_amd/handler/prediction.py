@@ -137,14 +137,19 @@ class Predictor:
         ntiles = np.ceil(spatial / tile).astype(np.int64)
         return tile, ol, ntiles
 
-    def _tiled(self, vol: torch.Tensor, out: torch.Tensor, out_kind: int, label_args=None):
+    def _tiled(self, vol: torch.Tensor, out: torch.Tensor, out_kind: int, label_args=None, halo_included: bool = False):
         """tiled_apply (elektronn3) on the device: zero-padded tile extraction, forward,
-        crop of the overlap, write into `out` (C,D,H,W).  vol: (D,H,W) uint8 / float32 on the device."""
+        crop of the overlap, write into `out` (C,D,H,W).  vol: (D,H,W) uint8 / float32 on the device.
+        `halo_included`: `vol` already carries `overlap_shape` voxels of REAL neighbouring data per side (zeros where the
+        dataset ends) instead of being zero-padded here; `out` then covers the inner region only.  This is how a chunk of a
+        larger volume is predicted so that the result equals the same tile grid run over the whole volume."""
         from ..engine import tile_gather, tile_scatter
-        spatial = np.asarray(vol.shape, dtype=np.int64)
+        ol_in = np.zeros(3, dtype=np.int64) if self.overlap_shape is None else self.overlap_shape
+        spatial = np.asarray(vol.shape, dtype=np.int64) - (2 * ol_in if halo_included else 0)
+        shift = ol_in if halo_included else np.zeros(3, dtype=np.int64)
         tile, ol, ntiles = self._geometry(spatial)
         tin = tile + 2 * ol
-        single = bool(np.all(ntiles == 1) and np.all(ol == 0) and np.all(tile == spatial))
+        single = bool(np.all(ntiles == 1) and np.all(ol == 0) and np.all(tile == spatial) and not halo_included)
         nch = 1 if label_args is not None else self.out_channels
 
         def run(inp, outp, slot):           # inp (n,D,H,W) -> outp (n,nch,D,H,W)
@@ -171,7 +176,7 @@ class Predictor:
                 with ring.stream(i):
                     for j, pos in enumerate(group):
                         lo = tile * np.asarray(pos, dtype=np.int64)
-                        tile_gather(vol, lo - ol, tin, tbuf[k][j])
+                        tile_gather(vol, lo - ol + shift, tin, tbuf[k][j])
                     n = len(group)
                     run(tbuf[k][:n], obuf[k][:n], k)
                     for j, pos in enumerate(group):
@@ -213,7 +218,7 @@ class Predictor:
         return out
 
     @torch.no_grad()
-    def predict_proba_u8_device(self, raw_u8: torch.Tensor) -> torch.Tensor:
+    def predict_proba_u8_device(self, raw_u8: torch.Tensor, halo_included: bool = False) -> torch.Tensor:
         """Fast path of ``dense_predicton_helper(raw.astype(float32)/255., self)``: `raw_u8` is the (D,H,W) uint8
         chunk ON THE DEVICE; returns uint8 ``floor(255*softmax)`` (C,D,H,W) on the device.  Bit-identical to the
         slow path by construction: the kernel normalises with the table float32(v)/255 (prediction.py:808) and
@@ -223,13 +228,15 @@ class Predictor:
         assert raw_u8.dtype == torch.uint8 and raw_u8.dim() == 3
         torch.cuda.set_device(self.device)
         raw_u8 = raw_u8.contiguous()
-        out = torch.empty((self.out_channels, *raw_u8.shape), dtype=torch.uint8, device=self.device)
-        self._tiled(raw_u8, out, L.SD_OUT_PROBS_U8)
+        inner = tuple(int(s) - (2 * int(o) if halo_included else 0) for s, o in
+                      zip(raw_u8.shape, (self.overlap_shape if self.overlap_shape is not None else (0, 0, 0))))
+        out = torch.empty((self.out_channels, *inner), dtype=torch.uint8, device=self.device)
+        self._tiled(raw_u8, out, L.SD_OUT_PROBS_U8, halo_included=halo_included)
         return out
 
 
     @torch.no_grad()
-    def predict_labels_u8_device(self, raw_u8: torch.Tensor, ids, thresholds) -> torch.Tensor:
+    def predict_labels_u8_device(self, raw_u8: torch.Tensor, ids, thresholds, halo_included: bool = False) -> torch.Tensor:
         """`predict_proba_u8_device` followed by the label rule of dense_predictor (prediction.py:813-833) for ONE
         multi-id target, evaluated in the network's final epilogue: (D,H,W) uint8 labels on the device.  `thresholds`
         are the resolved uint8-scale values, one per id."""
@@ -238,8 +245,11 @@ class Predictor:
         assert raw_u8.dtype == torch.uint8 and raw_u8.dim() == 3
         torch.cuda.set_device(self.device)
         raw_u8 = raw_u8.contiguous()
-        out = torch.empty((1, *raw_u8.shape), dtype=torch.uint8, device=self.device)
-        self._tiled(raw_u8, out, L.SD_OUT_PROBS_U8, label_args=([int(i) for i in ids], [float(t) for t in thresholds]))
+        inner = tuple(int(s) - (2 * int(o) if halo_included else 0) for s, o in
+                      zip(raw_u8.shape, (self.overlap_shape if self.overlap_shape is not None else (0, 0, 0))))
+        out = torch.empty((1, *inner), dtype=torch.uint8, device=self.device)
+        self._tiled(raw_u8, out, L.SD_OUT_PROBS_U8, label_args=([int(i) for i in ids], [float(t) for t in thresholds]),
+                    halo_included=halo_included)
         return out[0]
 
 

@@ -16,6 +16,7 @@ from typing import List, Optional, Sequence
 import torch
 import torch.distributed as dist
 
+from ._lib import host_box_copy, host_zero
 from .handler.basics import chunkify
 
 
@@ -116,63 +117,175 @@ def gather_to_root(local: torch.Tensor, dst: int = 0, async_op: bool = False, ou
     return bufs, (work if async_op else None)
 
 
-def scatter_from_root(payloads: Optional[Sequence[torch.Tensor]], like: torch.Tensor, src: int = 0) -> torch.Tensor:
-    """Coll-2: rank `src` hands payloads[r] (all shaped like `like`) to rank r; returns this rank's payload."""
+def scatter_from_root(payloads: Optional[Sequence[torch.Tensor]], like: torch.Tensor, src: int = 0, async_op: bool = False,
+                      out: Optional[torch.Tensor] = None):
+    """Coll-2: rank `src` hands payloads[r] (all shaped like `like`) to rank r; returns this rank's payload (and the
+    work handle when `async_op`)."""
     rank, world = world_info()
     if world == 1:
-        return payloads[0]
-    out = torch.empty_like(like)
-    dist.scatter(out, scatter_list=[p.contiguous() for p in payloads] if rank == src else None, src=src)
-    return out
+        return (payloads[0], None) if async_op else payloads[0]
+    if out is None:
+        out = torch.empty_like(like)
+    work = dist.scatter(out, scatter_list=[p.contiguous() for p in payloads] if rank == src else None, src=src,
+                        async_op=async_op)
+    return (out, work) if async_op else out
+
+
+_PINNED = {}
 
 
 def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Sequence[int], chunk_shape: Sequence[int],
-                               halo: Sequence[int], predict_fn, n_out: int, device=None) -> Optional[torch.Tensor]:
+                               halo: Sequence[int], predict_fn, n_out: int, device=None,
+                               pipelined: bool = True) -> Optional[torch.Tensor]:
     """Chunk-parallel dense prediction of one (z,y,x) uint8 volume over all ranks of the process group: the RCCL
     variant of the reference's "one worker per GPU, chunk ids dealt round-robin" (prediction.py:708-719), with the
     file system replaced by collectives.
 
-    Rank 0 holds `volume_u8` (other ranks pass None).  Chunks of `chunk_shape` are enumerated z-major; chunk i
-    belongs to rank ``i % world`` (== ``chunkify``).  Per round rank 0 cuts ``world`` chunks incl. `halo` (zeros
-    outside the volume, like ``kd.load_raw``) and scatters them; every rank runs
-    ``predict_fn(chunk_with_halo_u8) -> uint8 (n_out, *chunk_shape)`` (halo already cropped) and rank 0 gathers
-    the results into the output volume.  Returns (n_out, *vol_shape) uint8 on rank 0, None elsewhere."""
+    Rank 0 holds `volume_u8` in HOST memory (other ranks pass None); the (n_out, *vol_shape) uint8 result is assembled
+    in host memory on rank 0 as well (None elsewhere) -- rank 0's device only ever holds the payloads of two rounds.
+    Chunks of `chunk_shape` are enumerated z-major; chunk i belongs to rank ``i % world`` (== ``chunkify``).  Per round
+    rank 0 cuts ``world`` chunks incl. `halo` (zeros outside the volume, like ``kd.load_raw``) into pinned staging
+    buffers, uploads and scatters them; every rank runs ``predict_fn(chunk_with_halo_u8) -> uint8 (n_out, *chunk_shape)``
+    (halo already cropped) and rank 0 gathers the results, downloads them and stitches them into the output.
+
+    With `pipelined` the stages overlap (two buffer sets, copy streams beside the compute stream, asynchronous
+    collectives): while the GPUs predict round k, rank 0's host packs and uploads round k+1 and stitches round k-1.
+    Without it every round runs scatter -> predict -> gather -> stitch strictly in sequence (A/B and debugging)."""
     import itertools
     import numpy as np
     rank, world = world_info()
     vs, cs, ol = (np.asarray(v, dtype=np.int64) for v in (vol_shape, chunk_shape, halo))
     grid = [int(-(-vs[i] // cs[i])) for i in range(3)]
     ids = list(itertools.product(*[range(g) for g in grid]))
+    rounds = [ids[r0:r0 + world] for r0 in range(0, len(ids), world)]
     in_shape = tuple(int(v) for v in cs + 2 * ol)
-    like = torch.empty(in_shape, dtype=torch.uint8, device=device)
-    like_out = torch.empty((n_out, *[int(c) for c in cs]), dtype=torch.uint8, device=device)
-    out = padded = None
-    if rank == 0:
-        out = torch.zeros((n_out, *[int(g * c) for g, c in zip(grid, cs)]), dtype=torch.uint8, device=device)
-        padded = torch.zeros(tuple(int(g * c + 2 * o) for g, c, o in zip(grid, cs, ol)), dtype=torch.uint8,
-                             device=device)
-        padded[ol[0]:ol[0] + vs[0], ol[1]:ol[1] + vs[1], ol[2]:ol[2] + vs[2]] = volume_u8.to(device)
-    for r0 in range(0, len(ids), world):
-        batch = ids[r0:r0 + world]
-        payloads = None
-        if rank == 0:
-            payloads = []
-            for k in range(world):
-                if k < len(batch):
-                    z, y, x = (int(batch[k][i] * cs[i]) for i in range(3))
-                    payloads.append(padded[z:z + in_shape[0], y:y + in_shape[1], x:x + in_shape[2]].contiguous())
-                else:
-                    payloads.append(torch.zeros_like(like))
-        mine = scatter_from_root(payloads, like, src=0)
-        res = predict_fn(mine) if rank < len(batch) else torch.zeros_like(like_out)
-        bufs, _ = gather_to_root(res.contiguous(), dst=0)
-        if rank == 0:
-            for k in range(len(batch)):
-                z, y, x = (int(batch[k][i] * cs[i]) for i in range(3))
-                out[:, z:z + cs[0], y:y + cs[1], x:x + cs[2]] = bufs[k]
-    if rank == 0:
-        return out[:, :vs[0], :vs[1], :vs[2]].contiguous()
-    return None
+    out_shape = (n_out, *[int(c) for c in cs])
+    cuda = device is not None and torch.device(device).type == 'cuda'
+    root = rank == 0
+
+    def pinned(shape, tag):
+        # page-locked staging is expensive to create: kept across calls (one volume after another through the same geometry)
+        key = (tag, tuple(shape), cuda)
+        t = _PINNED.get(key)
+        if t is None:
+            t = torch.empty(shape, dtype=torch.uint8)
+            t = t.pin_memory() if cuda else t
+            if len(_PINNED) > 16:
+                _PINNED.clear()
+            _PINNED[key] = t
+        return t
+
+    in_buf = [torch.empty(in_shape, dtype=torch.uint8, device=device) for _ in range(2)]
+    res_buf = [torch.empty(out_shape, dtype=torch.uint8, device=device) for _ in range(2)]
+    out = vol = None
+    if root:
+        vol = (volume_u8.cpu() if volume_u8.is_cuda else volume_u8).contiguous()
+        out = torch.empty((n_out, *[int(v) for v in vs]), dtype=torch.uint8)
+        pin_in = [pinned((world, *in_shape), ('in', i)) for i in range(2)]       # packed payloads of a round
+        pin_out = [pinned((world, *out_shape), ('out', i)) for i in range(2)]    # gathered results of a round
+        stage = [torch.empty((world, *in_shape), dtype=torch.uint8, device=device) for _ in range(2)] if world > 1 else None
+        recv = [torch.empty((world, *out_shape), dtype=torch.uint8, device=device) for _ in range(2)] if world > 1 else None
+    else:
+        recv = None
+    if cuda:
+        cur = torch.cuda.current_stream(device)
+        s_in, s_out = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
+        ev_h2d = [torch.cuda.Event() for _ in range(2)]
+        ev_pred = [torch.cuda.Event() for _ in range(2)]
+        ev_d2h = [torch.cuda.Event() for _ in range(2)]
+    used = [False, False]
+
+    def pack(r):
+        """host: cut the chunk + halo boxes of round r out of the volume into pin_in[r % 2] (zeros outside the volume)"""
+        s = r & 1
+        if cuda and used[s]:
+            ev_h2d[s].synchronize()                              # the upload of round r-2 has left this staging buffer
+        for k in range(world):
+            dst = pin_in[s][k]
+            if k >= len(rounds[r]):
+                host_zero(dst)
+                continue
+            lo = np.asarray(rounds[r][k], dtype=np.int64) * cs - ol
+            hi = lo + np.asarray(in_shape, dtype=np.int64)
+            a, b = np.maximum(lo, 0), np.minimum(hi, vs)
+            if np.any(a > lo) or np.any(b < hi):
+                host_zero(dst)
+            if np.all(b > a):       # strided box copy on host threads (C helper; numpy / torch slicing runs on one core)
+                host_box_copy(dst[a[0] - lo[0]:b[0] - lo[0], a[1] - lo[1]:b[1] - lo[1], a[2] - lo[2]:b[2] - lo[2]],
+                              vol[a[0]:b[0], a[1]:b[1], a[2]:b[2]])
+
+    def issue_scatter(r):
+        """upload + scatter round r into in_buf[r % 2]; returns the collective's work handle (None for world size 1)"""
+        s = r & 1
+        work = None
+        if root:
+            pack(r)
+            target = stage[s] if world > 1 else in_buf[s]
+            if cuda:
+                with torch.cuda.stream(s_in):
+                    if used[s]:
+                        s_in.wait_event(ev_pred[s])              # the kernels of round r-2 have consumed in_buf / stage
+                    target.copy_(pin_in[s] if world > 1 else pin_in[s][0], non_blocking=True)
+                    ev_h2d[s].record(s_in)
+                cur.wait_event(ev_h2d[s])
+            else:
+                target.copy_(pin_in[s] if world > 1 else pin_in[s][0])
+        if world > 1:
+            _, work = scatter_from_root(list(stage[s].unbind(0)) if root else None, in_buf[s], src=0, async_op=True,
+                                        out=in_buf[s])
+        return work
+
+    def issue_gather(r):
+        """gather round r's results to rank 0 and download them into pin_out[r % 2] (asynchronously)"""
+        s = r & 1
+        if world > 1:
+            _, work = gather_to_root(res_buf[s], dst=0, async_op=True, out=recv[s] if root else None)
+            work.wait()                                          # NCCL: stream-level dependency; gloo: host wait
+        if cuda:
+            ev_pred[s].record(cur)
+        if root:
+            src = recv[s] if world > 1 else res_buf[s]
+            if cuda:
+                with torch.cuda.stream(s_out):
+                    s_out.wait_event(ev_pred[s])
+                    (pin_out[s] if world > 1 else pin_out[s][0]).copy_(src, non_blocking=True)
+                    ev_d2h[s].record(s_out)
+            else:
+                (pin_out[s] if world > 1 else pin_out[s][0]).copy_(src)
+        used[s] = True
+
+    def stitch(r):
+        """host: results of round r (pin_out[r % 2]) -> output volume"""
+        if not root:
+            return
+        s = r & 1
+        if cuda:
+            ev_d2h[s].synchronize()
+        for k in range(len(rounds[r])):
+            lo = np.asarray(rounds[r][k], dtype=np.int64) * cs
+            n = np.minimum(cs, vs - lo)
+            for c in range(n_out):
+                host_box_copy(out[c, lo[0]:lo[0] + n[0], lo[1]:lo[1] + n[1], lo[2]:lo[2] + n[2]],
+                              pin_out[s][k][c, :n[0], :n[1], :n[2]])
+
+    pend = issue_scatter(0) if rounds else None
+    for r in range(len(rounds)):
+        s = r & 1
+        if pend is not None:
+            pend.wait()
+        if rank < len(rounds[r]):
+            res_buf[s].copy_(predict_fn(in_buf[s]))
+        else:
+            res_buf[s].zero_()
+        issue_gather(r)
+        if not pipelined:
+            stitch(r)
+        pend = issue_scatter(r + 1) if r + 1 < len(rounds) else None     # host packs the next round while the GPUs compute
+        if pipelined and r >= 1:
+            stitch(r - 1)
+    if pipelined and rounds:
+        stitch(len(rounds) - 1)
+    return out if root else None
 
 
 def barrier():

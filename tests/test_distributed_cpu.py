@@ -107,10 +107,16 @@ def _worker_volume(rank, world, port, q):
         m = torch.nn.functional.max_pool3d(x, 3, stride=1, padding=1)[0, 0]
         core = m[halo[0]:-halo[0], halo[1]:-halo[1], halo[2]:-halo[2]]
         return torch.stack([core.to(torch.uint8), (255 - core).to(torch.uint8)])
-    out = par.predict_volume_distributed(vol, vol_shape, chunk, halo, predict_fn, n_out=2)
+    ok = True
+    for pipelined in (True, False):      # overlapped scatter / predict / gather and the lock-step variant: same result
+        out = par.predict_volume_distributed(vol, vol_shape, chunk, halo, predict_fn, n_out=2, pipelined=pipelined)
+        if rank == 0:
+            ref = torch.nn.functional.max_pool3d(vol[None, None].float(), 3, stride=1, padding=1)[0, 0].to(torch.uint8)
+            ok = ok and bool(torch.equal(out[0], ref) and torch.equal(out[1], 255 - ref))
+        else:
+            ok = ok and out is None
     if rank == 0:
-        ref = torch.nn.functional.max_pool3d(vol[None, None].float(), 3, stride=1, padding=1)[0, 0].to(torch.uint8)
-        q.put(bool(torch.equal(out[0], ref) and torch.equal(out[1], 255 - ref)))
+        q.put(ok)
     dist.destroy_process_group()
 
 
@@ -127,3 +133,18 @@ def test_two_rank_chunk_scatter_predict_gather():
         p.join(60)
         assert p.exitcode == 0
     assert ok, 'distributed chunk prediction does not reproduce the single-process result'
+
+
+def test_single_process_volume_prediction_is_the_same_code_path():
+    """world size 1 (no process group): the pipelined chunk loop must reproduce the whole-volume result as well."""
+    from syconn_amd import parallel as par
+    vol_shape, chunk, halo = (17, 20, 33), (8, 8, 16), (1, 2, 3)
+    vol = torch.from_numpy(np.random.default_rng(1).integers(0, 255, vol_shape, dtype=np.uint8))
+
+    def predict_fn(ch):
+        m = torch.nn.functional.max_pool3d(ch[None, None].float(), 3, stride=1, padding=1)[0, 0]
+        return m[halo[0]:-halo[0], halo[1]:-halo[1], halo[2]:-halo[2]].to(torch.uint8)[None]
+    ref = torch.nn.functional.max_pool3d(vol[None, None].float(), 3, stride=1, padding=1)[0, 0].to(torch.uint8)
+    for pipelined in (True, False):
+        out = par.predict_volume_distributed(vol, vol_shape, chunk, halo, predict_fn, n_out=1, pipelined=pipelined)
+        assert torch.equal(out[0], ref)

@@ -394,3 +394,27 @@ def test_reference_geometry_chunk_properties(gpu):
     sub[20:, :, 30:] = raw[0:158, 150:393, 0:301]
     one = Predictor(model, apply_softmax=True).predict_proba_u8_device(sub)
     assert torch.equal(one[:, 20:158, 31:212, 30:301], a[:, 0:138, 181:362, 0:271])
+
+
+def test_chunked_volume_prediction_equals_whole_volume_tiling(gpu):
+    """BASELINE configs[2]-[4] geometry: chunks that carry a halo of real neighbouring data and continue the tile grid
+    (`halo_included`) must reproduce the labels of the same tile grid run over the whole volume in one Predictor call --
+    through parallel.predict_volume_distributed (world size 1: same code path as the multi-GPU run, no collectives)."""
+    from syconn_amd import parallel as par
+    from syconn_amd.cnn import random_state_dict
+    from syconn_amd.handler.prediction import Predictor
+    sd = random_state_dict('semseg_spine', seed=3, final_scale=8.0, n_blocks=3, start_filts=16)
+    tile, halo, chunk = (16, 24, 24), (4, 8, 8), (32, 48, 24)
+    vol_shape = (70, 100, 50)                     # not a multiple of the chunk nor of the tile
+    vol = torch.from_numpy(np.random.default_rng(4).integers(0, 256, vol_shape, dtype=np.uint8))
+    pred = Predictor(sd, device=gpu, tile_shape=tile, overlap_shape=halo, apply_softmax=True)
+    ids, thr = [1, 2, 3, 4], [127.5] * 4
+    whole = pred.predict_labels_u8_device(vol.to(gpu), ids, thr).cpu()
+
+    def predict_fn(ch):
+        return pred.predict_labels_u8_device(ch, ids, thr, halo_included=True)[None]
+    for pipelined in (True, False):
+        got = par.predict_volume_distributed(vol, vol_shape, chunk, halo, predict_fn, n_out=1, device=gpu,
+                                             pipelined=pipelined)
+        assert got.shape == (1, *vol_shape) and torch.equal(got[0], whole)
+    assert len(torch.unique(whole)) >= 2
