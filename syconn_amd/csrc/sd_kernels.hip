@@ -418,6 +418,42 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     int z0, y0, x0, tn;
     coords(lb, z0, y0, x0, tn);
 
+    // FF: the normalised input patch of a block ((HY+2) x (HX+2) floats, two per thread) is fetched ONE BLOCK AHEAD into
+    // registers and parked in the other half of a double-buffered LDS patch, so that no block starts by waiting for a
+    // cold HBM load behind the previous block's output stores (vmcnt counts both, in order).
+    constexpr int FPX = HX + 2, FPY = HY + 2, FNP = FPX * FPY, FPT = (FNP + WAVES * 64 - 1) / (WAVES * 64);
+    float fpv[FF ? FPT : 1];
+    auto patch_fetch = [&](int bz0, int by0, int bx0, int btile) {
+#pragma unroll
+        for (int k = 0; k < FPT; ++k) {
+            const int i = tid + k * WAVES * 64;
+            const int px = i % FPX, py = i / FPX;
+            const int y = by0 - 2 + py, x = bx0 - 2 + px;
+            float v = 0.f;
+            if (i < FNP && (unsigned)bz0 < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
+                const size_t idx = ((size_t)bz0 * p.H + y) * p.W + x;
+                const char* const in = reinterpret_cast<const char*>(p.first_in) + (size_t)btile * p.first_in_tstride;
+                if (p.first_in_f32) v = reinterpret_cast<const float*>(in)[idx];
+                else v = (float)reinterpret_cast<const uint8_t*>(in)[idx] / 255.0f;
+            }
+            fpv[k] = v;
+        }
+    };
+    auto patch_park = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < FPT; ++k) {
+            const int i = tid + k * WAVES * 64;
+            if (i < FNP) fpatch[buf * FNP + i] = fpv[k];
+        }
+    };
+    // first-conv weight fragments and bias live in LDS as well: an ordinary global load inside the block loop would make
+    // the wave wait (vmcnt, in order) for the previous block's output stores
+    float* const ffw = fpatch + 2 * FNP;                      // [5 k-steps][64 lanes] + [32] bias
+    if constexpr (FF) {
+        patch_fetch(z0, y0, x0, tn);
+        patch_park(0);
+        for (int i = tid; i < 5 * 64 + 32; i += WAVES * 64) ffw[i] = i < 320 ? p.first_w[i] : p.first_bias[i - 320];
+    }
     if (WRES) {
         for (int s = 0; s < nstages; ++s) dma_weights(s, s);
         if (!FF) for (int f = 0; f < NA - 1; ++f) dma_stream_next();
@@ -439,32 +475,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
             // is never written).  Same arithmetic as k_conv_first: float32(v)/255 by IEEE division, the 9 taps as the
             // k dimension of exact-f32 32x32x2 MFMAs, bias after the chain, ReLU, rounding -- bit-identical values.
             static_assert(!FF || (KZ == 1 && WRES && NA == 2), "fused first conv: planar, resident weights");
-            constexpr int PXW = HX + 2, PYH = HY + 2, NPATCH = PXW * PYH, NSTEP1 = 5;
-            for (int i = tid; i < NPATCH; i += WAVES * 64) {
-                const int px = i % PXW, py = i / PXW;
-                const int y = y0 - 2 + py, x = x0 - 2 + px;
-                float v = 0.f;
-                if ((unsigned)z0 < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
-                    const size_t idx = ((size_t)z0 * p.H + y) * p.W + x;
-                    const char* const in = reinterpret_cast<const char*>(p.first_in) + (size_t)tn * p.first_in_tstride;
-                    if (p.first_in_f32) v = reinterpret_cast<const float*>(in)[idx];
-                    else v = (float)reinterpret_cast<const uint8_t*>(in)[idx] / 255.0f;
-                }
-                fpatch[i] = v;
-            }
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            constexpr int PXW = HX + 2, NSTEP1 = 5;
+            const float* const fp = fpatch + (round & 1) * FNP;      // parked by the prologue / during the previous block
             float w1[NSTEP1];
             int toff1[NSTEP1];
 #pragma unroll
             for (int st = 0; st < NSTEP1; ++st) {
-                w1[st] = p.first_w[st * 64 + lane];
+                w1[st] = ffw[st * 64 + lane];
                 int tap = 2 * st + half;
                 if (tap >= 9) tap = 0;                       // (its weight is zero)
                 toff1[st] = (tap / 3) * PXW + (tap % 3);
             }
             f32x4 b1[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) b1[q] = *reinterpret_cast<const f32x4*>(p.first_bias + 8 * q + 4 * half);
+            for (int q = 0; q < 4; ++q) b1[q] = *reinterpret_cast<const f32x4*>(ffw + 320 + 8 * q + 4 * half);
             for (int t = wave; t * 32 < NH; t += WAVES) {
                 const int hv = t * 32 + (lane & 31);
                 const int hvc = hv < NH ? hv : NH - 1;
@@ -475,7 +499,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                 for (int r = 0; r < 16; ++r) a1[r] = 0.f;
 #pragma unroll
                 for (int st = 0; st < NSTEP1; ++st)
-                    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[st], fpatch[base + toff1[st]], a1, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[st], fp[base + toff1[st]], a1, 0, 0, 0);
                 const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
                 const bool invol = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;     // z0 < D always
                 if (hv < NH) {
@@ -492,6 +516,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (nlb >= 0) patch_fetch(nz0, ny0, nx0, ntn);       // lands during stage 0 (its end waits vmcnt(0))
         }
         f32x16 acc[MT][NT];
 #pragma unroll
@@ -575,6 +600,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                 // all of this wave's LDS reads done + the next chunk's DMA landed, then the workgroup barrier (raw
                 // s_barrier: __syncthreads() would drain every DMA in flight with a vmcnt(0))
                 asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WAITN) : "memory");
+                if constexpr (FF) {
+                    if (s == 0 && nlb >= 0) patch_park((round + 1) & 1);     // ordered by the barrier that ends stage 1
+                }
                 if (s == SD_TS) SD_T(3);     // after the barrier of the probed stage
 #ifdef SD_STAGES
                 if (tcount == SD_TB && s < 14) sstamp[s] = __builtin_readcyclecounter();
@@ -1397,7 +1425,7 @@ template <typename T, int KZ, int NT, int WAVES, int NSLOT, int MT = 2, bool FF 
 static int launch_conv_k(ConvParams p, int NB, hipStream_t s) {
     using G = ConvGeo<KZ, WAVES, MT>;
     const size_t lds = conv_lds_bytes<KZ, NT, WAVES, MT, NSLOT>((p.nchunk0 + p.nchunk1) * KZ, p.final_wfrag != nullptr) +
-                       (FF ? (size_t)(G::BY + 4) * (G::BX + 4) * 4 : 0);
+                       (FF ? (size_t)2 * (G::BY + 4) * (G::BX + 4) * 4 + (5 * 64 + 32) * 4 : 0);
     p.nbx = (p.W + G::BX - 1) / G::BX; p.nby = (p.H + G::BY - 1) / G::BY; p.nbz = (p.D + G::BZ - 1) / G::BZ;
     static const int order = getenv("SD_BLOCK_ORDER") ? atoi(getenv("SD_BLOCK_ORDER")) : 1;
     p.block_order = order;
@@ -1440,7 +1468,7 @@ bool conv_can_fuse_first(int KZ, int NT, int NB, long vox, int nstages, bool fus
     if (KZ != 1 || NT > 2 || nstages != 2) return false;
     if ((vox / 512) * NB < 512) return false;                                   // the `big` rule of launch_conv_knt
     const size_t lds = NT == 1 ? conv_lds_bytes<1, 1, 8, 2, 2>(nstages, fused_final) : conv_lds_bytes<1, 2, 8, 2, 2>(nstages, fused_final);
-    return lds + 36 * 20 * 4 <= 96 * 1024;
+    return lds + 2 * 36 * 20 * 4 + 352 * 4 <= 96 * 1024;
 }
 
 template <typename T, int KZ, int NT>
