@@ -59,6 +59,8 @@ struct Op {
     int fuse_gn = -1;      // conv: index of the GroupNorm op whose statistics this conv's epilogue accumulates
     bool stats_done = false;   // groupnorm: statistics come from the producing conv
     int gn_pool = -1;          // groupnorm: index of the MaxPool op fused into the apply pass
+    bool gn_into_final = false;  // groupnorm: only the statistics run here, the final layer applies scale / shift itself
+    int final_gn = -1;           // final: index of the GroupNorm op whose apply pass it performs on the fly
     size_t fwfrag_off = 0;             // fused final 1x1x1: hi/lo MFMA weight fragments
     bool skipped = false;  // op is executed inside its producer
 };
@@ -393,6 +395,26 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
                 for (int ci = 0; ci < d.cin0; ++ci) wp[co * Cs + ci] = W[d.w_off + (size_t)co * d.cin0 + ci];
                 bp[co] = W[d.b_off + co];
             }
+            // the same weights as hi + lo parts in the activation dtype, MFMA A-fragment order, natural channel order
+            // (k_final_mfma): row = class (lane & 31), element jj of k-step c <-> channel 16c + 8*(lane>>5) + jj
+            {
+                const int nch = Cs / SD_CHUNK;
+                op.aux_off = blob_alloc((size_t)nch * 2 * 64 * 8 * 2);
+                uint16_t* fp = reinterpret_cast<uint16_t*>(blob.data() + op.aux_off);
+                auto back = [&](uint16_t bits) -> float {
+                    if (act_dtype == SD_BF16) { uint32_t u = (uint32_t)bits << 16; float f; std::memcpy(&f, &u, 4); return f; }
+                    _Float16 h; std::memcpy(&h, &bits, 2); return (float)h;
+                };
+                for (int c = 0; c < nch; ++c)
+                    for (int l = 0; l < 64; ++l)
+                        for (int jj = 0; jj < 8; ++jj) {
+                            const int co = l & 31, ch = c * SD_CHUNK + 8 * (l >> 5) + jj;
+                            const float wv = (co < d.cout && ch < d.cin0) ? W[d.w_off + (size_t)co * d.cin0 + ch] : 0.f;
+                            const uint16_t hi = cvt(wv, act_dtype);
+                            fp[((size_t)(c * 2 + 0) * 64 + l) * 8 + jj] = hi;
+                            fp[((size_t)(c * 2 + 1) * 64 + l) * 8 + jj] = cvt(wv - back(hi), act_dtype);
+                        }
+            }
             m->final_cout = d.cout;
             break;
         }
@@ -425,6 +447,17 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
                 !getenv("SD_NO_GN_FUSE")) {
                 g.gn_pool = (int)(i + 1);
                 nx.skipped = true;
+            }
+        }
+        // GroupNorm directly followed by the final 1x1x1 layer: the final layer normalises on the fly, the normalised
+        // tensor is never written (nor read again): one pass over the raw tensor instead of three
+        if (m->ops.size() >= 2 && !getenv("SD_NO_GN_FUSE")) {
+            Op& g = m->ops[m->ops.size() - 2];
+            Op& f = m->ops.back();
+            if (g.d.kind == SD_OP_GROUPNORM && g.d.src1 < 0 && g.gn_pool < 0 && f.d.kind == SD_OP_FINAL && f.d.src0 == g.d.src0 &&
+                !m->keep_all) {
+                g.gn_into_final = true;
+                f.final_gn = (int)m->ops.size() - 2;
             }
         }
         for (size_t i = 0; i + 1 < m->ops.size(); ++i) {
@@ -707,6 +740,7 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
             p.scale_shift = reinterpret_cast<float*>(wsb + (size_t)2 * p.C * 8);
             p.relu = d.relu;
             p.batch = N; p.tstride = tstride; p.skip_stats = op.stats_done ? 1 : 0;
+            p.skip_apply = op.gn_into_final ? 1 : 0;
             if (op.gn_pool >= 0) {
                 const sd_op_desc& pd = m->ops[op.gn_pool].d;
                 const Dims po = m->dims[pd.dst];
@@ -721,10 +755,15 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
             p.src = bufp(d.src0); p.Cs = m->bufCp[d.src0]; p.cin = d.cin0;
             p.w = reinterpret_cast<const float*>(m->dev_blob + op.wpack_off);
             p.bias = reinterpret_cast<const float*>(m->dev_blob + op.bias_off);
+            p.wfrag = m->dev_blob + op.aux_off;
             p.cout = d.cout; p.out = out_dev; p.out_kind = out_kind;
             p.nvox = (long)a.d * a.h * a.w;
             p.batch = N; p.tstride = tstride; p.out_tstride = out_tstride;
             if (lab) p.lab = *lab;
+            if (op.final_gn >= 0) {     // scale / shift were left by the GroupNorm op in the workspace scratch of every tile
+                p.gn_scale_shift = reinterpret_cast<const float*>(wsb + (size_t)2 * p.Cs * 8);
+                p.gn_relu = m->ops[op.final_gn].d.relu;
+            }
             if (a.d != D || a.h != H || a.w != W) return fail(SD_ERR_INVALID, "final layer shape != input shape");
             rc = launch_final(p, m->act_dtype, s);
             break;

@@ -108,6 +108,10 @@ struct FinalParams {
     long nvox;
     int batch; size_t tstride, out_tstride;
     LabelArgs lab;     // out_kind == SD_OUT_LABELS_U8
+    // GroupNorm apply (+ReLU) of `src` fused into this pass: x -> round_T(relu(x*scale + shift)) per channel before the
+    // 1x1x1 convolution (the normalised tensor is never written); scale_shift = [2*Cs] floats per tile or nullptr
+    const float* gn_scale_shift; int gn_relu;
+    const void* wfrag; // hi/lo MFMA A fragments of the weights in natural channel order: [Cs/16][2][64 lanes][8] of T
 };
 
 struct GnParams {
@@ -125,6 +129,7 @@ struct GnParams {
     int skip_stats;            // the producing convolution already accumulated `sums` (ConvParams::gn_sums)
     void* pool_dst;            // fused MaxPool3d(ceil_mode) of the normalised tensor ((pkz,2,2) windows), or nullptr
     int pkz, pD, pH, pW;       // pooling kz (1 or 2) and pooled extents
+    int skip_apply;            // statistics -> scale/shift only: the consumer (fused final layer) applies them itself
 };
 
 int launch_conv(const ConvParams& p, int act_dtype, int KZ, int NT, int NB, hipStream_t s);

@@ -1157,13 +1157,34 @@ __global__ __launch_bounds__(256) void k_final(const FinalParams p) {
         float acc[8];
 #pragma unroll
         for (int co = 0; co < 8; ++co) acc[co] = 0.f;
-        for (int c8 = 0; c8 < p.Cs / 8; ++c8) {
-            const v8 xv = *reinterpret_cast<const v8*>(src + ((size_t)(c8 >> 1) * p.nvox + v) * SD_CHUNK + (c8 & 1) * 8);
+        const float* const gss = p.gn_scale_shift
+            ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.gn_scale_shift) + blockIdx.z * p.tstride) : nullptr;
+        // all 16-byte pieces of the voxel are requested before the first one is used (the layer is a pure stream: what
+        // bounds it is bytes in flight per thread), in groups of up to 8 pieces = 64 channels
+        const int nc8 = p.Cs / 8;
+        for (int g0 = 0; g0 < nc8; g0 += 8) {
+            v8 xr[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float xf = (float)xv[e];
+            for (int k = 0; k < 8; ++k) {
+                const int c8 = g0 + k;
+                if (c8 < nc8)
+                    xr[k] = *reinterpret_cast<const v8*>(src + ((size_t)(c8 >> 1) * p.nvox + v) * SD_CHUNK + (c8 & 1) * 8);
+            }
 #pragma unroll
-                for (int co = 0; co < 8; ++co) acc[co] = fmaf(xf, w[co * p.Cs + c8 * 8 + e], acc[co]);
+            for (int k = 0; k < 8; ++k) {
+                const int c8 = g0 + k;
+                if (c8 >= nc8) break;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float xf = (float)xr[k][e];
+                    if (gss) {          // fused GroupNorm apply: same arithmetic and rounding point as k_gn_apply
+                        xf = fmaf(xf, gss[c8 * 8 + e], gss[p.Cs + c8 * 8 + e]);
+                        if (p.gn_relu) xf = fmaxf(xf, 0.f);
+                        xf = (float)(T)xf;
+                    }
+#pragma unroll
+                    for (int co = 0; co < 8; ++co) acc[co] = fmaf(xf, w[co * p.Cs + c8 * 8 + e], acc[co]);
+                }
             }
         }
         float mx = -INFINITY;
@@ -1200,6 +1221,120 @@ __global__ __launch_bounds__(256) void k_final(const FinalParams p) {
 #pragma unroll
             for (int co = 0; co < 8; ++co)
                 if (co < p.cout) out[(size_t)co * p.nvox + v] = acc[co];
+        }
+    }
+}
+
+// The same layer on the matrix core (the form used when the final layer cannot ride in a convolution's epilogue: GroupNorm
+// networks).  logits[class][voxel] = W[class][channel] . act[channel][voxel] with the fp32 weights as hi + lo parts of
+// the activation dtype (two MFMAs per 16-channel chunk, fp32-accurate products) and the activation fragment read
+// straight from the channel-blocked tensor (a lane's 16 bytes = 8 channels of its voxel: one coalesced 1 KiB piece per
+// wave and chunk).  A wave handles two 32-voxel tiles; the epilogue is the one of the fused final layer in k_conv_mfma.
+// The scalar version above spends ~500 VALU operations per voxel (8 classes x Cs FMAs); this one ~1 MFMA per 5 voxels.
+template <typename T>
+__global__ __launch_bounds__(256) void k_final_mfma(const FinalParams p) {
+    using v8 = typename Act<T>::v8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, vl = lane & 31;
+    const int nch = p.Cs / SD_CHUNK;
+    char* const wl = smem;                                               // [nch][2][64][16 B]
+    float* const gl = reinterpret_cast<float*>(smem + (size_t)nch * 2048);   // scale[Cs], shift[Cs] of this tile
+    float* const bl = gl + 2 * p.Cs;                                     // 8 class biases
+    const T* const src = reinterpret_cast<const T*>(reinterpret_cast<const char*>(p.src) + blockIdx.z * p.tstride);
+    for (int i = tid; i < nch * 128; i += 256)
+        *reinterpret_cast<v8*>(wl + (size_t)i * 16) = *reinterpret_cast<const v8*>(reinterpret_cast<const T*>(p.wfrag) + (size_t)i * 8);
+    if (p.gn_scale_shift) {
+        const float* const gss = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.gn_scale_shift) + blockIdx.z * p.tstride);
+        for (int i = tid; i < 2 * p.Cs; i += 256) gl[i] = gss[i];
+    }
+    if (tid < 8) bl[tid] = tid < p.cout ? p.bias[tid] : 0.f;
+    __syncthreads();
+    for (long v0 = ((long)blockIdx.x * 4 + wave) * 64; v0 < p.nvox; v0 += (long)gridDim.x * 256) {
+        f32x16 lg[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lg[i][r] = 0.f;
+        const long vv[2] = {v0 + vl, v0 + 32 + vl};
+#pragma unroll 2
+        for (int c = 0; c < nch; ++c) {
+            v8 x[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                v8 val = {};
+                if (vv[i] < p.nvox) val = *reinterpret_cast<const v8*>(src + ((size_t)c * p.nvox + vv[i]) * SD_CHUNK + half * 8);
+                x[i] = val;
+            }
+            if (p.gn_scale_shift) {       // fused GroupNorm apply + ReLU: same arithmetic and rounding point as k_gn_apply
+                const float* const sc = gl + c * SD_CHUNK + half * 8;
+                const float* const sh = sc + p.Cs;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float f = fmaf((float)x[i][e], sc[e], sh[e]);
+                        if (p.gn_relu) f = fmaxf(f, 0.f);
+                        x[i][e] = (T)f;
+                    }
+            }
+            const v8 w0 = *reinterpret_cast<const v8*>(wl + ((size_t)(c * 2 + 0) * 64 + lane) * 16);
+            const v8 w1 = *reinterpret_cast<const v8*>(wl + ((size_t)(c * 2 + 1) * 64 + lane) * 16);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                lg[i] = Act<T>::mfma(w0, x[i], lg[i]);
+                lg[i] = Act<T>::mfma(w1, x[i], lg[i]);
+            }
+        }
+        // rows = classes: lower lanes hold classes 0-3 of their voxel in registers 0-3, upper lanes classes 4-7; one
+        // half-wave swap per register gives the lower lane all 8 logits of tile 0's voxel, the upper lane tile 1's
+        float l[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float bmine = bl[4 * half + e];
+            unsigned a = __builtin_bit_cast(unsigned, lg[0][e] + bmine);
+            unsigned b2 = __builtin_bit_cast(unsigned, lg[1][e] + bmine);
+            swap32(a, b2);
+            l[e] = __builtin_bit_cast(float, a);
+            l[4 + e] = __builtin_bit_cast(float, b2);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int co = 0; co < 8; ++co)
+            if (co < p.cout) mx = fmaxf(mx, l[co]);
+        if (p.out_kind != SD_OUT_LOGITS_F32) {
+            float sum = 0.f;
+#pragma unroll
+            for (int co = 0; co < 8; ++co) {
+                l[co] = co < p.cout ? __expf(l[co] - mx) : 0.f;
+                sum += l[co];
+            }
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int co = 0; co < 8; ++co) l[co] *= inv;
+        }
+        const long v = vv[half];
+        if (v < p.nvox) {
+            if (p.out_kind == SD_OUT_LABELS_U8) {
+                uint8_t lab = 0;
+                for (int k = 0; k < p.lab.n; ++k) {
+                    const int id = p.lab.ids[k];
+                    float pv = 0.f;
+#pragma unroll
+                    for (int co = 0; co < 8; ++co) pv = (co == id) ? l[co] : pv;
+                    if ((int)(uint8_t)(pv * 255.f) >= p.lab.cuts[k]) lab = (uint8_t)id;
+                }
+                (reinterpret_cast<uint8_t*>(p.out) + blockIdx.z * p.out_tstride)[v] = lab;
+            } else if (p.out_kind == SD_OUT_PROBS_U8) {
+                uint8_t* out = reinterpret_cast<uint8_t*>(p.out) + blockIdx.z * p.out_tstride;
+#pragma unroll
+                for (int co = 0; co < 8; ++co)
+                    if (co < p.cout) out[(size_t)co * p.nvox + v] = (uint8_t)(l[co] * 255.f);
+            } else {
+                float* out = reinterpret_cast<float*>(reinterpret_cast<char*>(p.out) + blockIdx.z * p.out_tstride);
+#pragma unroll
+                for (int co = 0; co < 8; ++co)
+                    if (co < p.cout) out[(size_t)co * p.nvox + v] = l[co];
+            }
         }
     }
 }
@@ -1596,6 +1731,14 @@ int launch_pool(const PoolParams& p, int act_dtype, hipStream_t s) {
 }
 
 int launch_final(const FinalParams& p, int act_dtype, hipStream_t s) {
+    static const bool scalar_final = getenv("SD_FINAL_SCALAR") != nullptr;     // debugging aid: the FMA-chain version
+    const size_t lds = (size_t)(p.Cs / SD_CHUNK) * 2048 + (size_t)(2 * p.Cs + 8) * 4;
+    if (p.wfrag && !scalar_final && lds <= 64 * 1024) {
+        dim3 grid(grid_for(p.nvox, 256, 256 * 8), 1, p.batch), block(256);
+        if (act_dtype == SD_BF16) hipLaunchKernelGGL((k_final_mfma<bf16_t>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((k_final_mfma<f16_t>), grid, block, lds, s, p);
+        return SD_LAUNCH_CHECK();
+    }
     dim3 grid(grid_for(p.nvox), 1, p.batch), block(256);
     if (act_dtype == SD_BF16) hipLaunchKernelGGL((k_final<bf16_t>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((k_final<f16_t>), grid, block, 0, s, p);
@@ -1615,12 +1758,14 @@ int launch_groupnorm(const GnParams& p, int act_dtype, hipStream_t s) {
     if (act_dtype == SD_BF16) {
         if (!p.skip_stats) hipLaunchKernelGGL((k_gn_stats<bf16_t>), g1, b1, 0, s, p);
         hipLaunchKernelGGL(k_gn_finalize, dim3(1, 1, p.batch), dim3(256), 0, s, p);
-        if (p.pool_dst) hipLaunchKernelGGL((k_gn_apply_pool<bf16_t>), gp, b3, 0, s, p);
+        if (p.skip_apply) {}
+        else if (p.pool_dst) hipLaunchKernelGGL((k_gn_apply_pool<bf16_t>), gp, b3, 0, s, p);
         else hipLaunchKernelGGL((k_gn_apply<bf16_t>), g3, b3, 0, s, p);
     } else {
         if (!p.skip_stats) hipLaunchKernelGGL((k_gn_stats<f16_t>), g1, b1, 0, s, p);
         hipLaunchKernelGGL(k_gn_finalize, dim3(1, 1, p.batch), dim3(256), 0, s, p);
-        if (p.pool_dst) hipLaunchKernelGGL((k_gn_apply_pool<f16_t>), gp, b3, 0, s, p);
+        if (p.skip_apply) {}
+        else if (p.pool_dst) hipLaunchKernelGGL((k_gn_apply_pool<f16_t>), gp, b3, 0, s, p);
         else hipLaunchKernelGGL((k_gn_apply<f16_t>), g3, b3, 0, s, p);
     }
     return SD_LAUNCH_CHECK();

@@ -1,7 +1,7 @@
 # dev tool: GroupNorm network (mivcsj), default fusions vs SD_NO_FUSE: logits and (with SD_KEEP_ALL) every activation buffer
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle.unet_ref import build_unet
+from syconn_amd.cnn import random_state_dict as build_unet
 from syconn_amd import _lib as L
 from syconn_amd.engine import DenseModel
 net = build_unet('mivcsj', seed=3, final_scale=4.0)

@@ -1,5 +1,5 @@
 # dev helper: per-layer timing of one launch set of B n^3 tiles (usage: layer_times.py [arch] [n] [B]); times are per tile
-import sys, torch, numpy as np
+import os, sys, torch, numpy as np
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from syconn_amd.cnn import random_state_dict
 from syconn_amd import _lib as L
@@ -8,7 +8,7 @@ arch = sys.argv[1] if len(sys.argv) > 1 else 'semseg_spine'
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 m = random_state_dict(arch, seed=0)
-dm = DenseModel(m, 'bf16', torch.device('cuda', 0))
+dm = DenseModel(m, os.environ.get("SD_ACT", "bf16"), torch.device("cuda", 0))
 x = torch.randint(0, 256, (B, n, n, n), dtype=torch.uint8, device='cuda')
 out = torch.empty((B, dm.out_channels, n, n, n), dtype=torch.uint8, device='cuda')
 for _ in range(3): dm.forward_batch(x, L.SD_OUT_PROBS_U8, out)
