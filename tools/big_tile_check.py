@@ -1,6 +1,6 @@
 import sys, time, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle.unet_ref import build_unet
+from syconn_amd.cnn import random_state_dict as build_unet   # seeded random weights (no trained models exist)
 from syconn_amd import _lib as L
 from syconn_amd.engine import DenseModel
 dm = DenseModel(build_unet('myelin', seed=1, final_scale=6.0), 'bf16', torch.device('cuda', 0))

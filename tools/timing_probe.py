@@ -1,7 +1,7 @@
 # dev helper (needs a -DSD_TIMING build): per-wave cycle stamps of one conv op, second block of each workgroup
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle.unet_ref import build_unet
+from syconn_amd.cnn import random_state_dict as build_unet   # seeded random weights (no trained models exist)
 from syconn_amd import _lib as L
 from syconn_amd.engine import DenseModel
 op = int(sys.argv[1]); os.environ['SD_TIMING_OP'] = str(op)

@@ -1,7 +1,7 @@
 # dev probe: throughput of alternating tiles over S HIP streams (S workspaces) vs one stream
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle.unet_ref import build_unet
+from syconn_amd.cnn import random_state_dict as build_unet   # seeded random weights (no trained models exist)
 from syconn_amd import _lib as L
 from syconn_amd.engine import DenseModel
 arch = sys.argv[1] if len(sys.argv) > 1 else 'semseg_spine'
