@@ -10,9 +10,13 @@
 // "outside the window = background"; opening erodes and dilates inside the box.  oracle/objseg_ref.py spells this out and
 // is pinned to the reference's own functions (tests/golden/g9_objseg.npz).
 //
-// All passes are HBM-bound byte / int32 streams over the (x,y,z; z fastest) volume.  Connected components: 6-neighbour
-// union-find on linear voxel indices (atomicMin links, roots = smallest index of a component = its first voxel in raster
-// order), then the roots are ranked by an exclusive scan -> ids 1..N in scipy.ndimage.label's order, bit-exact.
+// Data layout: the binary volume lives BIT-PACKED along z (the fastest axis): one uint32 = 32 consecutive z voxels of a
+// (x,y) row of the volume padded by P = largest `iterations` per side.  A morphology step is then a handful of word loads,
+// funnel shifts and AND / OR per 32 voxels (an HBM/L2 stream of 1/8 byte per voxel) instead of 15 byte loads per voxel.
+// Connected components: labels start as the linear index of the voxel's z-RUN start (read off the bit mask, no atomics), so
+// only run heads and run/run adjacencies along y and x touch the union-find (atomicMin links, larger root under smaller: a
+// component's root is its first voxel in raster order); roots are ranked by an exclusive scan -> ids 1..N in
+// scipy.ndimage.label's order, bit-exact.
 #include "../../include/syconn_dense.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -26,8 +30,9 @@ namespace {
 constexpr int MAX_OFFS = 128;
 struct Offs { int n; signed char dx[MAX_OFFS], dy[MAX_OFFS], dz[MAX_OFFS]; };
 
-struct Dom { int X, Y, Z, P; int PX, PY, PZ; };      // volume extents, pad, padded extents
-__device__ __forceinline__ size_t pidx(const Dom& d, int x, int y, int z) { return ((size_t)x * d.PY + y) * d.PZ + z; }
+// volume extents, pad, padded extents (PZW = words per padded z-row)
+struct Dom { int X, Y, Z, P; int PX, PY, PZ, PZW; };
+__device__ __forceinline__ size_t widx(const Dom& d, int x, int y, int zw) { return ((size_t)x * d.PY + y) * d.PZW + zw; }
 
 // bbox[0..2] = min (padded coords), bbox[3..5] = max + 1; empty foreground: min > max
 __global__ __launch_bounds__(256) void k_bbox_init(int* bbox) {
@@ -35,65 +40,103 @@ __global__ __launch_bounds__(256) void k_bbox_init(int* bbox) {
     else if (threadIdx.x < 6) bbox[threadIdx.x] = 0;
 }
 
-__global__ __launch_bounds__(256) void k_threshold_pad(const uint8_t* prob, int cut, Dom d, uint8_t* A) {
-    const size_t total = (size_t)d.PX * d.PY * d.PZ;
+// one thread = one mask word: bit b = (prob[x][y][32 zw + b - P] >= cut), zero in the padding
+__global__ __launch_bounds__(256) void k_threshold_bits(const uint8_t* prob, int cut, Dom d, uint32_t* A) {
+    const size_t total = (size_t)d.PX * d.PY * d.PZW;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int z = (int)(i % d.PZ) - d.P, y = (int)((i / d.PZ) % d.PY) - d.P, x = (int)(i / ((size_t)d.PZ * d.PY)) - d.P;
-        uint8_t v = 0;
-        if ((unsigned)x < (unsigned)d.X && (unsigned)y < (unsigned)d.Y && (unsigned)z < (unsigned)d.Z)
-            v = (int)prob[((size_t)x * d.Y + y) * d.Z + z] >= cut ? 1 : 0;
-        A[i] = v;
+        const int zw = (int)(i % d.PZW), y = (int)((i / d.PZW) % d.PY) - d.P, x = (int)(i / ((size_t)d.PZW * d.PY)) - d.P;
+        uint32_t w = 0;
+        if ((unsigned)x < (unsigned)d.X && (unsigned)y < (unsigned)d.Y) {
+            const uint8_t* row = prob + ((size_t)x * d.Y + y) * d.Z;
+            const int z0 = zw * 32 - d.P;
+#pragma unroll 8
+            for (int b = 0; b < 32; ++b) {
+                const int z = z0 + b;
+                if ((unsigned)z < (unsigned)d.Z && (int)row[z] >= cut) w |= 1u << b;
+            }
+        }
+        A[i] = w;
     }
 }
 
-__global__ __launch_bounds__(256) void k_bbox(const uint8_t* A, Dom d, int* bbox) {
-    const size_t total = (size_t)d.PX * d.PY * d.PZ;
+__global__ __launch_bounds__(256) void k_bbox_bits(const uint32_t* A, Dom d, int* bbox) {
+    const size_t total = (size_t)d.PX * d.PY * d.PZW;
     int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {0, 0, 0};
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        if (A[i] == 1) {
-            const int c[3] = {(int)(i / ((size_t)d.PZ * d.PY)), (int)((i / d.PZ) % d.PY), (int)(i % d.PZ)};
-#pragma unroll
-            for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], c[a]); hi[a] = max(hi[a], c[a] + 1); }
+        const uint32_t w = A[i];
+        if (w) {
+            const int zw = (int)(i % d.PZW);
+            const int c[3] = {(int)(i / ((size_t)d.PZW * d.PY)), (int)((i / d.PZW) % d.PY), zw * 32 + __builtin_ctz(w)};
+            const int czh = zw * 32 + 32 - __builtin_clz(w);
+            lo[0] = min(lo[0], c[0]); lo[1] = min(lo[1], c[1]); lo[2] = min(lo[2], c[2]);
+            hi[0] = max(hi[0], c[0] + 1); hi[1] = max(hi[1], c[1] + 1); hi[2] = max(hi[2], czh);
         }
     }
+    __shared__ int red[4][6];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         for (int m = 32; m >= 1; m >>= 1) {
             lo[a] = min(lo[a], __shfl_xor(lo[a], m, 64));
             hi[a] = max(hi[a], __shfl_xor(hi[a], m, 64));
         }
-        if ((threadIdx.x & 63) == 0) {
-            if (lo[a] != 0x7fffffff) atomicMin(&bbox[a], lo[a]);
-            if (hi[a] != 0) atomicMax(&bbox[3 + a], hi[a]);
-        }
+        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][a] = lo[a]; red[threadIdx.x >> 6][3 + a] = hi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {          // one atomic per workgroup and bound (the six addresses are shared by the whole grid)
+        const int a = threadIdx.x;
+        int v = red[0][a];
+        for (int w = 1; w < 4; ++w) v = a < 3 ? min(v, red[w][a]) : max(v, red[w][a]);
+        if (a < 3) { if (v != 0x7fffffff) atomicMin(&bbox[a], v); }
+        else if (v != 0) atomicMax(&bbox[a], v);
     }
 }
 
-// One erosion (dilate == 0) or dilation (dilate == 1) step inside the window W = bbox grown by `wpad` per side (W lies
-// inside the padded buffer because wpad <= P).  Outside W the result is 0; reads outside W count as background.
-// crop != 0: additionally zero everything outside the bbox itself (the `res[n:-n, ...]` crop after a closing / dilation).
-__global__ __launch_bounds__(256) void k_morph_step(const uint8_t* src, uint8_t* dst, Dom d, const int* bbox, int wpad,
+// bits [lo, hi) of the padded z axis that fall into word zw
+__device__ __forceinline__ uint32_t zmask(int zw, int lo, int hi) {
+    const int a = max(lo - zw * 32, 0), b = min(hi - zw * 32, 32);
+    if (b <= a) return 0u;
+    const uint32_t upto_b = b >= 32 ? 0xffffffffu : ((1u << b) - 1u);
+    return upto_b & ~((1u << a) - 1u);
+}
+
+// One erosion (dilate == 0) or dilation (dilate == 1) step inside the window W = bbox grown by `wpad` per side.  Outside W
+// the result is 0; reads outside W (or outside the buffer) count as background.  crop != 0: additionally zero everything
+// outside the bbox itself (the `res[n:-n, ...]` crop after a closing / dilation).  One thread = one word = 32 voxels.
+__global__ __launch_bounds__(256) void k_morph_bits(const uint32_t* src, uint32_t* dst, Dom d, const int* bbox, int wpad,
                                                     int dilate, int crop, const Offs o) {
-    const size_t total = (size_t)d.PX * d.PY * d.PZ;
+    const size_t total = (size_t)d.PX * d.PY * d.PZW;
     const int wl[3] = {bbox[0] - wpad, bbox[1] - wpad, bbox[2] - wpad};
     const int wh[3] = {bbox[3] + wpad, bbox[4] + wpad, bbox[5] + wpad};
     const int cl[3] = {crop ? bbox[0] : wl[0], crop ? bbox[1] : wl[1], crop ? bbox[2] : wl[2]};
     const int ch[3] = {crop ? bbox[3] : wh[0], crop ? bbox[4] : wh[1], crop ? bbox[5] : wh[2]};
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int z = (int)(i % d.PZ), y = (int)((i / d.PZ) % d.PY), x = (int)(i / ((size_t)d.PZ * d.PY));
-        uint8_t r = 0;
-        if (x >= cl[0] && x < ch[0] && y >= cl[1] && y < ch[1] && z >= cl[2] && z < ch[2]) {
-            r = dilate ? 0 : 1;
+        const int zw = (int)(i % d.PZW), y = (int)((i / d.PZW) % d.PY), x = (int)(i / ((size_t)d.PZW * d.PY));
+        uint32_t r = 0;
+        const uint32_t keep = (x >= cl[0] && x < ch[0] && y >= cl[1] && y < ch[1]) ? zmask(zw, cl[2], ch[2]) : 0u;
+        if (keep) {
+            r = dilate ? 0u : 0xffffffffu;
             for (int k = 0; k < o.n; ++k) {
-                // erosion: all of v + S set; dilation: any of v - S set
-                const int ux = dilate ? x - o.dx[k] : x + o.dx[k], uy = dilate ? y - o.dy[k] : y + o.dy[k],
-                          uz = dilate ? z - o.dz[k] : z + o.dz[k];
-                uint8_t s = 0;
-                if (ux >= wl[0] && ux < wh[0] && uy >= wl[1] && uy < wh[1] && uz >= wl[2] && uz < wh[2])
-                    s = src[pidx(d, ux, uy, uz)];
-                if (dilate) { if (s) { r = 1; break; } }
-                else if (!s) { r = 0; break; }
+                // erosion: result bit z = AND over S of in[v + s]; dilation: OR over S of in[v - s]
+                const int sx = dilate ? -o.dx[k] : o.dx[k], sy = dilate ? -o.dy[k] : o.dy[k], sz = dilate ? -o.dz[k] : o.dz[k];
+                const int ux = x + sx, uy = y + sy;
+                uint32_t s = 0;
+                if (ux >= wl[0] && ux < wh[0] && uy >= wl[1] && uy < wh[1] && (unsigned)ux < (unsigned)d.PX &&
+                    (unsigned)uy < (unsigned)d.PY) {
+                    const uint32_t* row = src + widx(d, ux, uy, 0);
+                    // word of bits (32 zw + sz .. 32 zw + sz + 31), window-masked at the source
+                    const uint32_t c0 = row[zw] & zmask(zw, wl[2], wh[2]);
+                    if (sz == 0) s = c0;
+                    else if (sz > 0) {
+                        const uint32_t c1 = (zw + 1 < d.PZW) ? (row[zw + 1] & zmask(zw + 1, wl[2], wh[2])) : 0u;
+                        s = (c0 >> sz) | (c1 << (32 - sz));
+                    } else {
+                        const uint32_t c1 = (zw > 0) ? (row[zw - 1] & zmask(zw - 1, wl[2], wh[2])) : 0u;
+                        s = (c0 << (-sz)) | (c1 >> (32 + sz));
+                    }
+                }
+                r = dilate ? (r | s) : (r & s);
             }
+            r &= keep;
         }
         dst[i] = r;
     }
@@ -117,23 +160,51 @@ __device__ __forceinline__ void cc_union(int* L, int a, int b) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_cc_init(const uint8_t* A, Dom d, int* L, uint8_t* mask_out) {
+// foreground bit of volume voxel (x,y,z) (unpadded coordinates inside the volume)
+__device__ __forceinline__ bool fg(const uint32_t* A, const Dom& d, int x, int y, int z) {
+    const int pz = z + d.P;
+    return (A[widx(d, x + d.P, y + d.P, pz >> 5)] >> (pz & 31)) & 1u;
+}
+
+// L[i] = linear index of the first voxel of i's z-run (foreground) or -1; optional byte mask output.
+// One thread = one voxel; the run start is read off the mask words (scan back over all-ones words).
+__global__ __launch_bounds__(256) void k_cc_init_runs(const uint32_t* A, Dom d, int* L, uint8_t* mask_out) {
     const size_t total = (size_t)d.X * d.Y * d.Z;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int z = (int)(i % d.Z), y = (int)((i / d.Z) % d.Y), x = (int)(i / ((size_t)d.Z * d.Y));
-        const uint8_t v = A[pidx(d, x + d.P, y + d.P, z + d.P)];
-        L[i] = v ? (int)i : -1;
-        if (mask_out) mask_out[i] = v;
+        const uint32_t* row = A + widx(d, x + d.P, y + d.P, 0);
+        const int pz = z + d.P;
+        int zw = pz >> 5;
+        const int b = pz & 31;
+        uint32_t w = row[zw];
+        const bool f = (w >> b) & 1u;
+        int lab = -1;
+        if (f) {
+            // highest zero bit strictly below b in this word, else continue in the words below (padding bits are 0, and
+            // bits of z < 0 do not exist for P == 0: the loop stops at word 0)
+            uint32_t zeros = ~w & (b ? ((1u << b) - 1u) : 0u);
+            while (!zeros && zw > 0) { --zw; zeros = ~row[zw]; }
+            const int start_pz = zeros ? (zw * 32 + 32 - __builtin_clz(zeros)) : 0;
+            lab = (int)(i - (size_t)(pz - max(start_pz, d.P)));
+        }
+        L[i] = lab;
+        if (mask_out) mask_out[i] = f ? 1 : 0;
     }
 }
-__global__ __launch_bounds__(256) void k_cc_merge(Dom d, int* L) {
+// unions across y and x: a voxel links its run with the neighbour's run where the adjacency STARTS (its own run start or
+// the neighbour's run start), i.e. once per pair of touching runs and direction instead of once per voxel
+__global__ __launch_bounds__(256) void k_cc_merge_runs(const uint32_t* A, Dom d, int* L) {
     const size_t total = (size_t)d.X * d.Y * d.Z;
+    const size_t sy = (size_t)d.Z, sx = (size_t)d.Z * d.Y;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        if (L[i] < 0) continue;
+        const int li = L[i];
+        if (li < 0) continue;
         const int z = (int)(i % d.Z), y = (int)((i / d.Z) % d.Y), x = (int)(i / ((size_t)d.Z * d.Y));
-        if (z > 0 && L[i - 1] >= 0) cc_union(L, (int)i, (int)i - 1);
-        if (y > 0 && L[i - d.Z] >= 0) cc_union(L, (int)i, (int)(i - d.Z));
-        if (x > 0 && L[i - (size_t)d.Z * d.Y] >= 0) cc_union(L, (int)i, (int)(i - (size_t)d.Z * d.Y));
+        const bool my_start = z == 0 || !fg(A, d, x, y, z - 1);     // from the mask: L[i] of a run start may already be re-linked
+        if (y > 0 && fg(A, d, x, y - 1, z) && (my_start || z == 0 || !fg(A, d, x, y - 1, z - 1)))
+            cc_union(L, (int)i, (int)(i - sy));
+        if (x > 0 && fg(A, d, x - 1, y, z) && (my_start || z == 0 || !fg(A, d, x - 1, y, z - 1)))
+            cc_union(L, (int)i, (int)(i - sx));
     }
 }
 __global__ __launch_bounds__(256) void k_cc_compress(size_t total, int* L) {
@@ -208,13 +279,19 @@ inline int grid_for(size_t n, int cap = 8192) { size_t g = (n + 255) / 256; retu
 inline size_t rup256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct WsLayout { size_t a, b, rank, blockcnt, bbox, total; };
+Dom make_dom(int X, int Y, int Z, int P) {
+    Dom d{X, Y, Z, P, X + 2 * P, Y + 2 * P, Z + 2 * P, 0};
+    d.PZW = (d.PZ + 31) / 32;
+    return d;
+}
 WsLayout ws_layout(int X, int Y, int Z, int P) {
     WsLayout w{};
-    const size_t pvox = (size_t)(X + 2 * P) * (Y + 2 * P) * (Z + 2 * P), nvox = (size_t)X * Y * Z;
+    const Dom d = make_dom(X, Y, Z, P);
+    const size_t pwords = (size_t)d.PX * d.PY * d.PZW, nvox = (size_t)X * Y * Z;
     const size_t nblk = (nvox + SCAN_BLOCK - 1) / SCAN_BLOCK;
     size_t cur = 0;
-    w.a = cur; cur += rup256(pvox);
-    w.b = cur; cur += rup256(pvox);
+    w.a = cur; cur += rup256(pwords * 4);
+    w.b = cur; cur += rup256(pwords * 4);
     w.rank = cur; cur += rup256(nvox * 4);
     w.blockcnt = cur; cur += rup256((nblk + 1) * 4);
     w.bbox = cur; cur += 256;
@@ -267,34 +344,34 @@ int sd_object_segmentation(const uint8_t* prob_dev, int X, int Y, int Z, double 
     if (ws_bytes < w.total) return sd_fail_msg(SD_ERR_NOMEM, "sd_object_segmentation: workspace too small");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     char* const wb = reinterpret_cast<char*>(ws);
-    uint8_t* A = reinterpret_cast<uint8_t*>(wb + w.a);
-    uint8_t* B = reinterpret_cast<uint8_t*>(wb + w.b);
+    uint32_t* A = reinterpret_cast<uint32_t*>(wb + w.a);
+    uint32_t* B = reinterpret_cast<uint32_t*>(wb + w.b);
     int* rank = reinterpret_cast<int*>(wb + w.rank);
     int* blockcnt = reinterpret_cast<int*>(wb + w.blockcnt);
     int* bbox = reinterpret_cast<int*>(wb + w.bbox);
-    Dom d{X, Y, Z, P, X + 2 * P, Y + 2 * P, Z + 2 * P};
-    const size_t pvox = (size_t)d.PX * d.PY * d.PZ, nvox = (size_t)X * Y * Z;
+    const Dom d = make_dom(X, Y, Z, P);
+    const size_t pwords = (size_t)d.PX * d.PY * d.PZW, nvox = (size_t)X * Y * Z;
     // (uint8 p > t) <=> p >= floor(t) + 1; threshold 0 means "already a 0/1 mask" (object_extraction_steps.py:316): cut 1
     const double c = std::floor(threshold) + 1.0;
     const int cut = threshold == 0.0 ? 1 : (c < 0.0 ? 0 : (c > 256.0 ? 256 : (int)c));
-    hipLaunchKernelGGL(k_threshold_pad, dim3(grid_for(pvox)), dim3(256), 0, s, prob_dev, cut, d, A);
+    hipLaunchKernelGGL(k_threshold_bits, dim3(grid_for(pwords)), dim3(256), 0, s, prob_dev, cut, d, A);
     for (int i = 0; i < n_ops; ++i) {
         const int n = iterations[i];
         hipLaunchKernelGGL(k_bbox_init, dim3(1), dim3(256), 0, s, bbox);
-        hipLaunchKernelGGL(k_bbox, dim3(grid_for(pvox, 2048)), dim3(256), 0, s, A, d, bbox);
+        hipLaunchKernelGGL(k_bbox_bits, dim3(grid_for(pwords, 512)), dim3(256), 0, s, A, d, bbox);
         const int wpad = ops[i] == SD_MOP_OPENING ? 0 : n;
         const int nfirst = n, nsecond = ops[i] == SD_MOP_DILATION ? 0 : n;
         const int first_dilate = ops[i] == SD_MOP_OPENING ? 0 : 1;
         for (int k = 0; k < nfirst + nsecond; ++k) {
             const int dil = k < nfirst ? first_dilate : 1 - first_dilate;
             const int crop = (k == nfirst + nsecond - 1) ? 1 : 0;
-            hipLaunchKernelGGL(k_morph_step, dim3(grid_for(pvox)), dim3(256), 0, s, A, B, d, bbox, wpad, dil, crop, o);
+            hipLaunchKernelGGL(k_morph_bits, dim3(grid_for(pwords)), dim3(256), 0, s, A, B, d, bbox, wpad, dil, crop, o);
             std::swap(A, B);
         }
     }
     int* L = labels_dev;
-    hipLaunchKernelGGL(k_cc_init, dim3(grid_for(nvox)), dim3(256), 0, s, A, d, L, mask_out_dev);
-    hipLaunchKernelGGL(k_cc_merge, dim3(grid_for(nvox)), dim3(256), 0, s, d, L);
+    hipLaunchKernelGGL(k_cc_init_runs, dim3(grid_for(nvox)), dim3(256), 0, s, A, d, L, mask_out_dev);
+    hipLaunchKernelGGL(k_cc_merge_runs, dim3(grid_for(nvox)), dim3(256), 0, s, A, d, L);
     hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nvox)), dim3(256), 0, s, nvox, L);
     const int nblk = (int)((nvox + SCAN_BLOCK - 1) / SCAN_BLOCK);
     hipLaunchKernelGGL(k_cc_count, dim3(nblk), dim3(256), 0, s, nvox, L, blockcnt);

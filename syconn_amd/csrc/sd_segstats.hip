@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
+#include <cstdlib>
 #include <string>
 
 extern int sd_fail_msg(int code, const char* msg);      // sd_api.hip: sets sd_last_error()
@@ -106,14 +107,91 @@ __device__ __forceinline__ void obj_update(const ObjTable& t, u64 key, u64 lin, 
     atomicMax(&t.bbmax[2 * t.cap + s], z + len);
 }
 
-// One wave = 64 consecutive voxels of the flattened volume.  Per volume a lane is a run head iff it is the wave's first
-// lane, the first voxel of a z-row, or its label differs from the previous voxel's.
+// Workgroup-local aggregation: a small open-addressing table per volume in LDS collects the updates of the workgroup's
+// contiguous range of the volume (label volumes are spatially coherent: the same few ids come back row after row), and
+// only its occupied slots are merged into the global table when the workgroup is done -- global atomics drop from one
+// set per run to one set per (workgroup, id).  A full LDS table simply sends further new ids to the global table directly.
+constexpr int LDS_SLOTS = 512;                 // shared by the 1 + n_sub volumes of a scan (power-of-two share each)
+struct LTab { u64* keys; u64* first; unsigned* size; int* bb; int cap; };
+
+__device__ __forceinline__ int lds_find_or_insert(u64* keys, int cap, u64 k) {
+    const int mask = cap - 1;
+    int h = (int)(mix64(k) & (u64)mask);
+    for (int probe = 0; probe < 24 && probe < cap; ++probe, h = (h + 1) & mask) {
+        const u64 cur = keys[h];
+        if (cur == k) return h;
+        if (cur == EMPTY) {
+            const u64 old = atomicCAS(&keys[h], EMPTY, k);
+            if (old == EMPTY || old == k) return h;
+        }
+    }
+    return -1;
+}
+
+__device__ __forceinline__ void run_update(const LTab& lt, const ObjTable& gt, u64 key, u64 lin, int x, int y, int z, int len,
+                                           int* status) {
+    if (lt.cap) {
+        const int s = lds_find_or_insert(lt.keys, lt.cap, key);
+        if (s >= 0) {
+            atomicMin(&lt.first[s], lin);
+            atomicAdd(&lt.size[s], (unsigned)len);
+            atomicMin(&lt.bb[0 * lt.cap + s], x); atomicMin(&lt.bb[1 * lt.cap + s], y); atomicMin(&lt.bb[2 * lt.cap + s], z);
+            atomicMax(&lt.bb[3 * lt.cap + s], x + 1); atomicMax(&lt.bb[4 * lt.cap + s], y + 1);
+            atomicMax(&lt.bb[5 * lt.cap + s], z + len);
+            return;
+        }
+    }
+    obj_update(gt, key, lin, x, y, z, len, status);
+}
+
+__device__ __forceinline__ void lds_flush(const LTab& lt, const ObjTable& gt, int* status) {
+    for (int s = threadIdx.x; s < lt.cap; s += 256) {
+        const u64 k = lt.keys[s];
+        if (k == EMPTY) continue;
+        const long g = find_or_insert(gt.keys, gt.cap, k);
+        if (g < 0) { atomicExch(&status[0], 1); continue; }
+        atomicMin(&gt.first[g], lt.first[s]);
+        atomicAdd(&gt.size[g], (u64)lt.size[s]);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&gt.bbmin[a * gt.cap + g], lt.bb[a * lt.cap + s]);
+            atomicMax(&gt.bbmax[a * gt.cap + g], lt.bb[(3 + a) * lt.cap + s]);
+        }
+    }
+}
+
+// One wave = 64 consecutive voxels of the flattened volume; a workgroup owns a contiguous range of such wave-chunks.  Per
+// volume a lane is a run head iff it is the wave's first lane, the first voxel of a z-row, or its label differs from the
+// previous voxel's.
 template <typename L>
-__global__ __launch_bounds__(256) void k_segstats_scan(const ScanParams p) {
+__global__ __launch_bounds__(256) void k_segstats_scan(const ScanParams p, const int lcap) {
+    __shared__ u64 l_keys[LDS_SLOTS];
+    __shared__ u64 l_first[LDS_SLOTS];
+    __shared__ unsigned l_size[LDS_SLOTS];
+    __shared__ int l_bb[6 * LDS_SLOTS];
     const int lane = threadIdx.x & 63;
+    const int nvol = (p.cell ? 1 : 0) + p.n_sub;
+    for (int i = threadIdx.x; i < LDS_SLOTS; i += 256) {
+        l_keys[i] = EMPTY; l_first[i] = ~0ull; l_size[i] = 0;
+    }
+    for (int i = threadIdx.x; i < 6 * LDS_SLOTS; i += 256) {
+        // table t occupies slots [t*lcap, (t+1)*lcap): its bbox block is [6*t*lcap, 6*(t+1)*lcap), min rows first
+        const int t = lcap ? i / (6 * lcap) : 0, r = lcap ? (i - t * 6 * lcap) / lcap : 0;
+        l_bb[i] = r < 3 ? 0x7fffffff : 0;
+    }
+    __syncthreads();
+    auto ltab = [&](int t) {
+        LTab lt;
+        lt.cap = (p.want_props && lcap && t < nvol) ? lcap : 0;
+        lt.keys = l_keys + t * lcap; lt.first = l_first + t * lcap; lt.size = l_size + t * lcap; lt.bb = l_bb + 6 * t * lcap;
+        return lt;
+    };
+    const LTab cell_lt = ltab(0);
     const u64 nvox = (u64)p.X * p.Y * p.Z;
     const u64 nwaves = (nvox + 63) / 64;
-    for (u64 w = (u64)blockIdx.x * 4 + (threadIdx.x >> 6); w < nwaves; w += (u64)gridDim.x * 4) {
+    const u64 per_wg = (nwaves + gridDim.x - 1) / gridDim.x;
+    const u64 w_end = min(nwaves, (u64)(blockIdx.x + 1) * per_wg);
+    for (u64 w = (u64)blockIdx.x * per_wg + (threadIdx.x >> 6); w < w_end; w += 4) {
         const u64 base = w * 64, lin = base + lane;
         const int nvalid = (int)((nvox - base) < 64 ? (nvox - base) : 64);
         const bool valid = lane < nvalid;
@@ -128,7 +206,7 @@ __global__ __launch_bounds__(256) void k_segstats_scan(const ScanParams p) {
             chead = valid && (row_start || ck != prev);
             if (p.want_props) {
                 const int len = run_length(chead, lane, nvalid);
-                if (chead && ck != 0) obj_update(p.cell_t, ck, lin, x, y, z, len, p.status);
+                if (chead && ck != 0) run_update(cell_lt, p.cell_t, ck, lin, x, y, z, len, p.status);
             }
         }
         for (int ii = 0; ii < p.n_sub; ++ii) {
@@ -137,11 +215,11 @@ __global__ __launch_bounds__(256) void k_segstats_scan(const ScanParams p) {
             const bool shead = valid && (row_start || sk != prev);
             if (p.want_props) {
                 const int len = run_length(shead, lane, nvalid);
-                if (shead && sk != 0) obj_update(p.sub_t[ii], sk, lin, x, y, z, len, p.status);
+                if (shead && sk != 0) run_update(ltab((p.cell ? 1 : 0) + ii), p.sub_t[ii], sk, lin, x, y, z, len, p.status);
             }
             if (p.cell) {
-                // overlap counts: runs of a constant (subcell id, cell id) pair; both ids are inserted in their tables
-                // (by this very lane or an earlier head of the same run), their slots name the pair
+                // overlap counts: runs of a constant (subcell id, cell id) pair; both ids get a slot in their GLOBAL tables
+                // here (their properties may still sit in the LDS tables), the two slots name the pair
                 const bool phead = chead || shead;
                 const int plen = run_length(phead, lane, nvalid);
                 if (phead && sk != 0 && ck != 0) {
@@ -154,6 +232,11 @@ __global__ __launch_bounds__(256) void k_segstats_scan(const ScanParams p) {
                 }
             }
         }
+    }
+    __syncthreads();
+    if (p.want_props && lcap) {
+        if (p.cell) lds_flush(cell_lt, p.cell_t, p.status);
+        for (int ii = 0; ii < p.n_sub; ++ii) lds_flush(ltab((p.cell ? 1 : 0) + ii), p.sub_t[ii], p.status);
     }
 }
 
@@ -225,9 +308,16 @@ int sd_segstats_scan(const void* cell_dev, const void* const* sub_devs, int n_su
         }
     }
     const u64 nwaves = ((u64)X * Y * Z + 63) / 64;
-    const int grid = (int)std::min<u64>((nwaves + 3) / 4, 256 * 16);
-    if (dtype == SD_U64) hipLaunchKernelGGL(k_segstats_scan<uint64_t>, dim3(grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(k_segstats_scan<uint32_t>, dim3(grid), dim3(256), 0, s, p);
+    // each workgroup owns a contiguous range of >= 64 wave-chunks (4096 voxels = a few z-rows); LDS slots per volume
+    const int grid = (int)std::max<u64>(1, std::min<u64>((nwaves + 63) / 64, 256 * 8));
+    const int nvol = (cell_dev ? 1 : 0) + n_sub;
+    int lcap = 32;
+    while (lcap * 2 * nvol <= LDS_SLOTS) lcap *= 2;
+    if (lcap * nvol > LDS_SLOTS) lcap = 0;            // too many volumes for the shared LDS table: global updates only
+    static const bool no_lds = getenv("SD_SEGSTATS_NO_LDS") != nullptr;      // debugging aid / A-B
+    if (no_lds) lcap = 0;
+    if (dtype == SD_U64) hipLaunchKernelGGL(k_segstats_scan<uint64_t>, dim3(grid), dim3(256), 0, s, p, lcap);
+    else hipLaunchKernelGGL(k_segstats_scan<uint32_t>, dim3(grid), dim3(256), 0, s, p, lcap);
     return hipGetLastError() == hipSuccess ? SD_OK : sd_fail_msg(SD_ERR_HIP, "sd_segstats_scan: launch failed");
 }
 

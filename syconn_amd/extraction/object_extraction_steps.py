@@ -48,12 +48,15 @@ def _count_subsequent_mops(mops: Sequence[str]) -> Tuple[List[str], List[int]]:
 
 
 def object_segmentation_first_stage(prob, threshold: float, morph_ops: Sequence[str] = (), scaling=(10, 10, 20),
-                                    structure: Optional[np.ndarray] = None, return_mask: bool = False, device=None):
+                                    structure: Optional[np.ndarray] = None, return_mask: bool = False, device=None,
+                                    return_device: bool = False):
     """One probability map of a chunk -> ``(labels int32 (x,y,z), max_label)`` (+ the binary volume after the morphology if
     `return_mask`).  `prob`: uint8 (x,y,z) numpy array or device tensor; `threshold` in uint8 units as the reference
     compares it (``tmp_data > threshold``; 0: `prob` is already a 0/1 mask); `morph_ops`: names of ``scipy.ndimage``
     binary operations as in ``config['cell_objects']['extract_morph_op']``; `structure` defaults to
-    ``get_aniso_struct(scaling)``."""
+    ``get_aniso_struct(scaling)``.  `return_device`: leave the results on the GPU (int32 label tensor, 1-element count
+    tensor[, uint8 mask]) -- the label volume is 4 bytes per voxel, and its consumer (``find_object_properties`` /
+    ``segstats``, which take device tensors) does not need it on the host."""
     lib = L.load()
     if not torch.cuda.is_available():
         raise RuntimeError('syconn_amd: no MI355X visible to PyTorch-ROCm; this package has no CPU fallback')
@@ -92,6 +95,8 @@ def object_segmentation_first_stage(prob, threshold: float, morph_ops: Sequence[
                                        st.ctypes.data_as(C.c_void_p), *[int(s) for s in st.shape], labels.data_ptr(),
                                        max_label.data_ptr(), mask.data_ptr() if mask is not None else None, ws.data_ptr(),
                                        ws_bytes, torch.cuda.current_stream(device).cuda_stream), 'sd_object_segmentation')
+    if return_device:
+        return (labels, max_label) + ((mask,) if return_mask else ())
     out = (labels.cpu().numpy(), int(max_label.item()))
     if return_mask:
         out = out + (mask.cpu().numpy(),)

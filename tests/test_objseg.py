@@ -9,6 +9,7 @@ import os
 
 import numpy as np
 import pytest
+import torch
 from scipy import ndimage
 
 from oracle.objseg_ref import (apply_morphological_operations_ref, count_subsequent_mops, get_aniso_struct_ref,
@@ -102,3 +103,18 @@ def test_gpu_object_segmentation_worst_case_components_and_errors(gpu):
         object_segmentation_first_stage(prob, 100.0, ['binary_fill_holes'])
     with pytest.raises(TypeError):
         object_segmentation_first_stage(prob.astype(np.float32), 100.0)
+
+
+@pytest.mark.gpu
+def test_gpu_labels_stay_on_device_and_feed_the_statistics(gpu):
+    """object segmentation -> label-volume statistics without leaving the GPU (int32 labels as SD_U32 volume): sizes and
+    bounding boxes of the components equal what the oracle computes from the oracle's labels."""
+    from oracle.objprops_ref import find_object_properties_np
+    from syconn_amd.extraction.find_object_properties import find_object_properties
+    from syconn_amd.extraction.object_extraction_steps import object_segmentation_first_stage
+    prob, thr = _blobs((48, 56, 40), 9, 1.4, 0.8)
+    lab_dev, mx_dev = object_segmentation_first_stage(prob, thr, ['binary_closing', 'binary_opening'], return_device=True)
+    assert lab_dev.is_cuda and lab_dev.dtype == torch.int32
+    want, want_max = object_segmentation_ref(prob, thr, ['binary_closing', 'binary_opening'], (10, 10, 20))
+    assert int(mx_dev.item()) == want_max
+    assert find_object_properties(lab_dev) == find_object_properties_np(want.astype(np.uint32))

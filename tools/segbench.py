@@ -46,6 +46,7 @@ def main():
     p_dev = torch.from_numpy(prob).to(dev)
     for ops in ([], ['binary_closing', 'binary_opening']):
         t = sync_time(lambda: object_segmentation_first_stage(p_dev, thr, ops), reps=2)
+        t_dev = sync_time(lambda: object_segmentation_first_stage(p_dev, thr, ops, return_device=True), reps=5)
         lab, mx = object_segmentation_first_stage(p_dev, thr, ops)
         t0 = time.perf_counter()
         if n <= 256:
@@ -58,8 +59,8 @@ def main():
             tc = (time.perf_counter() - t0) * (n / 256) ** 3
         alg = n ** 3 * (1 + 4)                   # uint8 probability in, int32 labels out
         out['objseg_' + ('morph' if ops else 'plain')] = {
-            'ops': ops, 'components': mx, 'gpu_ms_incl_d2h_of_labels': t * 1e3, 'gpu_Mvox_s': n ** 3 / t / 1e6,
-            'algorithmic_GB_s': alg / t / 1e9, 'cpu_s_scipy_oracle' + ('' if n <= 256 else '_extrapolated'): tc,
+            'ops': ops, 'components': mx, 'gpu_ms_incl_d2h_of_labels': t * 1e3, 'gpu_ms_device_resident': t_dev * 1e3,
+            'gpu_Mvox_s': n ** 3 / t_dev / 1e6, 'algorithmic_GB_s': alg / t_dev / 1e9, 'cpu_s_scipy_oracle' + ('' if n <= 256 else '_extrapolated'): tc,
             'cpu_Mvox_s': n ** 3 / tc / 1e6}
 
     # ---- label-volume statistics ---------------------------------------------------------------------------------------
