@@ -106,3 +106,33 @@ def test_gpu_objprops_edge_cases(gpu):
         map_subcell_extract_props(np.zeros((2, 2, 2), np.uint64), np.zeros((1, 2, 2, 3), np.uint64))
     with pytest.raises(TypeError):
         find_object_properties(np.zeros((2, 2, 2), np.int16))
+
+
+@pytest.mark.gpu
+def test_gpu_objprops_full_chunk_size_properties(gpu):
+    """256x512x512 uint64 supervoxel-like volume with three organelle volumes (one pass over 4 volumes of 0.5 GiB each):
+    size-independent properties -- sizes sum to the number of non-zero voxels, overlap counts of an organelle id sum to its
+    voxels inside cells, bounding boxes contain the representative coordinate -- and equality with the numpy oracle on a
+    corner the oracle finishes in seconds."""
+    from syconn_amd.extraction.find_object_properties import segstats, find_object_properties
+    rng = np.random.default_rng(21)
+    shape = (256, 512, 512)
+    small = rng.integers(0, 3000, (17, 33, 33))
+    cell = np.kron(small, np.ones((16, 16, 16), np.int64))[:shape[0], :shape[1], :shape[2]].astype(np.uint64)
+    subs = []
+    for k in range(3):
+        s = rng.integers(0, 40, (33, 65, 65))
+        s[s > 6] = 0
+        subs.append(np.kron(s, np.ones((8, 8, 8), np.int64))[:shape[0], :shape[1], :shape[2]].astype(np.uint64) * (k + 1))
+    r = segstats(cell, subs)
+    assert int(r.cell[2].sum()) == int(np.count_nonzero(cell))
+    for k in range(3):
+        ids, first, size, bb = r.sub[k]
+        assert int(size.sum()) == int(np.count_nonzero(subs[k]))
+        s_ids, c_ids, cnt = r.pairs[k]
+        both = (subs[k] != 0) & (cell != 0)
+        assert int(cnt.sum()) == int(np.count_nonzero(both))
+        rc = np.stack(np.unravel_index(first, shape), axis=1)
+        assert np.all(rc >= bb[:, 0]) and np.all(rc < bb[:, 1])
+    corner = cell[:64, :128, :128]
+    assert find_object_properties(np.ascontiguousarray(corner)) == find_object_properties_np(np.ascontiguousarray(corner))

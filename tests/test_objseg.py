@@ -118,3 +118,26 @@ def test_gpu_labels_stay_on_device_and_feed_the_statistics(gpu):
     want, want_max = object_segmentation_ref(prob, thr, ['binary_closing', 'binary_opening'], (10, 10, 20))
     assert int(mx_dev.item()) == want_max
     assert find_object_properties(lab_dev) == find_object_properties_np(want.astype(np.uint32))
+
+
+@pytest.mark.gpu
+def test_gpu_full_chunk_size_against_scipy_and_properties(gpu):
+    """A chunk of the size SyConn segments at once (512^3, object_extraction_wrapper.py:92-93 `chunk_size = [512]*3`, here
+    384x512x512 to keep the CPU side at a few seconds): labels bit-identical to scipy.ndimage.label of the same mask, and
+    size-independent properties of the morphology: an opening only removes voxels, applying the same opening to its own
+    result changes nothing (idempotence), label count matches the label maximum."""
+    from syconn_amd.extraction.object_extraction_steps import object_segmentation_first_stage
+    rng = np.random.default_rng(12)
+    small = ndimage.gaussian_filter(rng.random((96, 128, 128)).astype(np.float32), 1.2)
+    prob = np.kron(small, np.ones((4, 4, 4), np.float32))
+    prob = ((prob - prob.min()) / (prob.max() - prob.min()) * 255).astype(np.uint8)
+    prob[::7, ::5, ::3] = 255                                    # specks: many tiny components and run fragments
+    thr = float(np.quantile(prob[::4, ::4, ::4], 0.85))
+    lab, mx, mask = object_segmentation_first_stage(prob, thr, [], return_mask=True)
+    want, want_max = ndimage.label(prob > thr)
+    assert mx == want_max and int(lab.max()) == mx and np.array_equal(lab, want)
+    lab_o, mx_o, mask_o = object_segmentation_first_stage(prob, thr, ['binary_opening'], return_mask=True)
+    assert not np.any(mask_o & ~mask.astype(bool)) and int(mask_o.sum()) < int(mask.sum())
+    lab_oo, mx_oo, mask_oo = object_segmentation_first_stage(mask_o, 0.0, ['binary_opening'], return_mask=True)
+    assert np.array_equal(mask_oo, mask_o) and mx_oo == mx_o and np.array_equal(lab_oo, lab_o)
+    assert np.array_equal(lab_o, ndimage.label(mask_o)[0])
