@@ -59,8 +59,7 @@ struct Op {
     int fuse_gn = -1;      // conv: index of the GroupNorm op whose statistics this conv's epilogue accumulates
     bool stats_done = false;   // groupnorm: statistics come from the producing conv
     int gn_pool = -1;          // groupnorm: index of the MaxPool op fused into the apply pass
-    bool gn_into_final = false;  // groupnorm: only the statistics run here, the final layer applies scale / shift itself
-    int final_gn = -1;           // final: index of the GroupNorm op whose apply pass it performs on the fly
+    bool gn_defer = false;       // groupnorm: statistics -> scale / shift only; every consumer of the buffer applies them itself
     size_t fwfrag_off = 0;             // fused final 1x1x1: hi/lo MFMA weight fragments
     bool skipped = false;  // op is executed inside its producer
 };
@@ -88,6 +87,11 @@ struct sd_model {
     int final_cout = 0;
     bool keep_all = false;   // SD_KEEP_ALL=1: also store activations that only feed a fused consumer (tests)
     bool ws_reuse = true;    // activation buffers with disjoint lifetimes share workspace memory
+    // deferred GroupNorm apply: buffer b holds the RAW tensor, its consumers apply scale / shift (+ReLU) on the fly from a
+    // per-tile [2*Cp] float table that lives in the workspace at gn_tab_off[b] (buf_gn[b] = index of the GroupNorm op)
+    std::vector<int> buf_gn;
+    std::vector<size_t> gn_tab_off;
+    size_t ws_base = 65536;  // first byte of the activation buffers (behind the scratch and the tables)
 };
 
 namespace {
@@ -139,10 +143,11 @@ int infer_shapes(const sd_model* m, int D, int H, int W, std::vector<Dims>& dims
 size_t plan_workspace(const sd_model* m, const std::vector<Dims>& dims, std::vector<size_t>& off) {
     const int nb = m->nbuf;
     off.assign(nb, 0);
+    const size_t WS_BASE = m->ws_base;      // statistics scratch + the scale / shift tables of deferred GroupNorm applies
     std::vector<size_t> bytes(nb, 0);
     for (int b = 1; b < nb; ++b) bytes[b] = rup_sz((size_t)dims[b].d * dims[b].h * dims[b].w * m->bufCp[b] * 2, 256);
     if (!m->ws_reuse) {
-        size_t cur = WS_SCRATCH;
+        size_t cur = WS_BASE;
         for (int b = 1; b < nb; ++b) { off[b] = cur; cur += bytes[b]; }
         return cur;
     }
@@ -166,14 +171,14 @@ size_t plan_workspace(const sd_model* m, const std::vector<Dims>& dims, std::vec
         if (last[b] >= 0 && bytes[b]) order.push_back(b);
     std::sort(order.begin(), order.end(), [&](int a, int b) { return first[a] != first[b] ? first[a] < first[b] : a < b; });
     std::vector<int> placed;
-    size_t top = WS_SCRATCH;
+    size_t top = WS_BASE;
     for (int b : order) {
         // candidate offsets: scratch end and the end of every placed buffer that is alive at the same time
         std::vector<std::pair<size_t, size_t>> busy;      // [begin, end) ranges this buffer must avoid
         for (int q : placed)
             if (first[q] <= last[b] && first[b] <= last[q]) busy.push_back({off[q], off[q] + bytes[q]});
         std::sort(busy.begin(), busy.end());
-        size_t cur = WS_SCRATCH;
+        size_t cur = WS_BASE;
         for (const auto& r : busy) {
             if (cur + bytes[b] <= r.first) break;
             cur = std::max(cur, r.second);
@@ -423,6 +428,9 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
         m->ops.push_back(op);
     }
     if (m->ops.empty() || m->ops.back().d.kind != SD_OP_FINAL) MODEL_FAIL("the plan must end with SD_OP_FINAL");
+    m->buf_gn.assign(m->nbuf, -1);
+    m->gn_tab_off.assign(m->nbuf, 0);
+    m->ws_base = WS_SCRATCH;
     // epilogue fusions (SD_NO_FUSE=1 keeps every layer a separate launch, for layer-wise debugging)
     if (!getenv("SD_NO_FUSE")) {
         // first conv (1 -> 32, 1x3x3) -> conv (1x3x3) of one input: the second conv computes its halo of the first conv's
@@ -449,17 +457,35 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
                 nx.skipped = true;
             }
         }
-        // GroupNorm directly followed by the final 1x1x1 layer: the final layer normalises on the fly, the normalised
-        // tensor is never written (nor read again): one pass over the raw tensor instead of three
-        if (m->ops.size() >= 2 && !getenv("SD_NO_GN_FUSE")) {
-            Op& g = m->ops[m->ops.size() - 2];
-            Op& f = m->ops.back();
-            if (g.d.kind == SD_OP_GROUPNORM && g.d.src1 < 0 && g.gn_pool < 0 && f.d.kind == SD_OP_FINAL && f.d.src0 == g.d.src0 &&
-                !m->keep_all) {
-                g.gn_into_final = true;
-                f.final_gn = (int)m->ops.size() - 2;
+        // Deferred GroupNorm apply: the op only turns the statistics into a scale / shift table; the tensor stays raw and
+        // every reader normalises on the fly (convolutions in their LDS halo, up-convolutions and the final layer on their
+        // register fragments, a pooling fused into the GroupNorm op writes the normalised pooled tensor only) -- the
+        // normalised tensor is never written nor re-read.  Possible when every later reader of the buffer is such an op.
+        if (!getenv("SD_NO_GN_FUSE") && !getenv("SD_NO_GN_DEFER") && !m->keep_all) {
+            for (size_t i = 0; i < m->ops.size(); ++i) {
+                Op& g = m->ops[i];
+                if (g.d.kind != SD_OP_GROUPNORM) continue;
+                const int b = g.d.src0;
+                bool ok = true, any = false;
+                for (size_t k = i + 1; k < m->ops.size() && ok; ++k) {
+                    const Op& r = m->ops[k];
+                    if (r.d.src0 != b && r.d.src1 != b) continue;
+                    any = true;
+                    if (r.d.kind == SD_OP_CONV) ok = !r.first && m->bufCp[b] <= 256;      // LDS table: 128 B per 16 channels and tile
+                    else if (r.d.kind == SD_OP_UPCONV)      // only the row kernel absorbs the apply cheaply; else keep the pass
+                        ok = upconv_rows_kernel(m->bufCp[b] / SD_CHUNK, rup(r.d.cout, SD_CHUNK));
+                    else if (r.d.kind == SD_OP_FINAL) ok = true;
+                    else if (r.d.kind == SD_OP_POOL) ok = (g.gn_pool == (int)k);
+                    else ok = false;                                                     // another GroupNorm etc.
+                }
+                if (ok && any) { g.gn_defer = true; m->buf_gn[b] = (int)i; }
             }
         }
+        for (int b = 1; b < m->nbuf; ++b)
+            if (m->buf_gn[b] >= 0) {
+                m->gn_tab_off[b] = m->ws_base;
+                m->ws_base += rup_sz((size_t)2 * m->bufCp[b] * 4, 256);
+            }
         for (size_t i = 0; i + 1 < m->ops.size(); ++i) {
             Op& c = m->ops[i];
             Op& nx = m->ops[i + 1];
@@ -699,7 +725,34 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
                         HIP_TRY(hipMemsetAsync(wsb + (size_t)t * tstride, 0, sizeof(double) * 2 * p.Cd, s));
                 }
                 p.nbx = (o.w + SD_BX - 1) / SD_BX; p.nby = (o.h + BY - 1) / BY; p.nbz = (o.d + BZ - 1) / BZ;
-                rc = launch_conv(p, m->act_dtype, d.kz, op.NT, op.NB, s);
+                auto gn_of = [&](int b, const float*& tab, int& relu) {
+                    if (b > 0 && m->buf_gn[b] >= 0) {
+                        tab = reinterpret_cast<const float*>(wsb + m->gn_tab_off[b]);
+                        relu = m->ops[m->buf_gn[b]].d.relu;
+                    }
+                };
+                gn_of(d.src0, p.gn0, p.gn_relu0);
+                if (d.src1 >= 0) gn_of(d.src1, p.gn1, p.gn_relu1);
+                if (p.gn0 || p.gn1) {
+                    // the kernel keeps the scale / shift of all its tiles in LDS (128 B per 16 channels and tile): launch
+                    // the tiles in groups that fit beside the halo / weight buffers (24 KiB are always free)
+                    const size_t per_tile = conv_gn_lds_per_tile(p.nchunk0 + p.nchunk1);
+                    const int group = (int)std::max<size_t>(1, std::min<size_t>((size_t)N, (24 * 1024) / per_tile));
+                    for (int t0 = 0; t0 < N && rc == SD_OK; t0 += group) {
+                        ConvParams q = p;
+                        q.batch = std::min(group, N - t0);
+                        auto adv = [&](const void* ptr) { return ptr ? reinterpret_cast<const char*>(ptr) + (size_t)t0 * tstride : nullptr; };
+                        q.src0 = adv(p.src0); q.src1 = adv(p.src1);
+                        q.dst = const_cast<char*>(reinterpret_cast<const char*>(adv(p.dst)));
+                        q.pool_dst = p.pool_dst ? const_cast<char*>(reinterpret_cast<const char*>(adv(p.pool_dst))) : nullptr;
+                        q.gn_sums = p.gn_sums ? reinterpret_cast<double*>(const_cast<char*>(reinterpret_cast<const char*>(adv(p.gn_sums)))) : nullptr;
+                        q.gn0 = reinterpret_cast<const float*>(adv(p.gn0)); q.gn1 = reinterpret_cast<const float*>(adv(p.gn1));
+                        q.final_out = p.final_out ? reinterpret_cast<char*>(p.final_out) + (size_t)t0 * out_tstride : nullptr;
+                        rc = launch_conv(q, m->act_dtype, d.kz, op.NT, op.NB, s);
+                    }
+                } else {
+                    rc = launch_conv(p, m->act_dtype, d.kz, op.NT, op.NB, s);
+                }
             }
             break;
         }
@@ -724,6 +777,10 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
             p.bias = reinterpret_cast<const float*>(m->dev_blob + op.bias_off);
             p.relu = d.relu; p.ntot = d.kz * 4 * p.Cd;
             p.batch = N; p.tstride = tstride;
+            if (m->buf_gn[d.src0] >= 0) {
+                p.gn = reinterpret_cast<const float*>(wsb + m->gn_tab_off[d.src0]);
+                p.gn_relu = m->ops[m->buf_gn[d.src0]].d.relu;
+            }
             rc = launch_upconv(p, m->act_dtype, op.NB, s);
             break;
         }
@@ -737,10 +794,11 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
             p.gamma = reinterpret_cast<const float*>(m->dev_blob + op.aux_off);
             p.beta = p.gamma + p.C;
             p.sums = reinterpret_cast<double*>(wsb);
-            p.scale_shift = reinterpret_cast<float*>(wsb + (size_t)2 * p.C * 8);
+            p.scale_shift = reinterpret_cast<float*>(op.gn_defer ? wsb + m->gn_tab_off[d.src0] : wsb + (size_t)2 * p.C * 8);
             p.relu = d.relu;
             p.batch = N; p.tstride = tstride; p.skip_stats = op.stats_done ? 1 : 0;
-            p.skip_apply = op.gn_into_final ? 1 : 0;
+            p.skip_apply = (op.gn_defer && op.gn_pool < 0) ? 1 : 0;
+            p.no_inplace = op.gn_defer ? 1 : 0;
             if (op.gn_pool >= 0) {
                 const sd_op_desc& pd = m->ops[op.gn_pool].d;
                 const Dims po = m->dims[pd.dst];
@@ -760,9 +818,9 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
             p.nvox = (long)a.d * a.h * a.w;
             p.batch = N; p.tstride = tstride; p.out_tstride = out_tstride;
             if (lab) p.lab = *lab;
-            if (op.final_gn >= 0) {     // scale / shift were left by the GroupNorm op in the workspace scratch of every tile
-                p.gn_scale_shift = reinterpret_cast<const float*>(wsb + (size_t)2 * p.Cs * 8);
-                p.gn_relu = m->ops[op.final_gn].d.relu;
+            if (m->buf_gn[d.src0] >= 0) {     // deferred GroupNorm apply of the input
+                p.gn_scale_shift = reinterpret_cast<const float*>(wsb + m->gn_tab_off[d.src0]);
+                p.gn_relu = m->ops[m->buf_gn[d.src0]].d.relu;
             }
             if (a.d != D || a.h != H || a.w != W) return fail(SD_ERR_INVALID, "final layer shape != input shape");
             rc = launch_final(p, m->act_dtype, s);

@@ -59,6 +59,9 @@ struct ConvParams {
     const float* first_w;      // [5 k-steps][64 lanes] exact-f32 MFMA A fragments of the 32 output channels
     const float* first_bias;   // folded bias, 32 floats
     int first_relu;
+    // deferred GroupNorm apply (k_conv_mfma<..., MODE 2>): src0 / src1 hold RAW convolution outputs; gn0 / gn1 = their
+    // per-tile [2*C] float tables (scale then shift; tile t at + t*tstride bytes) or nullptr when that input is final
+    const float* gn0; const float* gn1; int gn_relu0, gn_relu1;
 };
 
 struct FirstParams {
@@ -86,6 +89,7 @@ struct UpconvParams {
     int relu;
     int ntot;          // ntaps*Cd
     int batch; size_t tstride;
+    const float* gn; int gn_relu;   // deferred GroupNorm apply of `src` ([2*Cs] floats per tile) or nullptr
 };
 
 struct PoolParams {
@@ -129,15 +133,19 @@ struct GnParams {
     int skip_stats;            // the producing convolution already accumulated `sums` (ConvParams::gn_sums)
     void* pool_dst;            // fused MaxPool3d(ceil_mode) of the normalised tensor ((pkz,2,2) windows), or nullptr
     int pkz, pD, pH, pW;       // pooling kz (1 or 2) and pooled extents
-    int skip_apply;            // statistics -> scale/shift only: the consumer (fused final layer) applies them itself
+    int skip_apply;            // statistics -> scale/shift only: the consumers apply them on the fly (deferred apply)
+    int no_inplace;            // with pool_dst: write only the pooled normalised tensor, leave `buf` raw (deferred apply)
 };
 
 int launch_conv(const ConvParams& p, int act_dtype, int KZ, int NT, int NB, hipStream_t s);
+// LDS bytes a deferred-GroupNorm convolution needs per tile of the launch for its scale / shift table
+inline size_t conv_gn_lds_per_tile(int nchunks) { return (size_t)nchunks * 128; }
 // true when launch_conv would run this planar layer with LDS-resident weights and 512-voxel workgroups -- the form
 // that can compute a fused first convolution (ConvParams::first_in)
 bool conv_can_fuse_first(int KZ, int NT, int NB, long vox_all_tiles, int nstages, bool fused_final);
 int launch_first(const FirstParams& p, int act_dtype, int in_dtype, int KZ, hipStream_t s);
 int launch_upconv(const UpconvParams& p, int act_dtype, int NB, hipStream_t s);
+bool upconv_rows_kernel(int nchunk, int Cd);   // shapes served by k_upconv_rows (see sd_kernels.hip)
 int launch_pool(const PoolParams& p, int act_dtype, hipStream_t s);
 int launch_final(const FinalParams& p, int act_dtype, hipStream_t s);
 int launch_groupnorm(const GnParams& p, int act_dtype, hipStream_t s);

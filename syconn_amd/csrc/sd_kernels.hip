@@ -190,6 +190,27 @@ __device__ __forceinline__ void store_acc_tile(const f32x16& acc, T* base, size_
     store_tile_rows<T>(o, base, P, vidx, valid, cbase, half, Cd);
 }
 
+// Deferred GroupNorm apply of 8 channels of one voxel: relu(round_T(x*scale + shift)) == round_T(relu(x*scale + shift)), the
+// arithmetic of k_gn_apply.  Written as "fma in fp32 from a 16-bit source, round once, then packed max with +0" so that
+// the compiler can use v_fma_mix{lo,hi}_f16 (one instruction per element) and v_pk_max (one per pair).
+template <typename T>
+__device__ __forceinline__ typename Act<T>::v8 gn_apply8(typename Act<T>::v8 v, const float* sc, const float* sh, int relu) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u4;
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc), s1 = *reinterpret_cast<const f32x4*>(sc + 4);
+    const f32x4 t0 = *reinterpret_cast<const f32x4*>(sh), t1 = *reinterpret_cast<const f32x4*>(sh + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[e] = (T)fmaf((float)v[e], s0[e], t0[e]);
+        v[4 + e] = (T)fmaf((float)v[4 + e], s1[e], t1[e]);
+    }
+    if (relu) {
+        u4 u = __builtin_bit_cast(u4, v);
+        u.x = pk_max16(u.x, 0u); u.y = pk_max16(u.y, 0u); u.z = pk_max16(u.z, 0u); u.w = pk_max16(u.w, 0u);
+        v = __builtin_bit_cast(typename Act<T>::v8, u);
+    }
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // K2/K3: 3x3x3 / 1x3x3 'same' convolution, C_in >= 16, as a tap-looped implicit GEMM on the matrix cores,
 // software-pipelined with LDS-DMA (global_load_lds, 16 B per lane).  Per workgroup: WAVES*64 output voxels x
@@ -222,8 +243,14 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 // loop issues an ordinary VGPR load (bias and final-layer weights are preloaded), which would drain the ring.
 // NSLOT == 0: weight groups are streamed (double-buffered); the workgroups are persistent as well, and the first
 // weight group and halo chunk of a workgroup's next block are requested during the last stage of the current one.
-template <typename T, int KZ, int NT, int WAVES, int NSLOT, int MT, bool FF>
+// MODE 0: plain; 1 (FF): the first convolution is computed inside (see below); 2 (GN): one or both inputs are RAW tensors
+// whose GroupNorm apply (+ReLU) was deferred to this consumer: every lane rewrites the 16-byte halo pieces it DMA'd into
+// LDS as round_T(relu(x*scale + shift)) right after its own vmcnt wait and before the stage barrier (same arithmetic and
+// rounding point as k_gn_apply, so results are bit-identical to the separate apply pass), with the per-(tile, channel)
+// scale / shift of all tiles of the launch resident in LDS.  The normalised tensor is never written or re-read.
+template <typename T, int KZ, int NT, int WAVES, int NSLOT, int MT, int MODE>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(const ConvParams p) {
+    constexpr bool FF = MODE == 1, GN = MODE == 2;
     using v8 = typename Act<T>::v8;
     using G = ConvGeo<KZ, WAVES, MT>;
     constexpr bool WRES = NSLOT > 0;
@@ -252,6 +279,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     char* const fwl = reinterpret_cast<char*>(wl) + SD_CONV_PARAM_BYTES;
     char* const ldsDummy = fwl + (p.final_wfrag ? NT * 4096 : 0);
     float* const fpatch = reinterpret_cast<float*>(ldsDummy + 1024);      // FF: normalised input patch (HY+2) x (HX+2)
+    float* const gnl = fpatch;     // GN: [tile of the launch][chunk][16 scale, 16 shift] (FF and GN never coexist)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -279,6 +307,19 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     for (int idx = tid; idx < NT * 32; idx += WAVES * 64) {
         const int n = nb * NT * 32 + idx;
         wl[idx] = n < p.Cd ? p.bias[n] : 0.f;
+    }
+    if constexpr (GN) {
+        // scale / shift of every (tile, input channel): source tables are [2*C] floats per tile (scale then shift)
+        const int per_tile = nchunks * 32;
+        for (int i = tid; i < p.batch * per_tile; i += WAVES * 64) {
+            const int t = i / per_tile, r = i - t * per_tile, c = r >> 5, e = r & 31, ch = e & 15, is_shift = e >> 4;
+            const bool s0 = c < p.nchunk0;
+            const float* const base = s0 ? p.gn0 : p.gn1;
+            const int C = s0 ? p.C0 : p.C1, cc = s0 ? c : c - p.nchunk0;
+            float v = is_shift ? 0.f : 1.f;
+            if (base) v = reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)t * p.tstride)[is_shift * C + cc * SD_CHUNK + ch];
+            gnl[i] = v;
+        }
     }
     if (p.final_wfrag) {
         if (tid < 8) wl[NT * 32 + tid] = tid < p.final_cout ? p.final_b[tid] : 0.f;
@@ -382,6 +423,36 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
             }
         }
     };
+    // GN: what the last halo DMA of this wave was issued for (chunk, slot, block origin, tile); transformed in LDS once
+    // it has landed
+    int pd_c = -1, pd_slot = 0, pd_z = 0, pd_y = 0, pd_x = 0, pd_t = 0;
+    auto gn_note = [&](int c, int slot, int bz, int by, int bx, int bt, bool real) {
+        if constexpr (GN) { pd_c = real ? c : -1; pd_slot = slot; pd_z = bz; pd_y = by; pd_x = bx; pd_t = bt; }
+    };
+    auto gn_transform = [&]() {
+        if constexpr (GN) {
+            const int c = pd_c;
+            pd_c = -1;
+            if (c < 0) return;
+            const bool s0 = c < p.nchunk0;
+            if (!(s0 ? p.gn0 : p.gn1)) return;                     // this input is already normalised (wave-uniform)
+            const int relu = s0 ? p.gn_relu0 : p.gn_relu1;
+            const float* const tab = gnl + ((size_t)pd_t * nchunks + c) * 32;
+            char* const base = ldsA + pd_slot * A_BYTES + wave * 1024 + lane * 16;
+#pragma unroll
+            for (int j = 0; j < AJ; ++j) {
+                if (wave + j * WAVES >= A_INSTR) continue;         // wave-uniform
+                const int hp = hpack[j];
+                const int z = pd_z - PZ + (hp >> 20), y = pd_y - 1 + ((hp >> 10) & 1023), x = pd_x - 1 + ((hp >> 1) & 511);
+                const bool ok = hp >= 0 && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+                if (ok) {                                          // out-of-volume pieces stay zero: the conv's zero padding
+                    v8* const q = reinterpret_cast<v8*>(base + j * (WAVES * 1024));
+                    const float* const sc = tab + (hp & 1) * 8;
+                    *q = gn_apply8<T>(*q, sc, sc + 16, relu);
+                }
+            }
+        }
+    };
     // chunk number f of this workgroup's stream (f = round * nchunks + c) -> ring slot f % NA
     // The stream position is carried incrementally (chunk within block, block coordinates) so that the integer
     // divisions of block_of / coords run once per BLOCK, not once per chunk.
@@ -395,6 +466,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     auto dma_stream_next = [&]() {
         if (sf_c == 0) stream_block();
         dma_halo(sf_c, sf_slot, sf_z, sf_y, sf_x, sf_t, sf_ok);
+        gn_note(sf_c, sf_slot, sf_z, sf_y, sf_x, sf_t, sf_ok);
         if (++sf_c == nchunks) { sf_c = 0; ++sf_round; }
         if (++sf_slot == NA) sf_slot = 0;
     };
@@ -460,8 +532,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     } else {
         dma_weights(0, 0);
         dma_halo(0, 0, z0, y0, x0, tn, true);
+        gn_note(0, 0, z0, y0, x0, tn, true);
     }
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WAITN) : "memory");
+    if constexpr (GN) {
+        static_assert(!GN || WAITN == 0, "deferred GroupNorm apply: every halo DMA is awaited at its stage end");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // also: the scale / shift table is in LDS
+        gn_transform();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WAITN) : "memory");
+    }
 
     int gc = 0, gs = 0;   // chunk / stage counters across blocks (slot parity)
     for (int round = 0; lb >= 0; ++round) {
@@ -547,8 +627,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                     if (kz == 0) {
                         if (c + 1 < nchunks) {
                             dma_halo(c + 1, (gc + 1) & 1, z0, y0, x0, tn, true);
+                            gn_note(c + 1, (gc + 1) & 1, z0, y0, x0, tn, true);
                         } else if (nlb >= 0) {
                             dma_halo(0, (gc + 1) & 1, nz0, ny0, nx0, ntn, true);
+                            gn_note(0, (gc + 1) & 1, nz0, ny0, nx0, ntn, true);
                         }
                     }
                 } else if (kz == 0 && !FF) {
@@ -599,7 +681,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                 if (s == SD_TS) SD_T(2);     // after the MFMAs of the probed stage
                 // all of this wave's LDS reads done + the next chunk's DMA landed, then the workgroup barrier (raw
                 // s_barrier: __syncthreads() would drain every DMA in flight with a vmcnt(0))
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WAITN) : "memory");
+                if constexpr (GN) {
+                    // the chunk requested in this stage has landed: rewrite my pieces of it in place, then the barrier
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    gn_transform();
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WAITN) : "memory");
+                }
                 if constexpr (FF) {
                     if (s == 0 && nlb >= 0) patch_park((round + 1) & 1);     // ordered by the barrier that ends stage 1
                 }
@@ -919,7 +1008,7 @@ __global__ __launch_bounds__(256) void k_conv_first(const FirstParams p) {
 // K5: ConvTranspose3d k = s = (kz,2,2): every output voxel takes exactly one tap, so the layer is ONE dense
 // GEMM  [voxels x C_in] x [C_in x (taps*C_out)]  with a scatter epilogue.  No halo -> operands straight from
 // global memory (each voxel's chunk is 32 contiguous bytes; successive chunks hit the same lines in L1/L2).
-template <typename T>
+template <typename T, bool GN>
 __global__ __launch_bounds__(256) void k_upconv_mfma(const UpconvParams p) {
     using v8 = typename Act<T>::v8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -943,13 +1032,24 @@ __global__ __launch_bounds__(256) void k_upconv_mfma(const UpconvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    __shared__ __attribute__((aligned(16))) float gtab[GN ? 2 * 1024 : 4];    // deferred GroupNorm scale / shift of this tile (Cs <= 1024)
+    const float* gss = nullptr;
+    if constexpr (GN) {
+        const float* const g = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.gn) + blockIdx.z * p.tstride);
+        for (int i = tid; i < 2 * p.Cs; i += 256) gtab[i] = g[i];
+        __syncthreads();
+        gss = gtab;
+    }
 #pragma unroll 2
     for (int c = 0; c < p.nchunk; ++c) {
         v8 xf[2], wf[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             v8 val = {};
-            if (mv[i]) val = *reinterpret_cast<const v8*>(src + ((size_t)c * M + m[i]) * SD_CHUNK + (lane >> 5) * 8);
+            if (mv[i]) {
+                val = *reinterpret_cast<const v8*>(src + ((size_t)c * M + m[i]) * SD_CHUNK + (lane >> 5) * 8);
+                if constexpr (GN) val = gn_apply8<T>(val, gss + c * SD_CHUNK + (lane >> 5) * 8, gss + p.Cs + c * SD_CHUNK + (lane >> 5) * 8, p.gn_relu);
+            }
             xf[i] = val;
         }
 #pragma unroll
@@ -1001,7 +1101,7 @@ __global__ __launch_bounds__(256) void k_upconv_mfma(const UpconvParams p) {
 // WL: the weight fragments of the workgroup's taps live in LDS (loaded once) and the workgroup is persistent over
 // voxel groups; blockIdx.y selects the (z-tap, y-tap) pair, so a workgroup needs NTAB*NCH KiB of weights.  Without
 // WL every wave re-reads all its weights from L2 for each 32 voxels, which bounds the 128 -> 64 channel up-convolution.
-template <typename T, int NCH, int NTAB, bool WL>
+template <typename T, int NCH, int NTAB, bool WL, bool GN>
 __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
     using v8 = typename Act<T>::v8;
     using v4 = typename Act<T>::v4;
@@ -1018,6 +1118,14 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
     const T* const wp = reinterpret_cast<const T*>(p.wpack);
     char* const dst = reinterpret_cast<char*>(p.dst) + blockIdx.z * p.tstride;
     const int H2 = 2 * p.H, W2 = 2 * p.W;
+    __shared__ __attribute__((aligned(16))) float gtab[GN ? 2 * NCH * SD_CHUNK : 4];     // deferred GroupNorm scale / shift of this tile
+    const float* gss = nullptr;
+    if constexpr (GN) {
+        const float* const g = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.gn) + blockIdx.z * p.tstride);
+        for (int i = tid; i < 2 * NCH * SD_CHUNK; i += 256) gtab[i] = g[i];
+        __syncthreads();
+        gss = gtab;
+    }
 
     // weight fragments of one (z-tap, y-tap) pair: the NTAB column tiles [ab*NTAB, ab*NTAB + NTAB) live in blocks of two
     // tiles (NCH * 2 KiB each); an odd NTAB straddles one block more (the launcher sizes the LDS for NTAB/2 + 2 blocks)
@@ -1040,6 +1148,15 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
         v8 val = {};
         if (mv) val = *reinterpret_cast<const v8*>(src + ((size_t)c * M + m) * SD_CHUNK + half * 8);
         xf[c] = val;
+    }
+    if constexpr (GN) {
+        // one chunk after the other (compiler barrier in between): with all table reads hoisted to the top the kernel
+        // needs 18 more registers and loses a wave per SIMD, which costs this HBM-bound kernel more than the LDS latency
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (mv) xf[c] = gn_apply8<T>(xf[c], gss + c * SD_CHUNK + half * 8, gss + p.Cs + c * SD_CHUNK + half * 8, p.gn_relu);
+            asm volatile("" ::: "memory");
+        }
     }
     const int ab0 = WL ? a_wg : 0, nab = WL ? ab0 + 1 : p.kz * 2;
 #pragma unroll 1
@@ -1174,14 +1291,10 @@ __global__ __launch_bounds__(256) void k_final(const FinalParams p) {
             for (int k = 0; k < 8; ++k) {
                 const int c8 = g0 + k;
                 if (c8 >= nc8) break;
+                if (gss) xr[k] = gn_apply8<T>(xr[k], gss + c8 * 8, gss + p.Cs + c8 * 8, p.gn_relu);   // deferred GroupNorm apply
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    float xf = (float)xr[k][e];
-                    if (gss) {          // fused GroupNorm apply: same arithmetic and rounding point as k_gn_apply
-                        xf = fmaf(xf, gss[c8 * 8 + e], gss[p.Cs + c8 * 8 + e]);
-                        if (p.gn_relu) xf = fmaxf(xf, 0.f);
-                        xf = (float)(T)xf;
-                    }
+                    const float xf = (float)xr[k][e];
 #pragma unroll
                     for (int co = 0; co < 8; ++co) acc[co] = fmaf(xf, w[co * p.Cs + c8 * 8 + e], acc[co]);
                 }
@@ -1265,17 +1378,11 @@ __global__ __launch_bounds__(256) void k_final_mfma(const FinalParams p) {
                 if (vv[i] < p.nvox) val = *reinterpret_cast<const v8*>(src + ((size_t)c * p.nvox + vv[i]) * SD_CHUNK + half * 8);
                 x[i] = val;
             }
-            if (p.gn_scale_shift) {       // fused GroupNorm apply + ReLU: same arithmetic and rounding point as k_gn_apply
+            if (p.gn_scale_shift) {       // deferred GroupNorm apply + ReLU
                 const float* const sc = gl + c * SD_CHUNK + half * 8;
-                const float* const sh = sc + p.Cs;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float f = fmaf((float)x[i][e], sc[e], sh[e]);
-                        if (p.gn_relu) f = fmaxf(f, 0.f);
-                        x[i][e] = (T)f;
-                    }
+                    if (vv[i] < p.nvox) x[i] = gn_apply8<T>(x[i], sc, sc + p.Cs, p.gn_relu);
             }
             const v8 w0 = *reinterpret_cast<const v8*>(wl + ((size_t)(c * 2 + 0) * 64 + lane) * 16);
             const v8 w1 = *reinterpret_cast<const v8*>(wl + ((size_t)(c * 2 + 1) * 64 + lane) * 16);
@@ -1394,9 +1501,11 @@ __global__ __launch_bounds__(256) void k_gn_apply_pool(const GnParams p) {
         const long v = (idx >> 1) % npv;                                  // (chunk, pooled voxel, half)
         const int cg = (int)((idx >> 1) / npv) * 2 + (int)(idx & 1);
         const int xo = (int)(v % p.pW), yo = (int)((v / p.pW) % p.pH), zo = (int)(v / ((long)p.pW * p.pH));
-        float sc[8], sh[8], mx[8];
+        const float* const sc = scale_shift + cg * 8;
+        const float* const sh = scale_shift + p.C + cg * 8;
+        float mx[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { sc[e] = scale_shift[cg * 8 + e]; sh[e] = scale_shift[p.C + cg * 8 + e]; mx[e] = -INFINITY; }
+        for (int e = 0; e < 8; ++e) mx[e] = -INFINITY;
         for (int dz = 0; dz < p.pkz; ++dz) {
             const int z = zo * p.pkz + dz;
             if (z >= p.D) continue;
@@ -1409,15 +1518,11 @@ __global__ __launch_bounds__(256) void k_gn_apply_pool(const GnParams p) {
                     const int x = xo * 2 + dx;
                     if (x >= p.W) continue;
                     T* ptr = buf + ((size_t)(cg >> 1) * p.P + ((size_t)z * p.Hs + y) * p.Ws + x) * SD_CHUNK + (cg & 1) * 8;
-                    v8 val = *reinterpret_cast<const v8*>(ptr);
+                    // (one helper for every place a GroupNorm is applied: all plans round identically)
+                    const v8 val = gn_apply8<T>(*reinterpret_cast<const v8*>(ptr), sc, sh, p.relu);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float f = fmaf((float)val[e], sc[e], sh[e]);
-                        if (p.relu) f = fmaxf(f, 0.f);
-                        val[e] = (T)f;
-                        mx[e] = fmaxf(mx[e], (float)val[e]);          // max of the ROUNDED values, like the pooling pass
-                    }
-                    *reinterpret_cast<v8*>(ptr) = val;
+                    for (int e = 0; e < 8; ++e) mx[e] = fmaxf(mx[e], (float)val[e]);   // max of the ROUNDED values
+                    if (!p.no_inplace) *reinterpret_cast<v8*>(ptr) = val;
                 }
             }
         }
@@ -1465,14 +1570,8 @@ __global__ __launch_bounds__(256) void k_gn_apply(const GnParams p) {
         const int cg = (int)((idx >> 1) / nvx) * 2 + (int)(idx & 1);
         const int x = (int)(v % p.W), y = (int)((v / p.W) % p.H), z = (int)(v / ((long)p.W * p.H));
         T* ptr = buf + ((size_t)(cg >> 1) * p.P + ((size_t)z * p.Hs + y) * p.Ws + x) * SD_CHUNK + (cg & 1) * 8;
-        v8 val = *reinterpret_cast<const v8*>(ptr);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float f = fmaf((float)val[e], scale_shift[cg * 8 + e], scale_shift[p.C + cg * 8 + e]);
-            if (p.relu) f = fmaxf(f, 0.f);
-            val[e] = (T)f;
-        }
-        *reinterpret_cast<v8*>(ptr) = val;
+        *reinterpret_cast<v8*>(ptr) = gn_apply8<T>(*reinterpret_cast<const v8*>(ptr), scale_shift + cg * 8,
+                                                     scale_shift + p.C + cg * 8, p.relu);
     }
 }
 
@@ -1556,18 +1655,21 @@ static size_t conv_lds_bytes(int nstages, bool fuse_final = false) {
            SD_CONV_PARAM_BYTES + (fuse_final ? NT * 4096 : 0) + 1024;
 }
 
-template <typename T, int KZ, int NT, int WAVES, int NSLOT, int MT = 2, bool FF = false>
+template <typename T, int KZ, int NT, int WAVES, int NSLOT, int MT = 2, int MODE = 0>
 static int launch_conv_k(ConvParams p, int NB, hipStream_t s) {
     using G = ConvGeo<KZ, WAVES, MT>;
+    constexpr bool FF = MODE == 1;
     const size_t lds = conv_lds_bytes<KZ, NT, WAVES, MT, NSLOT>((p.nchunk0 + p.nchunk1) * KZ, p.final_wfrag != nullptr) +
-                       (FF ? (size_t)2 * (G::BY + 4) * (G::BX + 4) * 4 + (5 * 64 + 32) * 4 : 0);
+                       (FF ? (size_t)2 * (G::BY + 4) * (G::BX + 4) * 4 + (5 * 64 + 32) * 4 : 0) +
+                       (MODE == 2 ? (size_t)p.batch * conv_gn_lds_per_tile(p.nchunk0 + p.nchunk1) : 0);
+    if (lds > (size_t)SD_LDS_BYTES) return SD_ERR_INVALID;
     p.nbx = (p.W + G::BX - 1) / G::BX; p.nby = (p.H + G::BY - 1) / G::BY; p.nbz = (p.D + G::BZ - 1) / G::BZ;
     static const int order = getenv("SD_BLOCK_ORDER") ? atoi(getenv("SD_BLOCK_ORDER")) : 1;
     p.block_order = order;
     // per-DEVICE cache of the dynamic-LDS attribute and the occupancy answer of this instantiation (a function attribute
     // set on one device does not carry over to a model created on another one in the same process); guarded, because
     // two models may launch their first forward from different threads
-    auto kern = k_conv_mfma<T, KZ, NT, WAVES, NSLOT, MT, FF>;
+    auto kern = k_conv_mfma<T, KZ, NT, WAVES, NSLOT, MT, MODE>;
     static std::mutex mu;
     static LaunchCache cache[SD_MAX_DEVICES];
     int occ = 1;
@@ -1621,10 +1723,19 @@ static int launch_conv_knt(const ConvParams& p, int NB, hipStream_t s) {
     if constexpr (KZ == 1 && NT <= 2) {
         if (p.first_in) {
             if (!conv_can_fuse_first(KZ, NT, NB, vox, nstages, p.final_wfrag != nullptr)) return SD_ERR_INVALID;
-            return launch_conv_k<T, KZ, NT, 8, 2, 2, true>(p, NB, s);
+            return launch_conv_k<T, KZ, NT, 8, 2, 2, 1>(p, NB, s);
         }
     } else if (p.first_in) {
         return SD_ERR_INVALID;
+    }
+    if (p.gn0 || p.gn1) {      // deferred GroupNorm apply: same shape rules, MODE 2 kernels (LDS incl. the scale / shift table)
+        const size_t gl = (size_t)p.batch * conv_gn_lds_per_tile(p.nchunk0 + p.nchunk1);
+        if (big) {
+            if (conv_lds_bytes<KZ, NT, 8, 2, 2>(nstages, p.final_wfrag != nullptr) + gl <= 80 * 1024) return launch_conv_k<T, KZ, NT, 8, 2, 2, 2>(p, NB, s);
+            return launch_conv_k<T, KZ, NT, 8, 0, 2, 2>(p, NB, s);
+        }
+        if (conv_lds_bytes<KZ, NT, 4, 2, 2>(nstages, p.final_wfrag != nullptr) + gl <= 80 * 1024) return launch_conv_k<T, KZ, NT, 4, 2, 2, 2>(p, NB, s);
+        return launch_conv_k<T, KZ, NT, 4, 0, 2, 2>(p, NB, s);
     }
     if (big) {
         if (conv_lds_bytes<KZ, NT, 8, 2, 2>(nstages, p.final_wfrag != nullptr) <= 96 * 1024) return launch_conv_k<T, KZ, NT, 8, 2>(p, NB, s);
@@ -1669,24 +1780,26 @@ template <typename T, int NCH, int NTAB>
 static int launch_upconv_rows(const UpconvParams& p, hipStream_t s) {
     const long M = (long)p.D * p.H * p.W;
     dim3 grid((unsigned)((M + 127) / 128), 1, p.batch), block(256);
-    hipLaunchKernelGGL((k_upconv_rows<T, NCH, NTAB, false>), grid, block, 4 * 32 * 64 * NTAB, s, p);
+    if (p.gn) hipLaunchKernelGGL((k_upconv_rows<T, NCH, NTAB, false, true>), grid, block, 4 * 32 * 64 * NTAB, s, p);
+    else hipLaunchKernelGGL((k_upconv_rows<T, NCH, NTAB, false, false>), grid, block, 4 * 32 * 64 * NTAB, s, p);
     return SD_LAUNCH_CHECK();
 }
 template <typename T, int NCH, int NTAB>
 static int launch_upconv_rows_wl(const UpconvParams& p, hipStream_t s) {      // LDS-resident weights, persistent
     const long M = (long)p.D * p.H * p.W;
     const size_t lds = 4 * 32 * 64 * NTAB + (size_t)(NTAB / 2 + 2 * (NTAB & 1)) * NCH * 2048;
-    auto kern = k_upconv_rows<T, NCH, NTAB, true>;
+    auto kern = p.gn ? k_upconv_rows<T, NCH, NTAB, true, true> : k_upconv_rows<T, NCH, NTAB, true, false>;
     {
         static std::mutex mu;
-        static LaunchCache cache[SD_MAX_DEVICES];
+        static LaunchCache cache[2][SD_MAX_DEVICES];          // [plain / deferred-GroupNorm kernel][device]
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SD_MAX_DEVICES) return SD_ERR_HIP;
         std::lock_guard<std::mutex> lock(mu);
-        if (lds > cache[dev].attr_set) {
+        LaunchCache& c = cache[p.gn ? 1 : 0][dev];
+        if (lds > c.attr_set) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
                 hipSuccess) return SD_ERR_HIP;
-            cache[dev].attr_set = lds;
+            c.attr_set = lds;
         }
     }
     const int per_cu = std::max(1, (int)(SD_LDS_BYTES / lds));
@@ -1695,6 +1808,14 @@ static int launch_upconv_rows_wl(const UpconvParams& p, hipStream_t s) {      //
     hipLaunchKernelGGL(kern, grid, block, lds, s, p);
     return SD_LAUNCH_CHECK();
 }
+// true when launch_upconv runs this shape with the row-coalescing kernel (activations of all chunks in registers): the form
+// into which a deferred GroupNorm apply folds for less than the separate apply pass costs (the generic MFMA kernel pays
+// more for it than the pass it replaces: 192 -> 96 channels 80 -> 108 us vs a 10 us pass)
+bool upconv_rows_kernel(int nchunk, int Cd) {
+    return (nchunk == 4 && Cd == 32) || (nchunk == 3 && Cd == 32) || (nchunk == 2 && Cd == 16) || (nchunk == 8 && Cd == 64) ||
+           (nchunk == 6 && Cd == 48);
+}
+
 template <typename T>
 static int launch_upconv_t(const UpconvParams& p, int NB, hipStream_t s) {
     // the store-bound full-resolution shapes get the row-coalescing kernel (64 -> 32 channels: 77 -> 52 us at 128^3);
@@ -1709,16 +1830,17 @@ static int launch_upconv_t(const UpconvParams& p, int NB, hipStream_t s) {
     if (p.nchunk == 6 && p.Cd == 48) return no_wl ? launch_upconv_rows<T, 6, 3>(p, s) : launch_upconv_rows_wl<T, 6, 3>(p, s);
     const long M = (long)p.D * p.H * p.W;
     dim3 grid((unsigned)((M + 255) / 256), NB, p.batch), block(256);
-    hipLaunchKernelGGL((k_upconv_mfma<T>), grid, block, 0, s, p);
+    if (p.gn) hipLaunchKernelGGL((k_upconv_mfma<T, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((k_upconv_mfma<T, false>), grid, block, 0, s, p);
     return SD_LAUNCH_CHECK();
 }
 int launch_upconv(const UpconvParams& p, int act_dtype, int NB, hipStream_t s) {
-    if (!getenv("SD_UPCONV_OLD"))
+    if (!getenv("SD_UPCONV_OLD") || p.gn)
         return act_dtype == SD_BF16 ? launch_upconv_t<bf16_t>(p, NB, s) : launch_upconv_t<f16_t>(p, NB, s);
     const long M = (long)p.D * p.H * p.W;
     dim3 grid((unsigned)((M + 255) / 256), NB, p.batch), block(256);
-    if (act_dtype == SD_BF16) hipLaunchKernelGGL((k_upconv_mfma<bf16_t>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((k_upconv_mfma<f16_t>), grid, block, 0, s, p);
+    if (act_dtype == SD_BF16) hipLaunchKernelGGL((k_upconv_mfma<bf16_t, false>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((k_upconv_mfma<f16_t, false>), grid, block, 0, s, p);
     return SD_LAUNCH_CHECK();
 }
 

@@ -325,3 +325,30 @@ def test_large_single_tile_locality(gpu):
     sub = x[32:160, 128:384, 128:384].contiguous()
     c = dm.forward(sub, L.SD_OUT_PROBS_U8, slot=1)
     assert torch.equal(c[:, 48:80, 48:208, 48:208], a[:, 80:112, 176:336, 176:336])
+
+
+@pytest.mark.parametrize('act', ['f16', 'bf16'])
+def test_deferred_groupnorm_apply_is_bit_identical(gpu, monkeypatch, act):
+    """GroupNorm networks: the apply (+ReLU) pass of every GroupNorm is deferred to the readers of the raw tensor
+    (convolutions rewrite their LDS halo pieces, up-convolutions / the final layer their register fragments, a fused pooling
+    writes the normalised pooled tensor only).  Same arithmetic and rounding point as the separate in-place pass -> logits,
+    probabilities and labels must be bit-identical to the plan that runs every apply pass (SD_NO_GN_DEFER), for even and
+    odd extents (autocrop regions), batches, and a tile with many workgroups per layer."""
+    from syconn_amd import _lib as L
+    from syconn_amd.cnn import random_state_dict
+    from syconn_amd.engine import DenseModel
+    sd = random_state_dict('mivcsj', seed=7, final_scale=5.0)
+    monkeypatch.setenv('SD_NO_GN_DEFER', '1')
+    plain = DenseModel(sd, act_dtype=act, device=gpu)
+    monkeypatch.delenv('SD_NO_GN_DEFER')
+    fused = DenseModel(sd, act_dtype=act, device=gpu)
+    assert fused.workspace_bytes((32, 48, 48)) >= 0
+    for shape in ((2, 16, 32, 48), (3, 13, 37, 43), (1, 32, 112, 144)):
+        x = _input(shape, 3).to(gpu)
+        for kind in (L.SD_OUT_LOGITS_F32, L.SD_OUT_PROBS_U8):
+            a = plain.forward_batch(x, kind)
+            b = fused.forward_batch(x, kind, slot=1)
+            assert torch.equal(a, b), (act, shape, kind)
+        la = plain.forward_labels_batch(x, (1, 2, 3), (127.5, 127.5, 127.5))
+        lb = fused.forward_labels_batch(x, (1, 2, 3), (127.5, 127.5, 127.5), slot=1)
+        assert torch.equal(la, lb)
