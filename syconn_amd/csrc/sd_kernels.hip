@@ -342,13 +342,17 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     };
     // halo voxel handled by this lane in its j-th DMA instruction of a chunk, packed hz<<20 | hy<<10 | hx<<1 | half
     // (the 16-byte halves of a 32-byte record are swapped on odd halo rows); -1 = beyond the halo block
-    int hpack[AJ];
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) {
-        const int idx = (wave + j * WAVES) * 64 + lane;
+    auto hpack_of = [&](int j) -> int {
+        int idx = (wave + j * WAVES) * 64 + lane;
+        if constexpr (MT == 4) asm volatile("" : "+v"(idx));     // recomputed at every use (see dma_halo): no 8 live registers
         const int hv = idx >> 1;
         const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
-        hpack[j] = (idx < NH * 2) ? ((hz << 20) | (hy << 10) | (hx << 1) | ((idx & 1) ^ (hy & 1))) : -1;
+        return (idx < NH * 2) ? ((hz << 20) | (hy << 10) | (hx << 1) | ((idx & 1) ^ (hy & 1))) : -1;
+    };
+    int hpack[MT == 4 ? 1 : AJ];
+    if constexpr (MT != 4) {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) hpack[j] = hpack_of(j);
     }
     // logical block of (round, this workgroup); -1 when the round has no block for it
     const int nsb_all = nsb * p.batch;      // the tiles of a batched launch are simply more blocks
@@ -402,6 +406,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     // DMA chunk c of the block at (z0,y0,x0) into halo slot `slot`; real == false issues the same number of
     // instructions against the dummy slot (keeps the per-wave DMA count per chunk constant for the counted waits)
     auto dma_halo = [&](int c, int slot, int z0, int y0, int x0, int tile, bool real) {
+        if constexpr (MT == 4) {
+            // keep the per-piece source addresses from being hoisted out of the block loop (8 x 64-bit per wave): with 128
+            // accumulator registers there is no room for them; recomputing costs a few VALU ops per chunk
+            asm volatile("" : "+s"(z0), "+s"(y0), "+s"(x0));
+        }
         const char* sbase;
         int Hs, Ws, cc;
         size_t Ps;
@@ -413,7 +422,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         for (int j = 0; j < AJ; ++j) {
             const bool inst = real && (wave + j * WAVES < A_INSTR);       // wave-uniform
             if (inst || NA > 2) {
-                const int hp = hpack[j];
+                const int hp = MT == 4 ? hpack_of(j) : hpack[MT == 4 ? 0 : j];
                 const int z = z0 - PZ + (hp >> 20), y = y0 - 1 + ((hp >> 10) & 1023), x = x0 - 1 + ((hp >> 1) & 511);
                 const bool ok = inst && hp >= 0 && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H &&
                                 (unsigned)x < (unsigned)p.W;
@@ -442,7 +451,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
 #pragma unroll
             for (int j = 0; j < AJ; ++j) {
                 if (wave + j * WAVES >= A_INSTR) continue;         // wave-uniform
-                const int hp = hpack[j];
+                const int hp = MT == 4 ? hpack_of(j) : hpack[MT == 4 ? 0 : j];
                 const int z = pd_z - PZ + (hp >> 20), y = pd_y - 1 + ((hp >> 10) & 1023), x = pd_x - 1 + ((hp >> 1) & 511);
                 const bool ok = hp >= 0 && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
                 if (ok) {                                          // out-of-volume pieces stay zero: the conv's zero padding
@@ -644,6 +653,48 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                 // to their use behind an lgkmcnt(0) (it prefers reusing the fragment registers), which idles the
                 // matrix pipe for one LDS latency per tap.  LDS returns in order, so lgkmcnt(MT + NT) after issuing
                 // tap t+1 means tap t has landed; `tie` makes the MFMAs depend on the post-wait values.
+                if constexpr (MT == 4) {
+                    // 4 voxel tiles per wave (KZ == 3: z-neighbours, so tile i's fragment sits i * SLICE bytes behind tile 0's:
+                    // a ds_read offset immediate, ONE address register pair for all tiles).  Register budget: 128
+                    // accumulator registers leave no room for double-buffered fragments, so the x fragments are single-
+                    // buffered and REFILLED IN PLACE -- tile i's fragment of tap t+1 is requested right behind the two
+                    // MFMAs that last read tap t's; only the weight fragments are double-buffered.  LDS returns in
+                    // order: whenever a tile row starts, exactly 3 + NT younger reads are in flight (3 - i of this tap's x
+                    // fragments, NT weight fragments and i x fragments of the next tap) -> one constant lgkmcnt.
+                    static_assert(MT != 4 || KZ == 3, "MT = 4: z-stacked tiles");
+                    v8 xq[4], wq[2][NT];
+                    const uint32_t bA = lds_addr(bcur);
+                    const uint32_t xE = lds_addr(acur) + xoffE[0], xO = lds_addr(acur) + xoffO[0];
+                    auto load_x = [&](auto tc, auto ic) {
+                        constexpr int t9 = decltype(tc)::value, i = decltype(ic)::value, ky = t9 / 3, kx = t9 % 3;
+                        ds_read16<(ky * HX + kx) * 32 + i * SLICE>(xq[i], (ky & 1) ? xO : xE);
+                    };
+                    auto load_w = [&](auto tc) {
+                        constexpr int t9 = decltype(tc)::value;
+                        static_for<NT>([&](auto jc) {
+                            constexpr int j = decltype(jc)::value;
+                            ds_read16<(t9 * NT + j) * 1024>(wq[t9 & 1][j], bA);
+                        });
+                    };
+                    load_w(std::integral_constant<int, 0>{});
+                    static_for<4>([&](auto ic) { load_x(std::integral_constant<int, 0>{}, ic); });
+                    static_for<9>([&](auto tc) {
+                        constexpr int t9 = decltype(tc)::value, buf = t9 & 1;
+                        if constexpr (t9 + 1 < 9) load_w(std::integral_constant<int, t9 + 1>{});
+                        static_for<4>([&](auto ic) {
+                            constexpr int i = decltype(ic)::value;
+                            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(t9 + 1 < 9 ? 3 + NT : 3 - i));
+                            tie(xq[i]);
+                            if constexpr (i == 0) {
+#pragma unroll
+                                for (int j = 0; j < NT; ++j) tie(wq[buf][j]);
+                            }
+#pragma unroll
+                            for (int j = 0; j < NT; ++j) acc[i][j] = Act<T>::mfma(wq[buf][j], xq[i], acc[i][j]);
+                            if constexpr (t9 + 1 < 9) load_x(std::integral_constant<int, t9 + 1>{}, ic);
+                        });
+                    });
+                } else {
                 v8 xf[2][MT], wf[2][NT];
                 const uint32_t aE = lds_addr(acur), bA = lds_addr(bcur);
                 uint32_t xaE[MT], xaO[MT];
@@ -678,6 +729,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                         for (int j = 0; j < NT; ++j)
                             acc[i][j] = Act<T>::mfma(wf[buf][j], xf[buf][i], acc[i][j]);
                 });
+                }
                 if (s == SD_TS) SD_T(2);     // after the MFMAs of the probed stage
                 // all of this wave's LDS reads done + the next chunk's DMA landed, then the workgroup barrier (raw
                 // s_barrier: __syncthreads() would drain every DMA in flight with a vmcnt(0))
@@ -700,6 +752,86 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         }
 
     SD_T(4);   // all stages done
+    if constexpr (MT == 4) {
+        // ---- epilogue of the 4-tile form, one z-PAIR of tiles and one 32-channel group at a time (the packed values of
+        // all 8 accumulator tiles at once would not fit beside the accumulators): pack + ReLU, GroupNorm partial sums, main
+        // store, fused 2x2x2 pooling of the pair.
+        typedef __attribute__((ext_vector_type(4))) unsigned u4;
+        T* const dst4 = reinterpret_cast<T*>(reinterpret_cast<char*>(p.dst) + (size_t)tn * p.tstride);
+        const int vy = y0 + tys[0] + dy, vx = x0 + dxl, vz0 = z0 + tzs[0];
+        const bool vyx = vy < p.H && vx < p.W;
+        const size_t vo0 = (size_t)(vz0 * p.H + vy) * p.W + vx, vzs = (size_t)p.H * p.W;
+        float* const part = reinterpret_cast<float*>(ldsA + ((gc - 1) % NA) * A_BYTES);   // free: last chunk's halo slot
+        v8 s1, s2;
+        if (p.gn_sums) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = 8 * (e >> 2) + 4 * half + (e & 3);
+                s1[e] = (T)((c == (lane & 31)) ? 1.0f : 0.0f);
+                s2[e] = (T)((c + 16 == (lane & 31)) ? 1.0f : 0.0f);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float sj = 0.f, ssj = 0.f;
+#pragma unroll
+            for (int ip = 0; ip < 4; ip += 2) {
+                unsigned pk2[2][8];
+                bool val2[2];
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    val2[e2] = vyx && (vz0 + ip + e2) < p.D;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        pk2[e2][k] = Act<T>::pack2(acc[ip + e2][j][2 * k], acc[ip + e2][j][2 * k + 1]);
+                        if (p.relu) pk2[e2][k] = pk_max16(pk2[e2][k], 0u);
+                    }
+                    if (p.gn_sums) {
+                        u4 lo = {pk2[e2][0], pk2[e2][1], pk2[e2][2], pk2[e2][3]};
+                        u4 hi = {pk2[e2][4], pk2[e2][5], pk2[e2][6], pk2[e2][7]};
+                        if (!val2[e2]) { lo = u4{0u, 0u, 0u, 0u}; hi = lo; }
+                        f32x16 d;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) d[r] = 0.f;
+                        d = Act<T>::mfma(__builtin_bit_cast(v8, lo), s1, d);
+                        d = Act<T>::mfma(__builtin_bit_cast(v8, hi), s2, d);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { sj += d[r]; ssj = fmaf(d[r], d[r], ssj); }
+                    }
+                    if (p.store_main)
+                        store_tile_rows_pk<T>(pk2[e2], dst4, p.Pd, vo0 + (size_t)(ip + e2) * vzs, val2[e2], (nb * NT + j) * 32, half, p.Cd);
+                }
+                if (p.pool_dst) {
+                    T* const pdst = reinterpret_cast<T*>(reinterpret_cast<char*>(p.pool_dst) + (size_t)tn * p.tstride);
+                    unsigned m[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) m[k] = pk_max16(val2[0] ? pk2[0][k] : 0u, val2[1] ? pk2[1][k] : 0u);
+                    pool_xy_pk8(m);
+                    const int pz = (vz0 + ip) >> 1, py = (y0 + tys[0]) >> 1, px = (x0 + dxl) >> 1;
+                    const bool writer = (dy == 0) && ((dxl & 1) == 0);
+                    store_tile_rows_pk<T>(m, pdst, p.Pp, (size_t)(pz * p.pH + py) * p.pW + px, writer && val2[0],
+                                          (nb * NT + j) * 32, half, p.Cd);
+                }
+            }
+            if (p.gn_sums) {
+                float* const q = part + ((size_t)(wave * 2 + half) * (NT * 32) + j * 32 + (lane & 31)) * 2;
+                q[0] = sj; q[1] = ssj;
+            }
+        }
+        if (p.gn_sums) {
+            __syncthreads();
+            if (tid < NT * 64) {
+                const int stat = tid / (NT * 32), cw = tid % (NT * 32);
+                double t = 0.0;
+                for (int w = 0; w < WAVES * 2; ++w) t += (double)part[((size_t)w * (NT * 32) + cw) * 2 + stat];
+                const int ch = nb * NT * 32 + cw;
+                if (ch < p.Cd)
+                    atomicAdd(reinterpret_cast<double*>(reinterpret_cast<char*>(p.gn_sums) + (size_t)tn * p.tstride) +
+                                  (size_t)stat * p.gn_C + ch, t);
+            }
+            __syncthreads();
+        }
+    } else {
     // ---- epilogue: + bias, ReLU, round to the storage type (kept in `acc` as the rounded value) ----------
     bool valid[MT];
     size_t voxoff[MT];
@@ -901,6 +1033,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         }
     }
 
+    }
         SD_T(6);   // epilogue done
 #ifdef SD_TIMING
         if (tcount == SD_TB && lane == 0 && p.dbg) {
@@ -1740,8 +1873,12 @@ static int launch_conv_knt(const ConvParams& p, int NB, hipStream_t s) {
     if (big) {
         if (conv_lds_bytes<KZ, NT, 8, 2, 2>(nstages, p.final_wfrag != nullptr) <= 96 * 1024) return launch_conv_k<T, KZ, NT, 8, 2>(p, NB, s);
         if constexpr (KZ == 3 && NT == 2) {
-            static const bool mt4 = getenv("SD_MT4") != nullptr;      // experiment: 8x8x16 blocks, 4 voxel tiles per wave
-            if (mt4 && !p.final_wfrag && (vox / 1024) * NB >= 256) return launch_conv_k<T, KZ, NT, 8, 0, 4>(p, NB, s);
+            // 8x8x16 blocks, 4 z-stacked voxel tiles per wave: 0.75 LDS fragment reads per MFMA instead of 1.0, half as many
+            // stage barriers and block boundaries per MFMA (32->64 channels 52.6 -> 48.7 us per tile, 64->64 88 -> 85 us,
+            // 128->64 164 -> 162 us).  Taller blocks waste more on a ragged z extent, hence the rule on D.
+            static const bool mt2 = getenv("SD_MT2") != nullptr;      // A/B switch: the 4x8x16 / 2-tile form everywhere
+            if (!mt2 && !p.final_wfrag && (vox / 1024) * NB >= 256 && (p.D % 8 == 0 || p.D >= 96))
+                return launch_conv_k<T, KZ, NT, 8, 0, 4>(p, NB, s);
         }
         return launch_conv_k<T, KZ, NT, 8, 0>(p, NB, s);
     }
