@@ -192,3 +192,40 @@ def test_job_pickle_stream_contract(tmp_path):
             except EOFError:
                 break
     assert len(args) == 14 and args[0] == [1, 2, 3] and args[12] == 4
+
+
+def test_host_box_copy_and_zero_match_numpy():
+    """sd_host_box_copy / sd_host_zero (threaded strided box copies of the chunk pipeline) against numpy slicing, incl.
+    views into larger volumes on both sides, 1-voxel boxes and a box large enough to be split over threads."""
+    import torch
+    from syconn_amd._lib import host_box_copy, host_zero
+    rng = np.random.default_rng(3)
+    vol = rng.integers(0, 255, (70, 90, 130), dtype=np.uint8)
+    for (z, y, x), (dz, dy, dx) in (((0, 0, 0), (70, 90, 130)), ((3, 5, 7), (40, 33, 120)), ((69, 89, 129), (1, 1, 1)),
+                                    ((10, 0, 2), (1, 90, 1))):
+        dst = np.full((80, 100, 140), 7, np.uint8)
+        want = dst.copy()
+        want[2:2 + dz, 4:4 + dy, 6:6 + dx] = vol[z:z + dz, y:y + dy, x:x + dx]
+        host_box_copy(dst[2:2 + dz, 4:4 + dy, 6:6 + dx], vol[z:z + dz, y:y + dy, x:x + dx], n_threads=5)
+        assert np.array_equal(dst, want)
+    t = torch.from_numpy(rng.integers(1, 255, (3_000_001,), dtype=np.uint8))
+    host_zero(t, n_threads=7)
+    assert int(t.sum()) == 0
+
+
+def test_random_state_dict_loads_into_oracle_and_plans_identically():
+    """syconn_amd.cnn (product-side architecture tables + seeded weights) names every parameter like elektronn3 does: the
+    state_dict loads into the oracle UNet unchanged and gives the same plan as the nn.Module path."""
+    import torch
+    from oracle.unet_ref import ARCHS as ORACLE_ARCHS, UNet
+    from syconn_amd.cnn import ARCHS as SPEC_ARCHS, random_state_dict
+    from syconn_amd.plan import plan_from_model
+    assert SPEC_ARCHS == ORACLE_ARCHS
+    for arch in ('myelin', 'syntype', 'mivcsj'):
+        sd = random_state_dict(arch, seed=5, final_scale=3.0)
+        m = UNet(in_channels=1, **ORACLE_ARCHS[arch]).eval()
+        assert not any(m.load_state_dict(sd))
+        ops_a, blob_a, info_a = plan_from_model(sd)
+        ops_b, blob_b, info_b = plan_from_model(m)
+        assert len(ops_a) == len(ops_b) and info_a == info_b and np.array_equal(blob_a, blob_b)
+        assert all(bytes(a) == bytes(b) for a, b in zip(ops_a, ops_b))
