@@ -1876,7 +1876,7 @@ static int launch_conv_knt(const ConvParams& p, int NB, hipStream_t s) {
             // 8x8x16 blocks, 4 z-stacked voxel tiles per wave: 0.75 LDS fragment reads per MFMA instead of 1.0, half as many
             // stage barriers and block boundaries per MFMA (32->64 channels 52.6 -> 48.7 us per tile, 64->64 88 -> 85 us,
             // 128->64 164 -> 162 us).  Taller blocks waste more on a ragged z extent, hence the rule on D.
-            static const bool mt2 = getenv("SD_MT2") != nullptr;      // A/B switch: the 4x8x16 / 2-tile form everywhere
+            const bool mt2 = getenv("SD_MT2") != nullptr;      // A/B switch (read per launch): the 4x8x16 / 2-tile form everywhere
             if (!mt2 && !p.final_wfrag && (vox / 1024) * NB >= 256 && (p.D % 8 == 0 || p.D >= 96))
                 return launch_conv_k<T, KZ, NT, 8, 0, 4>(p, NB, s);
         }

@@ -352,3 +352,23 @@ def test_deferred_groupnorm_apply_is_bit_identical(gpu, monkeypatch, act):
         la = plain.forward_labels_batch(x, (1, 2, 3), (127.5, 127.5, 127.5))
         lb = fused.forward_labels_batch(x, (1, 2, 3), (127.5, 127.5, 127.5), slot=1)
         assert torch.equal(la, lb)
+
+
+def test_four_tile_form_is_bit_identical(gpu, monkeypatch):
+    """3x3x3 layers with 64-channel groups run with 4 z-stacked voxel tiles per wave (8x8x16 blocks) where the grid is large
+    enough; same per-output summation order as the 2-tile form (SD_MT2) -> bit-identical logits and labels, for z extents that
+    are multiples of 8, ragged ones (partial top blocks, odd y / x with ceil-mode pooling and autocrop) and batches."""
+    from syconn_amd import _lib as L
+    from syconn_amd.cnn import random_state_dict
+    from syconn_amd.engine import DenseModel
+    for arch, shapes in (('semseg_spine', ((2, 64, 128, 144), (1, 100, 150, 170), (3, 32, 97, 131))),
+                         ('syntype', ((2, 48, 112, 128),))):
+        sd = random_state_dict(arch, seed=11, final_scale=6.0)
+        monkeypatch.setenv('SD_MT2', '1')
+        two = DenseModel(sd, act_dtype='bf16', device=gpu)
+        a = [two.forward_batch(_input(sh, 4).to(gpu), L.SD_OUT_LOGITS_F32).clone() for sh in shapes]
+        monkeypatch.delenv('SD_MT2')                    # (the switch is read at every launch)
+        four = DenseModel(sd, act_dtype='bf16', device=gpu)
+        for sh, ref in zip(shapes, a):
+            b = four.forward_batch(_input(sh, 4).to(gpu), L.SD_OUT_LOGITS_F32, slot=1)
+            assert torch.equal(ref, b), (arch, sh)

@@ -14,7 +14,11 @@ for k in range(n):
     arch = list(ARCHS)[rng.integers(len(ARCHS))]
     act = 'bf16' if rng.random() < 0.7 else 'f16'
     nb = 1 + int(rng.integers(3))
-    shape = (int(rng.integers(1, 40)), int(rng.integers(1, 150)), int(rng.integers(1, 150)))
+    if os.environ.get('SD_FUZZ_BIG'):      # shapes with enough blocks for the persistent / 4-tile kernel forms
+        shape = (int(rng.choice([16, 24, 32, 40, 48, 64, 100])), int(rng.integers(90, 200)), int(rng.integers(90, 200)))
+        nb = 1 + int(rng.integers(2))
+    else:
+        shape = (int(rng.integers(1, 40)), int(rng.integers(1, 150)), int(rng.integers(1, 150)))
     net = build_unet(arch, seed=int(rng.integers(1000)), final_scale=4.0)
     g = torch.Generator().manual_seed(k)
     x = torch.randint(0, 256, (nb, *shape), dtype=torch.uint8, generator=g)
@@ -31,7 +35,8 @@ for k in range(n):
     e_max = float((got - ref).abs().max()) / scale
     e_rms = float(((got - ref) ** 2).mean().sqrt() / ((ref ** 2).mean().sqrt() + 1e-12))
     d12 = float((got - got2).abs().max()) / scale
-    same = d12 < (2e-3 if ARCHS[arch].get('normalization') == 'group8' else 1e-4)   # GroupNorm: statistics summed in another order
+    # GroupNorm: statistics summed in another order -> scale / shift differ in the last bit -> roundings of stored activations flip
+    same = d12 < ((2e-2 if act == 'bf16' else 3e-3) if ARCHS[arch].get('normalization') == 'group8' else 1e-4)
     ok = e_max <= TOL[act][0] * 1.5 and e_rms <= TOL[act][1] * 1.5 and same and bool(torch.isfinite(got).all())
     bad += not ok
     print(f'{k:3d} {arch:13s} {act} N={nb} {str(shape):16s} max {e_max:.2e} rms {e_rms:.2e} fused-unfused {d12:.1e} {"ok" if ok else "FAIL"}')
