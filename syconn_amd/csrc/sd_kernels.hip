@@ -251,6 +251,9 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
 template <typename T, int KZ, int NT, int WAVES, int NSLOT, int MT, int MODE>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(const ConvParams p) {
     constexpr bool FF = MODE == 1, GN = MODE == 2;
+    // register diet for the forms with >= 96 accumulator registers: nothing that can be recomputed per chunk stays live
+    // across the block loop (DMA source addresses, halo-piece decode table)
+    constexpr bool LEAN = MT == 4 || NT == 3;
     using v8 = typename Act<T>::v8;
     using G = ConvGeo<KZ, WAVES, MT>;
     constexpr bool WRES = NSLOT > 0;
@@ -344,13 +347,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     // (the 16-byte halves of a 32-byte record are swapped on odd halo rows); -1 = beyond the halo block
     auto hpack_of = [&](int j) -> int {
         int idx = (wave + j * WAVES) * 64 + lane;
-        if constexpr (MT == 4) asm volatile("" : "+v"(idx));     // recomputed at every use (see dma_halo): no 8 live registers
+        if constexpr (LEAN) asm volatile("" : "+v"(idx));     // recomputed at every use (see dma_halo): no AJ live registers
         const int hv = idx >> 1;
         const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
         return (idx < NH * 2) ? ((hz << 20) | (hy << 10) | (hx << 1) | ((idx & 1) ^ (hy & 1))) : -1;
     };
-    int hpack[MT == 4 ? 1 : AJ];
-    if constexpr (MT != 4) {
+    int hpack[LEAN ? 1 : AJ];
+    if constexpr (!LEAN) {
 #pragma unroll
         for (int j = 0; j < AJ; ++j) hpack[j] = hpack_of(j);
     }
@@ -406,9 +409,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     // DMA chunk c of the block at (z0,y0,x0) into halo slot `slot`; real == false issues the same number of
     // instructions against the dummy slot (keeps the per-wave DMA count per chunk constant for the counted waits)
     auto dma_halo = [&](int c, int slot, int z0, int y0, int x0, int tile, bool real) {
-        if constexpr (MT == 4) {
-            // keep the per-piece source addresses from being hoisted out of the block loop (8 x 64-bit per wave): with 128
-            // accumulator registers there is no room for them; recomputing costs a few VALU ops per chunk
+        if constexpr (LEAN) {
+            // keep the per-piece source addresses from being hoisted out of the block loop (up to 8 x 64-bit per wave): with
+            // 96-128 accumulator registers there is no room for them; recomputing costs a few VALU ops per chunk
             asm volatile("" : "+s"(z0), "+s"(y0), "+s"(x0));
         }
         const char* sbase;
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         for (int j = 0; j < AJ; ++j) {
             const bool inst = real && (wave + j * WAVES < A_INSTR);       // wave-uniform
             if (inst || NA > 2) {
-                const int hp = MT == 4 ? hpack_of(j) : hpack[MT == 4 ? 0 : j];
+                const int hp = LEAN ? hpack_of(j) : hpack[LEAN ? 0 : j];
                 const int z = z0 - PZ + (hp >> 20), y = y0 - 1 + ((hp >> 10) & 1023), x = x0 - 1 + ((hp >> 1) & 511);
                 const bool ok = inst && hp >= 0 && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H &&
                                 (unsigned)x < (unsigned)p.W;
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
 #pragma unroll
             for (int j = 0; j < AJ; ++j) {
                 if (wave + j * WAVES >= A_INSTR) continue;         // wave-uniform
-                const int hp = MT == 4 ? hpack_of(j) : hpack[MT == 4 ? 0 : j];
+                const int hp = LEAN ? hpack_of(j) : hpack[LEAN ? 0 : j];
                 const int z = pd_z - PZ + (hp >> 20), y = pd_y - 1 + ((hp >> 10) & 1023), x = pd_x - 1 + ((hp >> 1) & 511);
                 const bool ok = hp >= 0 && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
                 if (ok) {                                          // out-of-volume pieces stay zero: the conv's zero padding
