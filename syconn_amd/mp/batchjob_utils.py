@@ -93,6 +93,10 @@ def batchjob_script(params: list, name: str, n_cores: int = 1, suffix: str = "",
         base = os.environ.get('HIP_VISIBLE_DEVICES')
         devs = [d for d in base.split(',') if d] if base else [str(k) for k in range(ngpu)]
         devs = devs[:ngpu]
+        # SYCONN_AMD_WORKERS_PER_GPU=k (default 1): k dispatchers -- k concurrent worker processes -- per GPU.  One worker
+        # already overlaps its own file I/O with the GPU (dense_predictor); more than one is for I/O-bound file systems and
+        # for exercising the concurrent-writer path (neighbouring chunks of different workers share target cubes).
+        devs = devs * max(1, int(os.environ.get('SYCONN_AMD_WORKERS_PER_GPU', '1')))
 
     def run(job, device=None):
         i_job, storage, out = job

@@ -418,3 +418,36 @@ def test_chunked_volume_prediction_equals_whole_volume_tiling(gpu):
                                              pipelined=pipelined)
         assert got.shape == (1, *vol_shape) and torch.equal(got[0], whole)
     assert len(torch.unique(whole)) >= 2
+
+
+def test_two_concurrent_workers_write_the_same_dataset_as_one(gpu, tmp_path, monkeypatch):
+    """predict_dense_to_kd with chunk ids dealt to TWO worker processes that run at the same time (on this box: both on
+    the one GPU) and whose chunks (40x40x24) share the 64^3 target cubes: the written KnossosDataset -- probability map and
+    its pyramid -- must be byte-identical to the one a single worker writes.  Exercises chunkify -> pickle-stream jobs ->
+    concurrent dense_predictor processes -> per-cube locked read-modify-write."""
+    from syconn_amd import global_params
+    from syconn_amd.handler import prediction as P
+    from syconn_amd.handler.basics import kd_factory
+    from syconn_amd.handler.config import generate_default_conf
+    model = build_unet('myelin', seed=14, n_blocks=3, start_filts=8, final_scale=4.0)
+    geo = {'overlap_shape_tiles': [6, 6, 4], 'chunk_size': [40, 40, 24], 'tile_shape': [26, 26, 16], 'act_dtype': 'f16'}
+    shape_xyz = (150, 130, 70)                               # 4 x 4 x 3 = 48 chunks over 3 x 3 x 2 cubes of 64^3
+    wd, kd_path, vol = _make_wd(tmp_path, model, 'myelin', shape_xyz, 23, geo)
+    outs = {}
+    for nworkers in (1, 2):
+        # ngpu_total = nnodes_total * ngpus_per_node decides the number of jobs (prediction.py:708-709)
+        generate_default_conf(wd, scaling=(10, 10, 20), kd_seg=kd_path,
+                              key_value_pairs=[('ngpus_per_node', 1), ('nnodes_total', nworkers), ('dense_prediction', geo)])
+        global_params.wd = wd
+        global_params.config._load(wd)                          # same working dir, rewritten config.yml
+        assert global_params.config.ngpu_total == nworkers
+        monkeypatch.setenv('SYCONN_AMD_WORKERS_PER_GPU', str(nworkers))
+        P.predict_dense_to_kd(kd_path, f'{wd}/knossosdatasets/', f'{wd}/models/myelin/model.pts', n_channel=2,
+                              target_names=[f'myelin_w{nworkers}'], target_channels=[(1,)], mag=1, overwrite=True,
+                              cube_shape_kd=(64, 64, 64))
+        kd_out = kd_factory(f'{wd}/knossosdatasets/myelin_w{nworkers}/')
+        outs[nworkers] = [kd_out.load_raw(size=shape_xyz, offset=(0, 0, 0), mag=m) for m in (1, 2, 4)]
+    for a, b in zip(outs[1], outs[2]):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    assert outs[1][0].std() > 1.0
+    global_params.wd = None
