@@ -1864,6 +1864,10 @@ static int launch_conv_knt(const ConvParams& p, int NB, hipStream_t s) {
     } else if (p.first_in) {
         return SD_ERR_INVALID;
     }
+    // (one 16-wave workgroup per CU -- 1x64x16 blocks, 3-slot halo ring = a whole block of prefetch -- instead of two 8-wave
+    // workgroups with one chunk of prefetch each: op19 52.7 -> 53.1 us.  Cycle stamps of that layer, per 512-voxel block of
+    // 10.9 k cycles: DMA issue 2 x 0.86 k (24 halo gathers per chunk serialise in the CU's address path at ~36 cycles each),
+    // tap loops 2 x 0.9 k, DMA wait + barrier ~2 k, fused final / softmax / store epilogue 4.5 k -- no single bottleneck.)
     if (p.gn0 || p.gn1) {      // deferred GroupNorm apply: same shape rules, MODE 2 kernels (LDS incl. the scale / shift table)
         const size_t gl = (size_t)p.batch * conv_gn_lds_per_tile(p.nchunk0 + p.nchunk1);
         if (big) {
