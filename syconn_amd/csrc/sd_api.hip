@@ -62,6 +62,10 @@ struct Op {
     bool gn_defer = false;       // groupnorm: statistics -> scale / shift only; every consumer of the buffer applies them itself
     size_t fwfrag_off = 0;             // fused final 1x1x1: hi/lo MFMA weight fragments
     bool skipped = false;  // op is executed inside its producer
+    // up-convolution heading a fused level-0 decoder (sd_dec0.hip): indices of the merge conv and the second conv (whose
+    // fuse_final names the final layer); those ops are `skipped` and their output buffers are never materialised
+    int dec0_c1 = -1, dec0_c2 = -1;
+    bool in_dec0 = false;
 };
 
 }  // namespace
@@ -140,8 +144,12 @@ int infer_shapes(const sd_model* m, int D, int H, int W, std::vector<Dims>& dims
 // about a third of the sum of all activations -- which is what lets several such tiles run in one launch set.
 // `reuse == false` (SD_KEEP_ALL / SD_NO_FUSE / SD_NO_WS_REUSE: layer-wise debugging reads buffers back after the
 // forward) gives every buffer its own range.
+// shapes the fused level-0 decoder serves (sd_dec0.hip: cursor arithmetic); others run the layers separately
+bool dec0_shape_ok(const Dims& o) { return o.h >= 8 && (long)o.d * o.h < (1l << 24) && o.w < (1 << 24); }
+
 size_t plan_workspace(const sd_model* m, const std::vector<Dims>& dims, std::vector<size_t>& off) {
     const int nb = m->nbuf;
+    const bool dec0 = dec0_shape_ok(dims[0]);
     off.assign(nb, 0);
     const size_t WS_BASE = m->ws_base;      // statistics scratch + the scale / shift tables of deferred GroupNorm applies
     std::vector<size_t> bytes(nb, 0);
@@ -158,6 +166,12 @@ size_t plan_workspace(const sd_model* m, const std::vector<Dims>& dims, std::vec
     for (int i = 0; i < nops; ++i) {
         const Op& op = m->ops[i];
         const sd_op_desc& d = op.d;
+        if (op.in_dec0 && dec0) continue;               // runs inside the up-convolution's launch, writes no buffer
+        if (op.dec0_c1 >= 0 && dec0) {                  // reads the level-1 tensor and the skip tensor, writes the network output
+            touch_r(d.src0, i);
+            touch_r(m->ops[op.dec0_c1].d.src1, i);
+            continue;
+        }
         touch_r(d.src0, i);
         touch_r(d.src1, i);
         if (d.kind != SD_OP_FINAL) touch_w(d.dst, i);
@@ -525,6 +539,34 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
                             }
             }
         }
+        // Level-0 decoder as one streaming launch: planar up-convolution 64 -> 32, merge conv (32 + 32 -> 32), conv 32 -> 32
+        // with the fused final layer, all with folded BatchNorm + ReLU (no GroupNorm between them) and no other reader of
+        // the two intermediate tensors.
+        if (!m->keep_all && !getenv("SD_NO_DEC0")) {
+            for (size_t i = 0; i + 3 < m->ops.size(); ++i) {
+                Op& u = m->ops[i];
+                Op& c1 = m->ops[i + 1];
+                Op& c2 = m->ops[i + 2];
+                if (u.d.kind != SD_OP_UPCONV || u.d.kz != 1 || !u.d.relu || m->bufCp[u.d.src0] != 64 || m->bufCp[u.d.dst] != 32) continue;
+                if (c1.d.kind != SD_OP_CONV || c1.first || c1.d.kz != 1 || !c1.d.relu || c1.d.src0 != u.d.dst || c1.d.src1 < 0 ||
+                    m->bufCp[c1.d.src1] != 32 || m->bufCp[c1.d.dst] != 32 || c1.NT != 1 || c1.NB != 1 || c1.fuse_gn >= 0 ||
+                    c1.fuse_pool >= 0 || c1.fuse_final >= 0)
+                    continue;
+                if (c2.d.kind != SD_OP_CONV || c2.d.kz != 1 || !c2.d.relu || c2.d.src0 != c1.d.dst || c2.d.src1 >= 0 ||
+                    m->bufCp[c2.d.dst] != 32 || c2.NT != 1 || c2.NB != 1 || c2.fuse_final != (int)i + 3)
+                    continue;
+                if (m->buf_gn[u.d.src0] >= 0 || m->buf_gn[c1.d.src1] >= 0) continue;
+                bool other_reader = false;
+                for (size_t k = 0; k < m->ops.size(); ++k) {
+                    const sd_op_desc& r = m->ops[k].d;
+                    if (k != i + 1 && (r.src0 == u.d.dst || r.src1 == u.d.dst)) other_reader = true;
+                    if (k != i + 2 && (r.src0 == c1.d.dst || r.src1 == c1.d.dst)) other_reader = true;
+                }
+                if (other_reader) continue;
+                u.dec0_c1 = (int)i + 1; u.dec0_c2 = (int)i + 2;
+                c1.in_dec0 = c2.in_dec0 = true;      // (skipped per launch: dec0_shape_ok)
+            }
+        }
     }
 
     {
@@ -642,6 +684,7 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
                                                             : (size_t)m->final_cout * D * H * W * (out_kind == SD_OUT_PROBS_U8 ? 1 : 4);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     char* const wsb = reinterpret_cast<char*>(ws);
+    const bool dec0 = dec0_shape_ok(m->dims[0]);
     auto bufp = [&](int b) -> void* { return wsb + m->buf_off[b]; };
     hipEvent_t* ev = nullptr;
     if (m->profile_slots > 0)
@@ -652,7 +695,7 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
         const Op& op = m->ops[i];
         const sd_op_desc& d = op.d;
         if (ev) HIP_TRY(hipEventRecord(ev[i], s));
-        if (op.skipped) continue;
+        if (op.skipped || (op.in_dec0 && dec0)) continue;
         switch (d.kind) {
         case SD_OP_CONV: {
             const Dims o = m->dims[d.dst];
@@ -767,6 +810,27 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
             break;
         }
         case SD_OP_UPCONV: {
+            if (op.dec0_c1 >= 0 && dec0) {
+                const Op& c1 = m->ops[op.dec0_c1];
+                const Op& c2 = m->ops[op.dec0_c2];
+                const Op& fo = m->ops[c2.fuse_final];
+                const Dims a = m->dims[d.src0], o = m->dims[c1.d.src1];
+                if (o.d != D || o.h != H || o.w != W || a.d != D) return fail(SD_ERR_INVALID, "final layer shape != input shape");
+                Dec0Params p{};
+                p.l1 = bufp(d.src0); p.skip = bufp(c1.d.src1);
+                p.D = o.d; p.H = o.h; p.W = o.w; p.H1 = a.h; p.W1 = a.w; p.Ps = (size_t)o.d * o.h * o.w;
+                p.wup = m->dev_blob + op.wpack_off; p.bup = reinterpret_cast<const float*>(m->dev_blob + op.bias_off);
+                p.w1 = m->dev_blob + c1.wpack_off; p.b1 = reinterpret_cast<const float*>(m->dev_blob + c1.bias_off);
+                p.w2 = m->dev_blob + c2.wpack_off; p.b2 = reinterpret_cast<const float*>(m->dev_blob + c2.bias_off);
+                p.fw = m->dev_blob + c2.fwfrag_off; p.fb = reinterpret_cast<const float*>(m->dev_blob + fo.bias_off);
+                p.final_cout = fo.d.cout; p.final_kind = out_kind; p.final_out = out_dev;
+                if (lab) p.lab = *lab;
+                p.zero = m->dev_zero;
+                p.batch = N; p.tstride = tstride; p.out_tstride = out_tstride;
+                p.dbg = getenv("SD_DEC0_DBG") ? reinterpret_cast<long long*>(wsb) : nullptr;      // (timing builds) GroupNorm scratch
+                rc = launch_dec0(p, m->act_dtype, s);
+                break;
+            }
             UpconvParams p{};
             const Dims a = m->dims[d.src0];
             p.src = bufp(d.src0); p.Cs = m->bufCp[d.src0]; p.nchunk = p.Cs / SD_CHUNK;

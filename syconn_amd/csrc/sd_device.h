@@ -1,0 +1,126 @@
+// Device-side helpers shared by the kernel translation units (sd_kernels.hip, sd_dec0.hip): storage types, the MFMA
+// wrappers, packed 16-bit max, explicit LDS reads, cross-lane swaps, LDS-DMA.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <utility>
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <typename T> struct Act;
+template <> struct Act<bf16_t> {
+    using v8 = bf16x8;
+    using v4 = bf16x4;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ unsigned pack2(float a, float b) {     // RNE, one v_cvt_pk_bf16_f32
+        typedef __attribute__((ext_vector_type(2))) float f2;
+        typedef __attribute__((ext_vector_type(2))) __bf16 t2;
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a, b}, t2));
+    }
+};
+template <> struct Act<f16_t> {
+    using v8 = f16x8;
+    using v4 = f16x4;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ unsigned pack2(float a, float b) {     // RNE, one v_cvt_pk_f16_f32
+        typedef __attribute__((ext_vector_type(2))) float f2;
+        typedef __attribute__((ext_vector_type(2))) _Float16 t2;
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a, b}, t2));
+    }
+};
+// max of two packed pairs of NON-NEGATIVE-or-any 16-bit floats against each other as signed 16-bit integers: for
+// sign-magnitude floats this is the float max whenever at most one operand is negative (ReLU: max(x, +0) is exact
+// for every x incl. -0; pooling: all operands are >= 0 after the ReLU).  One v_pk_max_i16 for two channels.
+__device__ __forceinline__ unsigned pk_max16(unsigned a, unsigned b) {
+    typedef __attribute__((ext_vector_type(2))) short s2;
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, a), __builtin_bit_cast(s2, b)));
+}
+
+// Hardware places workgroup b on XCD b % 8 (observed; used for L2 locality only).  Map it to a logical block id
+// such that each XCD owns a contiguous run of logical ids (neighbouring blocks share halo voxels in that L2).
+// Bijective for any grid size.
+// ---- explicit LDS reads (see the tap loop of k_conv_mfma) --------------------------------------------------------
+template <int OFF, typename V>
+__device__ __forceinline__ void ds_read16(V& r, uint32_t addr) {     // 16 bytes per lane; completion via lgkmcnt
+    static_assert(sizeof(V) == 16 && OFF >= 0 && OFF < 65536, "ds_read_b128 offset");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+}
+template <typename V> __device__ __forceinline__ void tie(V& r) { asm volatile("" : "+v"(r)); }
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {        // LDS byte offset of a pointer into shared memory
+    return (uint32_t)(uintptr_t)p;
+}
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+// Cross-lane helpers (gfx950): v_permlane32_swap exchanges the upper half-wave of `a` with the lower half-wave
+// of `b`; v_permlane16_swap exchanges odd 16-lane rows of `a` with even rows of `b`.  Inline asm on purpose:
+// with the builtin hipcc (ROCm 7.2) folds away arithmetic that combines the two results when both inputs hold the
+// same value (tools/probe/pool.hip shows the dropped v_max).  `s_nop 1` = the 2 wait states a VALU write of an
+// operand needs before v_permlane*_swap reads it (nothing pads hazards inside an asm statement); the trailing
+// one keeps a dependent VALU read of the results out of the swap's shadow.
+__device__ __forceinline__ void swap32(unsigned& a, unsigned& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap32x4(unsigned& a0, unsigned& b0, unsigned& a1, unsigned& b1, unsigned& a2, unsigned& b2,
+                                         unsigned& a3, unsigned& b3) {     // four independent swaps, one hazard pad
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\t"
+                 "v_permlane32_swap_b32 %4, %5\n\tv_permlane32_swap_b32 %6, %7\n\ts_nop 1"
+                 : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3));
+}
+// packed-pair max over the 2x2 (y,x) pooling window: lane^1 by DPP, lane^16 by one batched v_permlane16_swap of
+// the eight registers of an accumulator tile; result valid in all four lanes
+__device__ __forceinline__ void pool_xy_pk8(unsigned (&m)[8]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        m[k] = pk_max16(m[k], (unsigned)__builtin_amdgcn_update_dpp(0, (int)m[k], 0xB1, 0xF, 0xF, true));
+    unsigned b[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) b[k] = m[k];
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %8\n\tv_permlane16_swap_b32 %1, %9\n\t"
+                 "v_permlane16_swap_b32 %2, %10\n\tv_permlane16_swap_b32 %3, %11\n\t"
+                 "v_permlane16_swap_b32 %4, %12\n\tv_permlane16_swap_b32 %5, %13\n\t"
+                 "v_permlane16_swap_b32 %6, %14\n\tv_permlane16_swap_b32 %7, %15\n\ts_nop 1"
+                 : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7]),
+                   "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[k] = pk_max16(m[k], b[k]);
+}
+__device__ __forceinline__ float max_xor1(float m) {       // max with lane^1 (DPP quad_perm [1,0,3,2])
+    return fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xF,
+                                                                            0xF, true)));
+}
+__device__ __forceinline__ float max_xor16(float m) {      // max with lane^16, result in both lanes
+    unsigned a = __builtin_bit_cast(unsigned, m), b = a;
+    swap16(a, b);                                           // a = rows [0,0,2,2], b = rows [1,1,3,3]
+    return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+}
+
+// 16 bytes per lane straight from global memory into LDS (lane i lands at lds_wave_base + 16*i)
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}

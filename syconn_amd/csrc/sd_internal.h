@@ -137,6 +137,30 @@ struct GnParams {
     int no_inplace;            // with pool_dst: write only the pooled normalised tensor, leave `buf` raw (deferred apply)
 };
 
+// Fused level-0 decoder (sd_dec0.hip): planar up-convolution 64 -> 32 + merge conv (32 + 32 -> 32) + conv 32 -> 32 + final
+// 1x1x1 in one streaming kernel.  Weight fragment blobs are the ones the separate layers use.
+struct Dec0Params {
+    const void* l1;    // level-1 tensor, 4 chunks, extents (D, H1, W1)
+    const void* skip;  // encoder skip tensor, 2 chunks, extents (D, H, W)
+    size_t Ps;         // D*H*W
+    int D, H, W, H1, W1;
+    const void* wup; const float* bup;   // up-conv fragments [tap pair][chunk][tap & 1][64][8], folded bias (32 floats)
+    const void* w1; const float* b1;     // merge conv fragments [chunk 0..3][tap][64][8], folded bias
+    const void* w2; const float* b2;     // second conv fragments [chunk 0..1][tap][64][8], folded bias
+    const void* fw; const float* fb;     // final layer: hi/lo fragments [2 k-steps][2][64][8], class bias
+    int final_cout, final_kind;
+    void* final_out;
+    LabelArgs lab;
+    int lab_fast; unsigned lab_cls[8];   // distinct label ids: per class (list position + 1) << 16 | cut, 0 = not listed (launch_dec0)
+    const void* zero;  // >= 16 zero bytes
+    int batch; size_t tstride, out_tstride;
+    // filled in by launch_dec0
+    int HP, HP1, nstrip, zsplit, nzg;
+    unsigned magic_hp, magic_hp1;
+    long long* dbg;    // SD_DEC0_TIMING builds: per-wave cycle stamps of one step (else unused)
+};
+int launch_dec0(Dec0Params p, int act_dtype, hipStream_t s);
+
 int launch_conv(const ConvParams& p, int act_dtype, int KZ, int NT, int NB, hipStream_t s);
 // LDS bytes a deferred-GroupNorm convolution needs per tile of the launch for its scale / shift table
 inline size_t conv_gn_lds_per_tile(int nchunks) { return (size_t)nchunks * 128; }
