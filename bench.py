@@ -116,6 +116,19 @@ def layer_accounting(ops, L, D, H, W, act_bytes=2, out_bytes_per_class=1, batch=
             rows.append(('final', 2.0 * vox * o.cin0 * o.cout, vox * (o.cin0 * act_bytes + o.cout * out_bytes_per_class)))
     for i in fused_first:             # the first conv's work is done inside its consumer: no launch of its own
         rows[i] = ('k_conv_first(fused into next)',) + tuple(rows[i][1:])
+    # level-0 decoder as one streaming launch (sd_dec0.hip; mirrors the plan pass in sd_api.hip): the planar up-convolution
+    # 64 -> 32, the merge conv, the second conv and the final layer run inside the up-convolution's launch
+    r16 = lambda c: -(-c // 16) * 16
+    if not os.environ.get('SD_NO_DEC0') and not os.environ.get('SD_NO_FUSE') and not os.environ.get('SD_KEEP_ALL') and H >= 8:
+        for i in range(len(ops) - 3):
+            u, c1, c2, f = ops[i:i + 4]
+            if (u.kind == L.SD_OP_UPCONV and u.kz == 1 and u.relu and r16(u.cin0) == 64 and r16(u.cout) == 32
+                    and c1.kind == L.SD_OP_CONV and c1.kz == 1 and c1.relu and c1.src0 == u.dst and c1.src1 >= 0
+                    and r16(c1.cin1) == 32 and r16(c1.cout) == 32
+                    and c2.kind == L.SD_OP_CONV and c2.kz == 1 and c2.relu and c2.src0 == c1.dst and c2.src1 < 0
+                    and r16(c2.cout) == 32 and f.kind == L.SD_OP_FINAL and i + 4 == len(ops)):
+                for j in (i, i + 1, i + 2, i + 3):
+                    rows[j] = ('k_dec0<up-conv + merge conv + conv + final>',) + tuple(rows[j][1:])
     return rows
 
 

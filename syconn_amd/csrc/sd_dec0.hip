@@ -274,6 +274,7 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
         }
         Cur cu = cur_at(32 * (-5 + 3) + l31, PW / 2, HP1);          // level-1 position of this lane in up-conv tile u
         Cur co = cur_at(ST * half + 32 * ow + l31, PW, HP);          // output position of this lane in the (even, odd) step pair
+        const f32x16 bias_up = bias_init(0), bias_c2 = bias_init(64);      // (registers: an LDS read + wait per tile otherwise)
         unsigned pkA[8], pkB[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) { pkA[i] = 0u; pkB[i] = 0u; }
@@ -376,8 +377,7 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
 #endif
             if (u >= 0) {
                 // ---- one output parity (py, px) of the up-convolution of level-1 tile u
-                f32x16 acc = bias_init(0), acc1;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                f32x16 acc = bias_up, acc1;
                 const uint32_t lt = LDS_L + (u & 3) * 4096 + rec_off(l31, half);
                 v8 xl[4];
                 static_for<4>([&](auto cc) { ds_read16<decltype(cc)::value * 1024>(xl[decltype(cc)::value], lt); });
@@ -401,8 +401,8 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
             D0_T(1);
             if (k >= 2) {
                 // ---- second conv of tile ow, two steps behind the merge conv
-                f32x16 acc = bias_init(64), acc1;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (also: the up-conv's ring writes are out)
+                f32x16 acc = bias_c2, acc1;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the up-conv's ring writes are out: the counted waits below start from zero
                 v8 xq[PF];
                 auto issue = [&](auto ic) {
                     constexpr int i = decltype(ic)::value, c = i & 1, t9 = i >> 1;

@@ -372,3 +372,50 @@ def test_four_tile_form_is_bit_identical(gpu, monkeypatch):
         for sh, ref in zip(shapes, a):
             b = four.forward_batch(_input(sh, 4).to(gpu), L.SD_OUT_LOGITS_F32, slot=1)
             assert torch.equal(ref, b), (arch, sh)
+
+
+@pytest.mark.parametrize('arch,act', [('semseg_spine', 'bf16'), ('semseg_spine', 'f16'), ('myelin', 'bf16'), ('syntype', 'f16')])
+def test_fused_level0_decoder_matches_separate_layers(gpu, monkeypatch, arch, act):
+    """sd_dec0.hip (up-convolution + merge conv + conv + final layer of the planar top level in ONE streaming launch) against the
+    layer-by-layer plan (SD_NO_DEC0=1): same rounded weights and the same rounding points, another fp32 summation order, so
+    logits agree to a few ulp of the storage type and uint8 probabilities to +-1 on a small fraction of voxels.  Shapes: odd
+    extents (crop of the up-convolved tensor), 1 / 2 / 3 x-strips, rows that do not divide the 128-position steps, batches,
+    and H < 8, which the streaming kernel does not serve (exact equality: both plans run the same kernels)."""
+    from syconn_amd import _lib as L
+    from syconn_amd.engine import DenseModel
+    net = build_unet(arch, seed=21, final_scale=6.0)
+    dm = DenseModel(net, act, gpu)
+    monkeypatch.setenv('SD_NO_DEC0', '1')
+    layers = DenseModel(net, act, gpu)
+    monkeypatch.delenv('SD_NO_DEC0')
+    tol_max, tol_rms = TOL_EMU[act], TOL_EMU_RMS[act] / 4
+    for nb, shape in ((1, (3, 9, 11)), (2, (2, 33, 70)), (1, (5, 64, 64)), (3, (4, 50, 129)), (1, (2, 131, 200)), (1, (3, 6, 40))):
+        x = _input((nb, *shape), 31 + shape[2]).to(gpu)
+        a, b = dm.forward_batch(x, L.SD_OUT_LOGITS_F32).cpu(), layers.forward_batch(x, L.SD_OUT_LOGITS_F32).cpu()
+        if shape[1] < 8:
+            assert torch.equal(a, b), shape
+            continue
+        scale, rms = float(b.abs().max()), float(b.pow(2).mean().sqrt())
+        e_max, e_rms = float((a - b).abs().max()) / scale, float((a - b).pow(2).mean().sqrt()) / rms
+        assert e_max <= tol_max and e_rms <= tol_rms, (arch, act, shape, e_max, e_rms)
+        for kind in (L.SD_OUT_PROBS_U8, L.SD_OUT_PROBS_F32):
+            pa, pb = dm.forward_batch(x, kind).cpu().float(), layers.forward_batch(x, kind).cpu().float()
+            unit = 1.0 if kind == L.SD_OUT_PROBS_U8 else 1.0 / 255
+            assert float((pa - pb).abs().max()) <= 1.001 * unit, (arch, act, shape, kind)
+            assert float(((pa - pb).abs() > 0.5 * unit).float().mean()) < 2e-2, (arch, act, shape, kind)
+
+
+def test_fused_level0_decoder_label_rules(gpu):
+    """Both label-rule forms of the streaming decoder kernel -- the per-class table (distinct ids) and the generic list (an
+    id listed twice: the later entry overrides) -- equal sd_postproc_labels applied to the kernel's own uint8 probabilities."""
+    from syconn_amd import _lib as L
+    from syconn_amd.engine import DenseModel, postproc_labels
+    net = build_unet('semseg_spine', seed=4, final_scale=6.0)
+    dm = DenseModel(net, 'bf16', gpu)
+    x = _input((2, 6, 70, 90), 77).to(gpu)
+    probs = dm.forward_batch(x, L.SD_OUT_PROBS_U8)
+    for ids, thr in (((4, 2, 1, 3), (40.0, 60.5, 30.0, 80.0)), ((1, 2, 1), (20.0, 50.0, 120.5)), ((3,), (-1.0,)), ((2, 2), (254.5, 10.0))):
+        want = torch.stack([postproc_labels(probs[i], list(ids), list(thr)) for i in range(2)])
+        got = dm.forward_labels_batch(x, ids, thr)
+        assert torch.equal(got, want), (ids, thr)
+    assert len(torch.unique(dm.forward_labels_batch(x, (4, 2, 1, 3), (40.0, 60.5, 30.0, 80.0)))) >= 3

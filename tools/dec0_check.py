@@ -18,6 +18,7 @@ def models(arch, act, seed=0):
 bad = 0
 shapes = [(1, (4, 32, 32)), (2, (3, 50, 70)), (1, (5, 33, 129)), (1, (2, 131, 64)), (3, (8, 64, 64)), (1, (1, 7, 5)), (1, (6, 96, 200))]
 if len(sys.argv) > 1 and sys.argv[1] == 'quick': shapes = shapes[:2]
+if len(sys.argv) > 1 and sys.argv[1] == 'time': shapes = []
 for arch in ('semseg_spine', 'myelin', 'syntype'):
     for act in ('bf16', 'f16'):
         a, b = models(arch, act)

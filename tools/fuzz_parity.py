@@ -1,6 +1,7 @@
 # dev tool: randomized parity sweep -- random architectures / tile shapes / batch sizes / dtypes against the fp32 oracle
 # (tolerances of tests/test_gpu_unet.py) and against the unfused launch sequence (same rounded activations; the fused final
-# layer evaluates the 1x1x1 conv as hi+lo MFMAs instead of fp32 FMAs -> logits agree to ~1e-5 relative, not bitwise).
+# layer evaluates the 1x1x1 conv as hi+lo MFMAs instead of fp32 FMAs -> logits agree to ~1e-5 relative, not bitwise; nets whose
+# level-0 decoder runs as the streaming kernel sd_dec0.hip sum in another order -> roundings of stored activations flip).
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle.unet_ref import ARCHS, build_unet
@@ -36,7 +37,8 @@ for k in range(n):
     e_rms = float(((got - ref) ** 2).mean().sqrt() / ((ref ** 2).mean().sqrt() + 1e-12))
     d12 = float((got - got2).abs().max()) / scale
     # GroupNorm: statistics summed in another order -> scale / shift differ in the last bit -> roundings of stored activations flip
-    same = d12 < ((2e-2 if act == 'bf16' else 3e-3) if ARCHS[arch].get('normalization') == 'group8' else 1e-4)
+    loose = ARCHS[arch].get('normalization') == 'group8' or (ARCHS[arch]['start_filts'] <= 32 and shape[1] >= 8)
+    same = d12 < ((2e-2 if act == 'bf16' else 3e-3) if loose else 1e-4)
     ok = e_max <= TOL[act][0] * 1.5 and e_rms <= TOL[act][1] * 1.5 and same and bool(torch.isfinite(got).all())
     bad += not ok
     print(f'{k:3d} {arch:13s} {act} N={nb} {str(shape):16s} max {e_max:.2e} rms {e_rms:.2e} fused-unfused {d12:.1e} {"ok" if ok else "FAIL"}')
