@@ -119,7 +119,8 @@ def layer_accounting(ops, L, D, H, W, act_bytes=2, out_bytes_per_class=1, batch=
     # level-0 decoder as one streaming launch (sd_dec0.hip; mirrors the plan pass in sd_api.hip): the planar up-convolution
     # 64 -> 32, the merge conv, the second conv and the final layer run inside the up-convolution's launch
     r16 = lambda c: -(-c // 16) * 16
-    if not os.environ.get('SD_NO_DEC0') and not os.environ.get('SD_NO_FUSE') and not os.environ.get('SD_KEEP_ALL') and H >= 8:
+    if (not os.environ.get('SD_NO_DEC0') and not os.environ.get('SD_NO_FUSE') and not os.environ.get('SD_KEEP_ALL') and H >= 8
+            and W * 10 >= -(-W // 64) * 64 * 7):
         for i in range(len(ops) - 3):
             u, c1, c2, f = ops[i:i + 4]
             if (u.kind == L.SD_OP_UPCONV and u.kz == 1 and u.relu and r16(u.cin0) == 64 and r16(u.cout) == 32

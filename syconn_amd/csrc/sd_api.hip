@@ -144,8 +144,13 @@ int infer_shapes(const sd_model* m, int D, int H, int W, std::vector<Dims>& dims
 // about a third of the sum of all activations -- which is what lets several such tiles run in one launch set.
 // `reuse == false` (SD_KEEP_ALL / SD_NO_FUSE / SD_NO_WS_REUSE: layer-wise debugging reads buffers back after the
 // forward) gives every buffer its own range.
-// shapes the fused level-0 decoder serves (sd_dec0.hip: cursor arithmetic); others run the layers separately
-bool dec0_shape_ok(const Dims& o) { return o.h >= 8 && (long)o.d * o.h < (1l << 24) && o.w < (1 << 24); }
+// shapes the fused level-0 decoder serves (sd_dec0.hip: cursor arithmetic) and is worth it for: it walks x-strips of 64
+// columns at the cost of full strips, so a width that fills its last strip badly is faster layer by layer (measured: 66
+// columns = 2 strips at 52 % -> 0.26 vs 0.21 ms; 331 columns = 6 strips at 86 % -> 1.24 vs 1.36 ms).  Others run the layers.
+bool dec0_shape_ok(const Dims& o) {
+    const int nstrip = (o.w + 63) / 64;
+    return o.h >= 8 && (long)o.d * o.h < (1l << 24) && o.w < (1 << 24) && o.w * 10 >= nstrip * 64 * 7;
+}
 
 size_t plan_workspace(const sd_model* m, const std::vector<Dims>& dims, std::vector<size_t>& off) {
     const int nb = m->nbuf;

@@ -473,9 +473,16 @@ int launch_dec0(Dec0Params p, int act_dtype, hipStream_t s) {
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
         if (ncu <= 0) ncu = 256;
     });
+    // Workgroups: one per (tile, strip, range of zsplit planes); only one fits a CU (LDS).  Pick the plane count per workgroup
+    // that minimises the makespan rounds * (zsplit + prologue): many small workgroups balance a grid that does not divide the
+    // CUs, few large ones save the per-workgroup prologue (LDS clear, weight fragments, pipeline fill ~ 1/8 plane).
     const int combos = p.batch * p.nstrip;
-    int nzg = std::min(p.D, std::max(1, (ncu + combos - 1) / combos));
-    p.zsplit = (p.D + nzg - 1) / nzg;
+    double best = 1e30;
+    for (int zs = 1; zs <= p.D; ++zs) {
+        const long nwg = (long)combos * ((p.D + zs - 1) / zs);
+        const double span = (double)((nwg + ncu - 1) / ncu) * (zs + 0.125);
+        if (span < best * 0.999 || (span < best * 1.001 && zs > p.zsplit)) { best = std::min(best, span); p.zsplit = zs; }
+    }
     p.nzg = (p.D + p.zsplit - 1) / p.zsplit;
     if ((long)p.zsplit * p.HP * PW > (1l << 30) || p.H < 8 || (long)p.D * p.H >= (1l << 24) || p.W >= (1 << 24))
         return SD_ERR_INVALID;      // 32-bit positions, 24-bit row arithmetic, cursor wraps once per advance
