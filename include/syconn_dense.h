@@ -141,6 +141,10 @@ int sd_profile_read(sd_model* m, int slot, float* ms_per_op, int n_ops);
 int sd_debug_read_buffer(sd_model* m, int buf, const void* workspace_dev, float* out_dev, int32_t* dims4,
                          void* stream);
 int sd_model_num_ops(const sd_model* m);
+/* Number of plan ops the last sd_forward* call executed as launches of their own (the others ran inside a fused launch:
+ * pooling / final layer in a convolution's epilogue, first convolution inside the second, the level-0 decoder inside its
+ * up-convolution's launch).  For tests that must know which plan a shape was served by. */
+int sd_debug_last_launch_count(const sd_model* m);
 
 const char* sd_last_error(void);
 const char* sd_version(void);

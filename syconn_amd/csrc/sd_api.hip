@@ -87,6 +87,7 @@ struct sd_model {
     std::vector<size_t> buf_off;
     int profile_slots = 0;             // 0 = off; else ring of event sets, one per sd_forward
     long n_forward = 0;
+    int last_launches = 0;             // ops of the last forward that ran as their own launch
     std::vector<hipEvent_t> events;    // [slot][n_ops + 1]
     int final_cout = 0;
     bool keep_all = false;   // SD_KEEP_ALL=1: also store activations that only feed a fused consumer (tests)
@@ -232,6 +233,7 @@ int sd_init(int device_ordinal) {
 }
 
 int sd_model_num_ops(const sd_model* m) { return m ? (int)m->ops.size() : 0; }
+int sd_debug_last_launch_count(const sd_model* m) { return m ? m->last_launches : 0; }
 
 int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_floats, int act_dtype,
                     sd_model** out) {
@@ -695,12 +697,14 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
     if (m->profile_slots > 0)
         ev = m->events.data() + (size_t)(m->n_forward % m->profile_slots) * (m->ops.size() + 1);
     ++m->n_forward;
+    m->last_launches = 0;
 
     for (size_t i = 0; i < m->ops.size(); ++i) {
         const Op& op = m->ops[i];
         const sd_op_desc& d = op.d;
         if (ev) HIP_TRY(hipEventRecord(ev[i], s));
         if (op.skipped || (op.in_dec0 && dec0)) continue;
+        ++m->last_launches;
         switch (d.kind) {
         case SD_OP_CONV: {
             const Dims o = m->dims[d.dst];

@@ -27,8 +27,9 @@
 //        then the second conv of one tile two steps behind the merge conv (18 MFMAs, weights in registers), the final
 //        1x1x1 on the matrix core (hi + lo weight parts), softmax, uint8 / labels, global store.
 // The only LDS fragment traffic is one activation fragment per MFMA; no weight fragment is ever re-read.
-// Every convolution sums in two independent accumulator chains (other fp32 summation order than the layer-by-layer kernels:
-// results agree to rounding, not bitwise).
+// Every convolution output is summed in the order of k_conv_mfma (bias, chunks in concat order, taps 0..8): bit-identical to
+// the layer-by-layer plan up to the up-convolution, whose row kernel adds the bias last (differs by fp32 rounding when it is
+// not zero).
 #include "sd_internal.h"
 #include "../../include/syconn_dense.h"
 #include "sd_device.h"
@@ -74,7 +75,6 @@ template <typename T, int KIND>
 __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
     using v8 = typename Act<T>::v8;
     typedef __attribute__((ext_vector_type(4))) unsigned u4;
-    typedef __attribute__((ext_vector_type(2))) float f32x2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const cst = reinterpret_cast<float*>(smem + LDS_CST);     // [0,32) up bias, [32,64) merge, [64,96) second, [96,104) classes
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
@@ -136,14 +136,13 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
         }
         return acc;
     };
-    // (acc + acc1) rounded + ReLU, zeroed where !ok, quads traded with lane^32; the lane's record (chunk = half, both
-    // 16-byte halves) goes to LDS byte address `rec` (physical half order given by `sw` = 0 / 16)
-    auto write_tile = [&](const f32x16& acc, const f32x16& acc1, bool ok, uint32_t rec, uint32_t sw) {
+    // acc rounded + ReLU, zeroed where !ok, quads traded with lane^32; the lane's record (chunk = half, both 16-byte halves)
+    // goes to LDS byte address `rec` (physical half order given by `sw` = 0 / 16)
+    auto write_tile = [&](const f32x16& acc, bool ok, uint32_t rec, uint32_t sw) {
         unsigned pk[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const f32x2 s = f32x2{acc[2 * k], acc[2 * k + 1]} + f32x2{acc1[2 * k], acc1[2 * k + 1]};      // v_pk_add_f32
-            pk[k] = pk_max16(Act<T>::pack2(s.x, s.y), 0u);
+            pk[k] = pk_max16(Act<T>::pack2(acc[2 * k], acc[2 * k + 1]), 0u);
             if (!ok) pk[k] = 0u;
         }
         swap32x4(pk[0], pk[4], pk[1], pk[5], pk[2], pk[6], pk[3], pk[7]);
@@ -213,23 +212,22 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
             }
             D0_T(1);
             if (k >= 0) {
-                // two independent accumulator chains (up-convolved chunks / skip chunks), alternating: an MFMA that has to wait for
-                // its predecessor on the same accumulator with other instructions in between loses its issue slot
-                f32x16 acc = bias_init(32), acc1;
+                f32x16 acc = bias_init(32);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                // 36 fragments through PF registers: fragment i + PF is requested right behind the MFMA that read fragment i's
-                // register; LDS returns in order -> counted waits (one per pair of MFMAs).  Even i: chunk (i/2)/9 of U, odd i: of S.
-                // A tap's address is advanced to the next step (+128 positions, ring wrap) right behind its last read, so that
-                // this VALU work issues in the shadow of the MFMAs.
+                // 36 fragments (chunks U0, U1, S0, S1 x 9 taps: the summation order of k_conv_mfma) through PF registers: fragment
+                // i + PF is requested right behind the MFMA that read fragment i's register; LDS returns in order -> counted waits
+                // (one per pair of MFMAs).  A tap's address is advanced to the next step (+128 positions, ring wrap) right behind
+                // its last read, so that this VALU work issues in the shadow of the MFMAs.  (Two independent accumulator chains
+                // were measured: no gain -- the partner wave fills the pipe -- and they cost 8 packed adds per tile.)
                 v8 xq[PF];
                 auto issue = [&](auto ic) {
-                    constexpr int i = decltype(ic)::value, c = (i >> 1) / 9, t9 = (i >> 1) % 9;
-                    if constexpr ((i & 1) == 0) {
+                    constexpr int i = decltype(ic)::value, c = i / 9, t9 = i % 9;
+                    if constexpr (c < 2) {
                         ds_read16<c * (RU * 32)>(xq[i % PF], aU[t9]);
                         if constexpr (c == 1) { const uint32_t a = aU[t9] + ST * 32; aU[t9] = a - (a >> 16) * (RU * 32); }
                     } else {
-                        ds_read16<c * (RS * 32)>(xq[i % PF], aS[t9]);
-                        if constexpr (c == 1) { const uint32_t a = aS[t9] + ST * 32; aS[t9] = min(a, a - RS * 32); }
+                        ds_read16<(c - 2) * (RS * 32)>(xq[i % PF], aS[t9]);
+                        if constexpr (c == 3) { const uint32_t a = aS[t9] + ST * 32; aS[t9] = min(a, a - RS * 32); }
                     }
                 };
                 static_for<PF>([&](auto ic) { issue(ic); });
@@ -237,14 +235,12 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
                     constexpr int i = decltype(ic)::value;
                     if constexpr ((i & 1) == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(i + PF <= 34 ? PF - 2 : (i + 2 <= 36 ? 34 - i : 0)));
                     tie(xq[i % PF]);
-                    if constexpr ((i & 1) == 0) acc = Act<T>::mfma(w1[i >> 1], xq[i % PF], acc);
-                    else if constexpr (i == 1) acc1 = Act<T>::mfma(w1[18], xq[i % PF], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
-                    else acc1 = Act<T>::mfma(w1[18 + (i >> 1)], xq[i % PF], acc1);
+                    acc = Act<T>::mfma(w1[i], xq[i % PF], acc);
                     if constexpr (i + PF < 36) issue(std::integral_constant<int, i + PF>{});
                 });
                 D0_T(2);
                 const bool ok = (unsigned)cm.plane < (unsigned)nz && cm.y < gH && (unsigned)(c0 - 2 + cm.xx) < (unsigned)gW;
-                write_tile(acc, acc1, ok, cC, cCsw);
+                write_tile(acc, ok, cC, cCsw);
                 cC = (cC & ~(uint32_t)(RC * 32 - 1)) | ((cC + ST * 32) & (RC * 32 - 1));
                 cur_adv(cm, ST - PW, 1, PW, HP);
             }
@@ -377,7 +373,7 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
 #endif
             if (u >= 0) {
                 // ---- one output parity (py, px) of the up-convolution of level-1 tile u
-                f32x16 acc = bias_up, acc1;
+                f32x16 acc = bias_up;
                 const uint32_t lt = LDS_L + (u & 3) * 4096 + rec_off(l31, half);
                 v8 xl[4];
                 static_for<4>([&](auto cc) { ds_read16<decltype(cc)::value * 1024>(xl[decltype(cc)::value], lt); });
@@ -385,27 +381,25 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
                     constexpr int c = decltype(cc)::value;
                     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(3 - c));
                     tie(xl[c]);
-                    if constexpr ((c & 1) == 0) acc = Act<T>::mfma(wu[c], xl[c], acc);
-                    else if constexpr (c == 1) acc1 = Act<T>::mfma(wu[c], xl[c], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
-                    else acc1 = Act<T>::mfma(wu[c], xl[c], acc1);
+                    acc = Act<T>::mfma(wu[c], xl[c], acc);
                 });
                 const int y = 2 * cu.y + py, xx = 2 * cu.xx + px;
                 const bool ok = (unsigned)cu.plane < (unsigned)nz && y < gH && (unsigned)(c0 - 2 + xx) < (unsigned)gW;
                 // position relative to 128u - 136 (>= 0, < 396 for every lane of the tile), then the ring index
                 const int qrel = (cu.plane * HP + y) * PW + xx - (ST * u - 136);
                 const uint32_t idx = wrap(uB + (uint32_t)qrel, RU);
-                write_tile(acc, acc1, ok, LDS_U + half * (RU * 32) + (idx << 5), ((idx >> 3) & 1u) << 4);
+                write_tile(acc, ok, LDS_U + half * (RU * 32) + (idx << 5), ((idx >> 3) & 1u) << 4);
             }
             cur_adv(cu, 32, 0, PW / 2, HP1);
             uB += ST; if (uB >= RU) uB -= RU;
             D0_T(1);
             if (k >= 2) {
                 // ---- second conv of tile ow, two steps behind the merge conv
-                f32x16 acc = bias_c2, acc1;
+                f32x16 acc = bias_c2;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the up-conv's ring writes are out: the counted waits below start from zero
                 v8 xq[PF];
                 auto issue = [&](auto ic) {
-                    constexpr int i = decltype(ic)::value, c = i & 1, t9 = i >> 1;
+                    constexpr int i = decltype(ic)::value, c = i / 9, t9 = i % 9;
                     ds_read16<c * (RC * 32)>(xq[i % PF], aC[t9]);
                     if constexpr (c == 1) aC[t9] = LDS_C | ((aC[t9] + ST * 32) & (RC * 32 - 1));     // next step's address
                 };
@@ -414,18 +408,13 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
                     constexpr int i = decltype(ic)::value;
                     if constexpr ((i & 1) == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(i + PF <= 16 ? PF - 2 : (i + 2 <= 18 ? 16 - i : 0)));
                     tie(xq[i % PF]);
-                    if constexpr ((i & 1) == 0) acc = Act<T>::mfma(w2[i >> 1], xq[i % PF], acc);
-                    else if constexpr (i == 1) acc1 = Act<T>::mfma(w2[9], xq[i % PF], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f});
-                    else acc1 = Act<T>::mfma(w2[9 + (i >> 1)], xq[i % PF], acc1);
+                    acc = Act<T>::mfma(w2[i], xq[i % PF], acc);
                     if constexpr (i + PF < 18) issue(std::integral_constant<int, i + PF>{});
                 });
                 D0_T(2);
                 unsigned pk[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const f32x2 s = f32x2{acc[2 * i], acc[2 * i + 1]} + f32x2{acc1[2 * i], acc1[2 * i + 1]};      // v_pk_add_f32
-                    pk[i] = pk_max16(Act<T>::pack2(s.x, s.y), 0u);
-                }
+                for (int i = 0; i < 8; ++i) pk[i] = pk_max16(Act<T>::pack2(acc[2 * i], acc[2 * i + 1]), 0u);
                 if ((k & 1) == 0) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) pkA[i] = pk[i];

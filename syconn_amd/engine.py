@@ -148,6 +148,10 @@ class DenseModel:
         L.check(self.lib.sd_debug_read_buffer(self._h, buf, self._ws.data_ptr(), out.data_ptr(), dims, _stream()))
         return out
 
+    def last_launch_count(self) -> int:
+        """Plan ops the last forward executed as launches of their own (fused ops run inside another op's launch)."""
+        return int(self.lib.sd_debug_last_launch_count(self._h))
+
     def profile(self, n_slots: int = 1):
         """Bracket every layer launch with HIP events; forward k records into slot k % n_slots (0 = off)."""
         L.check(self.lib.sd_profile_enable(self._h, int(n_slots)), 'sd_profile_enable')
