@@ -183,6 +183,7 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
         uint32_t cC = LDS_C + half * (RC * 32) + (((uint32_t)(32 * cw + l31 + QOFF) & (RC - 1)) << 5);   // ... its C1 record
         const uint32_t cCsw = ((((uint32_t)(32 * cw + l31 + QOFF)) >> 3) & 1u) << 4;
         const size_t chunk_l1 = (size_t)cw * p.D * gH1 * gW1 * 32;
+        const f32x16 bias_c1 = bias_init(32);
         for (int k = -5; k < nsteps; ++k) {
             D0_T(0);
             {   // skip pieces (tile cw of step k+3, both chunks)
@@ -212,8 +213,7 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
             }
             D0_T(1);
             if (k >= 0) {
-                f32x16 acc = bias_init(32);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                f32x16 acc = bias_c1;
                 // 36 fragments (chunks U0, U1, S0, S1 x 9 taps: the summation order of k_conv_mfma) through PF registers: fragment
                 // i + PF is requested right behind the MFMA that read fragment i's register; LDS returns in order -> counted waits
                 // (one per pair of MFMAs).  A tap's address is advanced to the next step (+128 positions, ring wrap) right behind
@@ -270,6 +270,9 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
         }
         Cur cu = cur_at(32 * (-5 + 3) + l31, PW / 2, HP1);          // level-1 position of this lane in up-conv tile u
         Cur co = cur_at(ST * half + 32 * ow + l31, PW, HP);          // output position of this lane in the (even, odd) step pair
+        v8 fwr[4];      // final layer: [k-step][hi / lo] weight fragments
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fwr[i] = *reinterpret_cast<const v8*>(smem + LDS_FW + (i * 64 + lane) * 16);
         const f32x16 bias_up = bias_init(0), bias_c2 = bias_init(64);      // (registers: an LDS read + wait per tile otherwise)
         unsigned pkA[8], pkB[8];
 #pragma unroll
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int hl = 0; hl < 2; ++hl) {
-                    const v8 fw = *reinterpret_cast<const v8*>(smem + LDS_FW + ((s2 * 2 + hl) * 64 + lane) * 16);
+                    const v8 fw = fwr[s2 * 2 + hl];
                     lg[0] = Act<T>::mfma(fw, __builtin_bit_cast(v8, u4{pkA[4 * s2], pkA[4 * s2 + 1], pkA[4 * s2 + 2], pkA[4 * s2 + 3]}), lg[0]);
                     lg[1] = Act<T>::mfma(fw, __builtin_bit_cast(v8, u4{pkB[4 * s2], pkB[4 * s2 + 1], pkB[4 * s2 + 2], pkB[4 * s2 + 3]}), lg[1]);
                 }
@@ -306,16 +309,27 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
             if (tsk == SD_DEC0_TIMING) ts[6] = __builtin_readcyclecounter();
 #endif
             if constexpr (KIND != SD_OUT_LOGITS_F32) {
-                const float mx = fmaxf(fmaxf(fmaxf(l[0], l[1]), fmaxf(l[2], l[3])), fmaxf(fmaxf(l[4], l[5]), fmaxf(l[6], l[7])));
+                // classes beyond final_cout hold -inf (weights 0, bias -inf): they are simply skipped, two at a time
+                float mx = fmaxf(l[0], l[1]);
+                if (gcout > 2) mx = fmaxf(mx, fmaxf(l[2], l[3]));
+                if (gcout > 4) mx = fmaxf(mx, fmaxf(l[4], l[5]));
+                if (gcout > 6) mx = fmaxf(mx, fmaxf(l[6], l[7]));
                 float sum = 0.f;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    l[c] = __expf(l[c] - mx);      // (absent classes: exp(-inf) = 0)
-                    sum += l[c];
+                for (int c2 = 0; c2 < 8; c2 += 2) {
+                    if (c2 == 0 || gcout > c2) {
+                        l[c2] = __expf(l[c2] - mx);
+                        l[c2 + 1] = __expf(l[c2 + 1] - mx);      // (an absent odd class: exp(-inf) = 0)
+                        sum += l[c2];
+                        sum += l[c2 + 1];
+                    } else {
+                        l[c2] = 0.f; l[c2 + 1] = 0.f;
+                    }
                 }
                 const float inv = 1.0f / sum;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) l[c] *= inv;
+                for (int c2 = 0; c2 < 8; c2 += 2)
+                    if (c2 == 0 || gcout > c2) { l[c2] *= inv; l[c2 + 1] *= inv; }
             }
 #ifdef SD_DEC0_TIMING
             if (tsk == SD_DEC0_TIMING) ts[7] = __builtin_readcyclecounter();
@@ -333,6 +347,7 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
                         unsigned best = 0u;
 #pragma unroll
                         for (int c = 0; c < 8; ++c) {
+                            if ((c & ~1) != 0 && gcout <= (c & ~1)) continue;      // (uniform; classes that exist, in pairs)
                             const unsigned cut = c < 4 ? cut0[c & 3] : cut1[c & 3], key = c < 4 ? key0[c & 3] : key1[c & 3];
                             const unsigned q = (unsigned)(l[c] * 255.f);
                             best = max(best, q >= cut ? key : 0u);
