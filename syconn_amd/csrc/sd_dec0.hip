@@ -273,7 +273,12 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
         v8 fwr[4];      // final layer: [k-step][hi / lo] weight fragments
 #pragma unroll
         for (int i = 0; i < 4; ++i) fwr[i] = *reinterpret_cast<const v8*>(smem + LDS_FW + (i * 64 + lane) * 16);
-        const f32x16 bias_up = bias_init(0), bias_c2 = bias_init(64);      // (registers: an LDS read + wait per tile otherwise)
+        const f32x16 bias_up = bias_init(0), bias_c2 = bias_init(64);
+        // class biases of this half-wave's four classes and the label tables: registers (an LDS read + wait each in the epilogue
+        // otherwise -- four of them serial in front of the swaps)
+        const f32x4 fbias = *reinterpret_cast<const f32x4*>(cst + 96 + 4 * half);
+        const u4 cut0 = reinterpret_cast<const u4*>(cst + 104)[0], cut1 = reinterpret_cast<const u4*>(cst + 104)[1];
+        const u4 key0 = reinterpret_cast<const u4*>(cst + 112)[0], key1 = reinterpret_cast<const u4*>(cst + 112)[1];      // (registers: an LDS read + wait per tile otherwise)
         unsigned pkA[8], pkB[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) { pkA[i] = 0u; pkB[i] = 0u; }
@@ -298,7 +303,7 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
             float l[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float bmine = cst[96 + 4 * half + e];
+                const float bmine = fbias[e];
                 unsigned a = __builtin_bit_cast(unsigned, lg[0][e] + bmine);
                 unsigned b2 = __builtin_bit_cast(unsigned, lg[1][e] + bmine);
                 swap32(a, b2);      // lower: a = even tile classes 0-3, b2 = its classes 4-7; upper: the odd tile's
@@ -341,9 +346,6 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
                     uint8_t lab = 0;
                     if constexpr (KIND == SD_OUT_LABELS_U8) {
                         // distinct ids: per class (list position + 1) << 16 | cut; the passing class latest in the list wins
-                        typedef __attribute__((ext_vector_type(4))) unsigned u4;
-                        const u4 cut0 = reinterpret_cast<const u4*>(cst + 104)[0], cut1 = reinterpret_cast<const u4*>(cst + 104)[1];
-                        const u4 key0 = reinterpret_cast<const u4*>(cst + 112)[0], key1 = reinterpret_cast<const u4*>(cst + 112)[1];
                         unsigned best = 0u;
 #pragma unroll
                         for (int c = 0; c < 8; ++c) {
