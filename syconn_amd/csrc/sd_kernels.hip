@@ -133,12 +133,29 @@ template <int KZ, int WAVES, int MT> struct ConvGeo {      // MT = voxel tiles (
 // LDS as round_T(relu(x*scale + shift)) right after its own vmcnt wait and before the stage barrier (same arithmetic and
 // rounding point as k_gn_apply, so results are bit-identical to the separate apply pass), with the per-(tile, channel)
 // scale / shift of all tiles of the launch resident in LDS.  The normalised tensor is never written or re-read.
+// halo DMA instructions with index < a_instr among pieces j0 ... j1-1 of wave w (piece j of wave w = instruction w + j * waves)
+constexpr int dma_count(int w, int waves, int a_instr, int j0, int j1) {
+    int n = 0;
+    for (int j = j0; j < j1; ++j) n += (w + j * waves < a_instr) ? 1 : 0;
+    return n;
+}
 template <typename T, int KZ, int NT, int WAVES, int NSLOT, int MT, int MODE>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(const ConvParams p) {
     constexpr bool FF = MODE == 1, GN = MODE == 2;
     // register diet for the forms with >= 96 accumulator registers: nothing that can be recomputed per chunk stays live
     // across the block loop (DMA source addresses, halo-piece decode table)
     constexpr bool LEAN = MT == 4 || NT == 3;
+    // SPREAD (asymmetric halo DMA): cycle stamps show that the two waves of a SIMD do not interleave their tap loops -- one
+    // runs its 72 MFMAs at full rate (2.4 k cycles) while the other waits, then they swap -- and that the halo burst of a
+    // kz = 0 stage (8 gathers per wave, ~3 k cycles with both waves of the SIMD issuing at the same time) delays BOTH of
+    // them.  So the burst is moved into the time a wave would wait anyway: waves 4-7 issue theirs BEFORE their tap loop
+    // (their SIMD partners 0-3 run MFMAs meanwhile), waves 0-3 AFTER their tap loop (their partners compute then).  Piece
+    // addresses advance by additions (no divisions) and use 24-bit multiplies.
+#ifdef SD_NO_SPREAD
+    constexpr bool SPREAD = false;
+#else
+    constexpr bool SPREAD = MT == 4 && NSLOT == 0 && MODE == 0;
+#endif
     using v8 = typename Act<T>::v8;
     using G = ConvGeo<KZ, WAVES, MT>;
     constexpr bool WRES = NSLOT > 0;
@@ -297,6 +314,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         if constexpr (LEAN) {
             // keep the per-piece source addresses from being hoisted out of the block loop (up to 8 x 64-bit per wave): with
             // 96-128 accumulator registers there is no room for them; recomputing costs a few VALU ops per chunk
+            z0 = __builtin_amdgcn_readfirstlane(z0); y0 = __builtin_amdgcn_readfirstlane(y0); x0 = __builtin_amdgcn_readfirstlane(x0);
             asm volatile("" : "+s"(z0), "+s"(y0), "+s"(x0));
         }
         const char* sbase;
@@ -441,6 +459,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     }
 
     int gc = 0, gs = 0;   // chunk / stage counters across blocks (slot parity)
+    int ph0 = 0;          // SPREAD: halo coordinates of this lane's first piece, packed z << 16 | y << 8 | x
+    if constexpr (SPREAD) {
+        const int hv0 = (wave * 64 + lane) >> 1;
+        ph0 = ((hv0 / (HX * HY)) << 16) | (((hv0 / HX) % HY) << 8) | (hv0 % HX);
+        static_assert(!SPREAD || (HX < 256 && HY < 256), "packed piece coordinates");
+    }
     for (int round = 0; lb >= 0; ++round) {
         const int nlb = block_of(round + 1);
         int nz0 = 0, ny0 = 0, nx0 = 0, ntn = 0;
@@ -512,6 +536,82 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         int s = 0;
         for (int c = 0; c < nchunks; ++c, ++gc) {
             const char* const abuf = ldsA + (gc % NA) * A_BYTES;
+            // SPREAD: the chunk fetched during this chunk's stages (the next chunk of this block, or the first chunk of the
+            // workgroup's next block); everything a piece needs is pinned in scalar registers here -- a kernel-argument
+            // s_load inside the tap loop would count on lgkmcnt and break the counted LDS waits
+            bool pf_real = false;
+            const char* pf_sbase = nullptr;
+            const char* pf_zero = reinterpret_cast<const char*>(p.zero);
+            char* pf_dst = nullptr;
+            int pf_Hs = 0, pf_Ws = 0, pf_z = 0, pf_y = 0, pf_x = 0, pf_D = p.D, pf_H = p.H, pf_W = p.W;
+            if constexpr (SPREAD) {
+                int pc = c + 1, pt = tn;
+                pf_real = true; pf_z = z0; pf_y = y0; pf_x = x0;
+                if (pc == nchunks) { pc = 0; pt = ntn; pf_z = nz0; pf_y = ny0; pf_x = nx0; pf_real = nlb >= 0; }
+                size_t Ps;
+                if (pc < p.nchunk0) { pf_sbase = (const char*)p.src0; Ps = p.P0; pf_Hs = p.H0; pf_Ws = p.W0; }
+                else { pf_sbase = (const char*)p.src1; Ps = p.P1; pf_Hs = p.H1; pf_Ws = p.W1; pc -= p.nchunk0; }
+                pf_sbase += (size_t)pc * Ps * (SD_CHUNK * sizeof(T)) + (size_t)pt * p.tstride;
+                pf_z -= PZ; pf_y -= 1; pf_x -= 1;
+                pf_dst = ldsA + ((gc + 1) & 1) * A_BYTES + wave * 1024;
+                // (uniform by construction; readfirstlane makes that explicit for values that went through VALU divisions)
+                auto rfl = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+                {
+                    const uint64_t a = reinterpret_cast<uint64_t>(pf_sbase);
+                    pf_sbase = reinterpret_cast<const char*>(((uint64_t)(unsigned)rfl((int)(a >> 32)) << 32) | (unsigned)rfl((int)a));
+                }
+                pf_Hs = rfl(pf_Hs); pf_Ws = rfl(pf_Ws); pf_z = rfl(pf_z); pf_y = rfl(pf_y); pf_x = rfl(pf_x);
+                asm volatile("" : "+s"(pf_sbase), "+s"(pf_zero), "+s"(pf_Hs), "+s"(pf_Ws), "+s"(pf_z), "+s"(pf_y), "+s"(pf_x),
+                             "+s"(pf_D), "+s"(pf_H), "+s"(pf_W));
+            }
+            // halo coordinates of this lane's NEXT piece, advanced piece by piece (one piece = WAVES * 32 halo voxels further):
+            // additions and two carries instead of the divisions of hpack_of (quarter-rate multiplies)
+            constexpr int SV = WAVES * 32, SDZ = SV / (HY * HX), SDY = (SV % (HY * HX)) / HX, SDX = SV % HX;
+            static_assert(SDY + 1 <= HY && SDX < HX, "piece stride");
+            int ph_x = ph0 & 255, ph_y = (ph0 >> 8) & 255, ph_z = ph0 >> 16;     // piece 0 (decoded once per kernel)
+            auto dma_piece = [&](int j) {                      // j-th halo piece of this wave (wave-uniform j, increasing)
+                const int k = wave + j * WAVES;
+                if (pf_real && j < AJ && k < A_INSTR) {
+                    const int idx = k * 64 + lane;
+                    const int z = pf_z + ph_z, y = pf_y + ph_y, x = pf_x + ph_x;
+                    const bool ok = idx < NH * 2 && (unsigned)z < (unsigned)pf_D && (unsigned)y < (unsigned)pf_H &&
+                                    (unsigned)x < (unsigned)pf_W;
+                    // 24-bit multiplies (full rate): z * H + y < 2^24 is checked on the host for this form
+                    const unsigned vox = __umul24(__umul24((unsigned)z, (unsigned)pf_Hs) + (unsigned)y, (unsigned)pf_Ws) + (unsigned)x;
+                    const unsigned hf = ((unsigned)(lane ^ ph_y) & 1u) << 4;
+                    const uint64_t off = ((uint64_t)(vox >> 27) << 32) | ((vox << 5) | hf);
+                    const char* src = pf_zero;
+                    if (ok) src = pf_sbase + off;
+#if !defined(SD_PIECE_MODE) || SD_PIECE_MODE == 0
+                    glds16(src, pf_dst + j * (WAVES * 1024));
+#elif SD_PIECE_MODE == 1      // (probe) address arithmetic only
+                    asm volatile("" :: "v"(src));
+#elif SD_PIECE_MODE == 2      // (probe) trivial source, dummy destination
+                    glds16(pf_zero, ldsDummy);
+#elif SD_PIECE_MODE == 3      // (probe) real source, dummy destination
+                    glds16(src, ldsDummy);
+#elif SD_PIECE_MODE == 4      // (probe) trivial source, real destination
+                    glds16(pf_zero, pf_dst + j * (WAVES * 1024));
+#endif
+                }
+                ph_x += SDX;
+                if (ph_x >= HX) { ph_x -= HX; ++ph_y; }
+                ph_y += SDY;
+                if (ph_y >= HY) { ph_y -= HY; ++ph_z; }
+                ph_z += SDZ;
+            };
+            // Schedule of a wave's AJ pieces over the three stages of a chunk.  Waves WAVES/2 ... WAVES-1 ("early") issue EB pieces
+            // BEFORE their tap loop in every stage; waves 0 ... WAVES/2-1 ("late") issue LB pieces AFTER their tap loop in the
+            // kz = 0 / 1 stages (what is issued at the end of the kz = 2 stage would be awaited at once).  *_MIN: pieces the
+            // highest wave of the group really issues in that stage (those with an instruction index < A_INSTR) -- the counted
+            // stage-end wait may leave exactly that many in flight: they are younger than the weight group.
+            constexpr int EB = (AJ + 2) / 3, LB = (AJ + 1) / 2;
+            constexpr int E0 = dma_count(WAVES - 1, WAVES, A_INSTR, 0, EB), E1 = dma_count(WAVES - 1, WAVES, A_INSTR, EB, 2 * EB);
+            constexpr int L0 = dma_count(WAVES / 2 - 1, WAVES, A_INSTR, 0, LB), L1 = dma_count(WAVES / 2 - 1, WAVES, A_INSTR, LB, 2 * LB);
+            static_assert(!SPREAD || (3 * EB >= AJ && 2 * LB >= AJ), "halo piece schedule");
+            auto halo_pieces = [&](int j0, int n) {
+                for (int j = j0; j < j0 + n; ++j) dma_piece(j);
+            };
 #pragma unroll 1
             for (int kz = 0; kz < KZ; ++kz, ++s, ++gs) {
                 if (s == SD_TS) SD_T(7);     // start of the probed stage
@@ -521,7 +621,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                     // last stage and the epilogue of this one
                     if (s + 1 < nstages) dma_weights(s + 1, (gs + 1) & 1);
                     else if (nlb >= 0) dma_weights(0, (gs + 1) & 1);
-                    if (kz == 0) {
+                    if constexpr (SPREAD) {
+                        if (wave >= WAVES / 2) halo_pieces(kz * EB, EB);
+                    }
+                    if (!SPREAD && kz == 0) {
                         if (c + 1 < nchunks) {
                             dma_halo(c + 1, (gc + 1) & 1, z0, y0, x0, tn, true);
                             gn_note(c + 1, (gc + 1) & 1, z0, y0, x0, tn, true);
@@ -626,6 +729,23 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     gn_transform();
                     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                } else if constexpr (SPREAD) {
+                    const bool late = wave < WAVES / 2;
+                    if (late && kz < 2) halo_pieces(kz * LB, LB);
+                    // the weight group of the next stage was issued BEFORE this stage's pieces (vmcnt completes in order)
+                    const int fly = !pf_real || kz == 2 ? 0 : late ? (kz == 0 ? L0 : L1) : (kz == 0 ? E0 : E1);
+                    if (fly == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    else if (fly == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    else if (fly == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    else if (late && s + 1 == nstages && !p.gn_sums) {
+                        // ASYMMETRIC EPILOGUE: waves 0 ... WAVES/2-1 ran their tap loop first; instead of waiting at the barrier
+                        // for their SIMD partners they convert and store their output tiles NOW, under the partners' MFMAs,
+                        // and meet the barrier after the epilogue (below).  Waves WAVES/2 ... run their epilogue after the
+                        // barrier, under the first-stage MFMAs of the others' next block.  No vmcnt wait sits between the
+                        // stores and the barrier: everything this wave has DMA'd is awaited here, before the stores.
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    }
+                    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 } else {
                     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WAITN) : "memory");
                 }
@@ -650,6 +770,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         const bool vyx = vy < p.H && vx < p.W;
         const size_t vo0 = (size_t)(vz0 * p.H + vy) * p.W + vx, vzs = (size_t)p.H * p.W;
         float* const part = reinterpret_cast<float*>(ldsA + ((gc - 1) % NA) * A_BYTES);   // free: last chunk's halo slot
+        const unsigned relu_floor = p.relu ? 0u : 0x80008000u;
         v8 s1, s2;
         if (p.gn_sums) {
 #pragma unroll
@@ -670,10 +791,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                 for (int e2 = 0; e2 < 2; ++e2) {
                     val2[e2] = vyx && (vz0 + ip + e2) < p.D;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        pk2[e2][k] = Act<T>::pack2(acc[ip + e2][j][2 * k], acc[ip + e2][j][2 * k + 1]);
-                        if (p.relu) pk2[e2][k] = pk_max16(pk2[e2][k], 0u);
-                    }
+                    for (int k = 0; k < 8; ++k)      // ReLU = packed max against 0; without it against the most negative pair (identity)
+                        pk2[e2][k] = pk_max16(Act<T>::pack2(acc[ip + e2][j][2 * k], acc[ip + e2][j][2 * k + 1]), relu_floor);
                     if (p.gn_sums) {
                         u4 lo = {pk2[e2][0], pk2[e2][1], pk2[e2][2], pk2[e2][3]};
                         u4 hi = {pk2[e2][4], pk2[e2][5], pk2[e2][6], pk2[e2][7]};
@@ -922,6 +1041,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     }
 
     }
+        if constexpr (SPREAD) {
+            if (wave < WAVES / 2 && !p.gn_sums) asm volatile("s_barrier" ::: "memory");     // (asymmetric epilogue, see the stage loop)
+        }
         SD_T(6);   // epilogue done
 #ifdef SD_TIMING
         if (tcount == SD_TB && lane == 0 && p.dbg) {
@@ -1769,7 +1891,9 @@ static int launch_conv_knt(const ConvParams& p, int NB, hipStream_t s) {
             // stage barriers and block boundaries per MFMA (32->64 channels 52.6 -> 48.7 us per tile, 64->64 88 -> 85 us,
             // 128->64 164 -> 162 us).  Taller blocks waste more on a ragged z extent, hence the rule on D.
             const bool mt2 = getenv("SD_MT2") != nullptr;      // A/B switch (read per launch): the 4x8x16 / 2-tile form everywhere
-            if (!mt2 && !p.final_wfrag && (vox / 1024) * NB >= 256 && (p.D % 8 == 0 || p.D >= 96))
+            // (its halo DMA addresses use 24-bit multiplies: plane-row index z * H + y and W below 2^24)
+            const bool mul24_ok = (long)(p.D + 2) * (std::max(p.H0, p.H1) + 2) < (1l << 24) && std::max(p.W0, p.W1) < (1 << 24);
+            if (!mt2 && mul24_ok && !p.final_wfrag && (vox / 1024) * NB >= 256 && (p.D % 8 == 0 || p.D >= 96))
                 return launch_conv_k<T, KZ, NT, 8, 0, 4>(p, NB, s);
         }
         return launch_conv_k<T, KZ, NT, 8, 0>(p, NB, s);
