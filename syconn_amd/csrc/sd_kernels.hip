@@ -151,15 +151,29 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     // them.  So the burst is moved into the time a wave would wait anyway: waves 4-7 issue theirs BEFORE their tap loop
     // (their SIMD partners 0-3 run MFMAs meanwhile), waves 0-3 AFTER their tap loop (their partners compute then).  Piece
     // addresses advance by additions (no divisions) and use 24-bit multiplies.
+#ifndef SD_LATE_W
+#define SD_LATE_W 1
+#endif
 #ifdef SD_NO_SPREAD
     constexpr bool SPREAD = false;
 #else
-    constexpr bool SPREAD = MT == 4 && NSLOT == 0 && MODE == 0;
+    // (only the 4-tile form: with 2 voxel tiles per wave one wave cannot saturate the matrix pipe from its one-tap-ahead LDS
+    // prefetch, the two waves of a SIMD really interleave, and the same schedule measured 2.4 % SLOWER on the 48-filter family)
+    constexpr bool SPREAD = MT == 4 && KZ == 3 && WAVES == 8 && NSLOT == 0 && MODE == 0;
 #endif
     using v8 = typename Act<T>::v8;
     using G = ConvGeo<KZ, WAVES, MT>;
     constexpr bool WRES = NSLOT > 0;
-    constexpr int NA = WRES ? NSLOT : 2;                  // halo slots
+    // RING (NSLOT < 0, planar layers with streamed weights): halo chunks AND weight groups go through rings of -NSLOT slots,
+    // two stages ahead of the MFMAs.  A stage of these layers is short (36 MFMAs per wave) and its DMA group (3 halo gathers
+    // + 3 weight pieces per wave, ~1.9 k cycles of the CU's address path with all 8 waves issuing at once) sat in front of
+    // every tap loop.  Two stages of slack allow the asymmetric placement of the 3x3x3 form: waves 4-7 issue their group
+    // before their tap loop, waves 0-3 after theirs, each under the MFMAs of its SIMD partner; the counted stage-end wait
+    // leaves exactly the group just issued in flight.
+    constexpr bool RING = NSLOT < 0;
+    static_assert(!RING || (KZ == 1 && MODE == 0 && MT == 2 && NSLOT == -3), "ring form: planar, plain, 2 voxel tiles per wave");
+    constexpr int NA = WRES ? NSLOT : RING ? -NSLOT : 2;   // halo slots
+    constexpr int NW = RING ? -NSLOT : 2;                  // weight slots (streamed weights)
     constexpr int BZ = G::BZ, BY = G::BY, BX = G::BX;
     constexpr int PZ = KZ / 2;
     constexpr int HZ = BZ + KZ - 1, HY = BY + 2, HX = BX + 2;
@@ -170,7 +184,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     constexpr int B_BYTES = B_INSTR * 1024;
     constexpr int SLICE = HY * HX * 32;
     constexpr int AJ = (A_INSTR + WAVES - 1) / WAVES;    // halo DMA instructions per wave per chunk
-    constexpr int WAITN = WRES ? (NA - 2) * AJ : 0;      // DMA instructions allowed in flight at a stage end
+    constexpr int WJ = (B_INSTR + WAVES - 1) / WAVES;    // weight DMA instructions per wave and stage
+    // DMA instructions allowed in flight at a stage end (RING: the group of AJ + WJ just issued)
+    constexpr int WAITN = WRES ? (NA - 2) * AJ : RING ? AJ + WJ : 0;
     static_assert(WAITN < 64, "vmcnt immediate");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nchunks = p.nchunk0 + p.nchunk1;
@@ -180,7 +196,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     // per-workgroup constants kept in LDS instead of registers (they would be live across the whole stage loop):
     // the folded bias of the NT*32 output channels (+ 8 class biases) and, with a fused final layer, its weight
     // fragments (NT*4 KiB, one 16-byte entry per lane and k-step)
-    float* const wl = reinterpret_cast<float*>(ldsB + (WRES ? nstages : 2) * B_BYTES);
+    float* const wl = reinterpret_cast<float*>(ldsB + (WRES ? nstages : NW) * B_BYTES);
     char* const fwl = reinterpret_cast<char*>(wl) + SD_CONV_PARAM_BYTES;
     char* const ldsDummy = fwl + (p.final_wfrag ? NT * 4096 : 0);
     float* const fpatch = reinterpret_cast<float*>(ldsDummy + 1024);      // FF: normalised input patch (HY+2) x (HX+2)
@@ -386,6 +402,23 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         if (++sf_slot == NA) sf_slot = 0;
     };
 
+    // RING: weight group and halo chunk of the next stream position (= two stages ahead) into its ring slot; every wave
+    // issues exactly WJ + AJ instructions (padding ones / positions behind the workgroup's last block go to the dummy slot)
+    auto ring_issue = [&]() {
+        if (sf_c == 0) stream_block();
+        const char* src = wbase + (size_t)sf_c * B_BYTES + lane * 16;
+        char* dst = ldsB + sf_slot * B_BYTES;
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            const int k = wave + j * WAVES;
+            const bool inst = sf_ok && k < B_INSTR;                    // wave-uniform
+            glds16(inst ? src + k * 1024 : reinterpret_cast<const char*>(p.zero), inst ? dst + k * 1024 : ldsDummy);
+        }
+        dma_halo(sf_c, sf_slot, sf_z, sf_y, sf_x, sf_t, sf_ok);
+        if (++sf_c == nchunks) { sf_c = 0; ++sf_round; }
+        if (++sf_slot == NA) sf_slot = 0;
+    };
+
 #ifdef SD_TIMING
     long long tstamp[8];
     long long sstamp[16];      // SD_STAGES: end of every stage of the probed block, [14] block start, [15] epilogue end
@@ -444,6 +477,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     if (WRES) {
         for (int s = 0; s < nstages; ++s) dma_weights(s, s);
         if (!FF) for (int f = 0; f < NA - 1; ++f) dma_stream_next();
+    } else if (RING) {
+        for (int f = 0; f < NA - 1; ++f) ring_issue();
     } else {
         dma_weights(0, 0);
         dma_halo(0, 0, z0, y0, x0, tn, true);
@@ -576,8 +611,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                     const int z = pf_z + ph_z, y = pf_y + ph_y, x = pf_x + ph_x;
                     const bool ok = idx < NH * 2 && (unsigned)z < (unsigned)pf_D && (unsigned)y < (unsigned)pf_H &&
                                     (unsigned)x < (unsigned)pf_W;
-                    // 24-bit multiplies (full rate): z * H + y < 2^24 is checked on the host for this form
-                    const unsigned vox = __umul24(__umul24((unsigned)z, (unsigned)pf_Hs) + (unsigned)y, (unsigned)pf_Ws) + (unsigned)x;
+                    const unsigned vox = ((unsigned)z * (unsigned)pf_Hs + (unsigned)y) * (unsigned)pf_Ws + (unsigned)x;   // < 2^32 voxels per tensor
                     const unsigned hf = ((unsigned)(lane ^ ph_y) & 1u) << 4;
                     const uint64_t off = ((uint64_t)(vox >> 27) << 32) | ((vox << 5) | hf);
                     const char* src = pf_zero;
@@ -615,12 +649,18 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
 #pragma unroll 1
             for (int kz = 0; kz < KZ; ++kz, ++s, ++gs) {
                 if (s == SD_TS) SD_T(7);     // start of the probed stage
-                if (!WRES) {
+                if constexpr (RING) {
+                    if (wave >= WAVES / 2) ring_issue();
+                } else if (!WRES) {
                     // next weight group / next halo chunk into the other buffer; at the end of a block these are
                     // the first group and chunk of the workgroup's NEXT block, so its prologue hides behind the
                     // last stage and the epilogue of this one
-                    if (s + 1 < nstages) dma_weights(s + 1, (gs + 1) & 1);
-                    else if (nlb >= 0) dma_weights(0, (gs + 1) & 1);
+                    // (SPREAD: the waves that run their tap loop first fetch their share of the weight group after it)
+                    // (not in the last stage of a block: those waves go on to their epilogue, which must not wait for a DMA)
+                    if (!(SPREAD && SD_LATE_W) || wave >= WAVES / 2 || s + 1 == nstages) {
+                        if (s + 1 < nstages) dma_weights(s + 1, (gs + 1) & 1);
+                        else if (nlb >= 0) dma_weights(0, (gs + 1) & 1);
+                    }
                     if constexpr (SPREAD) {
                         if (wave >= WAVES / 2) halo_pieces(kz * EB, EB);
                     }
@@ -637,7 +677,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                     dma_stream_next();           // chunk gc + NA - 1 of this workgroup's stream
                 }
                 if (s == SD_TS) SD_T(1);     // after the DMA issue of the probed stage
-                const char* const bcur = ldsB + (WRES ? s : (gs & 1)) * B_BYTES + lane * 16;
+                const char* const bcur = ldsB + (WRES ? s : RING ? gs % NW : (gs & 1)) * B_BYTES + lane * 16;
                 const char* const acur = abuf + kz * SLICE;
                 // software-pipelined over the 9 taps: the fragments of tap t+1 are in flight while tap t's MFMAs run.
                 // The LDS reads and their counted waits are inline asm: left to the compiler the reads are sunk next
@@ -729,14 +769,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     gn_transform();
                     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                } else if constexpr (RING) {
+                    if (wave < WAVES / 2) ring_issue();
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WAITN) : "memory");
                 } else if constexpr (SPREAD) {
                     const bool late = wave < WAVES / 2;
+                    if (SD_LATE_W && late && s + 1 < nstages) dma_weights(s + 1, (gs + 1) & 1);
                     if (late && kz < 2) halo_pieces(kz * LB, LB);
                     // the weight group of the next stage was issued BEFORE this stage's pieces (vmcnt completes in order)
                     const int fly = !pf_real || kz == 2 ? 0 : late ? (kz == 0 ? L0 : L1) : (kz == 0 ? E0 : E1);
+                    static_assert(!SPREAD || (E0 <= 4 && E1 <= 4 && L0 <= 4 && L1 <= 4), "counted waits below");
                     if (fly == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                     else if (fly == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                     else if (fly == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    else if (fly == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                     else if (late && s + 1 == nstages && !p.gn_sums) {
                         // ASYMMETRIC EPILOGUE: waves 0 ... WAVES/2-1 ran their tap loop first; instead of waiting at the barrier
                         // for their SIMD partners they convert and store their output tiles NOW, under the partners' MFMAs,
@@ -1794,7 +1840,7 @@ static size_t conv_lds_bytes(int nstages, bool fuse_final = false) {
     using G = ConvGeo<KZ, WAVES, MT>;
     constexpr int NH = (G::BZ + KZ - 1) * (G::BY + 2) * (G::BX + 2);
     constexpr int A_BYTES = (NH * 2 + 63) / 64 * 1024;
-    return (size_t)(NSLOT > 0 ? NSLOT : 2) * A_BYTES + (size_t)(NSLOT > 0 ? nstages : 2) * 9 * NT * 1024 +
+    return (size_t)(NSLOT > 0 ? NSLOT : NSLOT < 0 ? -NSLOT : 2) * A_BYTES + (size_t)(NSLOT > 0 ? nstages : NSLOT < 0 ? -NSLOT : 2) * 9 * NT * 1024 +
            SD_CONV_PARAM_BYTES + (fuse_final ? NT * 4096 : 0) + 1024;
 }
 
@@ -1891,10 +1937,17 @@ static int launch_conv_knt(const ConvParams& p, int NB, hipStream_t s) {
             // stage barriers and block boundaries per MFMA (32->64 channels 52.6 -> 48.7 us per tile, 64->64 88 -> 85 us,
             // 128->64 164 -> 162 us).  Taller blocks waste more on a ragged z extent, hence the rule on D.
             const bool mt2 = getenv("SD_MT2") != nullptr;      // A/B switch (read per launch): the 4x8x16 / 2-tile form everywhere
-            // (its halo DMA addresses use 24-bit multiplies: plane-row index z * H + y and W below 2^24)
-            const bool mul24_ok = (long)(p.D + 2) * (std::max(p.H0, p.H1) + 2) < (1l << 24) && std::max(p.W0, p.W1) < (1 << 24);
-            if (!mt2 && mul24_ok && !p.final_wfrag && (vox / 1024) * NB >= 256 && (p.D % 8 == 0 || p.D >= 96))
+            if (!mt2 && !p.final_wfrag && (vox / 1024) * NB >= 256 && (p.D % 8 == 0 || p.D >= 96))
                 return launch_conv_k<T, KZ, NT, 8, 0, 4>(p, NB, s);
+        }
+        if constexpr (KZ == 1 && NT == 3) {
+            // (measured: 48-filter family -6 % on these layers; the NT = 2 layers are LDS-bandwidth bound -- 1.0 fragment reads per
+            // MFMA -- and do not move)
+            // planar layers with streamed weights: 3-deep rings for halo chunks and weight groups, DMA groups issued under the
+            // SIMD partner's MFMAs (see RING in k_conv_mfma)
+            const bool no_ring = getenv("SD_NO_RING") != nullptr;       // A/B switch (read per launch)
+            if (!no_ring && nstages >= 3 && conv_lds_bytes<KZ, NT, 8, 2, -3>(nstages, p.final_wfrag != nullptr) <= (size_t)SD_LDS_BYTES)
+                return launch_conv_k<T, KZ, NT, 8, -3>(p, NB, s);
         }
         return launch_conv_k<T, KZ, NT, 8, 0>(p, NB, s);
     }

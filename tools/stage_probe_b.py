@@ -39,3 +39,9 @@ for g, sl in (('A', slice(0, waves // 2)), ('B', slice(waves // 2, waves))):
     rel = (raw[:, sl, :] - t0[:, :, None]).astype(np.float64)
     line = ' '.join(f'{np.median(rel[:, :, k]):7.0f}' for k in [14] + list(range(min(nst, 14))) + [15])
     print(f'group {g}: start, stage ends..., epilogue end: {line}')
+
+# phases of the probed stage (SD_TS) per group, relative to the stage start of the earliest wave of the workgroup
+t7 = t8[:, :, 7].min(axis=1, keepdims=True)
+for g, sl in (('A', slice(0, waves // 2)), ('B', slice(waves // 2, waves))):
+    rel = (t8[:, sl, :] - t7[:, :, None]).astype(np.float64)
+    print(f'group {g}: stage start {np.median(rel[:, :, 7]):6.0f}  dma issued {np.median(rel[:, :, 1]):6.0f}  mfma done {np.median(rel[:, :, 2]):6.0f}  barrier passed {np.median(rel[:, :, 3]):6.0f}')
