@@ -19,9 +19,13 @@
 
 
 // Store the 32 channels x 32 voxels of one accumulator tile whose values are already packed as 4 x (4 channels):
-// o[q] = channels cbase + 4*(lane>>5) + 8q + 0..3 of voxel (lane&31).  The lane pair (l, l^32) first trades
-// quads so that each lane owns 16 CONSECUTIVE channels (32 contiguous bytes) -> two 16-byte stores per lane
-// instead of four 8-byte ones.  Must be called by all 64 lanes (stores are predicated, swaps are not).
+// o[q] = channels cbase + 4*(lane>>5) + 8q + 0..3 of voxel (lane&31).  The lane pair (l, l^32) first trades quads
+// (0 <-> 1 and 2 <-> 3) so that the LOWER lane owns channels 0-7 and 16-23 and the UPPER lane channels 8-15 and 24-31 of
+// their voxel: the first store then writes the complete 32-byte records of 16-channel chunk cbase/16 -- lower lanes the
+// first 16 bytes, upper lanes the second -- i.e. two fully covered 512-byte row runs per instruction, the second store
+// the same for the next chunk.  (Before: each lane owned one whole 32-byte record and wrote it as two 16-byte pieces, so
+// every store instruction half-filled 64 sectors; the epilogue of a block is bound by the CU's address path.)
+// Must be called by all 64 lanes (stores are predicated, swaps are not).
 template <typename T>
 __device__ __forceinline__ void store_tile_rows(typename Act<T>::v4 (&o)[4], T* base, size_t P, size_t vidx, bool valid,
                                                 int cbase, int half, int Cd) {
@@ -30,15 +34,14 @@ __device__ __forceinline__ void store_tile_rows(typename Act<T>::v4 (&o)[4], T* 
     u2 a0 = __builtin_bit_cast(u2, o[0]), a1 = __builtin_bit_cast(u2, o[1]);
     u2 a2 = __builtin_bit_cast(u2, o[2]), a3 = __builtin_bit_cast(u2, o[3]);
     unsigned x;
-    x = a0.x; { unsigned y = a2.x; swap32(x, y); a0.x = x; a2.x = y; }
-    x = a0.y; { unsigned y = a2.y; swap32(x, y); a0.y = x; a2.y = y; }
-    x = a1.x; { unsigned y = a3.x; swap32(x, y); a1.x = x; a3.x = y; }
-    x = a1.y; { unsigned y = a3.y; swap32(x, y); a1.y = x; a3.y = y; }
-    const int n0 = cbase + half * 16;          // this lane now owns the whole 16-channel chunk n0/16 of its voxel
-    if (valid && n0 < Cd) {
-        T* const q = base + ((size_t)(n0 >> 4) * P + vidx) * SD_CHUNK;
-        { u4 v = {a0.x, a0.y, a2.x, a2.y}; *reinterpret_cast<u4*>(q) = v; }
-        { u4 v = {a1.x, a1.y, a3.x, a3.y}; *reinterpret_cast<u4*>(q + 8) = v; }
+    x = a0.x; { unsigned y = a1.x; swap32(x, y); a0.x = x; a1.x = y; }
+    x = a0.y; { unsigned y = a1.y; swap32(x, y); a0.y = x; a1.y = y; }
+    x = a2.x; { unsigned y = a3.x; swap32(x, y); a2.x = x; a3.x = y; }
+    x = a2.y; { unsigned y = a3.y; swap32(x, y); a2.y = x; a3.y = y; }
+    if (valid) {
+        T* const q = base + ((size_t)(cbase >> 4) * P + vidx) * SD_CHUNK + half * 8;
+        if (cbase < Cd) { u4 v = {a0.x, a0.y, a1.x, a1.y}; *reinterpret_cast<u4*>(q) = v; }
+        if (cbase + 16 < Cd) { u4 v = {a2.x, a2.y, a3.x, a3.y}; *reinterpret_cast<u4*>(q + P * SD_CHUNK) = v; }
     }
 }
 
@@ -48,12 +51,11 @@ __device__ __forceinline__ void store_tile_rows_pk(const unsigned (&pk)[8], T* b
                                                    int cbase, int half, int Cd) {
     typedef __attribute__((ext_vector_type(4))) unsigned u4;
     unsigned a0x = pk[0], a0y = pk[1], a1x = pk[2], a1y = pk[3], a2x = pk[4], a2y = pk[5], a3x = pk[6], a3y = pk[7];
-    swap32x4(a0x, a2x, a0y, a2y, a1x, a3x, a1y, a3y);
-    const int n0 = cbase + half * 16;
-    if (valid && n0 < Cd) {
-        T* const q = base + ((size_t)(n0 >> 4) * P + vidx) * SD_CHUNK;
-        { u4 v = {a0x, a0y, a2x, a2y}; *reinterpret_cast<u4*>(q) = v; }
-        { u4 v = {a1x, a1y, a3x, a3y}; *reinterpret_cast<u4*>(q + 8) = v; }
+    swap32x4(a0x, a1x, a0y, a1y, a2x, a3x, a2y, a3y);
+    if (valid) {
+        T* const q = base + ((size_t)(cbase >> 4) * P + vidx) * SD_CHUNK + half * 8;
+        if (cbase < Cd) { u4 v = {a0x, a0y, a1x, a1y}; *reinterpret_cast<u4*>(q) = v; }
+        if (cbase + 16 < Cd) { u4 v = {a2x, a2y, a3x, a3y}; *reinterpret_cast<u4*>(q + P * SD_CHUNK) = v; }
     }
 }
 
