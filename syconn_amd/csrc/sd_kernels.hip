@@ -785,12 +785,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                     else if (fly == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                     else if (fly == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                     else if (fly == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                    else if (late && s + 1 == nstages && !p.gn_sums) {
-                        // ASYMMETRIC EPILOGUE: waves 0 ... WAVES/2-1 ran their tap loop first; instead of waiting at the barrier
-                        // for their SIMD partners they convert and store their output tiles NOW, under the partners' MFMAs,
-                        // and meet the barrier after the epilogue (below).  Waves WAVES/2 ... run their epilogue after the
-                        // barrier, under the first-stage MFMAs of the others' next block.  No vmcnt wait sits between the
-                        // stores and the barrier: everything this wave has DMA'd is awaited here, before the stores.
+                    else if (s + 1 == nstages && !p.gn_sums) {
+                        // ASYMMETRIC EPILOGUE: the barrier that ends the last stage is taken INSIDE the epilogue.  Waves 0 ...
+                        // WAVES/2-1 ran their tap loop first: instead of waiting for their SIMD partners they convert and store
+                        // ALL their output tiles now, under the partners' MFMAs, and meet the barrier behind their epilogue.
+                        // Waves WAVES/2 ... finish their tap loop later, store their FIRST channel group while the others are
+                        // still in their epilogue, meet the barrier, and store the rest under the first-stage MFMAs of the
+                        // others' next block.  No vmcnt wait sits between the stores and the barrier: everything this wave
+                        // has DMA'd is awaited here, before the stores.
                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     }
                     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -871,6 +873,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
             if (p.gn_sums) {
                 float* const q = part + ((size_t)(wave * 2 + half) * (NT * 32) + j * 32 + (lane & 31)) * 2;
                 q[0] = sj; q[1] = ssj;
+            }
+            if constexpr (SPREAD) {      // (asymmetric epilogue, see the stage loop)
+                if (j == 0 && wave >= WAVES / 2 && !p.gn_sums) asm volatile("s_barrier" ::: "memory");
             }
         }
         if (p.gn_sums) {
