@@ -226,6 +226,27 @@ def test_full_architectures_many_workgroups(gpu, arch, shape):
 
 
 @pytest.mark.gpu
+def test_ring_form_is_bit_identical(gpu, monkeypatch):
+    """Planar layers of the 48-filter family with streamed weights run through 3-deep halo / weight rings (RING in k_conv_mfma,
+    DMA groups issued under the SIMD partner's MFMAs) where the grid is large enough; same per-output summation order as the
+    double-buffered form (SD_NO_RING) -> bit-identical logits, for even and ragged extents and for batches."""
+    from syconn_amd import _lib as L
+    from syconn_amd.cnn import random_state_dict
+    from syconn_amd.engine import DenseModel
+    shapes = ((2, 96, 160, 160), (3, 64, 150, 170))
+    sd = random_state_dict('semseg_axon', seed=12, final_scale=6.0)
+    monkeypatch.setenv('SD_NO_RING', '1')
+    plain = DenseModel(sd, act_dtype='bf16', device=gpu)
+    a = [plain.forward_batch(_input(sh, 5).to(gpu), L.SD_OUT_LOGITS_F32).clone() for sh in shapes]
+    monkeypatch.delenv('SD_NO_RING')                    # (the switch is read at every launch)
+    ring = DenseModel(sd, act_dtype='bf16', device=gpu)
+    for sh, ref in zip(shapes, a):
+        b = ring.forward_batch(_input(sh, 5).to(gpu), L.SD_OUT_LOGITS_F32, slot=1)
+        assert torch.isfinite(b).all()
+        assert torch.equal(ref, b), sh
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('arch,shape', [('semseg_spine', (24, 40, 48)), ('mivcsj', (16, 32, 48)), ('syntype', (13, 27, 29))])
 def test_forward_batch_equals_single_forwards(gpu, arch, shape):
     """sd_forward_batch (N tiles, one set of launches) is bit-identical to N sd_forward calls."""
