@@ -59,6 +59,19 @@ __device__ __forceinline__ void store_tile_rows_pk(const unsigned (&pk)[8], T* b
     }
 }
 
+// Same with the address arithmetic hoisted by the caller: q = this lane's 16-byte half of its voxel's record in the first
+// chunk, cstride = elements between the chunk planes, c0 / c1 = chunk exists (wave-uniform).
+template <typename T>
+__device__ __forceinline__ void store_tile_rows_pk_at(const unsigned (&pk)[8], T* q, size_t cstride, bool valid, bool c0, bool c1) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u4;
+    unsigned a0x = pk[0], a0y = pk[1], a1x = pk[2], a1y = pk[3], a2x = pk[4], a2y = pk[5], a3x = pk[6], a3y = pk[7];
+    swap32x4(a0x, a1x, a0y, a1y, a2x, a3x, a2y, a3y);
+    if (valid) {
+        if (c0) { u4 v = {a0x, a0y, a1x, a1y}; *reinterpret_cast<u4*>(q) = v; }
+        if (c1) { u4 v = {a2x, a2y, a3x, a3y}; *reinterpret_cast<u4*>(q + cstride) = v; }
+    }
+}
+
 // + bias, ReLU, round to the storage type and store one accumulator tile (lane owns voxel column lane&31 and
 // channel rows (r&3) + 8*(r>>2) + 4*(lane>>5)).
 template <typename T>
@@ -833,6 +846,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             float sj = 0.f, ssj = 0.f;
+            // this lane's half record of its voxel in z-plane vz0, first chunk of channel group j (tile z-planes and the
+            // second chunk are wave-uniform offsets from it)
+            T* const qj = dst4 + ((size_t)((nb * NT + j) * 2) * p.Pd + vo0) * SD_CHUNK + half * 8;
+            const size_t cstr = p.Pd * SD_CHUNK;
+            const bool cj0 = (nb * NT + j) * 32 < p.Cd, cj1 = (nb * NT + j) * 32 + 16 < p.Cd;
 #pragma unroll
             for (int ip = 0; ip < 4; ip += 2) {
                 unsigned pk2[2][8];
@@ -846,7 +864,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                     if (p.gn_sums) {
                         u4 lo = {pk2[e2][0], pk2[e2][1], pk2[e2][2], pk2[e2][3]};
                         u4 hi = {pk2[e2][4], pk2[e2][5], pk2[e2][6], pk2[e2][7]};
-                        if (!val2[e2]) { lo = u4{0u, 0u, 0u, 0u}; hi = lo; }
+                        unsigned zr = 0u;
+                        asm volatile("" : "+v"(zr));      // (keeps the eight selects inside this branch: BatchNorm nets never take it)
+                        if (!val2[e2]) { lo = u4{zr, zr, zr, zr}; hi = lo; }
                         f32x16 d;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) d[r] = 0.f;
@@ -856,7 +876,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                         for (int r = 0; r < 16; ++r) { sj += d[r]; ssj = fmaf(d[r], d[r], ssj); }
                     }
                     if (p.store_main)
-                        store_tile_rows_pk<T>(pk2[e2], dst4, p.Pd, vo0 + (size_t)(ip + e2) * vzs, val2[e2], (nb * NT + j) * 32, half, p.Cd);
+                        store_tile_rows_pk_at<T>(pk2[e2], qj + (size_t)(ip + e2) * (vzs * SD_CHUNK), cstr, val2[e2], cj0, cj1);
                 }
                 if (p.pool_dst) {
                     T* const pdst = reinterpret_cast<T*>(reinterpret_cast<char*>(p.pool_dst) + (size_t)tn * p.tstride);
