@@ -631,17 +631,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                     const uint64_t off = ((uint64_t)(vox >> 27) << 32) | ((vox << 5) | hf);
                     const char* src = pf_zero;
                     if (ok) src = pf_sbase + off;
-#if !defined(SD_PIECE_MODE) || SD_PIECE_MODE == 0
                     glds16(src, pf_dst + j * (WAVES * 1024));
-#elif SD_PIECE_MODE == 1      // (probe) address arithmetic only
-                    asm volatile("" :: "v"(src));
-#elif SD_PIECE_MODE == 2      // (probe) trivial source, dummy destination
-                    glds16(pf_zero, ldsDummy);
-#elif SD_PIECE_MODE == 3      // (probe) real source, dummy destination
-                    glds16(src, ldsDummy);
-#elif SD_PIECE_MODE == 4      // (probe) trivial source, real destination
-                    glds16(pf_zero, pf_dst + j * (WAVES * 1024));
-#endif
                 }
                 ph_x += SDX;
                 if (ph_x >= HX) { ph_x -= HX; ++ph_y; }
