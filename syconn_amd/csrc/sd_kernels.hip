@@ -1409,16 +1409,26 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
         // contiguous bytes (two x-taps x 16 channels) and consecutive input voxels of a row follow each other, so
         // the pieces are walked chunk-major: consecutive lanes = (voxel, tap, half) of ONE chunk = contiguous memory
         const int a = (p.kz == 2) ? (ab >> 1) : 0, b = ab & 1;
+        // a lane handles only TWO input voxels in this loop (v = lane / 4 in even iterations, 16 + lane / 4 in odd ones):
+        // their output positions are decoded once (32-bit divisions) instead of three 64-bit divisions per piece
+        size_t ovv[2];
+        bool okv[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const long mm = m0 + (lane >> 2) + 16 * e;
+            okv[e] = mm < M;
+            const unsigned mu = (unsigned)(okv[e] ? mm : 0), xy = mu % (unsigned)(p.W * p.H), z = mu / (unsigned)(p.W * p.H);
+            const unsigned y = xy / (unsigned)p.W, x = xy - y * (unsigned)p.W;
+            ovv[e] = ((size_t)(z * p.kz + a) * H2 + (2 * y + b)) * W2 + 2 * x;
+        }
 #pragma unroll
         for (int it = 0; it < (32 * PPV) / 64; ++it) {
             const int u = it * 64 + lane;
             const int chunk = u >> 7, r = u & 127;            // 128 pieces per chunk: 32 voxels x 2 taps x 2 halves
             const int v = r >> 2, tap = (r >> 1) & 1, hf = r & 1;
             const int piece = tap * (CD / 8) + chunk * 2 + hf;
-            const long mm = m0 + v;
-            if (mm < M) {
-                const int x = (int)(mm % p.W), y = (int)((mm / p.W) % p.H), z = (int)(mm / ((long)p.W * p.H));
-                const size_t ov = ((size_t)(z * p.kz + a) * H2 + (2 * y + b)) * W2 + 2 * x + tap;
+            if (okv[it & 1]) {
+                const size_t ov = ovv[it & 1] + tap;
                 const u4 val = *reinterpret_cast<const u4*>(tile + v * ROW + ((piece ^ (v & SWM)) * 16));
                 *reinterpret_cast<u4*>(dst + (((size_t)chunk * p.Pd + ov) * SD_CHUNK + hf * 8) * sizeof(T)) = val;
             }
@@ -2002,6 +2012,7 @@ int launch_first(const FirstParams& p, int act_dtype, int in_dtype, int KZ, hipS
 template <typename T, int NCH, int NTAB>
 static int launch_upconv_rows(const UpconvParams& p, hipStream_t s) {
     const long M = (long)p.D * p.H * p.W;
+    if (M >= (1l << 31)) return SD_ERR_INVALID;        // the kernel decodes input voxel indices with 32-bit arithmetic
     dim3 grid((unsigned)((M + 127) / 128), 1, p.batch), block(256);
     if (p.gn) hipLaunchKernelGGL((k_upconv_rows<T, NCH, NTAB, false, true>), grid, block, 4 * 32 * 64 * NTAB, s, p);
     else hipLaunchKernelGGL((k_upconv_rows<T, NCH, NTAB, false, false>), grid, block, 4 * 32 * 64 * NTAB, s, p);
@@ -2010,6 +2021,7 @@ static int launch_upconv_rows(const UpconvParams& p, hipStream_t s) {
 template <typename T, int NCH, int NTAB>
 static int launch_upconv_rows_wl(const UpconvParams& p, hipStream_t s) {      // LDS-resident weights, persistent
     const long M = (long)p.D * p.H * p.W;
+    if (M >= (1l << 31)) return SD_ERR_INVALID;
     const size_t lds = 4 * 32 * 64 * NTAB + (size_t)(NTAB / 2 + 2 * (NTAB & 1)) * NCH * 2048;
     auto kern = p.gn ? k_upconv_rows<T, NCH, NTAB, true, true> : k_upconv_rows<T, NCH, NTAB, true, false>;
     {
