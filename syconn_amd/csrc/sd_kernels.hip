@@ -1269,29 +1269,43 @@ __global__ __launch_bounds__(256) void k_upconv_mfma(const UpconvParams p) {
     using v4 = typename Act<T>::v4;
     T* const dst = reinterpret_cast<T*>(reinterpret_cast<char*>(p.dst) + blockIdx.z * p.tstride);
     const int H2 = 2 * p.H, W2 = 2 * p.W;
+    // The lane pair (l, l^32) holds channels 8q + 0..3 / 8q + 4..7 of the same voxel: trading quad q0 of the upper lane against
+    // quad q1 of the lower one gives every lane 8 consecutive channels = ONE 16-byte store per quad pair instead of two
+    // 8-byte ones (this generic form is bound by its scattered stores).  Swaps are executed by all lanes, stores are predicated.
+    const int half = lane >> 5;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        if (!mv[i]) continue;
-        const int x = (int)(m[i] % p.W), y = (int)((m[i] / p.W) % p.H), z = (int)(m[i] / ((long)p.W * p.H));
+        const unsigned mu = mv[i] ? (unsigned)m[i] : 0u;      // (< 2^31 input voxels: checked by the launcher)
+        const unsigned xy = mu % (unsigned)(p.W * p.H), z = mu / (unsigned)(p.W * p.H), y = xy / (unsigned)p.W, x = xy - y * (unsigned)p.W;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int nbase = (nb * 2 + j) * 32 + 4 * (lane >> 5);
+            const int nbase = (nb * 2 + j) * 32;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = nbase + 8 * q;
-                if (n < p.ntot) {
-                    const int tap = n / p.Cd, co = n - tap * p.Cd;
-                    const int a = (p.kz == 2) ? (tap >> 2) : 0, b = (tap >> 1) & 1, cx = tap & 1;
-                    const f32x4 bs = *reinterpret_cast<const f32x4*>(p.bias + n);
-                    v4 o;
+            for (int qp = 0; qp < 2; ++qp) {
+                unsigned d[2][2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int q = 2 * qp + h, n = nbase + 8 * q + 4 * half;
+                    f32x4 bs = {0.f, 0.f, 0.f, 0.f};
+                    if (n < p.ntot) bs = *reinterpret_cast<const f32x4*>(p.bias + n);
+                    float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float v = acc[i][j][4 * q + e] + bs[e];
-                        if (p.relu) v = fmaxf(v, 0.f);
-                        o[e] = (T)v;
+                        v[e] = acc[i][j][4 * q + e] + bs[e];
+                        if (p.relu) v[e] = fmaxf(v[e], 0.f);
                     }
+                    d[h][0] = Act<T>::pack2(v[0], v[1]);
+                    d[h][1] = Act<T>::pack2(v[2], v[3]);
+                }
+                swap32(d[0][0], d[1][0]);
+                swap32(d[0][1], d[1][1]);
+                const int n8 = nbase + 8 * (2 * qp + half);       // first of this lane's 8 consecutive channels
+                if (mv[i] && n8 < p.ntot) {
+                    const int tap = n8 / p.Cd, co = n8 - tap * p.Cd;
+                    const int a = (p.kz == 2) ? (tap >> 2) : 0, b = (tap >> 1) & 1, cx = tap & 1;
                     const size_t vo = ((size_t)(z * p.kz + a) * H2 + (2 * y + b)) * W2 + (2 * x + cx);
-                    *reinterpret_cast<v4*>(dst + ((size_t)(co >> 4) * p.Pd + vo) * SD_CHUNK + (co & 15)) = o;
+                    typedef __attribute__((ext_vector_type(4))) unsigned u4;
+                    *reinterpret_cast<u4*>(dst + ((size_t)(co >> 4) * p.Pd + vo) * SD_CHUNK + (co & 15)) = u4{d[0][0], d[0][1], d[1][0], d[1][1]};
                 }
             }
         }
@@ -2064,6 +2078,7 @@ static int launch_upconv_t(const UpconvParams& p, int NB, hipStream_t s) {
     // (192 -> 96 channels: k_upconv_mfma 76 us, LDS-weight rows kernel 83 us per tile in the channel-blocked layout)
     if (p.nchunk == 6 && p.Cd == 48) return no_wl ? launch_upconv_rows<T, 6, 3>(p, s) : launch_upconv_rows_wl<T, 6, 3>(p, s);
     const long M = (long)p.D * p.H * p.W;
+    if (M >= (1l << 31)) return SD_ERR_INVALID;        // (32-bit voxel decode in the kernel)
     dim3 grid((unsigned)((M + 255) / 256), NB, p.batch), block(256);
     if (p.gn) hipLaunchKernelGGL((k_upconv_mfma<T, true>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((k_upconv_mfma<T, false>), grid, block, 0, s, p);
