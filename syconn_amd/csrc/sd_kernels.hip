@@ -1452,6 +1452,12 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// element index -> coordinates with 32-bit arithmetic (the launchers reject tensors with >= 2^32 elements for these passes:
+// three 64-bit divisions per 16-byte access made the HBM-bound pooling / GroupNorm passes VALU-bound)
+__device__ __forceinline__ void decode_zyx(unsigned v, unsigned W, unsigned H, int& x, int& y, int& z) {
+    const unsigned r = v / W, zz = r / H;
+    x = (int)(v - r * W); y = (int)(r - zz * H); z = (int)zz;
+}
 // K4: MaxPool3d k=(kz,2,2), ceil_mode=True.  One thread per (output voxel, 8-channel group), 16-byte accesses.
 template <typename T>
 __global__ __launch_bounds__(256) void k_maxpool(const PoolParams p) {
@@ -1462,9 +1468,11 @@ __global__ __launch_bounds__(256) void k_maxpool(const PoolParams p) {
     T* const dst = reinterpret_cast<T*>(reinterpret_cast<char*>(p.dst) + blockIdx.z * p.tstride);
     const long npv = (long)p.Do * p.Ho * p.Wo;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const long v = (idx >> 1) % npv;                                  // (chunk, pooled voxel, half)
-        const int cg = (int)((idx >> 1) / npv) * 2 + (int)(idx & 1);
-        const int xo = (int)(v % p.Wo), yo = (int)((v / p.Wo) % p.Ho), zo = (int)(v / ((long)p.Wo * p.Ho));
+        const unsigned pv = (unsigned)(idx >> 1), ch = pv / (unsigned)npv;  // (chunk, pooled voxel, half)
+        const long v = pv - ch * (unsigned)npv;
+        const int cg = (int)ch * 2 + (int)(idx & 1);
+        int xo, yo, zo;
+        decode_zyx((unsigned)v, (unsigned)p.Wo, (unsigned)p.Ho, xo, yo, zo);
         float mx[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) mx[e] = -INFINITY;
@@ -1695,7 +1703,8 @@ __global__ __launch_bounds__(256) void k_gn_stats(const GnParams p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) { s[e] = 0.f; ss[e] = 0.f; }
     for (long v = (long)blockIdx.x * 256 + tid; v < nvox; v += (long)gridDim.x * 256) {
-        const int x = (int)(v % p.W), y = (int)((v / p.W) % p.H), z = (int)(v / ((long)p.W * p.H));
+        int x, y, z;
+        decode_zyx((unsigned)v, (unsigned)p.W, (unsigned)p.H, x, y, z);
         const T* q = buf + (((size_t)z * p.Hs + y) * p.Ws + x) * SD_CHUNK;
         const v8 lo = *reinterpret_cast<const v8*>(q), hi = *reinterpret_cast<const v8*>(q + 8);
 #pragma unroll
@@ -1728,9 +1737,11 @@ __global__ __launch_bounds__(256) void k_gn_apply_pool(const GnParams p) {
     const float* const scale_shift = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.scale_shift) + blockIdx.z * p.tstride);
     const long npv = (long)p.pD * p.pH * p.pW;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const long v = (idx >> 1) % npv;                                  // (chunk, pooled voxel, half)
-        const int cg = (int)((idx >> 1) / npv) * 2 + (int)(idx & 1);
-        const int xo = (int)(v % p.pW), yo = (int)((v / p.pW) % p.pH), zo = (int)(v / ((long)p.pW * p.pH));
+        const unsigned pv = (unsigned)(idx >> 1), ch = pv / (unsigned)npv;  // (chunk, pooled voxel, half)
+        const long v = pv - ch * (unsigned)npv;
+        const int cg = (int)ch * 2 + (int)(idx & 1);
+        int xo, yo, zo;
+        decode_zyx((unsigned)v, (unsigned)p.pW, (unsigned)p.pH, xo, yo, zo);
         const float* const sc = scale_shift + cg * 8;
         const float* const sh = scale_shift + p.C + cg * 8;
         float mx[8];
@@ -1796,9 +1807,11 @@ __global__ __launch_bounds__(256) void k_gn_apply(const GnParams p) {
     const long nvx = (long)p.D * p.H * p.W;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         // (chunk, voxel, half): consecutive threads touch consecutive 16-byte pieces of one chunk plane
-        const long v = (idx >> 1) % nvx;
-        const int cg = (int)((idx >> 1) / nvx) * 2 + (int)(idx & 1);
-        const int x = (int)(v % p.W), y = (int)((v / p.W) % p.H), z = (int)(v / ((long)p.W * p.H));
+        const unsigned pv = (unsigned)(idx >> 1), ch = pv / (unsigned)nvx;
+        const long v = pv - ch * (unsigned)nvx;
+        const int cg = (int)ch * 2 + (int)(idx & 1);
+        int x, y, z;
+        decode_zyx((unsigned)v, (unsigned)p.W, (unsigned)p.H, x, y, z);
         T* ptr = buf + ((size_t)(cg >> 1) * p.P + ((size_t)z * p.Hs + y) * p.Ws + x) * SD_CHUNK + (cg & 1) * 8;
         *reinterpret_cast<v8*>(ptr) = gn_apply8<T>(*reinterpret_cast<const v8*>(ptr), scale_shift + cg * 8,
                                                      scale_shift + p.C + cg * 8, p.relu);
@@ -2096,6 +2109,7 @@ int launch_upconv(const UpconvParams& p, int act_dtype, int NB, hipStream_t s) {
 
 int launch_pool(const PoolParams& p, int act_dtype, hipStream_t s) {
     const long total = (long)p.Do * p.Ho * p.Wo * (p.C / 8);
+    if (total >= (1l << 32)) return SD_ERR_INVALID;       // (32-bit element decode in the kernel)
     dim3 grid(grid_for(total), 1, p.batch), block(256);
     if (act_dtype == SD_BF16) hipLaunchKernelGGL((k_maxpool<bf16_t>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((k_maxpool<f16_t>), grid, block, 0, s, p);
@@ -2124,6 +2138,7 @@ int launch_groupnorm(const GnParams& p, int act_dtype, hipStream_t s) {
             if (hipMemsetAsync(reinterpret_cast<char*>(p.sums) + t * p.tstride, 0, sizeof(double) * 2 * p.C, s) != hipSuccess)
                 return SD_ERR_HIP;
     const long nvox = (long)p.D * p.H * p.W;
+    if (nvox * ng >= (1l << 32)) return SD_ERR_INVALID;   // (32-bit element decode in the kernels)
     dim3 g1(grid_for(nvox, 256 * 8, 1024), p.C / SD_CHUNK, p.batch), b1(256);
     dim3 g3(grid_for(nvox * ng), 1, p.batch), b3(256);
     dim3 gp(grid_for((long)std::max(p.pD, 1) * std::max(p.pH, 1) * std::max(p.pW, 1) * ng), 1, p.batch);
