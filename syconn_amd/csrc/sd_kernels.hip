@@ -1825,7 +1825,8 @@ __global__ __launch_bounds__(256) void k_tile_gather(const E* vol, int VD, int V
                                                      E* tile, int TD, int TH, int TW) {
     const long total = (long)TD * TH * TW;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int x = (int)(i % TW), y = (int)((i / TW) % TH), z = (int)(i / ((long)TW * TH));
+        int x, y, z;
+        decode_zyx((unsigned)i, (unsigned)TW, (unsigned)TH, x, y, z);      // (tiles have < 2^32 voxels: checked by the launcher)
         const int vz = oz + z, vy = oy + y, vx = ox + x;
         E v = 0;
         if ((unsigned)vz < (unsigned)VD && (unsigned)vy < (unsigned)VH && (unsigned)vx < (unsigned)VW)
@@ -1841,9 +1842,10 @@ __global__ __launch_bounds__(256) void k_tile_scatter(const E* tile, int C, int 
     const long per = (long)KD * KH * KW;
     const long total = per * C;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i / per);
+        const int c = (int)((unsigned)i / (unsigned)per);
         const long r = i - (long)c * per;
-        const int x = (int)(r % KW), y = (int)((r / KW) % KH), z = (int)(r / ((long)KW * KH));
+        int x, y, z;
+        decode_zyx((unsigned)r, (unsigned)KW, (unsigned)KH, x, y, z);
         const int vz = oz + z, vy = oy + y, vx = ox + x;
         if (vz < VD && vy < VH && vx < VW)
             vol[(((size_t)c * VD + vz) * VH + vy) * VW + vx] =
@@ -2160,6 +2162,7 @@ int launch_groupnorm(const GnParams& p, int act_dtype, hipStream_t s) {
 
 int launch_tile_gather(const void* vol, int esize, int VD, int VH, int VW, int oz, int oy, int ox, void* tile, int TD,
                        int TH, int TW, hipStream_t s) {
+    if ((long)TD * TH * TW >= (1l << 32)) return SD_ERR_INVALID;           // (32-bit element decode in the kernel)
     dim3 grid(grid_for((long)TD * TH * TW)), block(256);
     if (esize == 1)
         hipLaunchKernelGGL((k_tile_gather<uint8_t>), grid, block, 0, s, (const uint8_t*)vol, VD, VH, VW, oz, oy, ox,
@@ -2172,6 +2175,7 @@ int launch_tile_gather(const void* vol, int esize, int VD, int VH, int VW, int o
 
 int launch_tile_scatter(const void* tile, int esize, int C, int TD, int TH, int TW, int cz, int cy, int cx, int KD,
                         int KH, int KW, void* vol, int VD, int VH, int VW, int oz, int oy, int ox, hipStream_t s) {
+    if ((long)C * KD * KH * KW >= (1l << 32)) return SD_ERR_INVALID;      // (32-bit element decode in the kernel)
     dim3 grid(grid_for((long)C * KD * KH * KW)), block(256);
     if (esize == 1)
         hipLaunchKernelGGL((k_tile_scatter<uint8_t>), grid, block, 0, s, (const uint8_t*)tile, C, TD, TH, TW, cz, cy,

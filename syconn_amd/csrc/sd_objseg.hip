@@ -33,6 +33,12 @@ struct Offs { int n; signed char dx[MAX_OFFS], dy[MAX_OFFS], dz[MAX_OFFS]; };
 // volume extents, pad, padded extents (PZW = words per padded z-row)
 struct Dom { int X, Y, Z, P; int PX, PY, PZ, PZW; };
 __device__ __forceinline__ size_t widx(const Dom& d, int x, int y, int zw) { return ((size_t)x * d.PY + y) * d.PZW + zw; }
+// linear index -> (fastest, middle, slowest) coordinate with 32-bit arithmetic (volumes here have < 2^31 voxels: labels are
+// int32; three 64-bit divisions per voxel made these HBM-bound passes instruction-bound)
+__device__ __forceinline__ void dec3(size_t i, int n0, int n1, int& c0, int& c1, int& c2) {
+    const unsigned u = (unsigned)i, r = u / (unsigned)n0, q = r / (unsigned)n1;
+    c0 = (int)(u - r * (unsigned)n0); c1 = (int)(r - q * (unsigned)n1); c2 = (int)q;
+}
 
 // bbox[0..2] = min (padded coords), bbox[3..5] = max + 1; empty foreground: min > max
 __global__ __launch_bounds__(256) void k_bbox_init(int* bbox) {
@@ -44,7 +50,9 @@ __global__ __launch_bounds__(256) void k_bbox_init(int* bbox) {
 __global__ __launch_bounds__(256) void k_threshold_bits(const uint8_t* prob, int cut, Dom d, uint32_t* A) {
     const size_t total = (size_t)d.PX * d.PY * d.PZW;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int zw = (int)(i % d.PZW), y = (int)((i / d.PZW) % d.PY) - d.P, x = (int)(i / ((size_t)d.PZW * d.PY)) - d.P;
+        int zw, y, x;
+        dec3(i, d.PZW, d.PY, zw, y, x);
+        y -= d.P; x -= d.P;
         uint32_t w = 0;
         if ((unsigned)x < (unsigned)d.X && (unsigned)y < (unsigned)d.Y) {
             const uint8_t* row = prob + ((size_t)x * d.Y + y) * d.Z;
@@ -65,8 +73,9 @@ __global__ __launch_bounds__(256) void k_bbox_bits(const uint32_t* A, Dom d, int
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const uint32_t w = A[i];
         if (w) {
-            const int zw = (int)(i % d.PZW);
-            const int c[3] = {(int)(i / ((size_t)d.PZW * d.PY)), (int)((i / d.PZW) % d.PY), zw * 32 + __builtin_ctz(w)};
+            int zw, yy, xx;
+            dec3(i, d.PZW, d.PY, zw, yy, xx);
+            const int c[3] = {xx, yy, zw * 32 + __builtin_ctz(w)};
             const int czh = zw * 32 + 32 - __builtin_clz(w);
             lo[0] = min(lo[0], c[0]); lo[1] = min(lo[1], c[1]); lo[2] = min(lo[2], c[2]);
             hi[0] = max(hi[0], c[0] + 1); hi[1] = max(hi[1], c[1] + 1); hi[2] = max(hi[2], czh);
@@ -110,7 +119,8 @@ __global__ __launch_bounds__(256) void k_morph_bits(const uint32_t* src, uint32_
     const int cl[3] = {crop ? bbox[0] : wl[0], crop ? bbox[1] : wl[1], crop ? bbox[2] : wl[2]};
     const int ch[3] = {crop ? bbox[3] : wh[0], crop ? bbox[4] : wh[1], crop ? bbox[5] : wh[2]};
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int zw = (int)(i % d.PZW), y = (int)((i / d.PZW) % d.PY), x = (int)(i / ((size_t)d.PZW * d.PY));
+        int zw, y, x;
+        dec3(i, d.PZW, d.PY, zw, y, x);
         uint32_t r = 0;
         const uint32_t keep = (x >= cl[0] && x < ch[0] && y >= cl[1] && y < ch[1]) ? zmask(zw, cl[2], ch[2]) : 0u;
         if (keep) {
@@ -171,7 +181,8 @@ __device__ __forceinline__ bool fg(const uint32_t* A, const Dom& d, int x, int y
 __global__ __launch_bounds__(256) void k_cc_init_runs(const uint32_t* A, Dom d, int* L, uint8_t* mask_out) {
     const size_t total = (size_t)d.X * d.Y * d.Z;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int z = (int)(i % d.Z), y = (int)((i / d.Z) % d.Y), x = (int)(i / ((size_t)d.Z * d.Y));
+        int z, y, x;
+        dec3(i, d.Z, d.Y, z, y, x);
         const uint32_t* row = A + widx(d, x + d.P, y + d.P, 0);
         const int pz = z + d.P;
         int zw = pz >> 5;
@@ -199,7 +210,8 @@ __global__ __launch_bounds__(256) void k_cc_merge_runs(const uint32_t* A, Dom d,
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int li = L[i];
         if (li < 0) continue;
-        const int z = (int)(i % d.Z), y = (int)((i / d.Z) % d.Y), x = (int)(i / ((size_t)d.Z * d.Y));
+        int z, y, x;
+        dec3(i, d.Z, d.Y, z, y, x);
         const bool my_start = z == 0 || !fg(A, d, x, y, z - 1);     // from the mask: L[i] of a run start may already be re-linked
         if (y > 0 && fg(A, d, x, y - 1, z) && (my_start || z == 0 || !fg(A, d, x, y - 1, z - 1)))
             cc_union(L, (int)i, (int)(i - sy));

@@ -196,7 +196,14 @@ __global__ __launch_bounds__(256) void k_segstats_scan(const ScanParams p, const
         const int nvalid = (int)((nvox - base) < 64 ? (nvox - base) : 64);
         const bool valid = lane < nvalid;
         const u64 li = valid ? lin : (nvox - 1);
-        const int z = (int)(li % p.Z), y = (int)((li / p.Z) % p.Y), x = (int)(li / ((u64)p.Z * p.Y));
+        // (32-bit decode where the volume allows it: three 64-bit divisions per voxel made this pass instruction-bound)
+        int z, y, x;
+        if (nvox < (1ull << 32)) {
+            const unsigned u = (unsigned)li, r = u / (unsigned)p.Z, q = r / (unsigned)p.Y;
+            z = (int)(u - r * (unsigned)p.Z); y = (int)(r - q * (unsigned)p.Y); x = (int)q;
+        } else {
+            z = (int)(li % p.Z); y = (int)((li / p.Z) % p.Y); x = (int)(li / ((u64)p.Z * p.Y));
+        }
         const bool row_start = (lane == 0) || (z == 0);
         u64 ck = 0;
         bool chead = false;
