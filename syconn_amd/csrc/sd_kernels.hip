@@ -2192,12 +2192,14 @@ template <typename E>
 __global__ __launch_bounds__(256) void k_downsample2(const E* src, int H, int W, E* dst, int Do, int Ho, int Wo) {
     const long total = (long)Do * Ho * Wo;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int x = (int)(i % Wo), y = (int)((i / Wo) % Ho), z = (int)(i / ((long)Wo * Ho));
+        int x, y, z;
+        decode_zyx((unsigned)i, (unsigned)Wo, (unsigned)Ho, x, y, z);       // (< 2^32 output voxels: checked by the launcher)
         dst[i] = src[((size_t)(2 * z) * H + 2 * y) * W + 2 * x];
     }
 }
 int launch_downsample2(const void* src, int esize, int D, int H, int W, void* dst, hipStream_t s) {
     const int Do = (D + 1) / 2, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    if ((long)Do * Ho * Wo >= (1l << 32)) return SD_ERR_INVALID;
     dim3 grid(grid_for((long)Do * Ho * Wo)), block(256);
     if (esize == 1) hipLaunchKernelGGL((k_downsample2<uint8_t>), grid, block, 0, s, (const uint8_t*)src, H, W, (uint8_t*)dst, Do, Ho, Wo);
     else if (esize == 8) hipLaunchKernelGGL((k_downsample2<uint64_t>), grid, block, 0, s, (const uint64_t*)src, H, W, (uint64_t*)dst, Do, Ho, Wo);
