@@ -93,7 +93,10 @@ size_t sd_workspace_bytes(const sd_model* m, int D, int H, int W);
 
 /* One forward pass of the network on one tile = Predictor._predict (row P4: model(inp) [+ softmax(1)]).
  * in_dev: (D,H,W) planar, in_dtype SD_U8 (normalised as float32(v)/255, prediction.py:808) or SD_F32.
- * out_dev: (cout_final, D, H, W) planar, float32 or uint8 according to out_kind. */
+ * out_dev: (cout_final, D, H, W) planar, float32 or uint8 according to out_kind.
+ * Size limits (SD_ERR_INVALID beyond them): a tile has fewer than 2^31 voxels and every activation tensor fewer than 2^32
+ * 8-channel groups (the streaming passes decode element indices with 32-bit arithmetic); the reference's tiles are
+ * 178 x 243 x 331 = 1.4e7 voxels. */
 int sd_forward(sd_model* m, const void* in_dev, int in_dtype, int D, int H, int W, void* out_dev, int out_kind,
                void* workspace_dev, size_t ws_bytes, void* stream);
 
