@@ -90,6 +90,28 @@ def test_mivcsj_groupnorm(gpu):
     _run_case(gpu, model, (12, 35, 41), 'bf16')
 
 
+@pytest.mark.parametrize('defer', [True, False])
+def test_groupnorm_net_with_64_channel_groups_large(gpu, monkeypatch, defer):
+    """A GroupNorm variant of the 32-filter family on tiles large enough for the 4-tile 3x3x3 form: that form with FUSED
+    GroupNorm statistics (symmetric epilogue: the statistics reduction needs all waves) and the deferred-apply plan, against
+    the fp32 oracle (no architecture of the reference combines the two; the dispatch allows it)."""
+    from syconn_amd import _lib as L
+    from syconn_amd.engine import DenseModel
+    if not defer:
+        monkeypatch.setenv('SD_NO_GN_DEFER', '1')       # separate apply passes: plain conv kernels with fused statistics
+    model = build_unet('myelin', seed=6, normalization='group8')
+    raw = _input((64, 128, 144), 23)
+    with torch.no_grad():
+        ref = model((raw.float() / 255.)[None, None])[0]
+    dm = DenseModel(model, act_dtype='bf16', device=gpu)
+    out = dm.forward(raw.to(gpu), L.SD_OUT_LOGITS_F32).cpu()
+    assert torch.isfinite(out).all()
+    err = float((out - ref).abs().max()) / float(ref.abs().max())
+    rms = float((out - ref).pow(2).mean().sqrt()) / float(ref.pow(2).mean().sqrt())
+    print(f'myelin/group8 (64, 128, 144): rel err max {err:.2e} rms {rms:.2e}')
+    assert err < TOL_FP32['bf16'] and rms < TOL_FP32_RMS['bf16']
+
+
 def test_mivcsj_fp16(gpu):
     model = build_unet('mivcsj', seed=5)
     _run_case(gpu, model, (8, 32, 48), 'f16')
