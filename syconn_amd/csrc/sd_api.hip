@@ -401,7 +401,7 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
             if (d.src0 <= 0 || d.groups <= 0) MODEL_FAIL("groupnorm: bad arguments");
             const int C = m->bufC[d.src0], Cp = m->bufCp[d.src0];
             if (C % d.groups) MODEL_FAIL("groupnorm: channels not divisible by groups");
-            if ((size_t)Cp * 24 > WS_SCRATCH) MODEL_FAIL("groupnorm: too many channels");
+            if ((size_t)Cp * 16 > SD_GN_SCALE_OFF || SD_GN_SCALE_OFF + (size_t)Cp * 8 > WS_SCRATCH) MODEL_FAIL("groupnorm: too many channels");
             if (!chk(d.gamma_off, C) || !chk(d.beta_off, C)) MODEL_FAIL("groupnorm: offsets");
             op.aux_off = blob_alloc((size_t)2 * Cp * 4);
             float* gp = reinterpret_cast<float*>(blob.data() + op.aux_off);
@@ -698,6 +698,19 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
         ev = m->events.data() + (size_t)(m->n_forward % m->profile_slots) * (m->ops.size() + 1);
     ++m->n_forward;
     m->last_launches = 0;
+    {
+        // GroupNorm statistics scratch (sum and sum of squares per channel, doubles, at the start of every tile's workspace): zeroed
+        // ONCE per forward pass; every k_gn_finalize leaves it zeroed for the next GroupNorm op
+        int maxc = 0;
+        for (const Op& op : m->ops)
+            if (op.d.kind == SD_OP_GROUPNORM) maxc = std::max(maxc, m->bufCp[op.d.src0]);
+        if ((size_t)2 * maxc * sizeof(double) > SD_GN_SCALE_OFF || SD_GN_SCALE_OFF + (size_t)2 * maxc * sizeof(float) > 65536)
+            return fail(SD_ERR_INVALID, "GroupNorm: more channels than the statistics scratch holds");
+        if (maxc > 0) {
+            const int rc0 = launch_zero_scratch(wsb, tstride, 2 * maxc * (int)sizeof(double), N, s);
+            if (rc0 != SD_OK) return fail(rc0, "zeroing the GroupNorm scratch failed");
+        }
+    }
 
     for (size_t i = 0; i < m->ops.size(); ++i) {
         const Op& op = m->ops[i];
@@ -771,10 +784,8 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
                     p.first_bias = reinterpret_cast<const float*>(m->dev_blob + fo.bias_off);
                     p.first_relu = fo.d.relu;
                 }
-                if (op.fuse_gn >= 0) {
+                if (op.fuse_gn >= 0) {      // (scratch is zero: see the start of the forward pass and k_gn_finalize)
                     p.gn_sums = reinterpret_cast<double*>(wsb); p.gn_C = p.Cd;
-                    for (int t = 0; t < N; ++t)
-                        HIP_TRY(hipMemsetAsync(wsb + (size_t)t * tstride, 0, sizeof(double) * 2 * p.Cd, s));
                 }
                 p.nbx = (o.w + SD_BX - 1) / SD_BX; p.nby = (o.h + BY - 1) / BY; p.nbz = (o.d + BZ - 1) / BZ;
                 auto gn_of = [&](int b, const float*& tab, int& relu) {
@@ -867,7 +878,8 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
             p.gamma = reinterpret_cast<const float*>(m->dev_blob + op.aux_off);
             p.beta = p.gamma + p.C;
             p.sums = reinterpret_cast<double*>(wsb);
-            p.scale_shift = reinterpret_cast<float*>(op.gn_defer ? wsb + m->gn_tab_off[d.src0] : wsb + (size_t)2 * p.C * 8);
+            // (not deferred: a fixed place behind the statistics scratch -- the scratch itself must stay zero between GroupNorm ops)
+            p.scale_shift = reinterpret_cast<float*>(op.gn_defer ? wsb + m->gn_tab_off[d.src0] : wsb + SD_GN_SCALE_OFF);
             p.relu = d.relu;
             p.batch = N; p.tstride = tstride; p.skip_stats = op.stats_done ? 1 : 0;
             p.skip_apply = (op.gn_defer && op.gn_pool < 0) ? 1 : 0;

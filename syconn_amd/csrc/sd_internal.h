@@ -173,6 +173,10 @@ bool upconv_rows_kernel(int nchunk, int Cd);   // shapes served by k_upconv_rows
 int launch_pool(const PoolParams& p, int act_dtype, hipStream_t s);
 int launch_final(const FinalParams& p, int act_dtype, hipStream_t s);
 int launch_groupnorm(const GnParams& p, int act_dtype, hipStream_t s);
+// workspace scratch (first 64 KiB of a tile's workspace): [0, SD_GN_SCALE_OFF) GroupNorm sums (2 * C doubles, zero between ops),
+// [SD_GN_SCALE_OFF, 64 KiB) scale / shift of a GroupNorm whose apply is not deferred (2 * C floats)
+#define SD_GN_SCALE_OFF ((size_t)40960)
+int launch_zero_scratch(void* ws, size_t tstride, int nbytes, int batch, hipStream_t s);
 int launch_tile_gather(const void* vol, int esize, int VD, int VH, int VW, int oz, int oy, int ox, void* tile, int TD,
                        int TH, int TW, hipStream_t s);
 int launch_tile_scatter(const void* tile, int esize, int C, int TD, int TH, int TW, int cz, int cy, int cx, int KD,
