@@ -2104,6 +2104,9 @@ static int launch_upconv_t(const UpconvParams& p, int NB, hipStream_t s) {
     if (p.nchunk == 8 && p.Cd == 64 && !no_wl) return launch_upconv_rows_wl<T, 8, 4>(p, s);
     // (192 -> 96 channels: k_upconv_mfma 76 us, LDS-weight rows kernel 83 us per tile in the channel-blocked layout)
     if (p.nchunk == 6 && p.Cd == 48) return no_wl ? launch_upconv_rows<T, 6, 3>(p, s) : launch_upconv_rows_wl<T, 6, 3>(p, s);
+    // 192 -> 96 channels: the generic kernel re-reads the input for each of its 12 column blocks (PMC: 1.0 GB read for 0.2 GB
+    // algorithmic per 8 tiles) and writes partial lines; rows kernel with LDS-resident weights 70 -> 60 us per tile
+    if (p.nchunk == 12 && p.Cd == 96 && !no_wl) return launch_upconv_rows_wl<T, 12, 6>(p, s);
     const long M = (long)p.D * p.H * p.W;
     if (M >= (1l << 31)) return SD_ERR_INVALID;        // (32-bit voxel decode in the kernel)
     dim3 grid((unsigned)((M + 255) / 256), NB, p.batch), block(256);
