@@ -446,15 +446,16 @@ def _crop(t, halo):
 def cpu_baseline(args, sd, dm, tiles_host, ids, L):
     """The torch-CPU fp32 oracle (U-Net + softmax + uint8 + label rule) on a bounded sample of the same workload, timed
     on this box's host cores, and the margin-safe / margin-unsafe split of every label disagreement with the HIP path."""
-    from oracle.label_margin import label_split, merge_splits
+    from oracle.label_margin import TOL_LOGIT_REL, label_split, merge_splits
     from oracle.predictor_ref import label_rule_ref
     from oracle.unet_ref import ARCHS, UNet
+    from syconn_amd.engine import DenseModel
     ncls = dm.out_channels
     model = UNet(in_channels=1, **ARCHS[args.arch]).eval()
     model.load_state_dict(sd)
     ncpu = min(3, tiles_host.shape[0])                         # bounded sample: ~15 s of CPU work
     S = tiles_host.shape[1]
-    parts = []
+    ref = []
     with torch.no_grad():
         model((tiles_host[0, :16].float() / 255.)[None, None])     # warm the CPU kernels
         cpu_s = 0.0
@@ -464,20 +465,38 @@ def cpu_baseline(args, sd, dm, tiles_host, ids, L):
             u8 = (lg.softmax(0).numpy() * 255).astype(np.uint8)
             label_rule_ref(u8, ids, [None] * ncls)
             cpu_s += time.perf_counter() - t1
-            x = tiles_host[i:i + 1].to(dm.device)
-            parts.append(label_split(lg, dm.forward_batch(x, L.SD_OUT_LOGITS_F32)[0].cpu(),
-                                     dm.forward_batch(x, L.SD_OUT_PROBS_F32)[0].cpu(),
-                                     dm.forward_labels_batch(x, ids, [127.5] * len(ids))[0].cpu(), ids, [None] * ncls))
-    sp = merge_splits(parts)
+            ref.append(lg)
+
+    def split_for(m, act):
+        parts = []
+        for i in range(ncpu):
+            x = tiles_host[i:i + 1].to(m.device)
+            parts.append(label_split(ref[i], m.forward_batch(x, L.SD_OUT_LOGITS_F32)[0].cpu(),
+                                     m.forward_batch(x, L.SD_OUT_PROBS_F32)[0].cpu(),
+                                     m.forward_labels_batch(x, ids, [127.5] * len(ids))[0].cpu(), ids, [None] * ncls,
+                                     TOL_LOGIT_REL[act]))
+        return merge_splits(parts)
+
+    keys = ('label_agreement', 'label_mismatch_safe', 'label_mismatch_unsafe', 'label_unsafe_frac', 'argmax_agreement',
+            'argmax_mismatch_safe', 'argmax_mismatch_unsafe', 'argmax_unsafe_frac', 'tol_logit_rel_stated', 'logit_err_max_rel',
+            'logit_err_rms', 'median_top2_margin_over_tol')
+    sp = split_for(dm, args.act)
     cpu = {'value': ncpu * S ** 3 / cpu_s / 1e6, 'unit': 'Mvox/s', 'cores': torch.get_num_threads(), 'kind': 'port',
            'sample': f'{ncpu} {S}^3 tiles of the same workload through the torch-CPU fp32 oracle '
                      f'(U-Net + softmax + uint8 + label rule), {cpu_s:.1f} s'}
-    cpu.update({k: sp[k] for k in ('label_agreement', 'label_mismatch_safe', 'label_mismatch_unsafe', 'label_unsafe_frac',
-                                   'argmax_agreement', 'argmax_mismatch_safe', 'argmax_mismatch_unsafe',
-                                   'argmax_unsafe_frac', 'logit_err_max_rel', 'logit_err_rms',
-                                   'median_top2_margin_over_tol')})
+    cpu.update({k: sp[k] for k in keys})
+    # the same tiles in the other storage types of the library: fp16 (the library default) and the
+    # reference-precision mode 'f32' (fp32 storage + arithmetic like the reference, csrc/sd_f32.hip)
+    modes = {args.act: {k: sp[k] for k in keys}}
+    for act in ('bf16', 'f16', 'f32'):
+        if act in modes:
+            continue
+        m2 = DenseModel(sd, act_dtype=act, device=dm.device)
+        r = split_for(m2, act)
+        modes[act] = {k: r[k] for k in keys}
+        del m2
+    cpu['precision_modes'] = modes
     return cpu
-
 
 if __name__ == '__main__':
     main()

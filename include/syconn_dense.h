@@ -82,7 +82,10 @@ int sd_device_count(void);
 
 /* Build a model: validate the plan, fold BatchNorm, convert + pack weights into MFMA fragment order and upload
  * them.  Replaces torch.jit.load(model.pts).to(device) (prediction.py:777, 1061-1062).
- * act_dtype: SD_BF16 or SD_F16 (storage type of activations / MFMA operands; accumulation is fp32). */
+ * act_dtype: SD_BF16 or SD_F16 (storage type of activations / MFMA operands; accumulation is fp32), or SD_F32 = the
+ * REFERENCE-PRECISION mode: fp32 storage and fp32 FMA arithmetic like the reference's own torch path (Predictor is built
+ * without float16, prediction.py:777-779); planar activations, one plain launch per layer, ~25x slower than the bf16
+ * plan -- for label-exactness checks against an fp32 implementation, not for throughput. */
 int sd_model_create(const sd_op_desc* ops, int n_ops, const float* weights, size_t n_floats, int act_dtype,
                     sd_model** out);
 void sd_model_destroy(sd_model* m);

@@ -97,6 +97,7 @@ struct sd_model {
     std::vector<int> buf_gn;
     std::vector<size_t> gn_tab_off;
     size_t ws_base = 65536;  // first byte of the activation buffers (behind the scratch and the tables)
+    sd_f32_model* f32 = nullptr;   // act_dtype == SD_F32: the reference-precision plan (sd_f32.hip) serves every call
 };
 
 namespace {
@@ -238,9 +239,19 @@ int sd_debug_last_launch_count(const sd_model* m) { return m ? m->last_launches 
 int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_floats, int act_dtype,
                     sd_model** out) {
     if (!ops || n_ops <= 0 || !W || !out) return fail(SD_ERR_INVALID, "null argument");
-    if (act_dtype != SD_BF16 && act_dtype != SD_F16) return fail(SD_ERR_INVALID, "act_dtype must be SD_BF16 or SD_F16");
+    if (act_dtype != SD_BF16 && act_dtype != SD_F16 && act_dtype != SD_F32)
+        return fail(SD_ERR_INVALID, "act_dtype must be SD_BF16, SD_F16 or SD_F32");
     sd_model* m = new sd_model();
     m->act_dtype = act_dtype;
+    if (act_dtype == SD_F32) {       // reference-precision mode: its own plan, weights and kernels
+        if (hipGetDevice(&m->device) != hipSuccess) { delete m; return fail(SD_ERR_NODEVICE, "no current HIP device"); }
+        const int rc32 = f32_model_create(ops, n_ops, W, n_floats, &m->f32);
+        if (rc32 != SD_OK) { delete m; return rc32; }
+        for (int i = 0; i < n_ops; ++i) { Op op; op.d = ops[i]; m->ops.push_back(op); }
+        m->final_cout = f32_final_cout(m->f32);
+        *out = m;
+        return SD_OK;
+    }
     m->keep_all = getenv("SD_KEEP_ALL") != nullptr;
     m->ws_reuse = !m->keep_all && !getenv("SD_NO_FUSE") && !getenv("SD_NO_WS_REUSE");
     if (hipGetDevice(&m->device) != hipSuccess) { delete m; return fail(SD_ERR_NODEVICE, "no current HIP device"); }
@@ -602,11 +613,13 @@ void sd_model_destroy(sd_model* m) {
     if (!m) return;
     for (hipEvent_t e : m->events) (void)hipEventDestroy(e);
     if (m->dev_blob) (void)hipFree(m->dev_blob);
+    f32_model_destroy(m->f32);
     delete m;
 }
 
 size_t sd_workspace_bytes(const sd_model* m, int D, int H, int W) {
     if (!m || D <= 0 || H <= 0 || W <= 0) { fail(SD_ERR_INVALID, "bad tile shape"); return 0; }
+    if (m->f32) return f32_workspace_bytes(m->f32, D, H, W);
     std::vector<Dims> dims;
     std::vector<size_t> off;
     if (infer_shapes(m, D, H, W, dims) != SD_OK) return 0;
@@ -680,6 +693,15 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
     if (N <= 0 || N > 65535) return fail(SD_ERR_INVALID, "bad batch size");
     if (in_dtype != SD_U8 && in_dtype != SD_F32) return fail(SD_ERR_INVALID, "in_dtype must be SD_U8 or SD_F32");
     if (D <= 0 || H <= 0 || W <= 0) return fail(SD_ERR_INVALID, "bad tile shape");
+    if ((long)D * H * W >= (1l << 31)) return fail(SD_ERR_INVALID, "tile has 2^31 or more voxels");
+    if (m->f32) {
+        hipEvent_t* ev32 = nullptr;
+        if (m->profile_slots > 0) ev32 = m->events.data() + (size_t)(m->n_forward % m->profile_slots) * (m->ops.size() + 1);
+        ++m->n_forward;
+        m->last_launches = (int)m->ops.size();
+        return f32_forward(m->f32, in_dev, in_dtype, N, D, H, W, out_dev, out_kind, lab, ws, ws_bytes,
+                           reinterpret_cast<hipStream_t>(stream), ev32);
+    }
     int rc = infer_shapes(m, D, H, W, m->dims);
     if (rc != SD_OK) return rc;
     const size_t need = plan_workspace(m, m->dims, m->buf_off);
@@ -975,6 +997,7 @@ int sd_postproc_labels(const uint8_t* probs, int C, size_t nvox, const int32_t* 
 }
 
 int sd_debug_read_buffer(sd_model* m, int buf, const void* ws, float* out, int32_t* dims4, void* stream) {
+    if (m && m->f32) return f32_read_buffer(m->f32, buf, ws, out, dims4, reinterpret_cast<hipStream_t>(stream));
     if (!m || buf <= 0 || buf >= m->nbuf || m->dims.empty()) return fail(SD_ERR_INVALID, "sd_debug_read_buffer: bad argument");
     const Dims a = m->dims[buf];
     if (dims4) { dims4[0] = m->bufC[buf]; dims4[1] = a.d; dims4[2] = a.h; dims4[3] = a.w; }

@@ -27,9 +27,8 @@
 //        then the second conv of one tile two steps behind the merge conv (18 MFMAs, weights in registers), the final
 //        1x1x1 on the matrix core (hi + lo weight parts), softmax, uint8 / labels, global store.
 // The only LDS fragment traffic is one activation fragment per MFMA; no weight fragment is ever re-read.
-// Every convolution output is summed in the order of k_conv_mfma (bias, chunks in concat order, taps 0..8): bit-identical to
-// the layer-by-layer plan up to the up-convolution, whose row kernel adds the bias last (differs by fp32 rounding when it is
-// not zero).
+// Every output is summed in the order of the layer-wise kernels (bias, chunks in concat order, taps 0..8; the up-convolution
+// kernels start from the bias too): bit-identical to the layer-by-layer plan.
 #include "sd_internal.h"
 #include "../../include/syconn_dense.h"
 #include "sd_device.h"

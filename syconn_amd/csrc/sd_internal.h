@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/syconn_dense.h"
 
 // Activation tensors are CHANNEL-BLOCKED: a "chunk" is 16 consecutive channels = one MFMA k-step, and element
 // (chunk k, z, y, x, c) sits at ((k*P + (z*H + y)*W + x)*16 + c) with P = D*H*W the voxels of the buffer's own
@@ -186,3 +187,14 @@ int launch_box_majority(const uint8_t* vol, int D, int H, int W, const int32_t* 
                         int cut, double thresh_majority, uint8_t* out, hipStream_t s);
 int launch_labels(const uint8_t* probs, size_t nvox, const LabelArgs& a, void* out, int out_u64, hipStream_t s);
 int launch_read_buffer(const void* buf, int act_dtype, int C, int Cs, int D, int H, int W, float* out, hipStream_t s);
+
+// ---- reference-precision mode (sd_f32.hip): act_dtype = SD_F32, planar fp32 activations, plain FMA kernels ----------------
+struct sd_f32_model;
+int f32_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_floats, sd_f32_model** out);
+void f32_model_destroy(sd_f32_model* m);
+int f32_final_cout(const sd_f32_model* m);
+int f32_buf_channels(const sd_f32_model* m, int b);
+size_t f32_workspace_bytes(sd_f32_model* m, int D, int H, int W);
+int f32_forward(sd_f32_model* m, const void* in_dev, int in_dtype, int N, int D, int H, int W, void* out_dev, int out_kind,
+                const LabelArgs* lab, void* ws, size_t ws_bytes, hipStream_t s, hipEvent_t* ev);
+int f32_read_buffer(sd_f32_model* m, int buf, const void* ws, float* out, int32_t* dims4, hipStream_t s);

@@ -1230,13 +1230,17 @@ __global__ __launch_bounds__(256) void k_upconv_mfma(const UpconvParams p) {
         m[i] = (long)blockIdx.x * 256 + wave * 64 + i * 32 + (lane & 31);
         mv[i] = m[i] < M;
     }
+    // accumulators start from the folded bias (padded with zeros to NB*64 entries): the summation order of every plan that
+    // can serve an up-convolution (this kernel, k_upconv_rows, k_dec0) is bias first, then the chunks in order
     f32x16 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bs = *reinterpret_cast<const f32x4*>(p.bias + (nb * 2 + j) * 32 + 8 * q + 4 * (lane >> 5));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int e = 0; e < 4; ++e) acc[0][j][4 * q + e] = acc[1][j][4 * q + e] = bs[e];
+        }
 
     __shared__ __attribute__((aligned(16))) float gtab[GN ? 2 * 1024 : 4];    // deferred GroupNorm scale / shift of this tile (Cs <= 1024)
     const float* gss = nullptr;
@@ -1285,13 +1289,11 @@ __global__ __launch_bounds__(256) void k_upconv_mfma(const UpconvParams p) {
                 unsigned d[2][2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const int q = 2 * qp + h, n = nbase + 8 * q + 4 * half;
-                    f32x4 bs = {0.f, 0.f, 0.f, 0.f};
-                    if (n < p.ntot) bs = *reinterpret_cast<const f32x4*>(p.bias + n);
+                    const int q = 2 * qp + h;
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[i][j][4 * q + e] + bs[e];
+                        v[e] = acc[i][j][4 * q + e];
                         if (p.relu) v[e] = fmaxf(v[e], 0.f);
                     }
                     d[h][0] = Act<T>::pack2(v[0], v[1]);
@@ -1381,11 +1383,17 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
     const int ab0 = WL ? a_wg : 0, nab = WL ? ab0 + 1 : p.kz * 2;
 #pragma unroll 1
     for (int ab = ab0; ab < nab; ++ab) {
+        // the accumulators start from the folded bias (the summation order of k_conv_mfma and of the fused level-0 decoder:
+        // bias, then the input chunks in order -- the three plans must agree bit for bit)
         f32x16 acc[NTAB];
 #pragma unroll
         for (int j = 0; j < NTAB; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + ab * 2 * CD + 32 * j + 8 * q + 4 * half);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[j][4 * q + e] = b[e];
+            }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
 #pragma unroll
@@ -1406,12 +1414,10 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
         for (int j = 0; j < NTAB; ++j) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int nl = 32 * j + 8 * q + 4 * half;
-                const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + ab * 2 * CD + nl);
                 v4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = acc[j][4 * q + e] + b[e];
+                    float v = acc[j][4 * q + e];
                     if (p.relu) v = fmaxf(v, 0.f);
                     o[e] = (T)v;
                 }

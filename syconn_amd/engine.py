@@ -12,7 +12,9 @@ import torch
 from . import _lib as L
 from .plan import plan_from_model
 
-_ACT = {'bf16': L.SD_BF16, 'bfloat16': L.SD_BF16, 'f16': L.SD_F16, 'fp16': L.SD_F16, 'float16': L.SD_F16}
+# 'f32': the reference-precision plan (csrc/sd_f32.hip: fp32 storage and arithmetic like the reference's torch path, slow)
+_ACT = {'bf16': L.SD_BF16, 'bfloat16': L.SD_BF16, 'f16': L.SD_F16, 'fp16': L.SD_F16, 'float16': L.SD_F16,
+        'f32': L.SD_F32, 'fp32': L.SD_F32, 'float32': L.SD_F32}
 
 
 def _stream() -> int:

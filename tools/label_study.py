@@ -9,7 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import synthetic_em_tiles                                    # noqa: E402
-from oracle.label_margin import label_split, merge_splits              # noqa: E402
+from oracle.label_margin import TOL_LOGIT_REL, label_split, merge_splits              # noqa: E402
 from oracle.unet_ref import ARCHS, UNet                                 # noqa: E402
 from syconn_amd import _lib as L                                        # noqa: E402
 from syconn_amd.cnn import random_state_dict                            # noqa: E402
@@ -28,7 +28,7 @@ def main():
         ref.load_state_dict(sd)
         with torch.no_grad():
             ref_logits = [ref((tiles[i].float() / 255.)[None, None])[0] for i in range(ntiles)]
-        for act in ('bf16', 'f16'):
+        for act in ('bf16', 'f16', 'f32'):
             dm = DenseModel(sd, act_dtype=act, device=dev)
             ids = list(range(1, dm.out_channels))
             parts = []
@@ -37,7 +37,7 @@ def main():
                 parts.append(label_split(ref_logits[i], dm.forward_batch(x, L.SD_OUT_LOGITS_F32)[0].cpu(),
                                          dm.forward_batch(x, L.SD_OUT_PROBS_F32)[0].cpu(),
                                          dm.forward_labels_batch(x, ids, [127.5] * len(ids))[0].cpu(), ids,
-                                         [None] * dm.out_channels))
+                                         [None] * dm.out_channels, TOL_LOGIT_REL[act]))
             r = dict(arch=arch, act=act, final_scale=scale, tiles=ntiles, **merge_splits(parts))
             print(json.dumps(r), flush=True)
             out.append(r)
