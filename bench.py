@@ -446,7 +446,7 @@ def _crop(t, halo):
 def cpu_baseline(args, sd, dm, tiles_host, ids, L):
     """The torch-CPU fp32 oracle (U-Net + softmax + uint8 + label rule) on a bounded sample of the same workload, timed
     on this box's host cores, and the margin-safe / margin-unsafe split of every label disagreement with the HIP path."""
-    from oracle.label_margin import TOL_LOGIT_REL, label_split, merge_splits
+    from oracle.label_margin import label_split, merge_splits, stated_tolerance
     from oracle.predictor_ref import label_rule_ref
     from oracle.unet_ref import ARCHS, UNet
     from syconn_amd.engine import DenseModel
@@ -474,7 +474,7 @@ def cpu_baseline(args, sd, dm, tiles_host, ids, L):
             parts.append(label_split(ref[i], m.forward_batch(x, L.SD_OUT_LOGITS_F32)[0].cpu(),
                                      m.forward_batch(x, L.SD_OUT_PROBS_F32)[0].cpu(),
                                      m.forward_labels_batch(x, ids, [127.5] * len(ids))[0].cpu(), ids, [None] * ncls,
-                                     TOL_LOGIT_REL[act]))
+                                     stated_tolerance(args.arch, act)))
         return merge_splits(parts)
 
     keys = ('label_agreement', 'label_mismatch_safe', 'label_mismatch_unsafe', 'label_unsafe_frac', 'argmax_agreement',

@@ -110,6 +110,13 @@ int sd_forward(sd_model* m, const void* in_dev, int in_dtype, int D, int H, int 
 int sd_forward_batch(sd_model* m, const void* in_dev, int in_dtype, int N, int D, int H, int W, void* out_dev,
                      int out_kind, void* workspace_dev, size_t ws_bytes, void* stream);
 
+/* fp16 range guard.  With act_dtype SD_F16 an activation above 65504 is stored as inf and reaches the final layer as inf / NaN
+ * logits; the final-layer kernels raise a device flag when that happens (the reference computes in fp32 and cannot overflow
+ * there, prediction.py:777-779).  Copies the flag to *flag_out (1 = some forward pass since the last call overflowed: its
+ * results are invalid; rerun with SD_BF16 or SD_F32) and clears it.  SYNCHRONISES `stream` (the stream the forwards were
+ * enqueued on).  Always 0 for SD_BF16 / SD_F32 models, whose storage types share fp32's exponent range. */
+int sd_model_overflow(sd_model* m, void* stream, int* flag_out);
+
 /* Forward pass with the label rule of dense_predictor (prediction.py:813-833, row A7) applied in the final layer's
  * epilogue: out_dev (N, D, H, W) uint8 = what sd_postproc_labels computes from the SD_OUT_PROBS_U8 result of
  * sd_forward_batch -- label = 0; for i in order: if floor(255*p[ids[i]]) > thresholds[i] then label = ids[i] -- without

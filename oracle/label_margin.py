@@ -31,6 +31,12 @@ from .predictor_ref import label_rule_ref
 # stated tolerance of a full-size network per activation storage type: max |logit error| / max |oracle logit|
 # (fp32 accumulation everywhere; 'f32' = the reference-precision mode, which differs from torch-CPU by summation order only)
 TOL_LOGIT_REL = {'bf16': 1e-2, 'f16': 1.3e-3, 'f32': 2e-5}
+# the 5-level GroupNorm network (mivcsj: 26 stored layers, statistics over rounded tensors) is stated twice as wide
+TOL_LOGIT_REL_ARCH = {('mivcsj', 'bf16'): 2e-2, ('mivcsj', 'f16'): 2.5e-3}
+
+
+def stated_tolerance(arch: str, act: str) -> float:
+    return TOL_LOGIT_REL_ARCH.get((arch, act), TOL_LOGIT_REL[act])
 
 
 def _cut(t: Optional[float]) -> float:

@@ -16,7 +16,7 @@ LIB_NAME = 'libsyconn_dense_hip.so'
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get('SD_LIB_NAME', LIB_NAME))
 
 # every symbol include/syconn_dense.h declares (checked by tests/test_abi.py)
-EXPORTS = ['sd_init', 'sd_device_count', 'sd_model_create', 'sd_model_destroy', 'sd_workspace_bytes', 'sd_forward', 'sd_forward_batch', 'sd_forward_labels_batch',
+EXPORTS = ['sd_init', 'sd_device_count', 'sd_model_create', 'sd_model_destroy', 'sd_workspace_bytes', 'sd_model_overflow', 'sd_forward', 'sd_forward_batch', 'sd_forward_labels_batch',
            'sd_tile_gather', 'sd_tile_scatter', 'sd_postproc_labels', 'sd_profile_enable', 'sd_profile_read',
            'sd_debug_read_buffer', 'sd_model_num_ops', 'sd_debug_last_launch_count', 'sd_last_error', 'sd_version', 'sd_snappy_max_compressed_length',
            'sd_snappy_compress', 'sd_snappy_uncompressed_length', 'sd_snappy_uncompress', 'sd_downsample2', 'sd_box_majority',
@@ -53,6 +53,7 @@ def load():
     lib.sd_model_create.restype = i32
     lib.sd_model_destroy.argtypes = [vp]; lib.sd_model_destroy.restype = None
     lib.sd_workspace_bytes.argtypes = [vp, i32, i32, i32]; lib.sd_workspace_bytes.restype = sz
+    lib.sd_model_overflow.argtypes = [vp, vp, C.POINTER(C.c_int)]; lib.sd_model_overflow.restype = i32
     lib.sd_forward.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp, sz, vp]; lib.sd_forward.restype = i32
     lib.sd_forward_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, i32, vp, sz, vp]
     lib.sd_forward_batch.restype = i32
@@ -96,6 +97,11 @@ def load():
     lib.sd_host_zero.argtypes = [vp, i64, i32]; lib.sd_host_zero.restype = i32
     _lib = lib
     return lib
+
+
+class ActivationOverflowError(RuntimeError, FloatingPointError):
+    """fp16 activation storage overflowed (> 65504) during a forward pass: its results are invalid.  Use act_dtype='bf16'
+    (fp32's exponent range) or 'f32'."""
 
 
 def check(rc: int, what: str = ''):

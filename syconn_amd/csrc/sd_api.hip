@@ -82,6 +82,7 @@ struct sd_model {
     char* dev_blob = nullptr; // packed weights
     size_t blob_bytes = 0;
     void* dev_zero = nullptr;
+    int* dev_ovf = nullptr;   // fp16 range-guard flag (set by the final-layer kernels, read and cleared by sd_model_overflow)
     // last forward
     std::vector<Dims> dims;
     std::vector<size_t> buf_off;
@@ -589,9 +590,10 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
 
     {
         m->blob_bytes = rup_sz(blob.size(), 256);
-        hipError_t e = hipMalloc((void**)&m->dev_blob, m->blob_bytes + 1024 + 256);
-        if (e == hipSuccess) e = hipMemset(m->dev_blob + m->blob_bytes + 1024, 0, 256);
+        hipError_t e = hipMalloc((void**)&m->dev_blob, m->blob_bytes + 1024 + 512);
+        if (e == hipSuccess) e = hipMemset(m->dev_blob + m->blob_bytes + 1024, 0, 512);
         m->dev_zero = m->dev_blob + m->blob_bytes + 1024;
+        m->dev_ovf = reinterpret_cast<int*>(m->dev_blob + m->blob_bytes + 1024 + 256);
         if (e == hipSuccess) e = hipMemcpy(m->dev_blob, blob.data(), blob.size(), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             err = std::string("weight upload: ") + hipGetErrorString(e);
@@ -645,6 +647,17 @@ int sd_profile_read(sd_model* m, int slot, float* ms, int n_ops) {
     const int n = std::min<int>(n_ops, (int)m->ops.size());
     const hipEvent_t* ev = m->events.data() + (size_t)slot * (m->ops.size() + 1);
     for (int i = 0; i < n; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
+    return SD_OK;
+}
+
+int sd_model_overflow(sd_model* m, void* stream, int* flag_out) {
+    if (!m || !flag_out) return fail(SD_ERR_INVALID, "null argument");
+    *flag_out = 0;
+    if (m->f32 || m->act_dtype != SD_F16 || !m->dev_ovf) return SD_OK;       // only fp16 storage can overflow
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemcpyAsync(flag_out, m->dev_ovf, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (*flag_out) HIP_TRY(hipMemsetAsync(m->dev_ovf, 0, sizeof(int), s));
     return SD_OK;
 }
 
@@ -794,6 +807,7 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
                     p.final_wfrag = m->dev_blob + op.fwfrag_off;
                     p.final_b = reinterpret_cast<const float*>(m->dev_blob + fo.bias_off);
                     p.final_cout = fo.d.cout; p.final_kind = out_kind; p.final_out = out_dev;
+                    p.ovf = m->dev_ovf;
                     if (lab) p.lab = *lab;
                     p.store_main = m->keep_all ? 1 : 0;
                 }
@@ -867,7 +881,7 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
                 p.fw = m->dev_blob + c2.fwfrag_off; p.fb = reinterpret_cast<const float*>(m->dev_blob + fo.bias_off);
                 p.final_cout = fo.d.cout; p.final_kind = out_kind; p.final_out = out_dev;
                 if (lab) p.lab = *lab;
-                p.zero = m->dev_zero;
+                p.zero = m->dev_zero; p.ovf = m->dev_ovf;
                 p.batch = N; p.tstride = tstride; p.out_tstride = out_tstride;
                 p.dbg = getenv("SD_DEC0_DBG") ? reinterpret_cast<long long*>(wsb) : nullptr;      // (timing builds) GroupNorm scratch
                 rc = launch_dec0(p, m->act_dtype, s);
@@ -921,7 +935,7 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
             p.w = reinterpret_cast<const float*>(m->dev_blob + op.wpack_off);
             p.bias = reinterpret_cast<const float*>(m->dev_blob + op.bias_off);
             p.wfrag = m->dev_blob + op.aux_off;
-            p.cout = d.cout; p.out = out_dev; p.out_kind = out_kind;
+            p.cout = d.cout; p.out = out_dev; p.out_kind = out_kind; p.ovf = m->dev_ovf;
             p.nvox = (long)a.d * a.h * a.w;
             p.batch = N; p.tstride = tstride; p.out_tstride = out_tstride;
             if (lab) p.lab = *lab;

@@ -312,6 +312,7 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
 #ifdef SD_DEC0_TIMING
             if (tsk == SD_DEC0_TIMING) ts[6] = __builtin_readcyclecounter();
 #endif
+            float guard = 1.f;
             if constexpr (KIND != SD_OUT_LOGITS_F32) {
                 // classes beyond final_cout hold -inf (weights 0, bias -inf): they are simply skipped, two at a time
                 float mx = fmaxf(l[0], l[1]);
@@ -331,9 +332,12 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
                     }
                 }
                 const float inv = 1.0f / sum;
+                guard = sum;
 #pragma unroll
                 for (int c2 = 0; c2 < 8; c2 += 2)
                     if (c2 == 0 || gcout > c2) { l[c2] *= inv; l[c2 + 1] *= inv; }
+            } else {
+                guard = logit_probe<T>(l, gcout);
             }
 #ifdef SD_DEC0_TIMING
             if (tsk == SD_DEC0_TIMING) ts[7] = __builtin_readcyclecounter();
@@ -341,6 +345,7 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
             const int x = c0 - 2 + co.xx;
             if ((unsigned)co.plane < (unsigned)nz && co.y < gH && co.xx >= 2 && co.xx < PW - 2 && x < gW) {
                 const size_t v = (size_t)(__umul24(__umul24(z0 + co.plane, gH) + co.y, gW) + x);      // < 2^31 (launch_dec0)
+                range_guard<T>(guard, p.ovf);
                 if constexpr (KIND >= SD_OUT_LABELS_U8) {
                     uint8_t lab = 0;
                     if constexpr (KIND == SD_OUT_LABELS_U8) {

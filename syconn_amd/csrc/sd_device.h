@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include <utility>
 
 typedef __bf16 bf16_t;
@@ -123,4 +124,26 @@ __device__ __forceinline__ float max_xor16(float m) {      // max with lane^16, 
 __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// fp16 range guard.  fp16 storage overflows to +-inf above 65504 (bf16 and fp32 share fp32's exponent range and cannot), and
+// an inf activation reaches the final layer as an inf / NaN logit of EVERY class (w > 0: +inf, w < 0: -inf, w == 0: NaN; any
+// NaN on the way stays NaN).  The final-layer epilogues therefore test one value per voxel -- the softmax denominator (NaN as
+// soon as one logit is NaN or the maximum is +-inf) or, for raw logits, sum(logit * 0) -- and raise a device flag the host
+// reads after the forward pass (sd_model_overflow).  Compiled out for bf16: the headline path pays nothing.
+template <typename T>
+__device__ __forceinline__ void range_guard(float v, int* flag) {
+    if constexpr (std::is_same<T, f16_t>::value) {
+        if (!(fabsf(v) < 3.0e38f)) *flag = 1;
+    }
+}
+template <typename T>
+__device__ __forceinline__ float logit_probe(const float (&l)[8], int ncls) {     // 0 iff all existing logits are finite
+    float c = 0.f;
+    if constexpr (std::is_same<T, f16_t>::value) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < ncls) c = fmaf(l[k], 0.f, c);
+    }
+    return c;
 }

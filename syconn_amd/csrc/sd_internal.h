@@ -63,6 +63,7 @@ struct ConvParams {
     // deferred GroupNorm apply (k_conv_mfma<..., MODE 2>): src0 / src1 hold RAW convolution outputs; gn0 / gn1 = their
     // per-tile [2*C] float tables (scale then shift; tile t at + t*tstride bytes) or nullptr when that input is final
     const float* gn0; const float* gn1; int gn_relu0, gn_relu1;
+    int* ovf;          // fp16 range guard of the fused final layer (sd_device.h: range_guard)
 };
 
 struct FirstParams {
@@ -117,6 +118,7 @@ struct FinalParams {
     // 1x1x1 convolution (the normalised tensor is never written); scale_shift = [2*Cs] floats per tile or nullptr
     const float* gn_scale_shift; int gn_relu;
     const void* wfrag; // hi/lo MFMA A fragments of the weights in natural channel order: [Cs/16][2][64 lanes][8] of T
+    int* ovf;          // fp16 range guard (sd_device.h: range_guard)
 };
 
 struct GnParams {
@@ -159,6 +161,7 @@ struct Dec0Params {
     int HP, HP1, nstrip, zsplit, nzg;
     unsigned magic_hp, magic_hp1;
     long long* dbg;    // SD_DEC0_TIMING builds: per-wave cycle stamps of one step (else unused)
+    int* ovf;          // fp16 range guard (sd_device.h: range_guard)
 };
 int launch_dec0(Dec0Params p, int act_dtype, hipStream_t s);
 

@@ -1064,6 +1064,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
 #pragma unroll
             for (int co = 0; co < 8; ++co)
                 if (co < p.final_cout) mx = fmaxf(mx, l[co]);
+            float guard = 1.f;
             if (p.final_kind != SD_OUT_LOGITS_F32) {
                 float sum = 0.f;
 #pragma unroll
@@ -1072,10 +1073,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                     sum += l[co];
                 }
                 const float inv = 1.0f / sum;
+                guard = sum;
 #pragma unroll
                 for (int co = 0; co < 8; ++co) l[co] *= inv;
+            } else {
+                guard = logit_probe<T>(l, p.final_cout);
             }
             const bool vmine = half ? valid[tp + 1] : valid[tp];
+            if (vmine) range_guard<T>(guard, p.ovf);
             const size_t v = half ? voxoff[tp + 1] : voxoff[tp];
             if (vmine) {
                 if (p.final_kind == SD_OUT_LABELS_U8) {
@@ -1555,8 +1560,11 @@ __global__ __launch_bounds__(256) void k_final(const FinalParams p) {
             for (int co = 0; co < 8; ++co)
                 if (co < p.cout) { acc[co] = __expf(acc[co] - mx); sum += acc[co]; }
             const float inv = 1.0f / sum;     // same exp / reciprocal form as the fused epilogue of k_conv_mfma
+            range_guard<T>(sum, p.ovf);
 #pragma unroll
             for (int co = 0; co < 8; ++co) acc[co] *= inv;
+        } else {
+            range_guard<T>(logit_probe<T>(acc, p.cout), p.ovf);
         }
         if (p.out_kind == SD_OUT_LABELS_U8) {
             uint8_t lab = 0;
@@ -1652,6 +1660,7 @@ __global__ __launch_bounds__(256) void k_final_mfma(const FinalParams p) {
 #pragma unroll
         for (int co = 0; co < 8; ++co)
             if (co < p.cout) mx = fmaxf(mx, l[co]);
+        float guard = 1.f;
         if (p.out_kind != SD_OUT_LOGITS_F32) {
             float sum = 0.f;
 #pragma unroll
@@ -1660,11 +1669,15 @@ __global__ __launch_bounds__(256) void k_final_mfma(const FinalParams p) {
                 sum += l[co];
             }
             const float inv = 1.0f / sum;
+            guard = sum;
 #pragma unroll
             for (int co = 0; co < 8; ++co) l[co] *= inv;
+        } else {
+            guard = logit_probe<T>(l, p.cout);
         }
         const long v = vv[half];
         if (v < p.nvox) {
+            range_guard<T>(guard, p.ovf);
             if (p.out_kind == SD_OUT_LABELS_U8) {
                 uint8_t lab = 0;
                 for (int k = 0; k < p.lab.n; ++k) {

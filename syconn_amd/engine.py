@@ -142,6 +142,19 @@ class DenseModel:
                 'sd_forward_labels_batch')
         return out
 
+    def overflowed(self) -> bool:
+        """fp16 range guard (include/syconn_dense.h: sd_model_overflow): True if a forward pass since the last call stored
+        an activation beyond fp16's range (results invalid).  Synchronises the current stream; always False for bf16 / f32."""
+        flag = C.c_int(0)
+        L.check(self.lib.sd_model_overflow(self._h, _stream(), C.byref(flag)), 'sd_model_overflow')
+        return bool(flag.value)
+
+    def check_overflow(self):
+        if self.overflowed():
+            raise L.ActivationOverflowError(
+                'fp16 activation overflow (a stored activation exceeded 65504): the results of this forward pass are invalid; '
+                "use act_dtype='bf16' (fp32 exponent range) or 'f32'")
+
     def read_buffer(self, buf: int) -> torch.Tensor:
         """Activation buffer `buf` of the last forward as float32 (C,d,h,w) -- test support."""
         dims = (C.c_int32 * 4)()

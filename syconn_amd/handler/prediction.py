@@ -47,8 +47,10 @@ class Predictor:
     pickled ``.pt`` file, `state_dict_src`, `device`, `tile_shape`/`overlap_shape` (z,y,x), `out_shape`
     (C,z,y,x), `strict_shapes`, `apply_softmax`, `apply_argmax`, `float16`, `batch_size`, `verbose`.
     `transform`, `augmentations`, `offset` (valid convolutions) and `argmax_with_threshold` are unused by SyConn
-    and rejected.  Extra keyword `act_dtype` ('f16' default, 'bf16') names the storage type of activations on the
-    device; accumulation is fp32.  The reference computes in fp32 (`float16=False`, prediction.py:777-779); fp16 storage is
+    and rejected.  Extra keyword `act_dtype` ('f16' default, 'bf16', or 'f32' = the slow reference-precision mode: fp32 storage
+    and arithmetic like the reference) names the storage type of activations on the device; accumulation is fp32.  fp16 is
+    range-guarded: an overflow (> 65504) is detected on the device; the default then repeats the prediction in bf16, an
+    explicit 'f16' raises ``ActivationOverflowError`` (a ``RuntimeError``).  The reference computes in fp32 (`float16=False`, prediction.py:777-779); fp16 storage is
     the closest the matrix cores offer at full rate: against the fp32 oracle at the 128^3 headline configuration it
     changes 0.06 % of the threshold-rule labels (bf16: 0.45 %, max logit error 8.7e-4 vs 7.4e-3 of the logit range;
     tests/test_gpu_labels_headline.py).  bf16 keeps fp32's exponent range and is ~3 % faster.  `batch_size`: tiles per launch set (default: automatic,
@@ -107,9 +109,14 @@ class Predictor:
         self.apply_argmax = apply_argmax
         self.verbose = verbose
         self.report_inf_speed = report_inf_speed
+        # fp16 range guard: fp16 storage overflows above 65504 (the reference computes in fp32 and cannot).  The library flags
+        # it (sd_model_overflow).  With the DEFAULT storage type the prediction is then repeated in bf16 (fp32's exponent
+        # range) and the Predictor stays there; an explicitly requested 'f16' raises ActivationOverflowError instead.
+        self._bf16_fallback = act_dtype is None
         if act_dtype is None:
             act_dtype = 'f16'          # `float16=True` (elektronn3: model.half()) selects the same storage type
         self.act_dtype = act_dtype
+        self._gn_groups = group_norm_groups
         self._dm = DenseModel(model, act_dtype=act_dtype, device=self.device, group_norm_groups=group_norm_groups)
         self.out_channels = self._dm.out_channels
         if n_streams is None:
@@ -184,6 +191,21 @@ class Predictor:
                         keep = np.minimum(tile, spatial - lo)
                         tile_scatter(obuf[k][j], ol, keep, out, lo)
 
+    def _guarded(self, run):
+        """Run one tiled prediction; if the fp16 range guard fired, repeat it in bf16 (default storage type) or raise."""
+        from ..engine import DenseModel
+        run()
+        if self.act_dtype not in ('f16', 'fp16', 'float16') or not self._dm.overflowed():
+            return
+        if not self._bf16_fallback:
+            raise L.ActivationOverflowError(
+                "fp16 activation overflow (a stored activation exceeded 65504): results invalid; use act_dtype='bf16' or 'f32'")
+        log_main.warning('syconn_amd.Predictor: fp16 activation overflow detected -- switching this Predictor to bf16 storage '
+                         'and repeating the prediction')
+        self.act_dtype = 'bf16'
+        self._dm = DenseModel(self.model, act_dtype='bf16', device=self.device, group_norm_groups=self._gn_groups)
+        run()
+
     def _batch_for(self, tin, ntiles: int) -> int:
         """Tiles per launch set: `batch_size` if given (elektronn3's Predictor argument), else as many as keep the
         workspaces of one batch under ~8 GiB (at most 8): 128^3 tiles run 8 at a time, the reference's
@@ -211,7 +233,7 @@ class Predictor:
         out_dev = torch.empty((self.out_channels, *spatial), dtype=torch.float32, device=self.device)
         for b in range(n):
             vol = inp[b, 0].to(torch.float32).contiguous().to(self.device)
-            self._tiled(vol, out_dev, kind)
+            self._guarded(lambda: self._tiled(vol, out_dev, kind))
             out[b] = out_dev.cpu()
         if self.apply_argmax:
             out = out.argmax(1)
@@ -231,7 +253,7 @@ class Predictor:
         inner = tuple(int(s) - (2 * int(o) if halo_included else 0) for s, o in
                       zip(raw_u8.shape, (self.overlap_shape if self.overlap_shape is not None else (0, 0, 0))))
         out = torch.empty((self.out_channels, *inner), dtype=torch.uint8, device=self.device)
-        self._tiled(raw_u8, out, L.SD_OUT_PROBS_U8, halo_included=halo_included)
+        self._guarded(lambda: self._tiled(raw_u8, out, L.SD_OUT_PROBS_U8, halo_included=halo_included))
         return out
 
 
@@ -248,8 +270,9 @@ class Predictor:
         inner = tuple(int(s) - (2 * int(o) if halo_included else 0) for s, o in
                       zip(raw_u8.shape, (self.overlap_shape if self.overlap_shape is not None else (0, 0, 0))))
         out = torch.empty((1, *inner), dtype=torch.uint8, device=self.device)
-        self._tiled(raw_u8, out, L.SD_OUT_PROBS_U8, label_args=([int(i) for i in ids], [float(t) for t in thresholds]),
-                    halo_included=halo_included)
+        self._guarded(lambda: self._tiled(raw_u8, out, L.SD_OUT_PROBS_U8,
+                                          label_args=([int(i) for i in ids], [float(t) for t in thresholds]),
+                                          halo_included=halo_included))
         return out[0]
 
 

@@ -14,19 +14,23 @@ import pytest
 import torch
 
 from bench import BENCH_FINAL_SCALE, synthetic_em_tiles
-from oracle.label_margin import TOL_LOGIT_REL, label_split
+from oracle.label_margin import label_split, stated_tolerance
 from oracle.unet_ref import ARCHS, UNet
 
 pytestmark = pytest.mark.gpu
 
-# bounds on the fraction of voxels whose oracle value lies inside the STATED tolerance of a decision boundary (these may
-# legitimately differ; measured with the tolerance measured on the tensors in round 2: threshold rule 5.3e-2 / 6.6e-3, argmax
-# 1.2e-2 / 1.3e-3 -- the a-priori tolerance is ~1.4x wider) and on the labels that really differ (measured: 4.5e-3 / 5.8e-4
-# of the voxels for the threshold rule, 5e-4 / 6e-5 for argmax)
-MAX_UNSAFE_FRAC = {'bf16': (0.12, 0.03), 'f16': (0.02, 0.005)}
-MIN_AGREEMENT = {'bf16': (0.993, 0.999), 'f16': (0.999, 0.9998)}
-# median top-2 logit margin of the oracle / stated tolerance (scale-invariant for a ReLU network)
-MIN_MARGIN_OVER_TOL = {'bf16': 8.0, 'f16': 60.0}
+# per case: bounds on the fraction of voxels whose oracle value lies inside the STATED tolerance of a decision boundary (these
+# may legitimately differ) for (threshold rule, argmax), floors of the labels that really agree, and the floor of "median top-2
+# logit margin of the oracle / stated tolerance" (scale-invariant for a ReLU network).  Measured on MI355X (round 3):
+#   semseg_spine bf16: unsafe 0.171 / 0.017, agreement 0.99546 / 0.99949, margin 12.7
+#   semseg_spine f16 : unsafe 0.021 / 0.0020, agreement 0.99945 / 0.99994, margin 98
+#   mivcsj f16 (tolerance 2.5e-3; its random-init logits are flatter): agreement 0.9991 / 0.9992
+BOUNDS = {
+    ('semseg_spine', 'bf16'): dict(unsafe=(0.25, 0.03), agree=(0.993, 0.999), margin=8.0),
+    ('semseg_spine', 'f16'): dict(unsafe=(0.035, 0.005), agree=(0.999, 0.9998), margin=60.0),
+    ('semseg_axon', 'bf16'): dict(unsafe=(0.25, 0.03), agree=(0.993, 0.999), margin=8.0),
+    ('mivcsj', 'f16'): dict(unsafe=(0.06, 0.06), agree=(0.998, 0.998), margin=25.0),
+}
 
 
 @pytest.mark.parametrize('arch,act', [('semseg_spine', 'bf16'), ('semseg_spine', 'f16'), ('semseg_axon', 'bf16'), ('mivcsj', 'f16')])
@@ -47,13 +51,14 @@ def test_full_size_tile_labels_vs_fp32_oracle(gpu, arch, act):
     lg = dm.forward_batch(x, L.SD_OUT_LOGITS_F32)[0].cpu()
     pr = dm.forward_batch(x, L.SD_OUT_PROBS_F32)[0].cpu()
     lab = dm.forward_labels_batch(x, ids, thr_u8)[0].cpu()
-    r = label_split(ref_logits, lg, pr, lab, ids, [None] * dm.out_channels, TOL_LOGIT_REL[act])
+    tol, bd = stated_tolerance(arch, act), BOUNDS[(arch, act)]
+    r = label_split(ref_logits, lg, pr, lab, ids, [None] * dm.out_channels, tol)
     print(f'\n[{arch} {act}] 128^3 vs fp32 oracle: ' + ', '.join(f'{k}={v:.4g}' for k, v in r.items()))
-    assert r['logit_err_max_rel'] <= TOL_LOGIT_REL[act], r
+    assert r['logit_err_max_rel'] <= tol, r
     assert r['label_mismatch_safe'] == 0, r          # threshold rule of the reference: exact wherever it can be
     assert r['argmax_mismatch_safe'] == 0, r         # argmax: exact wherever the fp32 margin exceeds the stated tolerance
-    assert r['label_unsafe_frac'] <= MAX_UNSAFE_FRAC[act][0] and r['argmax_unsafe_frac'] <= MAX_UNSAFE_FRAC[act][1], r
-    assert r['label_agreement'] >= MIN_AGREEMENT[act][0] and r['argmax_agreement'] >= MIN_AGREEMENT[act][1], r
+    assert r['label_unsafe_frac'] <= bd['unsafe'][0] and r['argmax_unsafe_frac'] <= bd['unsafe'][1], r
+    assert r['label_agreement'] >= bd['agree'][0] and r['argmax_agreement'] >= bd['agree'][1], r
     # the workload is meaningful: several classes are really predicted, and most voxels carry a decisive margin
     assert len(torch.unique(lab)) >= 3
-    assert r['median_top2_margin_over_tol'] >= MIN_MARGIN_OVER_TOL[act], r
+    assert r['median_top2_margin_over_tol'] >= bd['margin'], r

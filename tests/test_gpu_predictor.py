@@ -356,6 +356,35 @@ def test_config3_geometry_batching_and_streams_do_not_change_results(gpu):
     assert int(s.max()) <= 255 and int(s.min()) > 255 - 6
 
 
+def test_config3_full_volume_equals_per_tile_path(gpu):
+    """BASELINE configs[2] at FULL size: semseg_axon, a 512^3 uint8 volume in overlapping 128^3 model tiles (useful
+    (112,96,96) + halo (8,16,16), grid 5x6x6 = 180 tiles, the last tile of every axis ragged, zeros outside the volume).
+    The stitched uint8 probabilities of the batched Predictor run must equal, bit for bit, what a SINGLE forward of each
+    sampled tile (gathered with zero padding, cropped by the halo) gives: corners, faces, interior and the ragged ends."""
+    from syconn_amd import _lib as L
+    from syconn_amd.engine import DenseModel, tile_gather
+    from syconn_amd.handler.prediction import Predictor
+    model = build_unet('semseg_axon', seed=4, final_scale=6.0)
+    g = torch.Generator().manual_seed(2)
+    vol = torch.randint(0, 256, (512, 512, 512), dtype=torch.uint8, generator=g).to(gpu)
+    tile, ol = np.array((112, 96, 96)), np.array((8, 16, 16))
+    p = Predictor(model, tile_shape=tuple(tile), overlap_shape=tuple(ol), out_shape=(6, 512, 512, 512), apply_softmax=True,
+                  act_dtype='bf16')
+    full = p.predict_proba_u8_device(vol)
+    assert tuple(full.shape) == (6, 512, 512, 512)
+    s = full[:, ::7, ::5, ::3].to(torch.int32).sum(0)
+    assert int(s.max()) <= 255 and int(s.min()) > 255 - 6
+    dm = DenseModel(model, act_dtype='bf16', device=gpu)
+    for pos in ((0, 0, 0), (4, 5, 5), (2, 3, 1), (4, 0, 2), (0, 5, 0), (1, 2, 5), (3, 4, 4)):
+        lo = tile * np.array(pos)
+        keep = np.minimum(tile, 512 - lo)
+        t = tile_gather(vol, lo - ol, tile + 2 * ol)
+        one = dm.forward(t, L.SD_OUT_PROBS_U8)
+        want = one[:, ol[0]:ol[0] + keep[0], ol[1]:ol[1] + keep[1], ol[2]:ol[2] + keep[2]]
+        got = full[:, lo[0]:lo[0] + keep[0], lo[1]:lo[1] + keep[1], lo[2]:lo[2] + keep[2]]
+        assert torch.equal(got, want), pos
+
+
 def test_predict_labels_device_equals_probs_then_rule(gpu):
     """Predictor.predict_labels_u8_device (label rule in the final epilogue, tiled) == label rule applied to
     predict_proba_u8_device, incl. a ragged last launch set and a single-tile volume."""

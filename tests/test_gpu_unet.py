@@ -17,8 +17,8 @@ pytestmark = pytest.mark.gpu
 # stated tolerances: max |diff| relative to max|logit| of the case, and RMS diff relative to RMS logit.
 # One bf16 ulp is 2^-8 = 3.9e-3 relative: a different summation order flips roundings of stored activations, so even
 # the same-precision emulation differs by a few ulp at the logits after ~20 layers; the RMS bound is the sharp one.
-TOL_EMU = {'bf16': 3e-2, 'f16': 5e-3}        # HIP vs same-precision emulation (max)
-TOL_EMU_RMS = {'bf16': 1.2e-2, 'f16': 2.5e-3}
+TOL_EMU = {'bf16': 2e-2, 'f16': 3e-3}        # HIP vs same-precision emulation (max; measured over all cases: 1.45e-2 / 2.0e-3)
+TOL_EMU_RMS = {'bf16': 1.2e-2, 'f16': 2.5e-3}   # (measured: 9.0e-3 / 1.7e-3)
 TOL_FP32 = {'bf16': 5e-2, 'f16': 8e-3}       # HIP vs fp32 oracle (max)
 TOL_FP32_RMS = {'bf16': 2e-2, 'f16': 4e-3}
 
