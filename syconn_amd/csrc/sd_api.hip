@@ -773,7 +773,7 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
                 p.wpack = reinterpret_cast<const float*>(m->dev_blob + op.wpack_off);
                 p.bias = reinterpret_cast<const float*>(m->dev_blob + op.bias_off);
                 p.relu = d.relu;
-                p.batch = N; p.tstride = tstride; p.in_tstride = in_tstride;
+                p.batch = N; p.tstride = tstride; p.in_tstride = in_tstride; p.ovf = m->dev_ovf;
                 p.nbx = (o.w + SD_BX - 1) / SD_BX; p.nby = (o.h + BY - 1) / BY; p.nbz = (o.d + BZ - 1) / BZ;
                 rc = launch_first(p, m->act_dtype, in_dtype, d.kz, s);
             } else {
@@ -791,7 +791,7 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
                 p.wpack = m->dev_blob + op.wpack_off;
                 p.bias = reinterpret_cast<const float*>(m->dev_blob + op.bias_off);
                 p.relu = d.relu; p.zero = m->dev_zero;
-                p.store_main = 1;
+                p.store_main = 1; p.ovf = m->dev_ovf;
                 p.batch = N; p.tstride = tstride; p.out_tstride = out_tstride;
 #ifdef SD_TIMING
                 p.dbg = (getenv("SD_TIMING_OP") && atoi(getenv("SD_TIMING_OP")) == (int)i) ? reinterpret_cast<long long*>(wsb + m->buf_off[1]) : nullptr;
@@ -895,7 +895,7 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
             p.Pd = (size_t)m->dims[d.dst].d * m->dims[d.dst].h * m->dims[d.dst].w;
             p.wpack = m->dev_blob + op.wpack_off;
             p.bias = reinterpret_cast<const float*>(m->dev_blob + op.bias_off);
-            p.relu = d.relu; p.ntot = d.kz * 4 * p.Cd;
+            p.relu = d.relu; p.ntot = d.kz * 4 * p.Cd; p.ovf = m->dev_ovf;
             p.batch = N; p.tstride = tstride;
             if (m->buf_gn[d.src0] >= 0) {
                 p.gn = reinterpret_cast<const float*>(wsb + m->gn_tab_off[d.src0]);

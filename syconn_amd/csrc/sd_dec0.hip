@@ -137,11 +137,13 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
     };
     // acc rounded + ReLU, zeroed where !ok, quads traded with lane^32; the lane's record (chunk = half, both 16-byte halves)
     // goes to LDS byte address `rec` (physical half order given by `sw` = 0 / 16)
+    StoreGuard<T> sguard;      // fp16 range guard over every value this lane rounds to the storage type (sd_device.h)
     auto write_tile = [&](const f32x16& acc, bool ok, uint32_t rec, uint32_t sw) {
         unsigned pk[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             pk[k] = pk_max16(Act<T>::pack2(acc[2 * k], acc[2 * k + 1]), 0u);
+            sguard.see(pk[k]);
             if (!ok) pk[k] = 0u;
         }
         swap32x4(pk[0], pk[4], pk[1], pk[5], pk[2], pk[6], pk[3], pk[7]);
@@ -251,6 +253,7 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
             D0_T(5);
         }
         D0_DUMP();
+        sguard.flush(p.ovf);
     } else {
         // -------------------------------------------------------------------------------------------- tail waves
         const int ow = wave - 4, py = ow >> 1, px = ow & 1;
@@ -435,7 +438,10 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
                 D0_T(2);
                 unsigned pk[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) pk[i] = pk_max16(Act<T>::pack2(acc[2 * i], acc[2 * i + 1]), 0u);
+                for (int i = 0; i < 8; ++i) {
+                    pk[i] = pk_max16(Act<T>::pack2(acc[2 * i], acc[2 * i + 1]), 0u);
+                    sguard.see(pk[i]);
+                }
                 if ((k & 1) == 0) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) pkA[i] = pk[i];
@@ -455,6 +461,7 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
         }
         if (pending) final_pair();
         D0_DUMP();
+        sguard.flush(p.ovf);
     }
 }
 

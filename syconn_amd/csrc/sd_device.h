@@ -126,11 +126,27 @@ __device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// fp16 range guard.  fp16 storage overflows to +-inf above 65504 (bf16 and fp32 share fp32's exponent range and cannot), and
-// an inf activation reaches the final layer as an inf / NaN logit of EVERY class (w > 0: +inf, w < 0: -inf, w == 0: NaN; any
-// NaN on the way stays NaN).  The final-layer epilogues therefore test one value per voxel -- the softmax denominator (NaN as
-// soon as one logit is NaN or the maximum is +-inf) or, for raw logits, sum(logit * 0) -- and raise a device flag the host
-// reads after the forward pass (sd_model_overflow).  Compiled out for bf16: the headline path pays nothing.
+// fp16 range guard.  fp16 storage overflows to +-inf above 65504 (bf16 and fp32 share fp32's exponent range and cannot).  An inf
+// does NOT reliably reach the logits: the next convolution turns it into NaNs, and the packed integer ReLU maps a NaN with the
+// sign bit set to 0 -- a whole tensor can come out as finite zeros (observed: tests/test_gpu_f32.py::test_fp16_range_guard).  So
+// the guard sits where overflow is BORN: every epilogue that rounds fp32 accumulators to the storage type keeps a per-lane running
+// maximum of |value| (one v_max3_f32 per two values) and raises a device flag when it reaches 65520 (the smallest magnitude
+// that rounds to inf); the final-layer epilogues additionally test the softmax denominator / the logits.  The host reads
+// the flag after the forward pass (sd_model_overflow).  Everything here compiles to nothing for bf16: the headline path pays nothing.
+template <typename T> struct StoreGuard {
+    unsigned m = 0u;       // running packed unsigned 16-bit maximum of the magnitudes stored so far
+    // pk: two values already rounded to the storage type, sign bits clear (behind a ReLU)
+    __device__ __forceinline__ void see(unsigned pk) {
+        if constexpr (std::is_same<T, f16_t>::value) {
+            typedef __attribute__((ext_vector_type(2))) unsigned short us2;
+            m = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(us2, m), __builtin_bit_cast(us2, pk)));
+        }
+    }
+    __device__ __forceinline__ void see_signed(unsigned pk) { see(pk & 0x7fff7fffu); }       // raw values of either sign
+    __device__ __forceinline__ void flush(int* flag) const {      // inf / NaN = exponent field all ones = magnitude >= 0x7c00
+        if constexpr (std::is_same<T, f16_t>::value) { if ((m & 0xffffu) >= 0x7c00u || (m >> 16) >= 0x7c00u) *flag = 1; }
+    }
+};
 template <typename T>
 __device__ __forceinline__ void range_guard(float v, int* flag) {
     if constexpr (std::is_same<T, f16_t>::value) {

@@ -63,7 +63,7 @@ struct ConvParams {
     // deferred GroupNorm apply (k_conv_mfma<..., MODE 2>): src0 / src1 hold RAW convolution outputs; gn0 / gn1 = their
     // per-tile [2*C] float tables (scale then shift; tile t at + t*tstride bytes) or nullptr when that input is final
     const float* gn0; const float* gn1; int gn_relu0, gn_relu1;
-    int* ovf;          // fp16 range guard of the fused final layer (sd_device.h: range_guard)
+    int* ovf;          // fp16 range guard flag (sd_device.h: StoreGuard on every store, range_guard in the fused final layer)
 };
 
 struct FirstParams {
@@ -76,6 +76,7 @@ struct FirstParams {
     int relu;
     int nbx, nby, nbz;
     int batch; size_t tstride, in_tstride;
+    int* ovf;          // fp16 range guard flag (sd_device.h)
 };
 
 struct UpconvParams {
@@ -92,6 +93,7 @@ struct UpconvParams {
     int ntot;          // ntaps*Cd
     int batch; size_t tstride;
     const float* gn; int gn_relu;   // deferred GroupNorm apply of `src` ([2*Cs] floats per tile) or nullptr
+    int* ovf;          // fp16 range guard flag (sd_device.h)
 };
 
 struct PoolParams {

@@ -508,6 +508,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WAITN) : "memory");
     }
 
+    StoreGuard<T> sguard;      // fp16 range guard over everything this lane rounds to the storage type (sd_device.h)
     int gc = 0, gs = 0;   // chunk / stage counters across blocks (slot parity)
     int ph0 = 0;          // SPREAD: halo coordinates of this lane's first piece, packed z << 16 | y << 8 | x
     if constexpr (SPREAD) {
@@ -559,6 +560,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                         unsigned lo = Act<T>::pack2(a1[4 * q] + b1[q][0], a1[4 * q + 1] + b1[q][1]);
                         unsigned hi = Act<T>::pack2(a1[4 * q + 2] + b1[q][2], a1[4 * q + 3] + b1[q][3]);
                         if (p.first_relu) { lo = pk_max16(lo, 0u); hi = pk_max16(hi, 0u); }
+                        sguard.see_signed(lo); sguard.see_signed(hi);
                         if (!invol) { lo = 0u; hi = 0u; }      // the second conv's zero padding
                         typedef __attribute__((ext_vector_type(2))) unsigned u2;
                         char* const slot = ldsA + ((gc + (q >> 1)) % NA) * A_BYTES;
@@ -824,6 +826,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         const size_t vo0 = (size_t)(vz0 * p.H + vy) * p.W + vx, vzs = (size_t)p.H * p.W;
         float* const part = reinterpret_cast<float*>(ldsA + ((gc - 1) % NA) * A_BYTES);   // free: last chunk's halo slot
         const unsigned relu_floor = p.relu ? 0u : 0x80008000u;
+        const unsigned guard_mask = 0x7fff7fffu;      // (range guard: magnitudes)
         v8 s1, s2;
         if (p.gn_sums) {
 #pragma unroll
@@ -850,7 +853,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                     val2[e2] = vyx && (vz0 + ip + e2) < p.D;
 #pragma unroll
                     for (int k = 0; k < 8; ++k)      // ReLU = packed max against 0; without it against the most negative pair (identity)
+                    {
                         pk2[e2][k] = pk_max16(Act<T>::pack2(acc[ip + e2][j][2 * k], acc[ip + e2][j][2 * k + 1]), relu_floor);
+                        sguard.see(pk2[e2][k] & guard_mask);
+                    }
                     if (p.gn_sums) {
                         u4 lo = {pk2[e2][0], pk2[e2][1], pk2[e2][2], pk2[e2][3]};
                         u4 hi = {pk2[e2][4], pk2[e2][5], pk2[e2][6], pk2[e2][7]};
@@ -929,7 +935,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int k = 0; k < 8; ++k) pk[i][j][k] = pk_max16(pk[i][j][k], 0u);
+                for (int k = 0; k < 8; ++k) { pk[i][j][k] = pk_max16(pk[i][j][k], 0u); sguard.see(pk[i][j][k]); }
+    } else if constexpr (std::is_same<T, f16_t>::value) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sguard.see_signed(pk[i][j][k]);
     }
     // ---- fused GroupNorm statistics ---------------------------------------------------------------------------------
     // sum and sum of squares per output channel over the block's valid voxels, from the ROUNDED values (what the
@@ -1130,6 +1143,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
 #endif
         lb = nlb; z0 = nz0; y0 = ny0; x0 = nx0; tn = ntn;
     }
+    sguard.flush(p.ovf);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1176,6 +1190,7 @@ __global__ __launch_bounds__(256) void k_conv_first(const FirstParams p) {
         toff[s] = (kz * HY + ky) * HX + kx;
     }
     T* const dst = reinterpret_cast<T*>(reinterpret_cast<char*>(p.dst) + blockIdx.z * p.tstride);
+    StoreGuard<T> sguard;
     const int ntiles = (p.Cd + 31) / 32;
     const int half = lane >> 5;
     const size_t P = (size_t)p.D * p.H * p.W;
@@ -1210,9 +1225,12 @@ __global__ __launch_bounds__(256) void k_conv_first(const FirstParams p) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) pk[k] = pk_max16(pk[k], 0u);
             }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sguard.see_signed(pk[k]);
             store_tile_rows_pk<T>(pk, dst, P, (size_t)(vz * p.H + vy) * p.W + vx, valid, nt * 32, half, p.Cd);
         }
     }
+    sguard.flush(p.ovf);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1275,8 +1293,8 @@ __global__ __launch_bounds__(256) void k_upconv_mfma(const UpconvParams p) {
             for (int j = 0; j < 2; ++j) acc[i][j] = Act<T>::mfma(wf[j], xf[i], acc[i][j]);
     }
 
-    using v4 = typename Act<T>::v4;
     T* const dst = reinterpret_cast<T*>(reinterpret_cast<char*>(p.dst) + blockIdx.z * p.tstride);
+    StoreGuard<T> sguard;
     const int H2 = 2 * p.H, W2 = 2 * p.W;
     // The lane pair (l, l^32) holds channels 8q + 0..3 / 8q + 4..7 of the same voxel: trading quad q0 of the upper lane against
     // quad q1 of the lower one gives every lane 8 consecutive channels = ONE 16-byte store per quad pair instead of two
@@ -1303,6 +1321,7 @@ __global__ __launch_bounds__(256) void k_upconv_mfma(const UpconvParams p) {
                     }
                     d[h][0] = Act<T>::pack2(v[0], v[1]);
                     d[h][1] = Act<T>::pack2(v[2], v[3]);
+                    sguard.see_signed(d[h][0]); sguard.see_signed(d[h][1]);
                 }
                 swap32(d[0][0], d[1][0]);
                 swap32(d[0][1], d[1][1]);
@@ -1317,6 +1336,7 @@ __global__ __launch_bounds__(256) void k_upconv_mfma(const UpconvParams p) {
             }
         }
     }
+    sguard.flush(p.ovf);
 }
 
 // K5, row-coalescing form for the HBM-bound up-convolutions (compile-time NCH input chunks, NTAB = C_out/16 MFMA
@@ -1345,6 +1365,7 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
     const T* const wp = reinterpret_cast<const T*>(p.wpack);
     char* const dst = reinterpret_cast<char*>(p.dst) + blockIdx.z * p.tstride;
     const int H2 = 2 * p.H, W2 = 2 * p.W;
+    StoreGuard<T> sguard;
     __shared__ __attribute__((aligned(16))) float gtab[GN ? 2 * NCH * SD_CHUNK : 4];     // deferred GroupNorm scale / shift of this tile
     const float* gss = nullptr;
     if constexpr (GN) {
@@ -1426,6 +1447,11 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
                     if (p.relu) v = fmaxf(v, 0.f);
                     o[e] = (T)v;
                 }
+                {
+                    typedef __attribute__((ext_vector_type(2))) unsigned u2g;
+                    const u2g ob = __builtin_bit_cast(u2g, o);
+                    sguard.see_signed(ob.x); sguard.see_signed(ob.y);
+                }
                 const int pc = (4 * j + q) ^ (vl & SWM);
                 *reinterpret_cast<v4*>(tile + vl * ROW + pc * 16 + half * 8) = o;
             }
@@ -1460,6 +1486,7 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
         }
     }
     }
+    sguard.flush(p.ovf);
 }
 
 // ---------------------------------------------------------------------------------------------------------
