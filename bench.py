@@ -398,7 +398,8 @@ def volume_main(args):
         chunk, halo, tile = (236, 481, 482), (20, 31, 30), (138, 181, 271)
     else:                                 # model tile 128^3 = useful (112,96,96) + halo (8,16,16); 2x2x2 tiles per chunk
         chunk, halo, tile = (224, 192, 192), (8, 16, 16), (112, 96, 96)
-    pred = Predictor(sd, device=dev, tile_shape=tile, overlap_shape=halo, apply_softmax=True, act_dtype=act)
+    pred = Predictor(sd, device=dev, tile_shape=tile, overlap_shape=halo, apply_softmax=True, act_dtype=act,
+                     defer_guard=True)      # (fp16 range guard asked once per volume: no sync per chunk inside the pipeline)
     ncls = pred.out_channels
     ids, thr = list(range(1, ncls)), [127.5] * (ncls - 1)      # channel_thresholds None -> 255/2 (prediction.py:824-825)
     in_halo = args.geometry != 'reference'
@@ -422,6 +423,8 @@ def volume_main(args):
     def step():
         out[0] = par.predict_volume_distributed(vol, vol_shape, chunk, halo, predict_fn, n_out=1, device=dev)
     elapsed = timed(step, lambda: None, steps, par, dev)
+    if pred.overflowed():
+        raise SystemExit('fp16 activation overflow during the volume workload: rerun with bf16')
     nvox = float(np.prod(vol_shape))
     if rank == 0:
         nchunks = int(np.prod([-(-v // c) for v, c in zip(vol_shape, chunk)]))

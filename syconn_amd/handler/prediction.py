@@ -66,7 +66,7 @@ class Predictor:
                  overlap_shape=None, offset=None, out_shape=None, out_dtype=None, float16=False,
                  apply_softmax=True, transform=None, augmentations=None, strict_shapes=False, apply_argmax=False,
                  argmax_with_threshold=None, verbose=False, report_inf_speed=False, act_dtype=None,
-                 group_norm_groups=None, n_streams=None):
+                 group_norm_groups=None, n_streams=None, defer_guard=False):
         from ..engine import DenseModel, StreamRing
         if transform is not None or augmentations is not None or argmax_with_threshold is not None:
             raise NotImplementedError('transform / augmentations / argmax_with_threshold are not used by SyConn\'s '
@@ -113,6 +113,9 @@ class Predictor:
         # it (sd_model_overflow).  With the DEFAULT storage type the prediction is then repeated in bf16 (fp32's exponent
         # range) and the Predictor stays there; an explicitly requested 'f16' raises ActivationOverflowError instead.
         self._bf16_fallback = act_dtype is None
+        # `defer_guard`: do not synchronise after every prediction (pipelined callers); the caller asks `overflowed()` once
+        # its stream of predictions is done and repeats them in bf16 itself
+        self.defer_guard = bool(defer_guard)
         if act_dtype is None:
             act_dtype = 'f16'          # `float16=True` (elektronn3: model.half()) selects the same storage type
         self.act_dtype = act_dtype
@@ -195,7 +198,7 @@ class Predictor:
         """Run one tiled prediction; if the fp16 range guard fired, repeat it in bf16 (default storage type) or raise."""
         from ..engine import DenseModel
         run()
-        if self.act_dtype not in ('f16', 'fp16', 'float16') or not self._dm.overflowed():
+        if self.defer_guard or self.act_dtype not in ('f16', 'fp16', 'float16') or not self._dm.overflowed():
             return
         if not self._bf16_fallback:
             raise L.ActivationOverflowError(
@@ -205,6 +208,10 @@ class Predictor:
         self.act_dtype = 'bf16'
         self._dm = DenseModel(self.model, act_dtype='bf16', device=self.device, group_norm_groups=self._gn_groups)
         run()
+
+    def overflowed(self) -> bool:
+        """fp16 range guard of the predictions since the last call (synchronises the current stream); for `defer_guard`."""
+        return self._dm.overflowed()
 
     def _batch_for(self, tin, ntiles: int) -> int:
         """Tiles per launch set: `batch_size` if given (elektronn3's Predictor argument), else as many as keep the

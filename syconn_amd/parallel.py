@@ -131,77 +131,113 @@ def scatter_from_root(payloads: Optional[Sequence[torch.Tensor]], like: torch.Te
     return (out, work) if async_op else out
 
 
-_PINNED = {}
+# pool of page-locked staging buffers (expensive to create: kept across calls).  A call TAKES its buffers out of the pool and
+# gives them back when it is done, so two concurrent calls never share one; at most _PINNED_CAP idle buffers are kept.
+_PINNED_POOL: dict = {}
+_PINNED_CAP = 16
+_PINNED_LOCK = __import__('threading').Lock()
+
+
+def _pinned_take(shape, pin: bool) -> torch.Tensor:
+    key = (tuple(int(v) for v in shape), bool(pin))
+    with _PINNED_LOCK:
+        free = _PINNED_POOL.get(key)
+        if free:
+            return free.pop()
+    t = torch.empty(key[0], dtype=torch.uint8)
+    return t.pin_memory() if pin else t
+
+
+def _pinned_give(t: torch.Tensor, pin: bool) -> None:
+    key = (tuple(t.shape), bool(pin))
+    with _PINNED_LOCK:
+        if sum(len(v) for v in _PINNED_POOL.values()) < _PINNED_CAP:
+            _PINNED_POOL.setdefault(key, []).append(t)
 
 
 def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Sequence[int], chunk_shape: Sequence[int],
                                halo: Sequence[int], predict_fn, n_out: int, device=None,
-                               pipelined: bool = True) -> Optional[torch.Tensor]:
+                               pipelined: bool = True, root_computes: bool = True,
+                               trace: Optional[list] = None) -> Optional[torch.Tensor]:
     """Chunk-parallel dense prediction of one (z,y,x) uint8 volume over all ranks of the process group: the RCCL
     variant of the reference's "one worker per GPU, chunk ids dealt round-robin" (prediction.py:708-719), with the
     file system replaced by collectives.
 
     Rank 0 holds `volume_u8` in HOST memory (other ranks pass None); the (n_out, *vol_shape) uint8 result is assembled
     in host memory on rank 0 as well (None elsewhere) -- rank 0's device only ever holds the payloads of two rounds.
-    Chunks of `chunk_shape` are enumerated z-major; chunk i belongs to rank ``i % world`` (== ``chunkify``).  Per round
-    rank 0 cuts ``world`` chunks incl. `halo` (zeros outside the volume, like ``kd.load_raw``) into pinned staging
-    buffers, uploads and scatters them; every rank runs ``predict_fn(chunk_with_halo_u8) -> uint8 (n_out, *chunk_shape)``
-    (halo already cropped) and rank 0 gathers the results, downloads them and stitches them into the output.
+    Chunks of `chunk_shape` are enumerated z-major and dealt round-robin over the WORKER ranks (== ``chunkify``): all
+    ranks, or ranks 1 .. world-1 with ``root_computes=False`` (rank 0 then only packs, uploads, downloads and stitches --
+    for volumes where its host threads and PCIe link are the bottleneck).  Per round rank 0 cuts one chunk per worker
+    incl. `halo` (zeros outside the volume, like ``kd.load_raw``) into pinned staging buffers, uploads and scatters
+    them; every worker runs ``predict_fn(chunk_with_halo_u8) -> uint8 (n_out, *chunk_shape)`` (halo already cropped) and
+    rank 0 gathers the results, downloads them and stitches them into the output.
 
-    With `pipelined` the stages overlap (two buffer sets, copy streams beside the compute stream, asynchronous
-    collectives): while the GPUs predict round k, rank 0's host packs and uploads round k+1 and stitches round k-1.
-    Without it every round runs scatter -> predict -> gather -> stitch strictly in sequence (A/B and debugging)."""
+    With `pipelined` the stages overlap (two buffer sets; copy streams and a COMMUNICATION stream beside the compute
+    stream): the scatter of round r+1 is issued BEFORE the prediction of round r is launched and both collectives are
+    issued from the communication stream -- an RCCL collective is ordered behind the work of the stream that is current
+    when it is issued, so issued from the compute stream it could not start before the kernels queued there had
+    finished.  While the GPUs predict round r, xGMI carries round r+1 in and round r-1 out, and rank 0's host packs
+    round r+2 and stitches round r-1 (the host part needs an asynchronous `predict_fn`).  Without `pipelined` every
+    round runs scatter -> predict -> gather -> stitch strictly in sequence (A/B and debugging).
+    `trace`: optional list that receives ('scatter' | 'predict' | 'gather' | 'stitch', round) in ISSUE order (tests)."""
     import itertools
     import numpy as np
     rank, world = world_info()
     vs, cs, ol = (np.asarray(v, dtype=np.int64) for v in (vol_shape, chunk_shape, halo))
     grid = [int(-(-vs[i] // cs[i])) for i in range(3)]
     ids = list(itertools.product(*[range(g) for g in grid]))
-    rounds = [ids[r0:r0 + world] for r0 in range(0, len(ids), world)]
+    workers = list(range(world)) if (root_computes or world == 1) else list(range(1, world))
+    nw = len(workers)
+    slot_of = {w: k for k, w in enumerate(workers)}              # rank -> position of its chunk in a round
+    rounds = [ids[r0:r0 + nw] for r0 in range(0, len(ids), nw)]
+    nr = len(rounds)
     in_shape = tuple(int(v) for v in cs + 2 * ol)
     out_shape = (n_out, *[int(c) for c in cs])
     cuda = device is not None and torch.device(device).type == 'cuda'
     root = rank == 0
+    my_slot = slot_of.get(rank, -1)
 
-    def pinned(shape, tag):
-        # page-locked staging is expensive to create: kept across calls (one volume after another through the same geometry)
-        key = (tag, tuple(shape), cuda)
-        t = _PINNED.get(key)
-        if t is None:
-            t = torch.empty(shape, dtype=torch.uint8)
-            t = t.pin_memory() if cuda else t
-            if len(_PINNED) > 16:
-                _PINNED.clear()
-            _PINNED[key] = t
-        return t
+    def note(what, r):
+        if trace is not None:
+            trace.append((what, r))
 
     in_buf = [torch.empty(in_shape, dtype=torch.uint8, device=device) for _ in range(2)]
     res_buf = [torch.empty(out_shape, dtype=torch.uint8, device=device) for _ in range(2)]
     out = vol = None
+    taken = []
     if root:
         vol = (volume_u8.cpu() if volume_u8.is_cuda else volume_u8).contiguous()
         out = torch.empty((n_out, *[int(v) for v in vs]), dtype=torch.uint8)
-        pin_in = [pinned((world, *in_shape), ('in', i)) for i in range(2)]       # packed payloads of a round
-        pin_out = [pinned((world, *out_shape), ('out', i)) for i in range(2)]    # gathered results of a round
+        pin_in = [_pinned_take((world, *in_shape), cuda) for _ in range(2)]       # packed payloads of a round, by RANK
+        pin_out = [_pinned_take((world, *out_shape), cuda) for _ in range(2)]     # gathered results of a round, by RANK
+        taken = pin_in + pin_out
         stage = [torch.empty((world, *in_shape), dtype=torch.uint8, device=device) for _ in range(2)] if world > 1 else None
         recv = [torch.empty((world, *out_shape), dtype=torch.uint8, device=device) for _ in range(2)] if world > 1 else None
     else:
         recv = None
     if cuda:
         cur = torch.cuda.current_stream(device)
-        s_in, s_out = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
-        ev_h2d = [torch.cuda.Event() for _ in range(2)]
-        ev_pred = [torch.cuda.Event() for _ in range(2)]
-        ev_d2h = [torch.cuda.Event() for _ in range(2)]
-    used = [False, False]
+        s_in, s_out, s_comm = (torch.cuda.Stream(device=device) for _ in range(3))
+        ev_h2d = [torch.cuda.Event() for _ in range(2)]       # upload of a round has left pin_in / reached stage
+        ev_scat = [torch.cuda.Event() for _ in range(2)]      # scatter of a round has consumed stage and filled in_buf
+        ev_pred = [torch.cuda.Event() for _ in range(2)]      # prediction of a round has consumed in_buf and filled res_buf
+        ev_gath = [torch.cuda.Event() for _ in range(2)]      # gather of a round has consumed res_buf and filled recv
+        ev_d2h = [torch.cuda.Event() for _ in range(2)]       # download of a round has left recv / reached pin_out
+    packed = [-1, -1]          # round whose payloads sit in pin_in[s] (uploaded)
 
-    def pack(r):
-        """host: cut the chunk + halo boxes of round r out of the volume into pin_in[r % 2] (zeros outside the volume)"""
+    def comm_ctx():
+        return torch.cuda.stream(s_comm) if cuda else __import__('contextlib').nullcontext()
+
+    def pack_upload(r):
+        """host: cut the chunk + halo boxes of round r out of the volume into pin_in[r % 2] (zeros outside the volume), then
+        upload them (copy-in stream)"""
+        if not root or r >= nr or packed[r & 1] == r:
+            return
         s = r & 1
-        if cuda and used[s]:
+        if cuda and packed[s] >= 0:
             ev_h2d[s].synchronize()                              # the upload of round r-2 has left this staging buffer
-        for k in range(world):
-            dst = pin_in[s][k]
+        for k, w in enumerate(workers):
+            dst = pin_in[s][w]
             if k >= len(rounds[r]):
                 host_zero(dst)
                 continue
@@ -213,78 +249,115 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
             if np.all(b > a):       # strided box copy on host threads (C helper; numpy / torch slicing runs on one core)
                 host_box_copy(dst[a[0] - lo[0]:b[0] - lo[0], a[1] - lo[1]:b[1] - lo[1], a[2] - lo[2]:b[2] - lo[2]],
                               vol[a[0]:b[0], a[1]:b[1], a[2]:b[2]])
+        target = stage[s] if world > 1 else in_buf[s]
+        src = pin_in[s] if world > 1 else pin_in[s][0]
+        if cuda:
+            with torch.cuda.stream(s_in):
+                if r >= 2:       # round r-2's scatter has consumed stage[s] (world > 1) / its kernels have consumed in_buf[s]
+                    s_in.wait_event(ev_scat[s] if world > 1 else ev_pred[s])
+                target.copy_(src, non_blocking=True)
+                ev_h2d[s].record(s_in)
+        else:
+            target.copy_(src)
+        packed[s] = r
 
     def issue_scatter(r):
-        """upload + scatter round r into in_buf[r % 2]; returns the collective's work handle (None for world size 1)"""
+        """scatter round r into in_buf[r % 2], issued from the communication stream; returns the work handle (None for
+        world size 1)"""
         s = r & 1
-        work = None
-        if root:
-            pack(r)
-            target = stage[s] if world > 1 else in_buf[s]
+        pack_upload(r)
+        note('scatter', r)
+        if world == 1:
             if cuda:
-                with torch.cuda.stream(s_in):
-                    if used[s]:
-                        s_in.wait_event(ev_pred[s])              # the kernels of round r-2 have consumed in_buf / stage
-                    target.copy_(pin_in[s] if world > 1 else pin_in[s][0], non_blocking=True)
-                    ev_h2d[s].record(s_in)
                 cur.wait_event(ev_h2d[s])
-            else:
-                target.copy_(pin_in[s] if world > 1 else pin_in[s][0])
-        if world > 1:
+            return None
+        with comm_ctx():
+            if cuda:
+                if root:
+                    s_comm.wait_event(ev_h2d[s])
+                if r >= 2:
+                    s_comm.wait_event(ev_pred[s])                # the kernels of round r-2 have consumed in_buf[s]
             _, work = scatter_from_root(list(stage[s].unbind(0)) if root else None, in_buf[s], src=0, async_op=True,
                                         out=in_buf[s])
         return work
 
     def issue_gather(r):
-        """gather round r's results to rank 0 and download them into pin_out[r % 2] (asynchronously)"""
+        """gather round r's results to rank 0 (communication stream) and download them into pin_out[r % 2] (copy-out stream)"""
         s = r & 1
+        note('gather', r)
         if world > 1:
-            _, work = gather_to_root(res_buf[s], dst=0, async_op=True, out=recv[s] if root else None)
-            work.wait()                                          # NCCL: stream-level dependency; gloo: host wait
-        if cuda:
-            ev_pred[s].record(cur)
+            with comm_ctx():
+                if cuda:
+                    s_comm.wait_event(ev_pred[s])
+                    if root and r >= 2:
+                        s_comm.wait_event(ev_d2h[s])             # the download of round r-2 has left recv[s]
+                _, work = gather_to_root(res_buf[s], dst=0, async_op=True, out=recv[s] if root else None)
+                work.wait()                                      # NCCL: orders s_comm behind the collective; gloo: host wait
+                if cuda:
+                    ev_gath[s].record(s_comm)
         if root:
             src = recv[s] if world > 1 else res_buf[s]
+            dst = pin_out[s] if world > 1 else pin_out[s][0]
             if cuda:
                 with torch.cuda.stream(s_out):
-                    s_out.wait_event(ev_pred[s])
-                    (pin_out[s] if world > 1 else pin_out[s][0]).copy_(src, non_blocking=True)
+                    s_out.wait_event(ev_gath[s] if world > 1 else ev_pred[s])
+                    dst.copy_(src, non_blocking=True)
                     ev_d2h[s].record(s_out)
             else:
-                (pin_out[s] if world > 1 else pin_out[s][0]).copy_(src)
-        used[s] = True
+                dst.copy_(src)
 
     def stitch(r):
         """host: results of round r (pin_out[r % 2]) -> output volume"""
+        note('stitch', r)
         if not root:
             return
         s = r & 1
         if cuda:
             ev_d2h[s].synchronize()
         for k in range(len(rounds[r])):
+            w = workers[k]
             lo = np.asarray(rounds[r][k], dtype=np.int64) * cs
             n = np.minimum(cs, vs - lo)
             for c in range(n_out):
                 host_box_copy(out[c, lo[0]:lo[0] + n[0], lo[1]:lo[1] + n[1], lo[2]:lo[2] + n[2]],
-                              pin_out[s][k][c, :n[0], :n[1], :n[2]])
+                              pin_out[s][w][c, :n[0], :n[1], :n[2]])
 
-    pend = issue_scatter(0) if rounds else None
-    for r in range(len(rounds)):
-        s = r & 1
-        if pend is not None:
-            pend.wait()
-        if rank < len(rounds[r]):
-            res_buf[s].copy_(predict_fn(in_buf[s]))
-        else:
-            res_buf[s].zero_()
-        issue_gather(r)
-        if not pipelined:
-            stitch(r)
-        pend = issue_scatter(r + 1) if r + 1 < len(rounds) else None     # host packs the next round while the GPUs compute
-        if pipelined and r >= 1:
-            stitch(r - 1)
-    if pipelined and rounds:
-        stitch(len(rounds) - 1)
+    try:
+        pend = issue_scatter(0) if nr else None
+        for r in range(nr):
+            s = r & 1
+            if pend is not None:
+                pend.wait()                                      # NCCL: the compute stream waits for scatter(r); gloo: host wait
+                if cuda:
+                    ev_scat[s].record(cur)
+            # the NEXT round's scatter goes out before this round's kernels are launched (its payloads were packed and
+            # uploaded while the previous round was predicted): xGMI transfer of r+1 under the kernels of r
+            pend = issue_scatter(r + 1) if (pipelined and r + 1 < nr) else None
+            note('predict', r)
+            if cuda and r >= 2:          # res_buf[s] is free again: round r-2's gather (download for world size 1) has read it
+                cur.wait_event(ev_gath[s] if world > 1 else ev_d2h[s])
+            if my_slot >= 0 and my_slot < len(rounds[r]):
+                res_buf[s].copy_(predict_fn(in_buf[s]))
+            else:
+                res_buf[s].zero_()
+            if cuda:
+                ev_pred[s].record(cur)
+            issue_gather(r)
+            if not pipelined:
+                stitch(r)
+                pend = issue_scatter(r + 1) if r + 1 < nr else None
+            else:
+                pack_upload(r + 2)                               # host packs round r+2 while the GPUs compute round r
+                if r >= 1:
+                    stitch(r - 1)
+        if pipelined and nr:
+            stitch(nr - 1)
+        if cuda:
+            cur.wait_stream(s_comm)                              # nothing of this call is still in flight when it returns
+            cur.wait_stream(s_in)
+    finally:
+        for t in taken:
+            _pinned_give(t, cuda)
     return out if root else None
 
 

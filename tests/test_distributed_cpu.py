@@ -108,13 +108,29 @@ def _worker_volume(rank, world, port, q):
         core = m[halo[0]:-halo[0], halo[1]:-halo[1], halo[2]:-halo[2]]
         return torch.stack([core.to(torch.uint8), (255 - core).to(torch.uint8)])
     ok = True
-    for pipelined in (True, False):      # overlapped scatter / predict / gather and the lock-step variant: same result
-        out = par.predict_volume_distributed(vol, vol_shape, chunk, halo, predict_fn, n_out=2, pipelined=pipelined)
+    # overlapped scatter / predict / gather, the lock-step variant, and "rank 0 does not compute": same result
+    for pipelined, root_computes in ((True, True), (False, True), (True, False)):
+        trace = []
+        out = par.predict_volume_distributed(vol, vol_shape, chunk, halo, predict_fn, n_out=2, pipelined=pipelined,
+                                             root_computes=root_computes, trace=trace)
         if rank == 0:
             ref = torch.nn.functional.max_pool3d(vol[None, None].float(), 3, stride=1, padding=1)[0, 0].to(torch.uint8)
             ok = ok and bool(torch.equal(out[0], ref) and torch.equal(out[1], 255 - ref))
         else:
             ok = ok and out is None
+        # ISSUE ORDER (every rank; collectives must be issued in the same order everywhere): pipelined -> the scatter of
+        # round r+1 goes out BEFORE the prediction of round r is launched and the gather of round r behind it; lock-step ->
+        # scatter(r+1) only after gather(r) and stitch(r)
+        pos = {e: i for i, e in enumerate(trace)}
+        nr = 1 + max(r for _, r in trace)
+        ok = ok and nr >= 3 and len(pos) == len(trace)
+        for r in range(nr):
+            ok = ok and pos[('scatter', r)] < pos[('predict', r)] < pos[('gather', r)] < pos[('stitch', r)]
+            if r + 1 < nr:
+                if pipelined:
+                    ok = ok and pos[('scatter', r + 1)] < pos[('predict', r)]
+                else:
+                    ok = ok and pos[('stitch', r)] < pos[('scatter', r + 1)]
     if rank == 0:
         q.put(ok)
     dist.destroy_process_group()
