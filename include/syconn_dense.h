@@ -223,7 +223,7 @@ int sd_segstats_compact_pairs(const void* pair_table, size_t cap_pair, const voi
  *   threshold   uint8 scale, mask = prob > threshold (0: prob already is a 0/1 mask, object_extraction_steps.py:316);
  *   ops/iterations (HOST arrays, n_ops entries): the reference's operation list with runs of equal operations merged
  *               into `iterations` (image.py:510-519).  SD_MOP_EROSION selects the reference's watershed branch
- *               (:319-352, vigra + skimage) and is rejected with SD_ERR_INVALID: not implemented.
+ *               (:319-352) and is rejected here with SD_ERR_INVALID: use sd_object_segmentation_watershed below.
  *   struct_host (sx,sy,sz) uint8 HOST array, odd extents: the structuring element (get_aniso_struct, image.py:522-539);
  *   labels_dev  (X,Y,Z) int32: 6-connected components numbered 1..N in raster order of their first voxel, 0 = background
  *               -- identical to scipy.ndimage.label; *max_label_dev = N;
@@ -235,6 +235,29 @@ int sd_object_segmentation(const uint8_t* prob_dev, int X, int Y, int Z, double 
                            const int32_t* iterations, int n_ops, const uint8_t* struct_host, int sx, int sy, int sz,
                            int32_t* labels_dev, int32_t* max_label_dev, uint8_t* mask_out_dev, void* workspace_dev,
                            size_t ws_bytes, void* stream);
+
+/* The WATERSHED branch of the same function (object_extraction_steps.py:319-352) -- what SyConn's default config selects for
+ * mi / sj / vc (config.yml:130-136: opening, closing, erosion(s)); taken when the operation list contains 'binary_erosion':
+ *   ops / iterations          the operations BEFORE the first erosion -> tmp_data (:320-322);
+ *   seed_ops / ...            the operations from the first erosion on (runs merged separately, image.py:510-519), applied to a
+ *                             copy of tmp_data -> scipy.ndimage.label -> markers (:323-327);
+ *   min_seed_vx               > 1: markers with fewer voxels are deleted and the freed ids handed to the largest surviving ids
+ *                             (the reference's hole filling + relabel_vol, :330-347; block_processing_C.pyx:161-169);
+ *   pixel_pitch_xyz           HOST int32[3] voxel size (scaling.astype(uint32)): the distance transform of tmp_data to its
+ *                             background is exact Euclidean with that pitch (vigra distanceTransform(background=False), :349);
+ *   labels_dev                skimage.segmentation.watershed(-distance, markers, mask=tmp_data) (:351): priority flood, 6-connected;
+ *   markers_out_dev           optional (X,Y,Z) int32: the relabelled marker volume -- everything up to here is scipy / numpy in the
+ *                             reference and reproduced bit for bit (pinned by tests/golden/g10_objseg_ws.npz);
+ *   distance_out_dev          optional (X,Y,Z) float32: the distance transform.
+ * vigra and skimage are absent from the reference tree and this image: distance transform and flood restate their published
+ * algorithms (flood order: value, then age, marker voxels of equal value by raster index) and are parity-UNPINNED. */
+size_t sd_objseg_watershed_workspace_bytes(int X, int Y, int Z, int max_iterations);
+int sd_object_segmentation_watershed(const uint8_t* prob_dev, int X, int Y, int Z, double threshold, const int32_t* ops,
+                                     const int32_t* iterations, int n_ops, const int32_t* seed_ops,
+                                     const int32_t* seed_iterations, int n_seed_ops, const uint8_t* struct_host, int sx, int sy,
+                                     int sz, int min_seed_vx, const int32_t* pixel_pitch_xyz, int32_t* labels_dev,
+                                     int32_t* max_label_dev, int32_t* markers_out_dev, float* distance_out_dev,
+                                     uint8_t* mask_out_dev, void* workspace_dev, size_t ws_bytes, void* stream);
 
 /* ---- host-side helpers of the chunk pipeline (no GPU) -----------------------------------------------------------------
  * Multi-threaded strided copy of an (nz, ny, nx)-byte box between two uint8 host arrays whose x-rows are contiguous

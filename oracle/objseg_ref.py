@@ -1,5 +1,5 @@
 """ORACLE (test infrastructure, NOT product code): CPU restatement of the first stage of SyConn's probability-map ->
-object segmentation, non-watershed branches:
+object segmentation:
 
     /root/reference/syconn/extraction/object_extraction_steps.py
         :316-317   tmp_data = np.array(tmp_data > threshold, dtype=np.uint8)
@@ -12,8 +12,20 @@ object segmentation, non-watershed branches:
                                                   dilation, write-back masks)
         :522-539   get_aniso_struct              (5x5x3 structuring element from the voxel scaling)
 
-The watershed branch (:319-352: erosion seeds + vigra distance transform + skimage watershed) is DEFERRED: vigra and
-skimage are absent from this image and its result cannot be pinned.
+        :319-352   watershed branch ('binary_erosion' in the operation list; the default config's mi / sj / vc lists):
+                   tmp_data = ops before the first erosion; markers = scipy.ndimage.label(ops from the first erosion on);
+                   min_seed_vx filter + id hole filling + relabel_vol (block_processing_C.pyx:161-169);
+                   distance = vigra distanceTransform(tmp_data, background=False, pixel_pitch=scaling);
+                   labels = skimage.segmentation.watershed(-distance, markers, mask=tmp_data)
+
+PARITY of the watershed branch: the marker volume (everything up to relabel_vol) is scipy / numpy in the reference and PINNED
+(``seed_markers_ref`` against ``tests/golden/g10_objseg_ws.npz``, produced by the reference's own statements).  vigra and
+skimage are absent from /root/reference and from this image (environment.yml pins vigra 1.11.1 / scikit-image 0.18/0.19):
+``distance_transform_ref`` restates "exact Euclidean distance of every foreground voxel to the nearest background voxel of the
+array, with pixel pitch" (computed with scipy's exact EDT), ``watershed_ref`` restates skimage's ``watershed_raveled`` (heap of
+(value, age); a neighbour is labelled when it is PUSHED; neighbour order of the sorted raveled offsets).  One point skimage
+leaves to its heap's internals is fixed here: marker voxels of equal value all enter with age 0 and are ordered by raster
+index.  **PARITY UNPINNED** for these two steps.
 
 Only ``tests/``, ``tools/`` probes and ``bench.py``'s ``cpu_baseline`` leg may import this.
 
@@ -128,8 +140,92 @@ def object_segmentation_ref(prob: np.ndarray, threshold: float, morph_ops: Seque
     """object_extraction_steps.py:316-317, 354-358 for one probability map (x,y,z) uint8: -> (labels int32, max_label)."""
     tmp = np.array(prob > threshold, dtype=np.uint8) if threshold != 0 else prob
     if 'binary_erosion' in morph_ops:
-        raise NotImplementedError('watershed branch (object_extraction_steps.py:319-352) is deferred')
+        raise ValueError('watershed branch: use object_segmentation_watershed_ref (needs min_seed_vx)')
     if len(morph_ops):
         tmp = apply_morphological_operations_ref(tmp.copy(), morph_ops, get_aniso_struct_ref(np.asarray(scaling)))
     labels, max_label = ndimage.label(tmp)
     return labels, int(max_label)
+
+
+# ---- watershed branch -----------------------------------------------------------------------------------------------------
+def relabel_vol_ref(vol: np.ndarray, label_map: dict) -> None:
+    """block_processing_C.pyx:161-169: in place, every voxel whose value is a key of `label_map` takes the mapped value."""
+    keys = np.fromiter(label_map.keys(), dtype=np.int64, count=len(label_map))
+    vals = np.fromiter(label_map.values(), dtype=np.int64, count=len(label_map))
+    if keys.size == 0:
+        return
+    lut = np.arange(int(max(vol.max(), keys.max())) + 1, dtype=np.int64)
+    lut[keys] = vals
+    vol[...] = lut[vol].astype(vol.dtype)
+
+
+def seed_markers_ref(tmp_data: np.ndarray, morph_ops: Sequence[str], struct: np.ndarray, min_seed_vx: int):
+    """object_extraction_steps.py:319-347 -> (tmp_data after the pre-erosion operations, markers uint32)."""
+    ops = list(morph_ops)
+    first_erosion_ix = ops.index('binary_erosion')
+    tmp_data = apply_morphological_operations_ref(tmp_data.copy(), ops[:first_erosion_ix], struct)
+    markers = apply_morphological_operations_ref(tmp_data.copy(), ops[first_erosion_ix:], struct)
+    markers = ndimage.label(markers)[0].astype(np.uint32)
+    if min_seed_vx > 1:
+        ixs, cnt = np.unique(markers, return_counts=True)
+        m = (ixs != 0) & (cnt < min_seed_vx)
+        ixs_del = np.sort(ixs[m])
+        ixs_keep = np.sort(ixs[~m])
+        label_m = {ix_del: 0 for ix_del in ixs_del}
+        ii = len(ixs_keep) - 1
+        for ix_del in ixs_del:            # the smallest freed ids go to the largest surviving ids, while they are smaller
+            if ii < 0 or (ix_del > ixs_keep[ii]) or (ixs_keep[ii] == 0):
+                break
+            label_m[ixs_keep[ii]] = ix_del
+            ii -= 1
+        relabel_vol_ref(markers, label_m)
+    return tmp_data, markers
+
+
+def distance_transform_ref(mask: np.ndarray, pixel_pitch) -> Tuple[np.ndarray, np.ndarray]:
+    """vigra distanceTransform(mask, background=False, pixel_pitch) restated: float32 Euclidean distance of every foreground
+    voxel to the nearest background voxel INSIDE the array (the border is not background); also returns the exact squared
+    distances (int64; pitches are integers)."""
+    fgm = mask != 0
+    if fgm.all():
+        d2 = np.full(mask.shape, 0x3f000000, dtype=np.int64)
+    else:
+        d = ndimage.distance_transform_edt(fgm, sampling=[float(v) for v in pixel_pitch])
+        d2 = np.rint(d * d).astype(np.int64)
+    return np.sqrt(d2.astype(np.float32)), d2
+
+
+def watershed_ref(d2: np.ndarray, markers: np.ndarray, mask: np.ndarray) -> np.ndarray:
+    """skimage.segmentation.watershed(-distance, markers, mask=mask) restated (watershed_raveled, connectivity 1, no
+    compactness, no watershed line), with value = -distance compared through the exact squared distance `d2`."""
+    import heapq
+    sh = mask.shape
+    out = np.where(mask != 0, markers, 0).astype(np.int32).ravel()
+    m = (mask != 0).ravel()
+    key = (-d2).ravel()
+    sx, sy = sh[1] * sh[2], sh[2]
+    heap = [(int(key[i]), 0, int(i)) for i in np.flatnonzero(out)]       # all markers enter with age 0
+    heapq.heapify(heap)
+    age = 0
+    while heap:
+        _, _, idx = heapq.heappop(heap)
+        x, r = divmod(idx, sx)
+        y, z = divmod(r, sy)
+        for ok, q in ((x > 0, idx - sx), (y > 0, idx - sy), (z > 0, idx - 1), (z + 1 < sh[2], idx + 1),
+                      (y + 1 < sh[1], idx + sy), (x + 1 < sh[0], idx + sx)):
+            if not ok or not m[q] or out[q]:
+                continue
+            age += 1
+            out[q] = out[idx]                                             # labelled at push time
+            heapq.heappush(heap, (int(key[q]), age, int(q)))
+    return out.reshape(sh)
+
+
+def object_segmentation_watershed_ref(prob: np.ndarray, threshold: float, morph_ops: Sequence[str], scaling, min_seed_vx: int):
+    """:316-352 for one probability map -> (labels int32, max_label, tmp_data, markers)."""
+    tmp = np.array(prob > threshold, dtype=np.uint8) if threshold != 0 else prob
+    struct = get_aniso_struct_ref(np.asarray(scaling))
+    tmp, markers = seed_markers_ref(tmp, morph_ops, struct, min_seed_vx)
+    _, d2 = distance_transform_ref(tmp, np.asarray(scaling).astype(np.uint32))
+    labels = watershed_ref(d2, markers, tmp)
+    return labels, int(labels.max()) if labels.size else 0, tmp, markers

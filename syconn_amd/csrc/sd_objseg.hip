@@ -1,5 +1,5 @@
-// First stage of probability map -> object segmentation on the device, non-watershed
-// branches of /root/reference/syconn/extraction/object_extraction_steps.py:204-366 (_object_segmentation_thread):
+// First stage of probability map -> object segmentation on the device:
+// /root/reference/syconn/extraction/object_extraction_steps.py:204-366 (_object_segmentation_thread).  Plain branches:
 //     :316-317  tmp_data = np.array(tmp_data > threshold, dtype=np.uint8)
 //     :354-356  mop_data = apply_morphological_operations(tmp_data.copy(), morph_ops, mop_kwargs=dict(structure=struct))
 //               this_labels_data, max_label = scipy.ndimage.label(mop_data)
@@ -9,6 +9,7 @@
 // zeros per side (less than the reach of the 5x5x3 element), clip their dilations to the padded window and erode with
 // "outside the window = background"; opening erodes and dilates inside the box.  oracle/objseg_ref.py spells this out and
 // is pinned to the reference's own functions (tests/golden/g9_objseg.npz).
+// Watershed branch (:319-352, what the default config selects for mi / sj / vc): see sd_object_segmentation_watershed below.
 //
 // Data layout: the binary volume lives BIT-PACKED along z (the fastest axis): one uint32 = 32 consecutive z voxels of a
 // (x,y) row of the volume padded by P = largest `iterations` per side.  A morphology step is then a handful of word loads,
@@ -287,6 +288,237 @@ __global__ __launch_bounds__(256) void k_cc_relabel(size_t total, int* L, const 
     }
 }
 
+
+// ---- watershed branch (object_extraction_steps.py:319-352) ---------------------------------------------------------------
+// generic single-workgroup exclusive scan of v[0..n) in place, total -> *total_out
+__global__ __launch_bounds__(1024) void k_scan_excl(int* v, const int* n_ptr, int n_add, int* total_out) {
+    __shared__ int part[1024];
+    __shared__ int carry;
+    const int n = *n_ptr + n_add;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int x = i < n ? v[i] : 0;
+        part[threadIdx.x] = x;
+        __syncthreads();
+        for (int s = 1; s < 1024; s <<= 1) {
+            const int t = threadIdx.x >= s ? part[threadIdx.x - s] : 0;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n) v[i] = carry + part[threadIdx.x] - x;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+__global__ __launch_bounds__(256) void k_fill_int(int* p, size_t n, int v) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
+}
+// cnt[label] += 1 over the volume (label > 0)
+__global__ __launch_bounds__(256) void k_count_labels(const int* L, size_t total, int* cnt) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int l = L[i];
+        if (l > 0) atomicAdd(&cnt[l], 1);
+    }
+}
+// min_seed_vx filter, step 1: del[i] = 1 where the seed with id i (1..N) has fewer than min_size voxels (:325-329)
+__global__ __launch_bounds__(256) void k_seed_flags(const int* cnt, const int* N, int min_size, int* del) {
+    const int n = *N;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i <= n; i += gridDim.x * 256) del[i] = (i >= 1 && cnt[i] < min_size) ? 1 : 0;
+}
+// step 2: rd[] = exclusive scan of del[] (rank among the deleted ids); the ids 1..N are dense, so the rank of a kept id among
+// the kept ones is (i - 1) - rd[i].  D[j] = j-th smallest deleted id, K[j] = j-th smallest kept id.
+__global__ __launch_bounds__(256) void k_seed_lists(const int* cnt, const int* rd, const int* N, int min_size, int* D, int* K) {
+    const int n = *N;
+    for (int i = 1 + blockIdx.x * 256 + threadIdx.x; i <= n; i += gridDim.x * 256) {
+        if (cnt[i] < min_size) D[rd[i]] = i;
+        else K[(i - 1) - rd[i]] = i;
+    }
+}
+// step 3 (:333-344): the j-th smallest deleted id is handed to the j-th LARGEST kept id as long as it is smaller than that id
+// (the reference walks both sorted lists and stops at the first pair that fails): J = length of that prefix
+__global__ __launch_bounds__(256) void k_seed_prefix(const int* D, const int* K, const int* N, const int* nd_ptr, int* J) {
+    const int nd = *nd_ptr, m = *N - nd, lim = min(nd, m);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicMin(J, lim);
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < lim; j += gridDim.x * 256)
+        if (!(D[j] < K[m - 1 - j])) atomicMin(J, j);
+}
+// step 4: map[i] = 0 (deleted) | D[j] (the j-th largest kept id, j < J) | i
+__global__ __launch_bounds__(256) void k_seed_map(const int* cnt, const int* rd, const int* D, const int* N, const int* nd_ptr,
+                                                  const int* J, int min_size, int* map) {
+    const int n = *N, m = n - *nd_ptr, jj = *J;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i <= n; i += gridDim.x * 256) {
+        int v = i;
+        if (i >= 1) {
+            if (cnt[i] < min_size) v = 0;
+            else { const int j = m - 1 - ((i - 1) - rd[i]); if (j < jj) v = D[j]; }
+        }
+        map[i] = v;
+    }
+}
+__global__ __launch_bounds__(256) void k_apply_map(int* L, size_t total, const int* map) {      // relabel_vol (block_processing_C.pyx:161-169)
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int l = L[i];
+        if (l > 0) L[i] = map[l];
+    }
+}
+
+// Exact anisotropic Euclidean distance transform of the foreground to the nearest background voxel INSIDE the array (vigra
+// distanceTransform(background=False, pixel_pitch): the array border is not background), as SQUARED distances in int32
+// (pitches are the integer voxel sizes, :349-350).  Separable: per z-row the distance to the nearest zero of the row, then the
+// lower envelope of parabolas along y and along x, searched outwards from the voxel itself -- a candidate at offset k cannot
+// beat the current best once (pitch * k)^2 >= best, so the search stops after about distance / pitch steps.
+constexpr int EDT_INF = 0x3f000000;
+__global__ __launch_bounds__(256) void k_edt_z(const uint32_t* A, Dom d, int pz, int* g) {
+    const int rows = d.X * d.Y;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < rows; r += gridDim.x * 256) {
+        const int x = r / d.Y, y = r - x * d.Y;
+        int* const row = g + (size_t)r * d.Z;
+        int last = -1;                          // z of the last background voxel seen
+        for (int z = 0; z < d.Z; ++z) {
+            if (!fg(A, d, x, y, z)) { last = z; row[z] = 0; }
+            else if (last >= 0) { const long t = (long)pz * (z - last); row[z] = (int)min(t * t, (long)EDT_INF); }
+            else row[z] = EDT_INF;
+        }
+        last = -1;
+        for (int z = d.Z - 1; z >= 0; --z) {
+            if (row[z] == 0) last = z;
+            else if (last >= 0) { const long t = (long)pz * (last - z); row[z] = min(row[z], (int)min(t * t, (long)EDT_INF)); }
+        }
+    }
+}
+// one axis pass: out[i] = min over k of in[i + k * stride] + (pitch * k)^2 along an axis of extent n (position c)
+__global__ __launch_bounds__(256) void k_edt_axis(const int* in, int* out, Dom d, int axis, int pitch) {
+    const size_t total = (size_t)d.X * d.Y * d.Z;
+    const size_t stride = axis == 1 ? (size_t)d.Z : (size_t)d.Z * d.Y;
+    const int n = axis == 1 ? d.Y : d.X;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        int best = in[i];
+        if (best != 0) {
+            int z, y, x;
+            dec3(i, d.Z, d.Y, z, y, x);
+            const int c = axis == 1 ? y : x;
+            for (int k = 1; k < n; ++k) {
+                const long pk = (long)pitch * k, q = pk * pk;
+                if (q >= (long)best) break;
+                if (c - k < 0 && c + k >= n) break;
+                if (c - k >= 0) best = (int)min((long)best, (long)in[i - (size_t)k * stride] + q);
+                if (c + k < n) best = (int)min((long)best, (long)in[i + (size_t)k * stride] + q);
+            }
+        }
+        out[i] = best;
+    }
+}
+
+// per mask component: smallest and largest marker id found inside it (mn = INT_MAX, mx = 0: none)
+__global__ __launch_bounds__(256) void k_comp_markers(const int* comp, const int* mk, size_t total, int* mn, int* mx) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int m = mk[i];
+        if (m > 0) { const int c = comp[i]; atomicMin(&mn[c], m); atomicMax(&mx[c], m); }
+    }
+}
+// heap capacity of a component that holds several markers = its voxel count (every voxel is pushed at most once)
+__global__ __launch_bounds__(256) void k_comp_sizes(const int* comp, size_t total, const int* mn, const int* mx, int* sz) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = comp[i];
+        if (c > 0 && mx[c] > mn[c]) atomicAdd(&sz[c], 1);
+    }
+}
+// out = the flood's start state: background 0; a component without markers 0; with ONE marker that marker everywhere (the
+// flood cannot leave the mask component and nothing competes); with several markers the markers themselves, which are also
+// appended to the component's heap array (unordered: k_ws_flood heapifies)
+constexpr unsigned WS_KMAX = 0x7fffffffu;
+__global__ __launch_bounds__(256) void k_ws_init(const int* comp, const int* mk, const int* g, size_t total, const int* mn,
+                                                 const int* mx, const int* off, int* hcnt, unsigned long long* hkey, int* hidx,
+                                                 int* out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = comp[i];
+        int o = 0;
+        if (c > 0 && mx[c] > 0) {
+            if (mx[c] == mn[c]) o = mx[c];
+            else {
+                o = mk[i];
+                if (o > 0) {
+                    const int slot = off[c] + atomicAdd(&hcnt[c], 1);
+                    hkey[slot] = (unsigned long long)(WS_KMAX - (unsigned)g[i]) << 32;      // age 0
+                    hidx[slot] = (int)i;
+                }
+            }
+        }
+        out[i] = o;
+    }
+}
+// Priority flood of one multi-marker component per THREAD: skimage.segmentation.watershed(-distance, markers, mask) restated
+// (watershed_raveled, connectivity 1, no compactness): pop the element with the smallest (value, age); every unlabelled mask
+// neighbour -- visited in the order -x, -y, -z, +z, +y, +x of the reference's (x,y,z) arrays -- takes the popped element's label
+// AT PUSH TIME and enters the heap with the next age.  value = -distance: compared through the exact squared distance.  All
+// markers enter with age 0; equal (value, age) -- possible only among marker voxels -- are ordered by raster index here
+// (skimage leaves that order to its heap's internals).  Ages are counted per component: comparisons only ever happen between
+// elements of one component, whose relative push order is the same as under a global counter.
+__device__ __forceinline__ bool ws_less(unsigned long long ka, int ia, unsigned long long kb, int ib) { return ka < kb || (ka == kb && ia < ib); }
+__global__ __launch_bounds__(64) void k_ws_flood(const int* comp, const int* g, Dom d, const int* NC, const int* mn, const int* mx,
+                                                 const int* off, const int* hcnt, unsigned long long* hkey, int* hidx, int* out) {
+    const int nc = *NC;
+    const int sY = d.Z, sX = d.Z * d.Y;
+    for (int c = 1 + blockIdx.x * 64 + threadIdx.x; c <= nc; c += gridDim.x * 64) {
+        if (!(mx[c] > mn[c])) continue;
+        unsigned long long* const K = hkey + off[c];
+        int* const I = hidx + off[c];
+        int n = hcnt[c];
+        auto sift_down = [&](int i) {
+            const unsigned long long k = K[i]; const int ix = I[i];
+            while (true) {
+                int ch = 2 * i + 1;
+                if (ch >= n) break;
+                if (ch + 1 < n && ws_less(K[ch + 1], I[ch + 1], K[ch], I[ch])) ++ch;
+                if (!ws_less(K[ch], I[ch], k, ix)) break;
+                K[i] = K[ch]; I[i] = I[ch]; i = ch;
+            }
+            K[i] = k; I[i] = ix;
+        };
+        for (int i = n / 2 - 1; i >= 0; --i) sift_down(i);
+        unsigned age = 0;
+        while (n > 0) {
+            const int idx = I[0];
+            const int lab = out[idx];
+            --n;
+            if (n > 0) { K[0] = K[n]; I[0] = I[n]; sift_down(0); }
+            int z, y, x;
+            dec3((size_t)idx, d.Z, d.Y, z, y, x);
+            const int nb[6] = {x > 0 ? idx - sX : -1, y > 0 ? idx - sY : -1, z > 0 ? idx - 1 : -1,
+                               z + 1 < d.Z ? idx + 1 : -1, y + 1 < d.Y ? idx + sY : -1, x + 1 < d.X ? idx + sX : -1};
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+                const int q = nb[e];
+                if (q < 0 || comp[q] != c || out[q] != 0) continue;
+                out[q] = lab;
+                const unsigned long long k = ((unsigned long long)(WS_KMAX - (unsigned)g[q]) << 32) | (unsigned long long)(++age);
+                int i = n++;                              // sift up
+                while (i > 0) {
+                    const int pa = (i - 1) >> 1;
+                    if (!ws_less(k, q, K[pa], I[pa])) break;
+                    K[i] = K[pa]; I[i] = I[pa]; i = pa;
+                }
+                K[i] = k; I[i] = q;
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_max_label(const int* L, size_t total, int* mx) {
+    int m = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) m = max(m, L[i]);
+    for (int s = 32; s >= 1; s >>= 1) m = max(m, __shfl_xor(m, s, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(mx, m);
+}
+// squared distances -> float32 distances (what vigra returns), optional output
+__global__ __launch_bounds__(256) void k_sqrt_out(const int* g, size_t total, float* out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) out[i] = sqrtf((float)g[i]);
+}
+
 inline int grid_for(size_t n, int cap = 8192) { size_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > (size_t)cap ? (size_t)cap : g)); }
 inline size_t rup256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -320,6 +552,101 @@ size_t sd_objseg_workspace_bytes(int X, int Y, int Z, int max_iterations) {
     return ws_layout(X, Y, Z, max_iterations).total;
 }
 
+}  // extern "C"
+
+namespace {
+// structuring element -> offset list; 0 on success
+int make_offsets(const uint8_t* struct_host, int sx, int sy, int sz, Offs& o) {
+    if (!struct_host || sx < 1 || sy < 1 || sz < 1 || !(sx & 1) || !(sy & 1) || !(sz & 1) || sx > 15 || sy > 15 || sz > 15)
+        return sd_fail_msg(SD_ERR_INVALID, "sd_object_segmentation: structuring element must have odd extents <= 15");
+    for (int x = 0; x < sx; ++x)
+        for (int y = 0; y < sy; ++y)
+            for (int z = 0; z < sz; ++z)
+                if (struct_host[((size_t)x * sy + y) * sz + z]) {
+                    if (o.n == MAX_OFFS) return sd_fail_msg(SD_ERR_INVALID, "sd_object_segmentation: structuring element too large");
+                    o.dx[o.n] = (signed char)(x - sx / 2); o.dy[o.n] = (signed char)(y - sy / 2); o.dz[o.n] = (signed char)(z - sz / 2);
+                    ++o.n;
+                }
+    if (o.n == 0) return sd_fail_msg(SD_ERR_INVALID, "sd_object_segmentation: empty structuring element");
+    return SD_OK;
+}
+int check_ops(const int32_t* ops, const int32_t* iterations, int n_ops, bool allow_erosion, int& P) {
+    for (int i = 0; i < n_ops; ++i) {
+        if (ops[i] == SD_MOP_EROSION && !allow_erosion)
+            return sd_fail_msg(SD_ERR_INVALID, "sd_object_segmentation: binary_erosion selects the reference's watershed branch "
+                                               "(object_extraction_steps.py:319-352): use sd_object_segmentation_watershed");
+        if (ops[i] != SD_MOP_OPENING && ops[i] != SD_MOP_CLOSING && ops[i] != SD_MOP_DILATION && ops[i] != SD_MOP_EROSION)
+            return sd_fail_msg(SD_ERR_INVALID, "sd_object_segmentation: unknown morphological operation");
+        if (iterations[i] < 1 || iterations[i] > 64) return sd_fail_msg(SD_ERR_INVALID, "sd_object_segmentation: iterations out of range");
+        if (ops[i] == SD_MOP_CLOSING || ops[i] == SD_MOP_DILATION) P = std::max(P, iterations[i]);
+    }
+    return SD_OK;
+}
+// the reference's operation list on the bit-packed volume A (B = scratch); the result is in A afterwards.
+// erosion / opening: erosions inside the bounding box (outside = background), opening then dilates clipped to the box;
+// closing / dilation: window = box + `iterations`, dilations clipped to it, closing then erodes, result cropped to the box
+void run_morph(hipStream_t s, uint32_t*& A, uint32_t*& B, const Dom& d, int* bbox, const int32_t* ops, const int32_t* iterations,
+               int n_ops, const Offs& o) {
+    const size_t pwords = (size_t)d.PX * d.PY * d.PZW;
+    for (int i = 0; i < n_ops; ++i) {
+        const int n = iterations[i];
+        hipLaunchKernelGGL(k_bbox_init, dim3(1), dim3(256), 0, s, bbox);
+        hipLaunchKernelGGL(k_bbox_bits, dim3(grid_for(pwords, 512)), dim3(256), 0, s, A, d, bbox);
+        const bool shrink_first = ops[i] == SD_MOP_OPENING || ops[i] == SD_MOP_EROSION;
+        const int wpad = shrink_first ? 0 : n;
+        const int nfirst = n, nsecond = (ops[i] == SD_MOP_DILATION || ops[i] == SD_MOP_EROSION) ? 0 : n;
+        const int first_dilate = shrink_first ? 0 : 1;
+        for (int k = 0; k < nfirst + nsecond; ++k) {
+            const int dil = k < nfirst ? first_dilate : 1 - first_dilate;
+            const int crop = (k == nfirst + nsecond - 1) ? 1 : 0;
+            hipLaunchKernelGGL(k_morph_bits, dim3(grid_for(pwords)), dim3(256), 0, s, A, B, d, bbox, wpad, dil, crop, o);
+            std::swap(A, B);
+        }
+    }
+}
+// scipy.ndimage.label of the bit-packed volume A into L (ids 1..N in raster order of the first voxel), N -> *max_label_dev
+void run_cc(hipStream_t s, const uint32_t* A, const Dom& d, int* L, int* rank, int* blockcnt, int* max_label_dev, uint8_t* mask_out) {
+    const size_t nvox = (size_t)d.X * d.Y * d.Z;
+    hipLaunchKernelGGL(k_cc_init_runs, dim3(grid_for(nvox)), dim3(256), 0, s, A, d, L, mask_out);
+    hipLaunchKernelGGL(k_cc_merge_runs, dim3(grid_for(nvox)), dim3(256), 0, s, A, d, L);
+    hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nvox)), dim3(256), 0, s, nvox, L);
+    const int nblk = (int)((nvox + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    hipLaunchKernelGGL(k_cc_count, dim3(nblk), dim3(256), 0, s, nvox, L, blockcnt);
+    hipLaunchKernelGGL(k_cc_scan_blocks, dim3(1), dim3(1024), 0, s, blockcnt, nblk, max_label_dev);
+    hipLaunchKernelGGL(k_cc_rank, dim3(nblk), dim3(256), 0, s, nvox, L, blockcnt, rank);
+    hipLaunchKernelGGL(k_cc_relabel, dim3(grid_for(nvox)), dim3(256), 0, s, nvox, L, rank);
+}
+int cut_of(double threshold) {
+    // (uint8 p > t) <=> p >= floor(t) + 1; threshold 0 means "already a 0/1 mask" (object_extraction_steps.py:316): cut 1
+    const double c = std::floor(threshold) + 1.0;
+    return threshold == 0.0 ? 1 : (c < 0.0 ? 0 : (c > 256.0 ? 256 : (int)c));
+}
+
+// workspace of the watershed branch: the plain layout + a copy of the mask bits, three more int32 volumes (markers, mask
+// components, squared distances), per-id tables (a volume of n voxels has at most n/2 + 1 six-connected components) and the heap arena
+struct WsLayout2 { WsLayout w; size_t mbits, mk, comp, g, tab[9], hkey, hidx, scal, total; size_t T; };
+WsLayout2 ws_layout2(int X, int Y, int Z, int P) {
+    WsLayout2 l{};
+    l.w = ws_layout(X, Y, Z, P);
+    const Dom d = make_dom(X, Y, Z, P);
+    const size_t pwords = (size_t)d.PX * d.PY * d.PZW, nvox = (size_t)X * Y * Z;
+    l.T = nvox / 2 + 1026;
+    size_t cur = l.w.total;
+    l.mbits = cur; cur += rup256(pwords * 4);
+    l.mk = cur; cur += rup256(nvox * 4);
+    l.comp = cur; cur += rup256(nvox * 4);
+    l.g = cur; cur += rup256(nvox * 4);
+    for (int i = 0; i < 9; ++i) { l.tab[i] = cur; cur += rup256(l.T * 4); }
+    l.hkey = cur; cur += rup256(nvox * 8);
+    l.hidx = cur; cur += rup256(nvox * 4);
+    l.scal = cur; cur += 256;
+    l.total = cur;
+    return l;
+}
+}  // namespace
+
+extern "C" {
+
 int sd_object_segmentation(const uint8_t* prob_dev, int X, int Y, int Z, double threshold, const int32_t* ops,
                            const int32_t* iterations, int n_ops, const uint8_t* struct_host, int sx, int sy, int sz,
                            int32_t* labels_dev, int32_t* max_label_dev, uint8_t* mask_out_dev, void* ws, size_t ws_bytes,
@@ -329,68 +656,112 @@ int sd_object_segmentation(const uint8_t* prob_dev, int X, int Y, int Z, double 
     if ((size_t)X * Y * Z >= (1ull << 31)) return sd_fail_msg(SD_ERR_INVALID, "sd_object_segmentation: volume must have < 2^31 voxels");
     if (threshold != threshold) return sd_fail_msg(SD_ERR_INVALID, "sd_object_segmentation: NaN threshold");
     int P = 0;
-    for (int i = 0; i < n_ops; ++i) {
-        if (ops[i] == SD_MOP_EROSION)
-            return sd_fail_msg(SD_ERR_INVALID, "sd_object_segmentation: binary_erosion selects the reference's watershed branch "
-                                               "(object_extraction_steps.py:319-352), which is not implemented");
-        if (ops[i] != SD_MOP_OPENING && ops[i] != SD_MOP_CLOSING && ops[i] != SD_MOP_DILATION)
-            return sd_fail_msg(SD_ERR_INVALID, "sd_object_segmentation: unknown morphological operation");
-        if (iterations[i] < 1 || iterations[i] > 64) return sd_fail_msg(SD_ERR_INVALID, "sd_object_segmentation: iterations out of range");
-        if (ops[i] != SD_MOP_OPENING) P = std::max(P, iterations[i]);
-    }
+    int rc = check_ops(ops, iterations, n_ops, false, P);
+    if (rc != SD_OK) return rc;
     Offs o{};
-    if (n_ops) {
-        if (!struct_host || sx < 1 || sy < 1 || sz < 1 || !(sx & 1) || !(sy & 1) || !(sz & 1) || sx > 15 || sy > 15 || sz > 15)
-            return sd_fail_msg(SD_ERR_INVALID, "sd_object_segmentation: structuring element must have odd extents <= 15");
-        for (int x = 0; x < sx; ++x)
-            for (int y = 0; y < sy; ++y)
-                for (int z = 0; z < sz; ++z)
-                    if (struct_host[((size_t)x * sy + y) * sz + z]) {
-                        if (o.n == MAX_OFFS) return sd_fail_msg(SD_ERR_INVALID, "sd_object_segmentation: structuring element too large");
-                        o.dx[o.n] = (signed char)(x - sx / 2); o.dy[o.n] = (signed char)(y - sy / 2); o.dz[o.n] = (signed char)(z - sz / 2);
-                        ++o.n;
-                    }
-        if (o.n == 0) return sd_fail_msg(SD_ERR_INVALID, "sd_object_segmentation: empty structuring element");
-    }
+    if (n_ops && (rc = make_offsets(struct_host, sx, sy, sz, o)) != SD_OK) return rc;
     const WsLayout w = ws_layout(X, Y, Z, P);
     if (ws_bytes < w.total) return sd_fail_msg(SD_ERR_NOMEM, "sd_object_segmentation: workspace too small");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     char* const wb = reinterpret_cast<char*>(ws);
     uint32_t* A = reinterpret_cast<uint32_t*>(wb + w.a);
     uint32_t* B = reinterpret_cast<uint32_t*>(wb + w.b);
-    int* rank = reinterpret_cast<int*>(wb + w.rank);
-    int* blockcnt = reinterpret_cast<int*>(wb + w.blockcnt);
-    int* bbox = reinterpret_cast<int*>(wb + w.bbox);
+    const Dom d = make_dom(X, Y, Z, P);
+    const size_t pwords = (size_t)d.PX * d.PY * d.PZW;
+    hipLaunchKernelGGL(k_threshold_bits, dim3(grid_for(pwords)), dim3(256), 0, s, prob_dev, cut_of(threshold), d, A);
+    run_morph(s, A, B, d, reinterpret_cast<int*>(wb + w.bbox), ops, iterations, n_ops, o);
+    run_cc(s, A, d, labels_dev, reinterpret_cast<int*>(wb + w.rank), reinterpret_cast<int*>(wb + w.blockcnt), max_label_dev, mask_out_dev);
+    return hipGetLastError() == hipSuccess ? SD_OK : sd_fail_msg(SD_ERR_HIP, "sd_object_segmentation: launch failed");
+}
+
+size_t sd_objseg_watershed_workspace_bytes(int X, int Y, int Z, int max_iterations) {
+    if (X <= 0 || Y <= 0 || Z <= 0 || max_iterations < 0) return 0;
+    return ws_layout2(X, Y, Z, max_iterations).total;
+}
+
+int sd_object_segmentation_watershed(const uint8_t* prob_dev, int X, int Y, int Z, double threshold, const int32_t* ops,
+                                     const int32_t* iterations, int n_ops, const int32_t* seed_ops,
+                                     const int32_t* seed_iterations, int n_seed_ops, const uint8_t* struct_host, int sx, int sy,
+                                     int sz, int min_seed_vx, const int32_t* pixel_pitch_xyz, int32_t* labels_dev,
+                                     int32_t* max_label_dev, int32_t* markers_out_dev, float* distance_out_dev,
+                                     uint8_t* mask_out_dev, void* ws, size_t ws_bytes, void* stream) {
+    if (!prob_dev || !labels_dev || !max_label_dev || !ws || X <= 0 || Y <= 0 || Z <= 0 || n_ops < 0 || n_seed_ops <= 0 ||
+        (n_ops && (!ops || !iterations)) || !seed_ops || !seed_iterations || !pixel_pitch_xyz)
+        return sd_fail_msg(SD_ERR_INVALID, "sd_object_segmentation_watershed: bad argument");
+    if ((size_t)X * Y * Z >= (1ull << 31)) return sd_fail_msg(SD_ERR_INVALID, "sd_object_segmentation_watershed: volume must have < 2^31 voxels");
+    if (threshold != threshold) return sd_fail_msg(SD_ERR_INVALID, "sd_object_segmentation_watershed: NaN threshold");
+    if (seed_ops[0] != SD_MOP_EROSION) return sd_fail_msg(SD_ERR_INVALID, "sd_object_segmentation_watershed: the seed operations start with the first binary_erosion");
+    for (int a = 0; a < 3; ++a)      // squared distances are int32: (pitch * extent)^2 must stay below EDT_INF / 3
+        if (pixel_pitch_xyz[a] < 1 || (double)pixel_pitch_xyz[a] * (a == 0 ? X : a == 1 ? Y : Z) > 18000.0)
+            return sd_fail_msg(SD_ERR_INVALID, "sd_object_segmentation_watershed: pixel pitch x extent out of range");
+    int P = 0;
+    int rc = check_ops(ops, iterations, n_ops, false, P);
+    if (rc == SD_OK) rc = check_ops(seed_ops, seed_iterations, n_seed_ops, true, P);
+    if (rc != SD_OK) return rc;
+    Offs o{};
+    if ((rc = make_offsets(struct_host, sx, sy, sz, o)) != SD_OK) return rc;
+    const WsLayout2 l = ws_layout2(X, Y, Z, P);
+    if (ws_bytes < l.total) return sd_fail_msg(SD_ERR_NOMEM, "sd_object_segmentation_watershed: workspace too small");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    char* const wb = reinterpret_cast<char*>(ws);
+    uint32_t* A = reinterpret_cast<uint32_t*>(wb + l.w.a);
+    uint32_t* B = reinterpret_cast<uint32_t*>(wb + l.w.b);
+    uint32_t* M = reinterpret_cast<uint32_t*>(wb + l.mbits);
+    int* rank = reinterpret_cast<int*>(wb + l.w.rank);
+    int* blockcnt = reinterpret_cast<int*>(wb + l.w.blockcnt);
+    int* bbox = reinterpret_cast<int*>(wb + l.w.bbox);
+    int* mk = reinterpret_cast<int*>(wb + l.mk);
+    int* comp = reinterpret_cast<int*>(wb + l.comp);
+    int* g = reinterpret_cast<int*>(wb + l.g);
+    int* tab[9];
+    for (int i = 0; i < 9; ++i) tab[i] = reinterpret_cast<int*>(wb + l.tab[i]);
+    int *cnt = tab[0], *rd = tab[1], *D = tab[2], *K = tab[3], *map = tab[4], *mn = tab[5], *mx = tab[6], *off = tab[7], *hcnt = tab[8];
+    unsigned long long* hkey = reinterpret_cast<unsigned long long*>(wb + l.hkey);
+    int* hidx = reinterpret_cast<int*>(wb + l.hidx);
+    int* scal = reinterpret_cast<int*>(wb + l.scal);      // [0] N seeds, [1] NC mask components, [2] deleted seeds, [3] J, [4] heap total
     const Dom d = make_dom(X, Y, Z, P);
     const size_t pwords = (size_t)d.PX * d.PY * d.PZW, nvox = (size_t)X * Y * Z;
-    // (uint8 p > t) <=> p >= floor(t) + 1; threshold 0 means "already a 0/1 mask" (object_extraction_steps.py:316): cut 1
-    const double c = std::floor(threshold) + 1.0;
-    const int cut = threshold == 0.0 ? 1 : (c < 0.0 ? 0 : (c > 256.0 ? 256 : (int)c));
-    hipLaunchKernelGGL(k_threshold_bits, dim3(grid_for(pwords)), dim3(256), 0, s, prob_dev, cut, d, A);
-    for (int i = 0; i < n_ops; ++i) {
-        const int n = iterations[i];
-        hipLaunchKernelGGL(k_bbox_init, dim3(1), dim3(256), 0, s, bbox);
-        hipLaunchKernelGGL(k_bbox_bits, dim3(grid_for(pwords, 512)), dim3(256), 0, s, A, d, bbox);
-        const int wpad = ops[i] == SD_MOP_OPENING ? 0 : n;
-        const int nfirst = n, nsecond = ops[i] == SD_MOP_DILATION ? 0 : n;
-        const int first_dilate = ops[i] == SD_MOP_OPENING ? 0 : 1;
-        for (int k = 0; k < nfirst + nsecond; ++k) {
-            const int dil = k < nfirst ? first_dilate : 1 - first_dilate;
-            const int crop = (k == nfirst + nsecond - 1) ? 1 : 0;
-            hipLaunchKernelGGL(k_morph_bits, dim3(grid_for(pwords)), dim3(256), 0, s, A, B, d, bbox, wpad, dil, crop, o);
-            std::swap(A, B);
-        }
+    const int gt = grid_for(l.T);
+
+    // tmp_data: threshold + the operations before the first erosion (:316-322)
+    hipLaunchKernelGGL(k_threshold_bits, dim3(grid_for(pwords)), dim3(256), 0, s, prob_dev, cut_of(threshold), d, A);
+    run_morph(s, A, B, d, bbox, ops, iterations, n_ops, o);
+    if (hipMemcpyAsync(M, A, pwords * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return sd_fail_msg(SD_ERR_HIP, "sd_object_segmentation_watershed: copy failed");
+    // markers: the erosions (and whatever follows them), scipy.ndimage.label (:323-327)
+    run_morph(s, A, B, d, bbox, seed_ops, seed_iterations, n_seed_ops, o);
+    run_cc(s, A, d, mk, rank, blockcnt, scal + 0, nullptr);
+    if (min_seed_vx > 1) {      // :330-347: drop seeds smaller than min_seed_vx, fill the holes in the id space from the top
+        hipLaunchKernelGGL(k_fill_int, dim3(gt), dim3(256), 0, s, cnt, l.T, 0);
+        hipLaunchKernelGGL(k_fill_int, dim3(1), dim3(256), 0, s, scal + 3, (size_t)1, 0x7fffffff);
+        hipLaunchKernelGGL(k_count_labels, dim3(grid_for(nvox)), dim3(256), 0, s, mk, nvox, cnt);
+        hipLaunchKernelGGL(k_seed_flags, dim3(gt), dim3(256), 0, s, cnt, scal + 0, min_seed_vx, rd);
+        hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, s, rd, scal + 0, 1, scal + 2);
+        hipLaunchKernelGGL(k_seed_lists, dim3(gt), dim3(256), 0, s, cnt, rd, scal + 0, min_seed_vx, D, K);
+        hipLaunchKernelGGL(k_seed_prefix, dim3(gt), dim3(256), 0, s, D, K, scal + 0, scal + 2, scal + 3);
+        hipLaunchKernelGGL(k_seed_map, dim3(gt), dim3(256), 0, s, cnt, rd, D, scal + 0, scal + 2, scal + 3, min_seed_vx, map);
+        hipLaunchKernelGGL(k_apply_map, dim3(grid_for(nvox)), dim3(256), 0, s, mk, nvox, map);
     }
-    int* L = labels_dev;
-    hipLaunchKernelGGL(k_cc_init_runs, dim3(grid_for(nvox)), dim3(256), 0, s, A, d, L, mask_out_dev);
-    hipLaunchKernelGGL(k_cc_merge_runs, dim3(grid_for(nvox)), dim3(256), 0, s, A, d, L);
-    hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nvox)), dim3(256), 0, s, nvox, L);
-    const int nblk = (int)((nvox + SCAN_BLOCK - 1) / SCAN_BLOCK);
-    hipLaunchKernelGGL(k_cc_count, dim3(nblk), dim3(256), 0, s, nvox, L, blockcnt);
-    hipLaunchKernelGGL(k_cc_scan_blocks, dim3(1), dim3(1024), 0, s, blockcnt, nblk, max_label_dev);
-    hipLaunchKernelGGL(k_cc_rank, dim3(nblk), dim3(256), 0, s, nvox, L, blockcnt, rank);
-    hipLaunchKernelGGL(k_cc_relabel, dim3(grid_for(nvox)), dim3(256), 0, s, nvox, L, rank);
-    return hipGetLastError() == hipSuccess ? SD_OK : sd_fail_msg(SD_ERR_HIP, "sd_object_segmentation: launch failed");
+    if (markers_out_dev && hipMemcpyAsync(markers_out_dev, mk, nvox * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return sd_fail_msg(SD_ERR_HIP, "sd_object_segmentation_watershed: copy failed");
+    // distance transform of tmp_data (:349-350) and its connected components (the flood never leaves one)
+    hipLaunchKernelGGL(k_edt_z, dim3(grid_for((size_t)X * Y)), dim3(256), 0, s, M, d, (int)pixel_pitch_xyz[2], g);
+    hipLaunchKernelGGL(k_edt_axis, dim3(grid_for(nvox)), dim3(256), 0, s, g, rank, d, 1, (int)pixel_pitch_xyz[1]);
+    hipLaunchKernelGGL(k_edt_axis, dim3(grid_for(nvox)), dim3(256), 0, s, rank, g, d, 2, (int)pixel_pitch_xyz[0]);
+    if (distance_out_dev) hipLaunchKernelGGL(k_sqrt_out, dim3(grid_for(nvox)), dim3(256), 0, s, g, nvox, distance_out_dev);
+    run_cc(s, M, d, comp, rank, blockcnt, scal + 1, mask_out_dev);
+    hipLaunchKernelGGL(k_fill_int, dim3(gt), dim3(256), 0, s, mn, l.T, 0x7fffffff);
+    hipLaunchKernelGGL(k_fill_int, dim3(gt), dim3(256), 0, s, mx, l.T, 0);
+    hipLaunchKernelGGL(k_fill_int, dim3(gt), dim3(256), 0, s, off, l.T, 0);
+    hipLaunchKernelGGL(k_fill_int, dim3(gt), dim3(256), 0, s, hcnt, l.T, 0);
+    hipLaunchKernelGGL(k_comp_markers, dim3(grid_for(nvox)), dim3(256), 0, s, comp, mk, nvox, mn, mx);
+    hipLaunchKernelGGL(k_comp_sizes, dim3(grid_for(nvox)), dim3(256), 0, s, comp, nvox, mn, mx, off);
+    hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, s, off, scal + 1, 1, scal + 4);
+    // watershed (:351): start state + marker heaps, then one sequential priority flood per multi-marker component
+    hipLaunchKernelGGL(k_ws_init, dim3(grid_for(nvox)), dim3(256), 0, s, comp, mk, g, nvox, mn, mx, off, hcnt, hkey, hidx, labels_dev);
+    hipLaunchKernelGGL(k_ws_flood, dim3(2048), dim3(64), 0, s, comp, g, d, scal + 1, mn, mx, off, hcnt, hkey, hidx, labels_dev);
+    hipLaunchKernelGGL(k_fill_int, dim3(1), dim3(256), 0, s, max_label_dev, (size_t)1, 0);
+    hipLaunchKernelGGL(k_max_label, dim3(grid_for(nvox, 1024)), dim3(256), 0, s, labels_dev, nvox, max_label_dev);
+    return hipGetLastError() == hipSuccess ? SD_OK : sd_fail_msg(SD_ERR_HIP, "sd_object_segmentation_watershed: launch failed");
 }
 
 }  // extern "C"
