@@ -122,3 +122,67 @@ def object_segmentation_first_stage(prob, threshold: float, morph_ops: Sequence[
     if return_device:
         return (labels, max_label) + extra
     return (labels.cpu().numpy(), int(max_label.item())) + tuple(e.cpu().numpy() for e in extra)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# chunk driver (thin: no job machinery, no h5 files)
+def auto_overlap(morph_ops: dict, scaling, sigmas=None) -> np.ndarray:
+    """The ``overlap == "auto"`` rule of ``object_segmentation`` (object_extraction_steps.py:152-166): 4 sigma of the largest
+    Gaussian (none by default), at least twice the number of erosions laterally enlarged by the anisotropy."""
+    max_sigma = np.zeros(3) if sigmas is None else np.array([np.max(sigmas)] * 3)
+    overlap = np.ceil(max_sigma * 4)
+    aniso = scaling[2] // scaling[0]
+    n_erosions = 0
+    for v in morph_ops.values():
+        n_erosions = max(n_erosions, 2 * aniso * int(np.sum(np.array(v) == 'binary_erosion')))
+    return np.max([overlap, [n_erosions, n_erosions, n_erosions // aniso]], axis=0).astype(np.int32)
+
+
+def object_segmentation(cset, hdf5names: Sequence[str], prob_kd_path_dict: dict, thresholds: Sequence[float],
+                        overlap="auto", chunk_list: Optional[Sequence[int]] = None, morph_ops: Optional[dict] = None,
+                        min_seed_vx: Optional[dict] = None, scaling=None, with_properties: bool = True, device=None):
+    """``object_segmentation`` + ``_object_segmentation_thread`` (object_extraction_steps.py:42-201, 204-366) for the branch
+    SyConn's pipeline takes after the dense prediction (object_extraction_wrapper.py:58-150: probability maps in
+    KnossosDatasets ``prob_kd_path_dict``, ``load_raw``): per chunk of `cset` load size + 2 * overlap around the chunk from every
+    dataset (x,y,z like ``kd.load_raw(...).swapaxes(0, 2)``), threshold (uint8 scale; fractions <= 1 are scaled by 255 as in
+    ``from_probabilities_to_kd``, :251-253), apply ``config['cell_objects']['extract_morph_op'][name]`` and label.
+
+    Returns ``(results, [overlap, stitch_overlap], props)``: `results` = the reference's ``[chunk.number, hdf5_name,
+    max_label]`` rows; `props[(chunk.number, hdf5_name)]`` = ``find_object_properties`` of that label volume (rep_coords,
+    bounding_box, sizes in chunk-local (x,y,z) incl. the overlap margin) computed from the label volume while it is STILL ON THE
+    DEVICE -- the int32 labels (4 bytes per voxel) never cross PCIe; the reference writes them to an h5 file per chunk and reads
+    them back for the statistics.  Not reproduced: Gaussian pre-smoothing, the membrane hooks, `swapdata`, overlay-cube input."""
+    from .. import global_params
+    from ..knossos import KnossosDataset
+    from .find_object_properties import find_object_properties
+    conf = global_params.config
+    morph_ops = conf['cell_objects']['extract_morph_op'] if morph_ops is None else morph_ops
+    min_seed_vx = conf['cell_objects']['min_seed_vx'] if min_seed_vx is None else min_seed_vx
+    scaling = np.array(conf['scaling'] if scaling is None else scaling)
+    if isinstance(overlap, str) and overlap == "auto":
+        overlap = auto_overlap(morph_ops, scaling)
+    overlap = np.asarray(overlap, dtype=np.int64)
+    stitch_overlap = np.max([overlap.copy(), [1, 1, 1]], axis=0)
+    thresholds = np.array(thresholds, dtype=np.float64)
+    if len(thresholds) and thresholds[0] <= 1.:
+        thresholds = thresholds * 255
+    kds = {}
+    for k, path in prob_kd_path_dict.items():
+        kds[k] = KnossosDataset()
+        kds[k].initialize_from_knossos_path(path)
+    chunk_ids = list(cset.chunk_dict.keys()) if chunk_list is None else list(chunk_list)
+    results, props = [], {}
+    for nb in chunk_ids:
+        chunk = cset.chunk_dict[nb]
+        box_offset = np.array(chunk.coordinates) - overlap
+        size = np.array(chunk.size) + 2 * overlap
+        for i, name in enumerate(hdf5names):
+            tmp_data = np.ascontiguousarray(kds[name].load_raw(size=size, offset=box_offset, mag=1).swapaxes(0, 2))
+            ops = list(morph_ops.get(name, [])) if name in morph_ops else []
+            seed = int(min_seed_vx.get(name, 0)) if name in min_seed_vx else 0
+            labels, max_label = object_segmentation_first_stage(tmp_data, float(thresholds[i]), ops, scaling, device=device,
+                                                                return_device=True, min_seed_vx=seed)
+            if with_properties:
+                props[(chunk.number, name)] = find_object_properties(labels)
+            results.append([chunk.number, name, int(max_label.item())])
+    return results, [overlap, stitch_overlap], props

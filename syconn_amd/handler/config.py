@@ -30,6 +30,19 @@ DEFAULTS = {
         'tile_shape': [271, 181, 138],         # prediction.py:677
         'act_dtype': 'f16',
     },
+    # first consumer of the probability maps (object extraction): the reference's defaults,
+    # /root/reference/syconn/handler/config.yml:108-136
+    'cell_objects': {
+        'probathresholds': {'mi': 0.428571429, 'sj': 0.19047619, 'vc': 0.285714286, 'er': 0.5, 'golgi': 0.5},
+        'min_seed_vx': {'mi': 50, 'sj': 10, 'vc': 10, 'er': 30, 'golgi': 30},
+        'extract_morph_op': {
+            'mi': ['binary_opening', 'binary_closing', 'binary_erosion', 'binary_erosion', 'binary_erosion', 'binary_erosion'],
+            'sj': ['binary_opening', 'binary_closing', 'binary_erosion'],
+            'vc': ['binary_opening', 'binary_closing', 'binary_erosion'],
+            'er': ['binary_dilation'] * 3 + ['binary_erosion'] * 3,
+            'golgi': ['binary_dilation'] * 3 + ['binary_erosion'] * 3,
+        },
+    },
 }
 
 

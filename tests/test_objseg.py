@@ -243,3 +243,57 @@ def test_gpu_watershed_equals_oracle(gpu, shape, sigma, q, ops, scaling, min_see
         comp, nc = ndimage.label(tmp)
         multi = sum(1 for c in range(1, nc + 1) if len(np.unique(markers[comp == c])) > 2)
         print(f'{shape}: {nc} mask components, {multi} with several markers, {want_max} labels')
+
+
+def test_auto_overlap_rule_and_default_config():
+    """`overlap == "auto"` of object_segmentation (object_extraction_steps.py:152-166) with the default operation lists
+    (config.yml:130-136: mi has 4 erosions, aniso 2) and the defaults the chunk driver reads from the config"""
+    from syconn_amd.extraction.object_extraction_steps import auto_overlap
+    from syconn_amd.handler.config import DEFAULTS
+    co = DEFAULTS['cell_objects']
+    assert auto_overlap(co['extract_morph_op'], [10, 10, 20]).tolist() == [16, 16, 8]
+    assert auto_overlap({'sj': co['extract_morph_op']['sj']}, [10, 10, 20]).tolist() == [4, 4, 2]
+    assert co['min_seed_vx']['mi'] == 50 and abs(co['probathresholds']['sj'] - 0.19047619) < 1e-12
+
+
+@pytest.mark.gpu
+def test_gpu_chunk_driver_kd_to_labels_to_properties(gpu, tmp_path):
+    """KnossosDataset probability maps -> per chunk threshold / default-config morphology / watershed labels on the device ->
+    find_object_properties from the device-resident labels (object_extraction_wrapper.py:58-150 -> object_segmentation ->
+    _object_segmentation_thread): rows and properties equal the oracle run on the same chunk boxes."""
+    from oracle.objprops_ref import find_object_properties_np
+    from oracle.objseg_ref import object_segmentation_watershed_ref
+    from syconn_amd.extraction.object_extraction_steps import object_segmentation
+    from syconn_amd.handler.config import DEFAULTS
+    from syconn_amd.knossos import ChunkDataset, KnossosDataset
+    co = DEFAULTS['cell_objects']
+    scaling = (10, 10, 20)
+    paths, vols = {}, {}
+    for i, name in enumerate(('sj', 'vc')):
+        prob, _ = _blobs((96, 80, 48), 30 + i, 2.2, 0.5)                 # (x,y,z)
+        vols[name] = prob
+        kd = KnossosDataset()
+        kd.initialize_without_conf(str(tmp_path / name), boundary=prob.shape, scale=scaling, experiment_name=name, mags=[1])
+        kd.save_raw(offset=(0, 0, 0), mags=[1], data=np.ascontiguousarray(prob.swapaxes(0, 2)), data_mag=1)
+        paths[name] = str(tmp_path / name)
+    cset = ChunkDataset()
+    cset.initialize(None, (96, 80, 48), (48, 40, 48), str(tmp_path / 'cd'), box_coords=[0, 0, 0], fit_box_size=True)
+    thr = [0.45, 0.5]
+    results, (overlap, stitch), props = object_segmentation(cset, ['sj', 'vc'], paths, thr, morph_ops=co['extract_morph_op'],
+                                                            min_seed_vx=co['min_seed_vx'], scaling=scaling)
+    assert overlap.tolist() == [16, 16, 8] and len(results) == 2 * len(cset.chunk_dict) == 8
+    n_obj = 0
+    for nb, chunk in cset.chunk_dict.items():
+        lo = np.array(chunk.coordinates) - overlap
+        size = np.array(chunk.size) + 2 * overlap
+        for i, name in enumerate(('sj', 'vc')):
+            box = np.zeros(size, np.uint8)                              # kd.load_raw: zeros outside the dataset
+            a, b = np.maximum(lo, 0), np.minimum(lo + size, vols[name].shape)
+            box[a[0] - lo[0]:b[0] - lo[0], a[1] - lo[1]:b[1] - lo[1], a[2] - lo[2]:b[2] - lo[2]] = \
+                vols[name][a[0]:b[0], a[1]:b[1], a[2]:b[2]]
+            want, want_max, _, _ = object_segmentation_watershed_ref(box, thr[i] * 255, co['extract_morph_op'][name], scaling,
+                                                                     co['min_seed_vx'][name])
+            assert [nb, name, want_max] in results
+            assert props[(nb, name)] == find_object_properties_np(want.astype(np.uint32))
+            n_obj += want_max
+    assert n_obj > 8
