@@ -150,9 +150,14 @@ int infer_shapes(const sd_model* m, int D, int H, int W, std::vector<Dims>& dims
 // shapes the fused level-0 decoder serves (sd_dec0.hip: cursor arithmetic) and is worth it for: it walks x-strips of 64
 // columns at the cost of full strips, so a width that fills its last strip badly is faster layer by layer (measured: 66
 // columns = 2 strips at 52 % -> 0.26 vs 0.21 ms; 331 columns = 6 strips at 86 % -> 1.24 vs 1.36 ms).  Others run the layers.
+// (ONE predicate for plan_workspace, forward_impl and launch_dec0: the kernel's own limits -- 32-bit stream positions, 24-bit
+// row arithmetic, H >= 8 for the cursor wraps -- are part of it, so a shape that passes here never fails in the launcher after
+// the intermediate buffers have been dropped from the workspace)
 bool dec0_shape_ok(const Dims& o) {
     const int nstrip = (o.w + 63) / 64;
-    return o.h >= 8 && (long)o.d * o.h < (1l << 24) && o.w < (1 << 24) && o.w * 10 >= nstrip * 64 * 7;
+    const long hp = 2 * (o.h / 2 + 1);
+    return o.h >= 8 && (long)o.d * o.h < (1l << 24) && o.w < (1 << 24) && (long)o.d * hp * 68 <= (1l << 30) &&
+           (long)o.d * o.h * o.w < (1l << 31) && o.w * 10 >= nstrip * 64 * 7;
 }
 
 size_t plan_workspace(const sd_model* m, const std::vector<Dims>& dims, std::vector<size_t>& off) {
@@ -840,6 +845,7 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
                     for (int t0 = 0; t0 < N && rc == SD_OK; t0 += group) {
                         ConvParams q = p;
                         q.batch = std::min(group, N - t0);
+                        q.batch_total = N;      // the kernel form is chosen for the whole launch set, not per tile group
                         auto adv = [&](const void* ptr) { return ptr ? reinterpret_cast<const char*>(ptr) + (size_t)t0 * tstride : nullptr; };
                         q.src0 = adv(p.src0); q.src1 = adv(p.src1);
                         q.dst = const_cast<char*>(reinterpret_cast<const char*>(adv(p.dst)));

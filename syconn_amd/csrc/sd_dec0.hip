@@ -502,7 +502,7 @@ int launch_dec0(Dec0Params p, int act_dtype, hipStream_t s) {
     }
     p.nzg = (p.D + p.zsplit - 1) / p.zsplit;
     if ((long)p.zsplit * p.HP * PW > (1l << 30) || p.H < 8 || (long)p.D * p.H >= (1l << 24) || p.W >= (1 << 24))
-        return SD_ERR_INVALID;      // 32-bit positions, 24-bit row arithmetic, cursor wraps once per advance
+        return SD_ERR_INVALID;      // 32-bit positions, 24-bit row arithmetic, cursor wraps once per advance (== dec0_shape_ok, sd_api.hip)
     if ((long)p.D * p.H * p.W >= (1l << 31)) return SD_ERR_INVALID;
     if (p.final_kind < 0 || p.final_kind > SD_OUT_LABELS_U8) return SD_ERR_INVALID;
     const int kind = p.final_kind == SD_OUT_LABELS_U8 && !p.lab_fast ? 4 : p.final_kind;

@@ -50,6 +50,8 @@ struct ConvParams {
     void* final_out;   // planar (cout, D*H*W)
     long long* dbg;         // SD_TIMING builds: per-wave cycle stamps
     int batch; size_t tstride, out_tstride;
+    int batch_total;   // > 0: tiles of the whole launch SET when it is issued in tile groups (deferred GroupNorm): the kernel
+                       // form (512- / 256-voxel workgroups, 4-tile form) must not depend on the size of the last group
     // fused GroupNorm statistics: per-channel sum / sum of squares of the stored outputs are added to
     // gn_sums[0..gn_C) / gn_sums[gn_C..2*gn_C) of the block's tile (doubles, zeroed by the host), or nullptr
     double* gn_sums; int gn_C;

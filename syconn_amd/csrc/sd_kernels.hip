@@ -2013,7 +2013,7 @@ bool conv_can_fuse_first(int KZ, int NT, int NB, long vox, int nstages, bool fus
 
 template <typename T, int KZ, int NT>
 static int launch_conv_knt(const ConvParams& p, int NB, hipStream_t s) {
-    const long vox = (long)p.D * p.H * p.W * p.batch;      // all tiles of a batched launch
+    const long vox = (long)p.D * p.H * p.W * (p.batch_total > 0 ? p.batch_total : p.batch);      // all tiles of a batched launch set
     const int nstages = (p.nchunk0 + p.nchunk1) * KZ;
     // 512-voxel workgroups when they still give every CU work, else 256-voxel workgroups
     const bool big = (vox / 512) * NB >= 512;
@@ -2134,8 +2134,9 @@ static int launch_upconv_rows_wl(const UpconvParams& p, hipStream_t s) {      //
 // into which a deferred GroupNorm apply folds for less than the separate apply pass costs (the generic MFMA kernel pays
 // more for it than the pass it replaces: 192 -> 96 channels 80 -> 108 us vs a 10 us pass)
 bool upconv_rows_kernel(int nchunk, int Cd) {
-    return (nchunk == 4 && Cd == 32) || (nchunk == 3 && Cd == 32) || (nchunk == 2 && Cd == 16) || (nchunk == 8 && Cd == 64) ||
-           (nchunk == 6 && Cd == 48);
+    static const bool no_wl = getenv("SD_NO_UPCONV_WL") != nullptr;
+    return (nchunk == 4 && Cd == 32) || (nchunk == 3 && Cd == 32) || (nchunk == 2 && Cd == 16) || (nchunk == 8 && Cd == 64 && !no_wl) ||
+           (nchunk == 6 && Cd == 48) || (nchunk == 12 && Cd == 96 && !no_wl);
 }
 
 template <typename T>

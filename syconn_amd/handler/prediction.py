@@ -287,14 +287,10 @@ class Predictor:
 def dense_predicton_helper(raw: np.ndarray, predictor: 'Predictor', is_zyx=False, return_zyx=False) -> np.ndarray:
     """prediction.py:846-868.  `raw`: float array (X,Y,Z) or (Z,Y,X) already scaled to 0..1; returns the
     inference result as uint8 (C, ...) between 0..255 (truncated ``pred*255``)."""
-    if not is_zyx:
-        raw = xyz2zyx(raw)
-    pred = predictor.predict(raw[None, None]).numpy()
-    pred = np.array(pred[0]) * 255  # remove N-axis
-    pred = pred.astype(np.uint8)
-    if not return_zyx:
-        pred = zyx2xyz(pred)
-    return pred
+    vol_zyx = raw if is_zyx else xyz2zyx(raw)
+    probs = predictor.predict(vol_zyx[None, None]).numpy()[0]           # (C, Z, Y, X) float32, batch axis dropped
+    out = (np.array(probs) * 255).astype(np.uint8)                      # float32 product, truncating cast (:864-865)
+    return out if return_zyx else zyx2xyz(out)
 
 
 def _resolve_threshold(t) -> float:
@@ -324,6 +320,11 @@ def dense_predictor(args):
     cd.initialize(kd, cube_of_interest[1], chunk_size, target_p + '/cd_tmp/', box_coords=cube_of_interest[0],
                   list_of_coords=[], fit_box_size=True, overlap=overlap_shape)
     target_kd_dict = {path: basics.kd_factory(path) for path in target_kd_path_list}
+    if not os.environ.get('SYCONN_AMD_NO_WRITE_COMBINING'):
+        # chunks are not aligned to the target cubes: assemble the cubes this worker touches in memory and write each once
+        # (KnossosDataset.enable_write_combining; flushed at the end of this worker)
+        for tkd in target_kd_dict.values():
+            tkd.enable_write_combining()
 
     ix = 0
     tile_shape = np.array(tile_shape)
@@ -436,6 +437,8 @@ def dense_predictor(args):
                 writes.pop(0).result()
         for w in writes:
             w.result()
+    for tkd in target_kd_dict.values():
+        tkd.flush()
 
 
 def _wd_set() -> bool:

@@ -58,13 +58,40 @@ def _cube_lock(fn: str):
     chunks (482x481x236 by default) that are not aligned to the 256^3 target cubes, so neighbouring chunks of DIFFERENT
     worker processes update the same cube file at about the same time; ``os.replace`` only makes the file swap atomic,
     not the read-modify-write (upstream knossos_utils serialises cube writes per cube as well).  ``flock`` on a sidecar
-    file: held per open file description, so it also serialises the I/O threads of one process."""
+    file: held per open file description, so it also serialises the I/O threads of one process.
+
+    The sidecar is REMOVED again by the holder before it releases the lock (a dataset is not littered with one lock file
+    per cube); a waiter that acquires the lock on a meanwhile-unlinked file notices (inode check) and starts over.
+    Requirement: the file system must implement ``flock`` across the processes / nodes that write one dataset (local file
+    systems, NFSv4, Lustre mounted with ``-o flock``).  A file system that refuses it (ENOLCK / ENOTSUP / EOPNOTSUPP) is a
+    hard error -- silently running without the lock would lose updates."""
+    import errno
     os.makedirs(os.path.dirname(fn), exist_ok=True)
-    fd = os.open(fn + '.lock', os.O_CREAT | os.O_RDWR, 0o666)
+    lock = fn + '.lock'
+    while True:
+        fd = os.open(lock, os.O_CREAT | os.O_RDWR, 0o666)
+        try:
+            fcntl.flock(fd, fcntl.LOCK_EX)
+        except OSError as e:
+            os.close(fd)
+            if e.errno in (errno.ENOLCK, errno.ENOTSUP, getattr(errno, 'EOPNOTSUPP', errno.ENOTSUP)):
+                raise RuntimeError(f'{lock}: this file system does not support flock(); concurrent workers would lose cube '
+                                   f'updates.  Mount it with flock support or run one worker per dataset.') from e
+            raise
+        try:
+            same = os.fstat(fd).st_ino == os.stat(lock).st_ino
+        except FileNotFoundError:
+            same = False
+        if same:
+            break
+        os.close(fd)                              # the previous holder unlinked this file: lock the new one
     try:
-        fcntl.flock(fd, fcntl.LOCK_EX)
         yield
     finally:
+        try:
+            os.unlink(lock)
+        except FileNotFoundError:
+            pass
         try:
             fcntl.flock(fd, fcntl.LOCK_UN)
         finally:
@@ -81,6 +108,7 @@ class KnossosDataset:
         self._mags: List[int] = [1]
         self.scales = []
         self._initialized = False
+        self._wc = None                  # write-combining cache (enable_write_combining)
 
     # -- properties used by the dense path ---------------------------------------------------------
     @property
@@ -263,13 +291,17 @@ class KnossosDataset:
             if np.any(hi <= lo):
                 continue
             c_lo, c_hi = lo // cs, (hi - 1) // cs
-            def one(cx, cy, cz, mag=mag, d=d, off=off, lo=lo, hi=hi):
+            def one(cx, cy, cz, mag=mag, d=d, off=off, lo=lo, hi=hi, bnd=bnd):
                 fn = self._cube_file(mag, cx, cy, cz, ext)
                 c0 = np.array([cx, cy, cz]) * cs
                 a, b = np.maximum(lo, c0), np.minimum(hi, c0 + cs)
                 whole = np.all(a == c0) and np.all(b == c0 + cs)
                 dst = tuple(slice(int(a[i] - c0[i]), int(b[i] - c0[i])) for i in (2, 1, 0))
                 src = tuple(slice(int(a[i] - off[i]), int(b[i] - off[i])) for i in (2, 1, 0))
+                if self._wc is not None and not whole:
+                    need = int(np.prod(np.minimum(c0 + cs, bnd) - c0))      # voxels of this cube inside the dataset
+                    self._wc_add((mag, ext, cx, cy, cz), fn, dtype, tuple(cs[::-1]), dst, d[src], need)
+                    return
                 with _cube_lock(fn):                  # read-modify-write of a cube shared with other workers
                     cube = None if whole else self._read_cube(fn, ext, dtype, tuple(cs[::-1]))
                     if cube is None:
@@ -279,6 +311,62 @@ class KnossosDataset:
 
             _map_cubes(one, itertools.product(range(c_lo[0], c_hi[0] + 1), range(c_lo[1], c_hi[1] + 1),
                                               range(c_lo[2], c_hi[2] + 1)))
+
+    # ---- write combining ---------------------------------------------------------------------------------------------
+    # Chunks (482 x 481 x 236 by default) are not aligned to the target cubes (256^3 at three mags): written chunk by chunk
+    # every cube is read, patched and rewritten about four times.  With write combining the partial cubes a process has
+    # touched stay in memory; a cube whose voxels (inside the dataset) have all arrived is written ONCE without being read,
+    # the rest is merged into the file (read-modify-write under the cube lock, only the boxes this process wrote) when the
+    # cache overflows or at `flush()`.  Regions of different chunks never overlap, so the final dataset is the same.
+    def enable_write_combining(self, max_cubes: int = 64):
+        import collections
+        import threading
+        self._wc = collections.OrderedDict()
+        self._wc_max = int(max_cubes)
+        self._wc_mutex = threading.Lock()
+
+    def _wc_add(self, key, fn, dtype, shape, dst, block, need):
+        evict = None
+        with self._wc_mutex:
+            ent = self._wc.get(key)
+            if ent is None:
+                ent = self._wc[key] = dict(fn=fn, ext=key[1], dtype=dtype, cube=np.zeros(shape, dtype=dtype), boxes=[], have=0,
+                                           need=need)
+            self._wc.move_to_end(key)
+            ent['cube'][dst] = block
+            ent['boxes'].append(dst)
+            ent['have'] += int(block.size)
+            if ent['have'] >= ent['need']:
+                del self._wc[key]
+                done = ent
+            else:
+                done = None
+                if len(self._wc) > self._wc_max:
+                    evict = self._wc.popitem(last=False)[1]
+        if done is not None:                      # complete: nobody else writes into this cube
+            with _cube_lock(done['fn']):
+                self._write_cube(done['fn'], done['ext'], done['cube'])
+        if evict is not None:
+            self._wc_merge(evict)
+
+    def _wc_merge(self, ent):
+        with _cube_lock(ent['fn']):
+            cube = self._read_cube(ent['fn'], ent['ext'], ent['dtype'], ent['cube'].shape)
+            if cube is None:
+                cube = ent['cube']                # (zeros outside the boxes written here)
+            else:
+                for box in ent['boxes']:
+                    cube[box] = ent['cube'][box]
+            self._write_cube(ent['fn'], ent['ext'], cube)
+
+    def flush(self):
+        """Write out every partially assembled cube (no-op without write combining)."""
+        if self._wc is None:
+            return
+        with self._wc_mutex:
+            pending = list(self._wc.values())
+            self._wc.clear()
+        _map_cubes(lambda e: self._wc_merge(e), [(e,) for e in pending])
 
     def save_raw(self, offset, mags, data, data_mag: int = 1, fast_resampling: bool = True, upsample: bool = True,
                  **_):

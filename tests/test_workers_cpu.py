@@ -13,6 +13,7 @@ import sys
 import time
 
 import numpy as np
+import pytest
 
 from syconn_amd.knossos import KnossosDataset
 
@@ -23,10 +24,12 @@ def _vol(shape_zyx, seed):
     return np.random.default_rng(seed).integers(1, 255, shape_zyx, dtype=np.uint8)
 
 
-def _writer(path, boxes, seed, ext, barrier):
+def _writer(path, boxes, seed, ext, barrier, combine=False):
     kd = KnossosDataset().initialize_from_knossos_path(path)
+    if combine:
+        kd.enable_write_combining(max_cubes=3)          # (tiny cache: evictions = read-modify-write merges in mid-run)
     barrier.wait()
-    for rep in range(3):                       # repeated passes widen the race window; the content is idempotent
+    for rep in range(1 if combine else 3):                       # repeated passes widen the race window; the content is idempotent
         for off_xyz, size_xyz in boxes:
             z, y, x = off_xyz[2], off_xyz[1], off_xyz[0]
             data = _vol((96, 96, 96), seed)[z:z + size_xyz[2], y:y + size_xyz[1], x:x + size_xyz[0]]
@@ -36,6 +39,7 @@ def _writer(path, boxes, seed, ext, barrier):
             else:
                 kd.save_seg(offset=np.array(off_xyz), mags=[1], data=data.astype(np.uint64), data_mag=1,
                             fast_resampling=True, upsample=False)
+    kd.flush()
 
 
 def _boxes():
@@ -55,14 +59,18 @@ def _make_kd(path):
     return kd
 
 
-def test_two_processes_sharing_cubes_lose_no_update(tmp_path):
+@pytest.mark.parametrize('combine', [False, True])
+def test_two_processes_sharing_cubes_lose_no_update(tmp_path, combine):
+    """`combine`: every writer assembles the cubes it touches in memory (KnossosDataset.enable_write_combining: complete cubes
+    are written once, partial ones merged under the cube lock at eviction / flush) -- same dataset, and no lock file is
+    left behind either way."""
     boxes = _boxes()
     for ext in ('raw', 'seg'):
         p = tmp_path / f'kd_{ext}'
         _make_kd(p)
         ctx = mp.get_context('fork')
         barrier = ctx.Barrier(2)
-        procs = [ctx.Process(target=_writer, args=(str(p), boxes[i::2], 7, ext, barrier)) for i in range(2)]
+        procs = [ctx.Process(target=_writer, args=(str(p), boxes[i::2], 7, ext, barrier, combine)) for i in range(2)]
         for pr in procs:
             pr.start()
         for pr in procs:
@@ -79,6 +87,28 @@ def test_two_processes_sharing_cubes_lose_no_update(tmp_path):
         else:
             got = kd.load_seg(size=np.array([96, 96, 96]), offset=np.zeros(3, int), mag=1)
             assert np.array_equal(got, want.astype(np.uint64))
+        assert not [f for _, _, fs in os.walk(p) for f in fs if f.endswith('.lock')]
+
+
+def test_write_combining_writes_complete_cubes_once(tmp_path, monkeypatch):
+    """one writer covering the whole dataset: with write combining every cube file is written exactly once and never read"""
+    p = tmp_path / 'kd'
+    _make_kd(p)
+    kd = KnossosDataset().initialize_from_knossos_path(str(p))
+    kd.enable_write_combining(max_cubes=64)
+    n_write, n_read = [0], [0]
+    w0, r0 = kd._write_cube, kd._read_cube
+    monkeypatch.setattr(kd, '_write_cube', lambda *a, **k: (n_write.__setitem__(0, n_write[0] + 1), w0(*a, **k))[1])
+    monkeypatch.setattr(kd, '_read_cube', lambda *a, **k: (n_read.__setitem__(0, n_read[0] + 1), r0(*a, **k))[1])
+    want = _vol((96, 96, 96), 3)
+    for off_xyz, size_xyz in _boxes():
+        z, y, x = off_xyz[2], off_xyz[1], off_xyz[0]
+        kd.save_raw(offset=np.array(off_xyz), mags=[1], data=want[z:z + 24, y:y + 24, x:x + 24], data_mag=1)
+    kd.flush()
+    assert n_write[0] == 8 and n_read[0] == 0          # 96^3 in 64^3 cubes: 2 x 2 x 2 files
+    monkeypatch.undo()
+    got = KnossosDataset().initialize_from_knossos_path(str(p)).load_raw(size=np.array([96, 96, 96]), offset=np.zeros(3, int), mag=1)
+    assert np.array_equal(got, want)
 
 
 _JOB_SCRIPT = '''
