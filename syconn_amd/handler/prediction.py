@@ -362,17 +362,37 @@ def dense_predictor(args):
     # sequential and in chunk order).  The reference does read -> predict -> write strictly in sequence.
     from concurrent.futures import ThreadPoolExecutor
     dev = predictor.device
+    torch.cuda.set_device(dev)
+    s_in, s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+
+    import time as _time
+    spent = {'read': 0.0, 'gpu': 0.0, 'write': 0.0}       # seconds per pipeline stage (SYCONN_AMD_IO_TIMING=1 logs them)
 
     def read_chunk(ch_id):
+        t0 = _time.perf_counter()
         ch = cd.chunk_dict[ch_id]
         ol = ch.overlap
         size = np.array(np.array(ch.size) + 2 * np.array(ol), dtype=np.int32)
         coords = np.array(np.array(ch.coordinates) - np.array(ol), dtype=np.int32)
-        return np.ascontiguousarray(kd.load_raw(size=size * mag, offset=coords * mag, mag=mag))     # uint8, ZYX
+        out = np.ascontiguousarray(kd.load_raw(size=size * mag, offset=coords * mag, mag=mag))     # uint8, ZYX
+        # upload from the reader thread on the copy-in stream: the (pageable) host-to-device copy of chunk k+1 runs beside the
+        # kernels of chunk k instead of in front of them
+        with torch.cuda.stream(s_in):
+            out_dev = torch.from_numpy(out).to(dev)
+            ev = s_in.record_event()
+        spent['read'] += _time.perf_counter() - t0
+        return out_dev, ev
 
-    def write_chunk(jobs):
-        for save, kwargs in jobs:
-            save(**kwargs)
+    def write_chunk(jobs, ev):
+        t0 = _time.perf_counter()
+        # download on the copy-out stream, from the writer thread: only waits for THIS chunk's kernels (event), not for the
+        # next chunk's work that the main thread has queued on the compute stream meanwhile
+        with torch.cuda.stream(s_out):
+            s_out.wait_event(ev)
+            host = [(save, kwargs, lvl.cpu().numpy()) for save, kwargs, lvl in jobs]
+        for save, kwargs, data in host:
+            save(data=data.astype(np.uint64) if save.__name__ == 'save_seg' else data, **kwargs)
+        spent['write'] += _time.perf_counter() - t0
 
     class _Inline:                       # SYCONN_AMD_SEQ_IO=1: no overlap, everything in the caller's thread (debugging / A-B)
         def __enter__(self):
@@ -396,9 +416,12 @@ def dense_predictor(args):
         for n, ch_id in enumerate(chunk_ids):
             ch = cd.chunk_dict[ch_id]
             ol = ch.overlap
-            raw = nxt.result()
+            raw_dev, ev_in = nxt.result()
             nxt = reader.submit(read_chunk, chunk_ids[n + 1]) if n + 1 < len(chunk_ids) else None
-            raw_dev = torch.from_numpy(raw).to(dev)
+            t_gpu = _time.perf_counter()
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_event(ev_in)
+            raw_dev.record_stream(cur)
             # one multi-id target (mivcsj, syntype): only its label volume is needed -> label rule in the final epilogue
             only_labels = len(target_channels) == 1 and len(target_channels[0]) > 1
             if only_labels:
@@ -421,24 +444,32 @@ def dense_predictor(args):
                 if save_as_raw:
                     # no thresholding and only one label in the target KnossosDataset -> store probability map
                     for k, lvl in enumerate(mag_pyramid(crop[ids[-1]], 3)):
+                        lvl.record_stream(s_out)
                         jobs.append((target_kd_dict[path].save_raw,
-                                     dict(offset=ch.coordinates * mag, data=lvl.cpu().numpy(), data_mag=mag * 2 ** k,
-                                          mags=[mag * 2 ** k], fast_resampling=True, upsample=False)))
+                                     dict(offset=ch.coordinates * mag, data_mag=mag * 2 ** k,
+                                          mags=[mag * 2 ** k], fast_resampling=True, upsample=False), lvl))
                 else:
                     thr = [_resolve_threshold(channel_thresholds[label]) for label in ids]
                     lab = crop[0] if only_labels else postproc_labels(crop, ids, thr, out_dtype=torch.uint8)
-                    for k, lvl in enumerate(mag_pyramid(lab, 3)):  # uint8 on the device and over PCIe, widened here
+                    for k, lvl in enumerate(mag_pyramid(lab, 3)):  # uint8 on the device and over PCIe, widened by the writer
+                        lvl.record_stream(s_out)
                         jobs.append((target_kd_dict[path].save_seg,
-                                     dict(offset=ch.coordinates * mag, data=lvl.cpu().numpy().astype(np.uint64),
-                                          data_mag=mag * 2 ** k, mags=[mag * 2 ** k], fast_resampling=True,
-                                          upsample=False)))
-            writes.append(writer.submit(write_chunk, jobs))
+                                     dict(offset=ch.coordinates * mag, data_mag=mag * 2 ** k, mags=[mag * 2 ** k],
+                                          fast_resampling=True, upsample=False), lvl))
+            ev_done = cur.record_event()
+            spent['gpu'] += _time.perf_counter() - t_gpu
+            writes.append(writer.submit(write_chunk, jobs, ev_done))
             while len(writes) > 2:                   # bound the host memory held by queued results
                 writes.pop(0).result()
         for w in writes:
             w.result()
+    t0 = _time.perf_counter()
     for tkd in target_kd_dict.values():
         tkd.flush()
+    spent['write'] += _time.perf_counter() - t0
+    if os.environ.get('SYCONN_AMD_IO_TIMING'):
+        log_main.warning('dense_predictor stages over %d chunk(s): read + H2D %.2f s (reader thread), launch %.2f s (main thread), '
+                         'D2H + write %.2f s (writer thread)', len(chunk_ids), spent['read'], spent['gpu'], spent['write'])
 
 
 def _wd_set() -> bool:
