@@ -177,7 +177,9 @@ __device__ __forceinline__ bool fg(const uint32_t* A, const Dom& d, int x, int y
     return (A[widx(d, x + d.P, y + d.P, pz >> 5)] >> (pz & 31)) & 1u;
 }
 
-// L[i] = linear index of the first voxel of i's z-run (foreground) or -1; optional byte mask output.
+// L[i] = linear index of the first voxel of i's z-run for FOREGROUND voxels (background entries stay unwritten: the passes
+// below read the 1/8 byte-per-voxel bit mask first and touch the 4 byte-per-voxel label only where it is set -- at 5-20 %
+// foreground that removes most of the label traffic of the five passes); optional byte mask output.
 // One thread = one voxel; the run start is read off the mask words (scan back over all-ones words).
 __global__ __launch_bounds__(256) void k_cc_init_runs(const uint32_t* A, Dom d, int* L, uint8_t* mask_out) {
     const size_t total = (size_t)d.X * d.Y * d.Z;
@@ -199,40 +201,62 @@ __global__ __launch_bounds__(256) void k_cc_init_runs(const uint32_t* A, Dom d, 
             const int start_pz = zeros ? (zw * 32 + 32 - __builtin_clz(zeros)) : 0;
             lab = (int)(i - (size_t)(pz - max(start_pz, d.P)));
         }
-        L[i] = lab;
+        if (f) L[i] = lab;                  // background entries of L are never read (every later pass asks the bit mask first)
         if (mask_out) mask_out[i] = f ? 1 : 0;
     }
 }
-// unions across y and x: a voxel links its run with the neighbour's run where the adjacency STARTS (its own run start or
-// the neighbour's run start), i.e. once per pair of touching runs and direction instead of once per voxel
+// unions across y and x, one thread per MASK WORD (32 voxels of a z-row): where this row and a neighbouring row are both
+// foreground they touch along a z-interval; one union per interval suffices (each side of it lies inside one z-run), issued at
+// the interval's first voxel = the set bits of  adj & ~(adj << 1 | carry from the word below)  -- a few bit operations per 32
+// voxels instead of a coordinate decode and five mask probes per voxel.
 __global__ __launch_bounds__(256) void k_cc_merge_runs(const uint32_t* A, Dom d, int* L) {
-    const size_t total = (size_t)d.X * d.Y * d.Z;
-    const size_t sy = (size_t)d.Z, sx = (size_t)d.Z * d.Y;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int li = L[i];
-        if (li < 0) continue;
-        int z, y, x;
-        dec3(i, d.Z, d.Y, z, y, x);
-        const bool my_start = z == 0 || !fg(A, d, x, y, z - 1);     // from the mask: L[i] of a run start may already be re-linked
-        if (y > 0 && fg(A, d, x, y - 1, z) && (my_start || z == 0 || !fg(A, d, x, y - 1, z - 1)))
-            cc_union(L, (int)i, (int)(i - sy));
-        if (x > 0 && fg(A, d, x - 1, y, z) && (my_start || z == 0 || !fg(A, d, x - 1, y, z - 1)))
-            cc_union(L, (int)i, (int)(i - sx));
+    const size_t total = (size_t)d.X * d.Y * d.PZW;
+    const int vlo = d.P, vhi = d.P + d.Z;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+        int zw, y, x;
+        dec3(t, d.PZW, d.Y, zw, y, x);
+        const uint32_t vm = zmask(zw, vlo, vhi);
+        if (!vm) continue;
+        const uint32_t* row = A + widx(d, x + d.P, y + d.P, 0);
+        const uint32_t w = row[zw] & vm;
+        if (!w) continue;
+        const uint32_t wlow = zw > 0 ? (row[zw - 1] & zmask(zw - 1, vlo, vhi)) : 0u;
+        const int ibase = (int)(((size_t)x * d.Y + y) * d.Z) + zw * 32 - d.P;      // linear voxel index of bit 0 of this word
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+            if (dir == 0 ? y == 0 : x == 0) continue;
+            const uint32_t* nrow = dir == 0 ? A + widx(d, x + d.P, y - 1 + d.P, 0) : A + widx(d, x - 1 + d.P, y + d.P, 0);
+            const uint32_t adj = w & nrow[zw];
+            if (!adj) continue;
+            const uint32_t carry = zw > 0 ? ((wlow & nrow[zw - 1]) >> 31) : 0u;
+            uint32_t starts = adj & ~((adj << 1) | carry);
+            const int noff = dir == 0 ? d.Z : d.Z * d.Y;
+            while (starts) {
+                const int bit = __builtin_ctz(starts);
+                starts &= starts - 1;
+                cc_union(L, ibase + bit, ibase + bit - noff);
+            }
+        }
     }
 }
-__global__ __launch_bounds__(256) void k_cc_compress(size_t total, int* L) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256)
-        if (L[i] >= 0) L[i] = cc_find(L, (int)i);
-}
-
 constexpr int SCAN_PER_THREAD = 8, SCAN_BLOCK = 256 * SCAN_PER_THREAD;
-// roots per block of SCAN_BLOCK voxels
-__global__ __launch_bounds__(256) void k_cc_count(size_t total, const int* L, int* blockcnt) {
+// path compression (L[i] = root of i) fused with the count of roots per block of SCAN_BLOCK voxels (a root is a foreground
+// voxel with L[i] == i: fixed once the merges are done, so it can be counted while other blocks still compress)
+__global__ __launch_bounds__(256) void k_cc_compress_count(const uint32_t* A, Dom d, size_t total, int* L, int* blockcnt) {
     __shared__ int red[4];
-    const size_t base = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * SCAN_PER_THREAD;
+    const size_t base = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
     int c = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_PER_THREAD; ++k) c += (base + k < total && L[base + k] == (int)(base + k)) ? 1 : 0;
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+        const size_t i = base + (size_t)k * 256;           // consecutive threads = consecutive voxels
+        if (i >= total) continue;
+        int z, y, x;
+        dec3(i, d.Z, d.Y, z, y, x);
+        if (!fg(A, d, x, y, z)) continue;
+        const int r = cc_find(L, (int)i);
+        L[i] = r;
+        c += r == (int)i ? 1 : 0;
+    }
     for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
     __syncthreads();
@@ -263,14 +287,22 @@ __global__ __launch_bounds__(1024) void k_cc_scan_blocks(int* blockcnt, int n, i
     if (threadIdx.x == 0) *max_label = carry;
 }
 // rank[root] = 1 + number of roots with a smaller raster index
-__global__ __launch_bounds__(256) void k_cc_rank(size_t total, const int* L, const int* blockcnt, int* rank) {
+__global__ __launch_bounds__(256) void k_cc_rank(const uint32_t* A, Dom d, size_t total, const int* L, const int* blockcnt, int* rank) {
     __shared__ int wsum[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t base = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * SCAN_PER_THREAD;
     bool root[SCAN_PER_THREAD];
     int c = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_PER_THREAD; ++k) { root[k] = base + k < total && L[base + k] == (int)(base + k); c += root[k]; }
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+        root[k] = false;
+        if (base + k < total) {
+            int z, y, x;
+            dec3(base + k, d.Z, d.Y, z, y, x);
+            root[k] = fg(A, d, x, y, z) && L[base + k] == (int)(base + k);
+        }
+        c += root[k];
+    }
     int incl = c;                                             // inclusive scan over the wave's lanes
     for (int s = 1; s < 64; s <<= 1) { const int t = __shfl_up(incl, s, 64); if (lane >= s) incl += t; }
     if (lane == 63) wsum[wave] = incl;
@@ -281,10 +313,11 @@ __global__ __launch_bounds__(256) void k_cc_rank(size_t total, const int* L, con
     for (int k = 0; k < SCAN_PER_THREAD; ++k)
         if (root[k]) rank[base + k] = ++off;
 }
-__global__ __launch_bounds__(256) void k_cc_relabel(size_t total, int* L, const int* rank) {
+__global__ __launch_bounds__(256) void k_cc_relabel(const uint32_t* A, Dom d, size_t total, int* L, const int* rank) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int r = L[i];
-        L[i] = r < 0 ? 0 : rank[r];      // rank[] is a separate buffer: roots read here are never overwritten
+        int z, y, x;
+        dec3(i, d.Z, d.Y, z, y, x);
+        L[i] = fg(A, d, x, y, z) ? rank[L[i]] : 0;      // rank[] is a separate buffer: roots read here are never overwritten
     }
 }
 
@@ -318,12 +351,24 @@ __global__ __launch_bounds__(1024) void k_scan_excl(int* v, const int* n_ptr, in
 __global__ __launch_bounds__(256) void k_fill_int(int* p, size_t n, int v) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
 }
+// cnt[key] += 1 for every lane with key > 0, aggregated over runs of equal keys in consecutive lanes (voxels of one object sit
+// next to each other: one atomic per run instead of one per voxel; all 64 lanes must call)
+__device__ __forceinline__ void count_runs(int key, int* cnt) {
+    const int lane = threadIdx.x & 63;
+    const int prev = __shfl_up(key, 1, 64);
+    const bool head = lane == 0 || key != prev;
+    const unsigned long long heads = __ballot(head);
+    if (head && key > 0) {
+        const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+        const int len = above ? (__builtin_ctzll(above) + 1) : (64 - lane);
+        atomicAdd(&cnt[key], len);
+    }
+}
 // cnt[label] += 1 over the volume (label > 0)
 __global__ __launch_bounds__(256) void k_count_labels(const int* L, size_t total, int* cnt) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int l = L[i];
-        if (l > 0) atomicAdd(&cnt[l], 1);
-    }
+    const size_t n64 = (total + 63) / 64 * 64;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n64; i += (size_t)gridDim.x * 256)
+        count_runs(i < total ? L[i] : 0, cnt);
 }
 // min_seed_vx filter, step 1: del[i] = 1 where the seed with id i (1..N) has fewer than min_size voxels (:325-329)
 __global__ __launch_bounds__(256) void k_seed_flags(const int* cnt, const int* N, int min_size, int* del) {
@@ -374,21 +419,35 @@ __global__ __launch_bounds__(256) void k_apply_map(int* L, size_t total, const i
 // beat the current best once (pitch * k)^2 >= best, so the search stops after about distance / pitch steps.
 constexpr int EDT_INF = 0x3f000000;
 __global__ __launch_bounds__(256) void k_edt_z(const uint32_t* A, Dom d, int pz, int* g) {
-    const int rows = d.X * d.Y;
-    for (int r = blockIdx.x * 256 + threadIdx.x; r < rows; r += gridDim.x * 256) {
-        const int x = r / d.Y, y = r - x * d.Y;
-        int* const row = g + (size_t)r * d.Z;
-        int last = -1;                          // z of the last background voxel seen
-        for (int z = 0; z < d.Z; ++z) {
-            if (!fg(A, d, x, y, z)) { last = z; row[z] = 0; }
-            else if (last >= 0) { const long t = (long)pz * (z - last); row[z] = (int)min(t * t, (long)EDT_INF); }
-            else row[z] = EDT_INF;
+    // one thread per voxel (coalesced stores): the nearest background voxel of the z-row below and above is read off the mask
+    // words -- bits outside the volume's own z range (the morphology padding) do not count as background
+    const size_t total = (size_t)d.X * d.Y * d.Z;
+    const int vlo = d.P, vhi = d.P + d.Z;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        int z, y, x;
+        dec3(i, d.Z, d.Y, z, y, x);
+        const uint32_t* row = A + widx(d, x + d.P, y + d.P, 0);
+        const int pzv = z + d.P, zw = pzv >> 5, b = pzv & 31;
+        const uint32_t w = row[zw];
+        int best = 0;
+        if ((w >> b) & 1u) {
+            long dist = -1;
+            {   // downwards
+                uint32_t zeros = ~w & zmask(zw, vlo, vhi) & (b ? ((1u << b) - 1u) : 0u);
+                int k = zw;
+                while (!zeros && (k - 1) * 32 + 31 >= vlo && k > 0) { --k; zeros = ~row[k] & zmask(k, vlo, vhi); }
+                if (zeros) dist = pzv - (k * 32 + 31 - __builtin_clz(zeros));
+            }
+            {   // upwards
+                uint32_t zeros = ~w & zmask(zw, vlo, vhi) & (b == 31 ? 0u : ~((2u << b) - 1u));
+                int k = zw;
+                while (!zeros && (k + 1) * 32 < vhi && k + 1 < d.PZW) { ++k; zeros = ~row[k] & zmask(k, vlo, vhi); }
+                if (zeros) { const long up = (k * 32 + __builtin_ctz(zeros)) - pzv; dist = dist < 0 ? up : min(dist, up); }
+            }
+            if (dist < 0) best = EDT_INF;
+            else { const long t = (long)pz * dist; best = (int)min(t * t, (long)EDT_INF); }
         }
-        last = -1;
-        for (int z = d.Z - 1; z >= 0; --z) {
-            if (row[z] == 0) last = z;
-            else if (last >= 0) { const long t = (long)pz * (last - z); row[z] = min(row[z], (int)min(t * t, (long)EDT_INF)); }
-        }
+        g[i] = best;
     }
 }
 // one axis pass: out[i] = min over k of in[i + k * stride] + (pitch * k)^2 along an axis of extent n (position c)
@@ -418,14 +477,19 @@ __global__ __launch_bounds__(256) void k_edt_axis(const int* in, int* out, Dom d
 __global__ __launch_bounds__(256) void k_comp_markers(const int* comp, const int* mk, size_t total, int* mn, int* mx) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int m = mk[i];
-        if (m > 0) { const int c = comp[i]; atomicMin(&mn[c], m); atomicMax(&mx[c], m); }
+        if (m > 0) {          // (plain reads first: after the first few voxels of a component almost no atomic is needed)
+            const int c = comp[i];
+            if (m < __hip_atomic_load(&mn[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&mn[c], m);
+            if (m > __hip_atomic_load(&mx[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&mx[c], m);
+        }
     }
 }
 // heap capacity of a component that holds several markers = its voxel count (every voxel is pushed at most once)
 __global__ __launch_bounds__(256) void k_comp_sizes(const int* comp, size_t total, const int* mn, const int* mx, int* sz) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c = comp[i];
-        if (c > 0 && mx[c] > mn[c]) atomicAdd(&sz[c], 1);
+    const size_t n64 = (total + 63) / 64 * 64;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n64; i += (size_t)gridDim.x * 256) {
+        const int c = i < total ? comp[i] : 0;
+        count_runs((c > 0 && mx[c] > mn[c]) ? c : 0, sz);
     }
 }
 // out = the flood's start state: background 0; a component without markers 0; with ONE marker that marker everywhere (the
@@ -608,13 +672,12 @@ void run_morph(hipStream_t s, uint32_t*& A, uint32_t*& B, const Dom& d, int* bbo
 void run_cc(hipStream_t s, const uint32_t* A, const Dom& d, int* L, int* rank, int* blockcnt, int* max_label_dev, uint8_t* mask_out) {
     const size_t nvox = (size_t)d.X * d.Y * d.Z;
     hipLaunchKernelGGL(k_cc_init_runs, dim3(grid_for(nvox)), dim3(256), 0, s, A, d, L, mask_out);
-    hipLaunchKernelGGL(k_cc_merge_runs, dim3(grid_for(nvox)), dim3(256), 0, s, A, d, L);
-    hipLaunchKernelGGL(k_cc_compress, dim3(grid_for(nvox)), dim3(256), 0, s, nvox, L);
+    hipLaunchKernelGGL(k_cc_merge_runs, dim3(grid_for((size_t)d.X * d.Y * d.PZW)), dim3(256), 0, s, A, d, L);
     const int nblk = (int)((nvox + SCAN_BLOCK - 1) / SCAN_BLOCK);
-    hipLaunchKernelGGL(k_cc_count, dim3(nblk), dim3(256), 0, s, nvox, L, blockcnt);
+    hipLaunchKernelGGL(k_cc_compress_count, dim3(nblk), dim3(256), 0, s, A, d, nvox, L, blockcnt);
     hipLaunchKernelGGL(k_cc_scan_blocks, dim3(1), dim3(1024), 0, s, blockcnt, nblk, max_label_dev);
-    hipLaunchKernelGGL(k_cc_rank, dim3(nblk), dim3(256), 0, s, nvox, L, blockcnt, rank);
-    hipLaunchKernelGGL(k_cc_relabel, dim3(grid_for(nvox)), dim3(256), 0, s, nvox, L, rank);
+    hipLaunchKernelGGL(k_cc_rank, dim3(nblk), dim3(256), 0, s, A, d, nvox, L, blockcnt, rank);
+    hipLaunchKernelGGL(k_cc_relabel, dim3(grid_for(nvox)), dim3(256), 0, s, A, d, nvox, L, rank);
 }
 int cut_of(double threshold) {
     // (uint8 p > t) <=> p >= floor(t) + 1; threshold 0 means "already a 0/1 mask" (object_extraction_steps.py:316): cut 1
@@ -744,7 +807,7 @@ int sd_object_segmentation_watershed(const uint8_t* prob_dev, int X, int Y, int 
     if (markers_out_dev && hipMemcpyAsync(markers_out_dev, mk, nvox * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
         return sd_fail_msg(SD_ERR_HIP, "sd_object_segmentation_watershed: copy failed");
     // distance transform of tmp_data (:349-350) and its connected components (the flood never leaves one)
-    hipLaunchKernelGGL(k_edt_z, dim3(grid_for((size_t)X * Y)), dim3(256), 0, s, M, d, (int)pixel_pitch_xyz[2], g);
+    hipLaunchKernelGGL(k_edt_z, dim3(grid_for(nvox)), dim3(256), 0, s, M, d, (int)pixel_pitch_xyz[2], g);
     hipLaunchKernelGGL(k_edt_axis, dim3(grid_for(nvox)), dim3(256), 0, s, g, rank, d, 1, (int)pixel_pitch_xyz[1]);
     hipLaunchKernelGGL(k_edt_axis, dim3(grid_for(nvox)), dim3(256), 0, s, rank, g, d, 2, (int)pixel_pitch_xyz[0]);
     if (distance_out_dev) hipLaunchKernelGGL(k_sqrt_out, dim3(grid_for(nvox)), dim3(256), 0, s, g, nvox, distance_out_dev);

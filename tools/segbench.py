@@ -63,6 +63,13 @@ def main():
             'gpu_Mvox_s': n ** 3 / t_dev / 1e6, 'algorithmic_GB_s': alg / t_dev / 1e9, 'cpu_s_scipy_oracle' + ('' if n <= 256 else '_extrapolated'): tc,
             'cpu_Mvox_s': n ** 3 / tc / 1e6}
 
+    # ---- the default-config watershed branch (config.yml:130-136 'sj' / 'vc' list; object_extraction_steps.py:319-352) --------------
+    ws_ops = ['binary_opening', 'binary_closing', 'binary_erosion']
+    t_ws = sync_time(lambda: object_segmentation_first_stage(p_dev, thr, ws_ops, return_device=True, min_seed_vx=10), reps=3)
+    lab_ws, mx_ws = object_segmentation_first_stage(p_dev, thr, ws_ops, min_seed_vx=10)
+    out['objseg_watershed'] = {'ops': ws_ops, 'min_seed_vx': 10, 'labels': mx_ws, 'gpu_ms_device_resident': t_ws * 1e3,
+                               'gpu_Mvox_s': n ** 3 / t_ws / 1e6, 'labelled_voxels': int((lab_ws > 0).sum())}
+
     # ---- label-volume statistics ---------------------------------------------------------------------------------------
     lab64 = lab.astype(np.uint64)
     c_dev = torch.from_numpy(cell.view(np.int64)).to(dev)
