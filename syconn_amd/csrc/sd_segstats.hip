@@ -128,6 +128,23 @@ __device__ __forceinline__ int lds_find_or_insert(u64* keys, int cap, u64 k) {
     return -1;
 }
 
+// LDS table of (subcell LDS slot, cell LDS slot) pairs -> overlap count of this workgroup's range (32-bit keys: both ids are
+// named by their slots in the workgroup's LDS object tables)
+constexpr int LDS_PSLOTS = 1024;
+__device__ __forceinline__ int lds_pair_slot(unsigned* keys, int cap, unsigned k) {
+    const int mask = cap - 1;
+    int h = (int)((k * 2654435761u) >> 7) & mask;
+    for (int probe = 0; probe < 16 && probe < cap; ++probe, h = (h + 1) & mask) {
+        const unsigned cur = keys[h];
+        if (cur == k) return h;
+        if (cur == 0u) {
+            const unsigned old = atomicCAS(&keys[h], 0u, k);
+            if (old == 0u || old == k) return h;
+        }
+    }
+    return -1;
+}
+
 __device__ __forceinline__ void run_update(const LTab& lt, const ObjTable& gt, u64 key, u64 lin, int x, int y, int z, int len,
                                            int* status) {
     if (lt.cap) {
@@ -169,11 +186,16 @@ __global__ __launch_bounds__(256) void k_segstats_scan(const ScanParams p, const
     __shared__ u64 l_first[LDS_SLOTS];
     __shared__ unsigned l_size[LDS_SLOTS];
     __shared__ int l_bb[6 * LDS_SLOTS];
+    __shared__ unsigned l_pkey[LDS_PSLOTS];      // overlap pairs of this workgroup (see lds_pair_slot), split over the subcell volumes
+    __shared__ unsigned l_pcnt[LDS_PSLOTS];
     const int lane = threadIdx.x & 63;
     const int nvol = (p.cell ? 1 : 0) + p.n_sub;
+    int pcap = 0;                                 // pair slots per subcell volume (power of two)
+    if (p.cell && p.n_sub > 0 && p.want_props && lcap) { pcap = LDS_PSLOTS; while (pcap * p.n_sub > LDS_PSLOTS) pcap >>= 1; }
     for (int i = threadIdx.x; i < LDS_SLOTS; i += 256) {
         l_keys[i] = EMPTY; l_first[i] = ~0ull; l_size[i] = 0;
     }
+    for (int i = threadIdx.x; i < LDS_PSLOTS; i += 256) { l_pkey[i] = 0u; l_pcnt[i] = 0u; }
     for (int i = threadIdx.x; i < 6 * LDS_SLOTS; i += 256) {
         // table t occupies slots [t*lcap, (t+1)*lcap): its bbox block is [6*t*lcap, 6*(t+1)*lcap), min rows first
         const int t = lcap ? i / (6 * lcap) : 0, r = lcap ? (i - t * 6 * lcap) / lcap : 0;
@@ -230,6 +252,16 @@ __global__ __launch_bounds__(256) void k_segstats_scan(const ScanParams p, const
                 const bool phead = chead || shead;
                 const int plen = run_length(phead, lane, nvalid);
                 if (phead && sk != 0 && ck != 0) {
+                    // workgroup-local first: the pair is named by the two ids' slots in the LDS object tables and counted in
+                    // LDS; the three global hash lookups + the global atomic happen once per (workgroup, pair) at the end
+                    if (pcap) {
+                        const LTab slt = ltab(1 + ii);
+                        const int ls = lds_find_or_insert(slt.keys, slt.cap, sk), lc = lds_find_or_insert(cell_lt.keys, cell_lt.cap, ck);
+                        if (ls >= 0 && lc >= 0) {
+                            const int ps = lds_pair_slot(l_pkey + ii * pcap, pcap, (((unsigned)ls << 16) | (unsigned)lc) + 1u);
+                            if (ps >= 0) { atomicAdd(&l_pcnt[ii * pcap + ps], (unsigned)plen); continue; }
+                        }
+                    }
                     const long ss = find_or_insert(p.sub_t[ii].keys, p.sub_t[ii].cap, sk);
                     const long cs = find_or_insert(p.cell_t.keys, p.cell_t.cap, ck);
                     if (ss < 0 || cs < 0) { atomicExch(&p.status[0], 1); continue; }
@@ -241,6 +273,22 @@ __global__ __launch_bounds__(256) void k_segstats_scan(const ScanParams p, const
         }
     }
     __syncthreads();
+    if (pcap) {
+        for (int ii = 0; ii < p.n_sub; ++ii) {
+            const LTab slt = ltab(1 + ii);
+            for (int sidx = threadIdx.x; sidx < pcap; sidx += 256) {
+                const unsigned k = l_pkey[ii * pcap + sidx];
+                if (k == 0u) continue;
+                const u64 sk = slt.keys[(k - 1u) >> 16], ck = cell_lt.keys[(k - 1u) & 0xffffu];
+                const long ss = find_or_insert(p.sub_t[ii].keys, p.sub_t[ii].cap, sk);
+                const long cs = find_or_insert(p.cell_t.keys, p.cell_t.cap, ck);
+                if (ss < 0 || cs < 0) { atomicExch(&p.status[0], 1); continue; }
+                const long ps = find_or_insert(p.pair_keys[ii], p.pair_cap, (((u64)ss << 32) | (u64)cs) + 1);
+                if (ps < 0) { atomicExch(&p.status[1], 1); continue; }
+                atomicAdd(&p.pair_cnt[ii][ps], (u64)l_pcnt[ii * pcap + sidx]);
+            }
+        }
+    }
     if (p.want_props && lcap) {
         if (p.cell) lds_flush(cell_lt, p.cell_t, p.status);
         for (int ii = 0; ii < p.n_sub; ++ii) lds_flush(ltab((p.cell ? 1 : 0) + ii), p.sub_t[ii], p.status);
