@@ -280,13 +280,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     // (the 16-byte halves of a 32-byte record are swapped on odd halo rows); -1 = beyond the halo block
     auto hpack_of = [&](int j) -> int {
         int idx = (wave + j * WAVES) * 64 + lane;
-        if constexpr (LEAN) asm volatile("" : "+v"(idx));     // recomputed at every use (see dma_halo): no AJ live registers
+        if constexpr (LEAN && !GN) asm volatile("" : "+v"(idx));     // recomputed at every use (see dma_halo): no AJ live registers
         const int hv = idx >> 1;
         const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
         return (idx < NH * 2) ? ((hz << 20) | (hy << 10) | (hx << 1) | ((idx & 1) ^ (hy & 1))) : -1;
     };
-    int hpack[LEAN ? 1 : AJ];
-    if constexpr (!LEAN) {
+    // (deferred GroupNorm apply: the decode table stays in registers -- it is needed twice per chunk, for the DMA and for the in-LDS
+    // rewrite, and the ~30 VALU operations of a re-decode per piece are what the rewrite is made of)
+    constexpr bool HPACK_REGS = !LEAN || GN;
+    int hpack[HPACK_REGS ? AJ : 1];
+    if constexpr (HPACK_REGS) {
 #pragma unroll
         for (int j = 0; j < AJ; ++j) hpack[j] = hpack_of(j);
     }
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         for (int j = 0; j < AJ; ++j) {
             const bool inst = real && (wave + j * WAVES < A_INSTR);       // wave-uniform
             if (inst || NA > 2) {
-                const int hp = LEAN ? hpack_of(j) : hpack[LEAN ? 0 : j];
+                const int hp = HPACK_REGS ? hpack[HPACK_REGS ? j : 0] : hpack_of(j);
                 const int z = z0 - PZ + (hp >> 20), y = y0 - 1 + ((hp >> 10) & 1023), x = x0 - 1 + ((hp >> 1) & 511);
                 const bool ok = inst && hp >= 0 && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H &&
                                 (unsigned)x < (unsigned)p.W;
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
 #pragma unroll
             for (int j = 0; j < AJ; ++j) {
                 if (wave + j * WAVES >= A_INSTR) continue;         // wave-uniform
-                const int hp = LEAN ? hpack_of(j) : hpack[LEAN ? 0 : j];
+                const int hp = HPACK_REGS ? hpack[HPACK_REGS ? j : 0] : hpack_of(j);
                 const int z = pd_z - PZ + (hp >> 20), y = pd_y - 1 + ((hp >> 10) & 1023), x = pd_x - 1 + ((hp >> 1) & 511);
                 const bool ok = hp >= 0 && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
                 if (ok) {                                          // out-of-volume pieces stay zero: the conv's zero padding
@@ -683,6 +686,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                 } else if (kz == 0 && !FF) {
                     dma_stream_next();           // chunk gc + NA - 1 of this workgroup's stream
                 }
+                // Deferred GroupNorm apply, 3x3x3 layers: the chunk requested in the kz = 0 stage is only needed three stages later,
+                // so its in-LDS rewrite does not have to sit between that stage's DMA wait and its barrier (where every wave of
+                // the workgroup did it at the same time, ~2 k cycles per chunk with the matrix pipe idle).  It runs in the kz = 1
+                // stage instead, ASYMMETRICALLY: waves 0 ... WAVES/2-1 rewrite their pieces BEFORE their tap loop, their SIMD
+                // partners WAVES/2 ... AFTER theirs -- each group's VALU / LDS work runs under the other group's MFMAs.
+                constexpr bool GN_ASYNC = GN && KZ == 3 && !WRES;
+                if constexpr (GN_ASYNC) {
+                    if (kz == 1 && wave < WAVES / 2) { gn_transform(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+                }
                 if (s == SD_TS) SD_T(1);     // after the DMA issue of the probed stage
                 const char* const bcur = ldsB + (WRES ? s : RING ? gs % NW : (gs & 1)) * B_BYTES + lane * 16;
                 const char* const acur = abuf + kz * SLICE;
@@ -771,7 +783,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                 if (s == SD_TS) SD_T(2);     // after the MFMAs of the probed stage
                 // all of this wave's LDS reads done + the next chunk's DMA landed, then the workgroup barrier (raw
                 // s_barrier: __syncthreads() would drain every DMA in flight with a vmcnt(0))
-                if constexpr (GN) {
+                if constexpr (GN_ASYNC) {
+                    if (kz == 1 && wave >= WAVES / 2) gn_transform();
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                } else if constexpr (GN) {
                     // the chunk requested in this stage has landed: rewrite my pieces of it in place, then the barrier
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     gn_transform();
