@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256) void k_ws_init(const int* comp, const int* mk,
         out[i] = o;
     }
 }
-// Priority flood of one multi-marker component per THREAD: skimage.segmentation.watershed(-distance, markers, mask) restated
+// Priority flood of one multi-marker component per workgroup: skimage.segmentation.watershed(-distance, markers, mask) restated
 // (watershed_raveled, connectivity 1, no compactness): pop the element with the smallest (value, age); every unlabelled mask
 // neighbour -- visited in the order -x, -y, -z, +z, +y, +x of the reference's (x,y,z) arrays -- takes the popped element's label
 // AT PUSH TIME and enters the heap with the next age.  value = -distance: compared through the exact squared distance.  All
@@ -524,50 +524,74 @@ __global__ __launch_bounds__(256) void k_ws_init(const int* comp, const int* mk,
 // (skimage leaves that order to its heap's internals).  Ages are counted per component: comparisons only ever happen between
 // elements of one component, whose relative push order is the same as under a global counter.
 __device__ __forceinline__ bool ws_less(unsigned long long ka, int ia, unsigned long long kb, int ib) { return ka < kb || (ka == kb && ia < ib); }
+// One WORKGROUP (one wave, lane 0 works) per multi-marker component: the algorithm is a chain of dependent heap accesses, so what
+// matters is their latency -- the first WS_LDS_CAP heap entries (the heap holds the flood's current FRONT, a few thousand voxels
+// for organelle-sized components) live in LDS (~64 cycles per access instead of ~1000 for global memory), entries beyond that
+// spill to the component's arena slice.  Components run in parallel (two workgroups per CU).
+constexpr int WS_LDS_CAP = 4608;             // 4608 * 12 bytes = 54 KiB
 __global__ __launch_bounds__(64) void k_ws_flood(const int* comp, const int* g, Dom d, const int* NC, const int* mn, const int* mx,
                                                  const int* off, const int* hcnt, unsigned long long* hkey, int* hidx, int* out) {
+    __shared__ unsigned long long lk[WS_LDS_CAP];
+    __shared__ int li[WS_LDS_CAP];
+    if (threadIdx.x != 0) return;
     const int nc = *NC;
     const int sY = d.Z, sX = d.Z * d.Y;
-    for (int c = 1 + blockIdx.x * 64 + threadIdx.x; c <= nc; c += gridDim.x * 64) {
+    for (int c = 1 + blockIdx.x; c <= nc; c += gridDim.x) {
         if (!(mx[c] > mn[c])) continue;
-        unsigned long long* const K = hkey + off[c];
-        int* const I = hidx + off[c];
+        unsigned long long* const GK = hkey + off[c];
+        int* const GI = hidx + off[c];
         int n = hcnt[c];
+        auto getk = [&](int i) -> unsigned long long { return i < WS_LDS_CAP ? lk[i] : GK[i]; };
+        auto geti = [&](int i) -> int { return i < WS_LDS_CAP ? li[i] : GI[i]; };
+        auto put = [&](int i, unsigned long long k, int ix) { if (i < WS_LDS_CAP) { lk[i] = k; li[i] = ix; } else { GK[i] = k; GI[i] = ix; } };
+        for (int i = 0; i < n && i < WS_LDS_CAP; ++i) { lk[i] = GK[i]; li[i] = GI[i]; }      // markers (unordered) -> LDS part
         auto sift_down = [&](int i) {
-            const unsigned long long k = K[i]; const int ix = I[i];
+            const unsigned long long k = getk(i); const int ix = geti(i);
             while (true) {
                 int ch = 2 * i + 1;
                 if (ch >= n) break;
-                if (ch + 1 < n && ws_less(K[ch + 1], I[ch + 1], K[ch], I[ch])) ++ch;
-                if (!ws_less(K[ch], I[ch], k, ix)) break;
-                K[i] = K[ch]; I[i] = I[ch]; i = ch;
+                unsigned long long kc = getk(ch); int ic = geti(ch);
+                if (ch + 1 < n) {
+                    const unsigned long long k2 = getk(ch + 1); const int i2 = geti(ch + 1);
+                    if (ws_less(k2, i2, kc, ic)) { ++ch; kc = k2; ic = i2; }
+                }
+                if (!ws_less(kc, ic, k, ix)) break;
+                put(i, kc, ic); i = ch;
             }
-            K[i] = k; I[i] = ix;
+            put(i, k, ix);
         };
         for (int i = n / 2 - 1; i >= 0; --i) sift_down(i);
         unsigned age = 0;
         while (n > 0) {
-            const int idx = I[0];
+            const int idx = geti(0);
             const int lab = out[idx];
             --n;
-            if (n > 0) { K[0] = K[n]; I[0] = I[n]; sift_down(0); }
+            if (n > 0) { put(0, getk(n), geti(n)); sift_down(0); }
             int z, y, x;
             dec3((size_t)idx, d.Z, d.Y, z, y, x);
             const int nb[6] = {x > 0 ? idx - sX : -1, y > 0 ? idx - sY : -1, z > 0 ? idx - 1 : -1,
                                z + 1 < d.Z ? idx + 1 : -1, y + 1 < d.Y ? idx + sY : -1, x + 1 < d.X ? idx + sX : -1};
+            // the 18 loads of the six neighbours are independent: issued together, one memory latency
+            int cq[6], oq[6], gq[6];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+                const int q = nb[e] < 0 ? idx : nb[e];
+                cq[e] = comp[q]; oq[e] = out[q]; gq[e] = g[q];
+            }
 #pragma unroll
             for (int e = 0; e < 6; ++e) {
                 const int q = nb[e];
-                if (q < 0 || comp[q] != c || out[q] != 0) continue;
+                if (q < 0 || cq[e] != c || oq[e] != 0) continue;
                 out[q] = lab;
-                const unsigned long long k = ((unsigned long long)(WS_KMAX - (unsigned)g[q]) << 32) | (unsigned long long)(++age);
+                const unsigned long long k = ((unsigned long long)(WS_KMAX - (unsigned)gq[e]) << 32) | (unsigned long long)(++age);
                 int i = n++;                              // sift up
                 while (i > 0) {
                     const int pa = (i - 1) >> 1;
-                    if (!ws_less(k, q, K[pa], I[pa])) break;
-                    K[i] = K[pa]; I[i] = I[pa]; i = pa;
+                    const unsigned long long kp = getk(pa); const int ip = geti(pa);
+                    if (!ws_less(k, q, kp, ip)) break;
+                    put(i, kp, ip); i = pa;
                 }
-                K[i] = k; I[i] = q;
+                put(i, k, q);
             }
         }
     }
@@ -821,7 +845,7 @@ int sd_object_segmentation_watershed(const uint8_t* prob_dev, int X, int Y, int 
     hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, s, off, scal + 1, 1, scal + 4);
     // watershed (:351): start state + marker heaps, then one sequential priority flood per multi-marker component
     hipLaunchKernelGGL(k_ws_init, dim3(grid_for(nvox)), dim3(256), 0, s, comp, mk, g, nvox, mn, mx, off, hcnt, hkey, hidx, labels_dev);
-    hipLaunchKernelGGL(k_ws_flood, dim3(2048), dim3(64), 0, s, comp, g, d, scal + 1, mn, mx, off, hcnt, hkey, hidx, labels_dev);
+    hipLaunchKernelGGL(k_ws_flood, dim3(4096), dim3(64), 0, s, comp, g, d, scal + 1, mn, mx, off, hcnt, hkey, hidx, labels_dev);
     hipLaunchKernelGGL(k_fill_int, dim3(1), dim3(256), 0, s, max_label_dev, (size_t)1, 0);
     hipLaunchKernelGGL(k_max_label, dim3(grid_for(nvox, 1024)), dim3(256), 0, s, labels_dev, nvox, max_label_dev);
     return hipGetLastError() == hipSuccess ? SD_OK : sd_fail_msg(SD_ERR_HIP, "sd_object_segmentation_watershed: launch failed");

@@ -70,6 +70,31 @@ def main():
     out['objseg_watershed'] = {'ops': ws_ops, 'min_seed_vx': 10, 'labels': mx_ws, 'gpu_ms_device_resident': t_ws * 1e3,
                                'gpu_Mvox_s': n ** 3 / t_ws / 1e6, 'labelled_voxels': int((lab_ws > 0).sum())}
 
+    # the same branch on an organelle-like volume: ~3000 separate ellipsoids (radius 5-14 voxels), about a third of them touching
+    # a neighbour -- many small mask components, few markers each (what thresholded mi / vc / sj maps look like)
+    sph = np.zeros((n, n, n), np.uint8)
+    r2 = np.random.default_rng(5)
+    for _ in range(int(3000 * (n / 512) ** 3)):
+        c = r2.integers(16, n - 16, 3)
+        r = r2.integers(5, 15)
+        if r2.random() < 0.35:
+            c2 = np.clip(c + r2.integers(-r, r + 1, 3) * 1.4, 16, n - 17).astype(int)
+            centres = (c, c2)
+        else:
+            centres = (c,)
+        for cc in centres:
+            lo, hi = np.maximum(cc - r, 0), np.minimum(cc + r + 1, n)
+            g = np.ogrid[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
+            m = ((g[0] - cc[0]) ** 2 + (g[1] - cc[1]) ** 2 + ((g[2] - cc[2]) * 1.6) ** 2) <= r * r
+            sph[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]][m] = 255
+    s_dev2 = torch.from_numpy(sph).to(dev)
+    t_ws2 = sync_time(lambda: object_segmentation_first_stage(s_dev2, 127.5, ws_ops, return_device=True, min_seed_vx=10), reps=3)
+    lab2, mx2 = object_segmentation_first_stage(s_dev2, 127.5, ws_ops, min_seed_vx=10)
+    plain2, pmx2 = object_segmentation_first_stage(s_dev2, 127.5, ws_ops[:2])
+    out['objseg_watershed_organelle_like'] = {'ops': ws_ops, 'min_seed_vx': 10, 'mask_components_after_opening_closing': pmx2,
+                                              'labels': mx2, 'gpu_ms_device_resident': t_ws2 * 1e3,
+                                              'gpu_Mvox_s': n ** 3 / t_ws2 / 1e6, 'labelled_voxels': int((lab2 > 0).sum())}
+
     # ---- label-volume statistics ---------------------------------------------------------------------------------------
     lab64 = lab.astype(np.uint64)
     c_dev = torch.from_numpy(cell.view(np.int64)).to(dev)
