@@ -338,7 +338,11 @@ class KnossosDataset:
             ent['have'] += int(block.size)
             if ent['have'] >= ent['need']:
                 del self._wc[key]
-                done = ent
+                # "complete" only if the boxes really tile the cube: a region written twice would be counted twice
+                bx = ent['boxes']
+                disjoint = all(any(a[i].stop <= b[i].start or b[i].stop <= a[i].start for i in range(3))
+                               for n_, a in enumerate(bx) for b in bx[n_ + 1:])
+                done, evict = (ent, None) if disjoint else (None, ent)
             else:
                 done = None
                 if len(self._wc) > self._wc_max:

@@ -158,3 +158,20 @@ def test_batchjob_script_one_worker_per_gpu(tmp_path, monkeypatch):
         iv = sorted((a, b) for d, a, b in rec.values() if d == dev)
         for (a0, b0), (a1, b1) in zip(iv, iv[1:]):
             assert a1 >= b0 - 1e-3, f'two workers overlapped on GPU {dev}'
+
+
+def test_write_combining_survives_a_region_written_twice(tmp_path):
+    """a region saved twice is counted twice by the completeness counter: the cube must then be MERGED into the file, not written
+    as 'complete' with zeros where nothing arrived yet"""
+    p = tmp_path / 'kd'
+    _make_kd(p)
+    want = _vol((96, 96, 96), 5)
+    first = KnossosDataset().initialize_from_knossos_path(str(p))
+    first.save_raw(offset=np.array((0, 0, 32)), mags=[1], data=want[32:64, :64, :64], data_mag=1)      # on disk before
+    kd = KnossosDataset().initialize_from_knossos_path(str(p))
+    kd.enable_write_combining()
+    for _ in range(2):                                                                                  # 2 x half a cube = "complete"
+        kd.save_raw(offset=np.array((0, 0, 0)), mags=[1], data=want[:32, :64, :64], data_mag=1)
+    kd.flush()
+    got = KnossosDataset().initialize_from_knossos_path(str(p)).load_raw(size=np.array([64, 64, 64]), offset=np.zeros(3, int), mag=1)
+    assert np.array_equal(got, want[:64, :64, :64])
