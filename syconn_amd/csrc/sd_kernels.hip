@@ -1778,9 +1778,21 @@ __global__ __launch_bounds__(256) void k_gn_stats(const GnParams p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) { red[tid][e] = s[e]; red[tid][16 + e] = ss[e]; }
     __syncthreads();
+    // fixed-order two-stage reduction over the 256 threads: thread (segment g, value v) sums 32 rows, then 32 threads sum the 8
+    // segments (a single stage had 32 threads walk 256 rows each: as long as the streaming loop of a block itself)
+    __shared__ double part[8][32];
+    {
+        const int v = tid & 31, gseg = tid >> 5;
+        double t = 0.0;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) t += (double)red[gseg * 32 + k][v];
+        part[gseg][v] = t;
+    }
+    __syncthreads();
     if (tid < 32) {
         double t = 0.0;
-        for (int k = 0; k < 256; ++k) t += (double)red[k][tid];
+#pragma unroll
+        for (int gseg = 0; gseg < 8; ++gseg) t += part[gseg][tid];
         atomicAdd(&sums[(tid >> 4) * p.C + chunk * SD_CHUNK + (tid & 15)], t);
     }
 }
@@ -1808,25 +1820,30 @@ __global__ __launch_bounds__(256) void k_gn_apply_pool(const GnParams p) {
         float mx[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) mx[e] = -INFINITY;
-        for (int dz = 0; dz < p.pkz; ++dz) {
-            const int z = zo * p.pkz + dz;
-            if (z >= p.D) continue;
+        // all window loads are issued before the first value is used (clamped addresses, masked use): the pass is a pure stream
+        // and what bounds it is bytes in flight per thread
+        T* ptrs[8];
+        bool okv[8];
+        v8 vals[8];
 #pragma unroll
-            for (int dy = 0; dy < 2; ++dy) {
-                const int y = yo * 2 + dy;
-                if (y >= p.H) continue;
+        for (int k = 0; k < 8; ++k) {
+            const int dz = k >> 2, dy = (k >> 1) & 1, dx = k & 1;
+            const int z = zo * p.pkz + dz, y = yo * 2 + dy, x = xo * 2 + dx;
+            okv[k] = dz < p.pkz && z < p.D && y < p.H && x < p.W;
+            const int zc = okv[k] ? z : zo * p.pkz, yc = okv[k] ? y : yo * 2, xc = okv[k] ? x : xo * 2;
+            ptrs[k] = buf + ((size_t)(cg >> 1) * p.P + ((size_t)zc * p.Hs + yc) * p.Ws + xc) * SD_CHUNK + (cg & 1) * 8;
+        }
 #pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
-                    const int x = xo * 2 + dx;
-                    if (x >= p.W) continue;
-                    T* ptr = buf + ((size_t)(cg >> 1) * p.P + ((size_t)z * p.Hs + y) * p.Ws + x) * SD_CHUNK + (cg & 1) * 8;
-                    // (one helper for every place a GroupNorm is applied: all plans round identically)
-                    const v8 val = gn_apply8<T>(*reinterpret_cast<const v8*>(ptr), sc, sh, p.relu);
+        for (int k = 0; k < 8; ++k)
+            if (k < 4 || p.pkz == 2) vals[k] = *reinterpret_cast<const v8*>(ptrs[k]);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) mx[e] = fmaxf(mx[e], (float)val[e]);   // max of the ROUNDED values
-                    if (!p.no_inplace) *reinterpret_cast<v8*>(ptr) = val;
-                }
-            }
+        for (int k = 0; k < 8; ++k) {
+            if (!(k < 4 || p.pkz == 2) || !okv[k]) continue;
+            // (one helper for every place a GroupNorm is applied: all plans round identically)
+            const v8 val = gn_apply8<T>(vals[k], sc, sh, p.relu);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mx[e] = fmaxf(mx[e], (float)val[e]);   // max of the ROUNDED values
+            if (!p.no_inplace) *reinterpret_cast<v8*>(ptrs[k]) = val;
         }
         v8 o;
 #pragma unroll
@@ -2215,7 +2232,7 @@ int launch_groupnorm(const GnParams& p, int act_dtype, hipStream_t s) {
     // (the statistics scratch is zero here: zeroed at the start of the forward pass and again by every k_gn_finalize)
     const long nvox = (long)p.D * p.H * p.W;
     if (nvox * ng >= (1l << 32)) return SD_ERR_INVALID;   // (32-bit element decode in the kernels)
-    dim3 g1(grid_for(nvox, 256 * 8, 1024), p.C / SD_CHUNK, p.batch), b1(256);
+    dim3 g1(grid_for(nvox, 256 * 16, 1024), p.C / SD_CHUNK, p.batch), b1(256);
     dim3 g3(grid_for(nvox * ng), 1, p.batch), b3(256);
     dim3 gp(grid_for((long)std::max(p.pD, 1) * std::max(p.pH, 1) * std::max(p.pW, 1) * ng), 1, p.batch);
     if (act_dtype == SD_BF16) {
