@@ -175,3 +175,23 @@ def test_predictor_falls_back_to_bf16_on_fp16_overflow(gpu):
     assert torch.equal(p.predict_proba_u8_device(raw.to(gpu)), want)
     with pytest.raises(L.ActivationOverflowError):
         Predictor(model, act_dtype='f16', **kw).predict((raw.float() / 255.)[None, None].numpy())
+
+
+@pytest.mark.parametrize('arch', sorted(ARCHS))
+def test_f32_mode_against_committed_golden_logits(gpu, arch):
+    """the reference-precision mode against the COMMITTED fp32 logits of all 8 architectures (tests/golden/g4_unet_logits.npz:
+    even and odd tiles, generated by the oracle in the build container -- a fixture that travels, independent of the CPU and
+    oneDNN kernel of the box the test runs on); bf16 / fp16 are checked against the same fixture with their tolerances in
+    tests/test_gpu_unet.py"""
+    import os
+    from syconn_amd import _lib as L
+    from syconn_amd.engine import DenseModel
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g4_unet_logits.npz'))
+    dm = DenseModel(build_unet(arch, seed=100), act_dtype='f32', device=gpu)
+    for tag in ('even', 'odd'):
+        x = torch.from_numpy(g[f'{arch}_{tag}_in'])
+        ref = torch.from_numpy(g[f'{arch}_{tag}_logits'])
+        out = dm.forward(x.to(gpu), L.SD_OUT_LOGITS_F32).cpu()
+        err = float((out - ref).abs().max()) / float(ref.abs().max())
+        assert out.shape == ref.shape and err <= TOL_F32, (arch, tag, err)
+        assert torch.equal(out.argmax(0), ref.argmax(0)) or float((out.argmax(0) != ref.argmax(0)).float().mean()) < 1e-4
