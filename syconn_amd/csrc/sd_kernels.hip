@@ -280,14 +280,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     // (the 16-byte halves of a 32-byte record are swapped on odd halo rows); -1 = beyond the halo block
     auto hpack_of = [&](int j) -> int {
         int idx = (wave + j * WAVES) * 64 + lane;
-        if constexpr (LEAN && !GN) asm volatile("" : "+v"(idx));     // recomputed at every use (see dma_halo): no AJ live registers
+        if constexpr (LEAN && !GN && !(NT == 3 && MT == 2)) asm volatile("" : "+v"(idx));     // recomputed at every use (see dma_halo): no AJ live registers
         const int hv = idx >> 1;
         const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
         return (idx < NH * 2) ? ((hz << 20) | (hy << 10) | (hx << 1) | ((idx & 1) ^ (hy & 1))) : -1;
     };
     // (deferred GroupNorm apply: the decode table stays in registers -- it is needed twice per chunk, for the DMA and for the in-LDS
     // rewrite, and the ~30 VALU operations of a re-decode per piece are what the rewrite is made of)
-    constexpr bool HPACK_REGS = !LEAN || GN;
+    constexpr bool HPACK_REGS = !LEAN || GN || (NT == 3 && MT == 2);
     int hpack[HPACK_REGS ? AJ : 1];
     if constexpr (HPACK_REGS) {
 #pragma unroll
