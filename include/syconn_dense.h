@@ -259,6 +259,16 @@ int sd_object_segmentation_watershed(const uint8_t* prob_dev, int X, int Y, int 
                                      int32_t* max_label_dev, int32_t* markers_out_dev, float* distance_out_dev,
                                      uint8_t* mask_out_dev, void* workspace_dev, size_t ws_bytes, void* stream);
 
+/* The flood of that branch on its own: skimage.segmentation.watershed(-distance, markers, mask) (:351; watershed_raveled with
+ * connectivity 1, no compactness, no watershed line) for distance^2 = d2_dev (int32 >= 0), an int32 marker volume (0 = none;
+ * markers outside the mask are ignored) and a uint8 mask, all (X,Y,Z) with z fastest.  Pop order: higher d2 first, then
+ * first-in first-out, marker voxels (all queued before anything else) among themselves by raster index; a voxel takes the label
+ * of the popped neighbour that reaches it first.  Runs level-synchronously, one workgroup per mask component that holds several
+ * markers (csrc/sd_objseg.hip::k_ws_flood); SD_WS_SEQUENTIAL=1 in the environment selects a sequential restatement (one lane per
+ * component) that the tests cross-check it with.  Workspace: sd_objseg_watershed_workspace_bytes(X, Y, Z, 0). */
+int sd_marker_flood(const int32_t* d2_dev, const int32_t* markers_dev, const uint8_t* mask_dev, int X, int Y, int Z,
+                    int32_t* labels_dev, int32_t* max_label_dev, void* workspace_dev, size_t ws_bytes, void* stream);
+
 /* ---- host-side helpers of the chunk pipeline (no GPU) -----------------------------------------------------------------
  * Multi-threaded strided copy of an (nz, ny, nx)-byte box between two uint8 host arrays whose x-rows are contiguous
  * (strides in bytes), and a multi-threaded memset: what numpy slicing does on one core when the reference cuts a chunk

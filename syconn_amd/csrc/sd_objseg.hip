@@ -23,6 +23,7 @@
 #include <stdint.h>
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 extern int sd_fail_msg(int code, const char* msg);
 
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(256) void k_comp_sizes(const int* comp, size_t tota
 // flood cannot leave the mask component and nothing competes); with several markers the markers themselves, which are also
 // appended to the component's heap array (unordered: k_ws_flood heapifies)
 constexpr unsigned WS_KMAX = 0x7fffffffu;
-__global__ __launch_bounds__(256) void k_ws_init(const int* comp, const int* mk, const int* g, size_t total, const int* mn,
+__global__ __launch_bounds__(256) void k_ws_init_seq(const int* comp, const int* mk, const int* g, size_t total, const int* mn,
                                                  const int* mx, const int* off, int* hcnt, unsigned long long* hkey, int* hidx,
                                                  int* out) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -529,7 +530,7 @@ __device__ __forceinline__ bool ws_less(unsigned long long ka, int ia, unsigned 
 // for organelle-sized components) live in LDS (~64 cycles per access instead of ~1000 for global memory), entries beyond that
 // spill to the component's arena slice.  Components run in parallel (two workgroups per CU).
 constexpr int WS_LDS_CAP = 4608;             // 4608 * 12 bytes = 54 KiB
-__global__ __launch_bounds__(64) void k_ws_flood(const int* comp, const int* g, Dom d, const int* NC, const int* mn, const int* mx,
+__global__ __launch_bounds__(64) void k_ws_flood_seq(const int* comp, const int* g, Dom d, const int* NC, const int* mn, const int* mx,
                                                  const int* off, const int* hcnt, unsigned long long* hkey, int* hidx, int* out) {
     __shared__ unsigned long long lk[WS_LDS_CAP];
     __shared__ int li[WS_LDS_CAP];
@@ -593,6 +594,319 @@ __global__ __launch_bounds__(64) void k_ws_flood(const int* comp, const int* g, 
                 }
                 put(i, k, q);
             }
+        }
+    }
+}
+// ---- level-synchronous form of the same flood (the product path; k_ws_flood_seq above is kept as its cross-check) ----------------
+// With level = squared distance (higher = popped first) the sequential pop sequence is: take the FIFO of the highest non-empty
+// level W, generation by generation (a generation = the FIFO's content when its first element is popped; what a generation
+// pushes at level W is the next one).  A popped element e_i ("block" i) labels its unlabelled neighbours; neighbours ABOVE W
+// start a cascade that floods the whole connected set of unlabelled voxels above W it touches -- and labels that set's
+// unlabelled rim -- before e_{i+1} is popped.  So, per generation, all blocks can run at once:
+//   * an unlabelled voxel at or below W next to a generation element or next to a cascade region goes to the claimer with the
+//     smallest block index (atomicMin on a per-voxel claim word); a cascade region belongs to the smallest block touching it
+//     (min-propagation inside the region until nothing changes);
+//   * what the generation pushes is ordered by block index; the order INSIDE a block is free: its elements carry one label and
+//     stay contiguous in every FIFO, so by induction no comparison between two different labels ever depends on it.
+// FIFO order is carried by a 32-bit stamp T: marker voxels T = raster index (all markers precede every pushed element, ties among
+// them by raster index as in k_ws_flood_seq), pushed elements T = 2^31 + (elements popped before this generation) + block index.
+// Only marker voxels with an unlabelled neighbour are queued (popping any other marker does nothing).
+// tools/experiments/ws_levelsync_proto.py checks this formulation (with a shuffled in-block order) against the sequential
+// restatement on tie-heavy and cascade-heavy landscapes; tests compare the kernel with oracle/objseg_ref.py and with k_ws_flood_seq.
+//
+// One workgroup per multi-marker mask component.  Queued elements wait in two unordered bags per component -- NEAR (level >=
+// lo) and FAR (below), so that the per-level pass only touches the levels about to be popped --, a generation lives sorted by
+// (T, voxel) in LDS (global memory beyond WSP_CAP elements).
+constexpr int WSP_NT = 256;
+constexpr int WSP_CAP = 2048;
+constexpr unsigned WSP_FREE = 0xffffffffu;
+struct WsPool {
+    int* bl[2]; unsigned* bt[2]; int* bv[2];      // bags: level, stamp, voxel (NEAR from the left end of a component's slice, FAR from the right)
+    unsigned long long* ga[2];                    // generations beyond the LDS capacity
+    int* cl; int* wl;                             // voxels claimed in this generation at or below W; cascade voxels (BFS queue)
+    unsigned* claim;                              // per voxel: smallest claiming block of the generation that labels it
+};
+__device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned ld_agent(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// slot = (*counter)++ for the lanes with pred, one atomic per wave; every lane of the wave must call
+__device__ __forceinline__ int wave_slot(int* counter, bool pred) {
+    const unsigned long long m = __ballot(pred);
+    if (!m) return -1;
+    const int lane = threadIdx.x & 63, leader = __builtin_ctzll(m);
+    int b = 0;
+    if (lane == leader) b = atomicAdd(counter, __builtin_popcountll(m));
+    b = __shfl(b, leader, 64);
+    return pred ? b + __builtin_popcountll(m & ((1ull << lane) - 1ull)) : -1;
+}
+__device__ __forceinline__ int bcast(const int* p) { __syncthreads(); const int v = *p; __syncthreads(); return v; }
+// ascending bitonic network for any n (positions >= n count as +infinity and never move); keys are unique
+template <class Get, class Put>
+__device__ __forceinline__ void ws_sort(int n, Get get, Put put) {
+    for (unsigned long long k = 2; (k >> 1) < (unsigned long long)n; k <<= 1) {
+        bool flip = true;
+        for (unsigned j = (unsigned)(k >> 1); j > 0; j >>= 1) {
+            for (unsigned i = threadIdx.x; i < (unsigned)n; i += WSP_NT) {
+                const unsigned p = flip ? (i ^ (unsigned)(k - 1)) : (i ^ j);
+                if (p > i && p < (unsigned)n) {
+                    const unsigned long long a = get(i), b = get(p);
+                    if (a > b) { put(i, b); put(p, a); }
+                }
+            }
+            flip = false;
+            __syncthreads();
+        }
+    }
+}
+// start state as k_ws_init_seq; the marker voxels that can push anything enter the component's bag (left-aligned, buffer 0)
+__global__ __launch_bounds__(256) void k_ws_init(const int* comp, const int* mk, const int* g, Dom d, size_t total, const int* mn,
+                                                 const int* mx, const int* off, int* hcnt, WsPool P, int* out) {
+    const int sY = d.Z, sX = d.Z * d.Y;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = comp[i];
+        int o = 0;
+        if (c > 0 && mx[c] > 0) {
+            if (mx[c] == mn[c]) o = mx[c];
+            else {
+                o = mk[i];
+                if (o > 0) {
+                    int z, y, x;
+                    dec3(i, d.Z, d.Y, z, y, x);
+                    const int idx = (int)i;
+                    const int nb[6] = {x > 0 ? idx - sX : -1, y > 0 ? idx - sY : -1, z > 0 ? idx - 1 : -1,
+                                       z + 1 < d.Z ? idx + 1 : -1, y + 1 < d.Y ? idx + sY : -1, x + 1 < d.X ? idx + sX : -1};
+                    bool open = false;
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) open |= nb[e] >= 0 && comp[nb[e]] == c && mk[nb[e]] == 0;
+                    if (open) {
+                        const int slot = off[c] + atomicAdd(&hcnt[c], 1);
+                        P.bl[0][slot] = g[i]; P.bt[0][slot] = (unsigned)idx; P.bv[0][slot] = idx;
+                    }
+                }
+            }
+        }
+        out[i] = o;
+    }
+}
+__global__ __launch_bounds__(WSP_NT) void k_ws_flood(const int* __restrict__ comp, const int* __restrict__ g, Dom d, const int* NC,
+                                                     const int* mn, const int* mx, const int* off, const int* off_total,
+                                                     const int* hcnt, WsPool P, int* out) {
+    __shared__ unsigned long long sA[2][WSP_CAP];
+    __shared__ int s_nA2, s_nCL, s_tail, s_dirty, s_near, s_far, s_nextW, s_max;
+    const int tid = threadIdx.x, nc = *NC;
+    const int sY = d.Z, sX = d.Z * d.Y;
+    for (int c = 1 + blockIdx.x; c <= nc; c += gridDim.x) {
+        if (!(mx[c] > mn[c])) continue;
+        const int base = off[c];
+        const int cap = (c < nc ? off[c + 1] : *off_total) - base;
+        int nNear = 0, nFar = hcnt[c], nearBuf = 0, farBuf = 0, lo = 0, delta = 0, W = 0, cur = 0, nA = 0;
+        bool farLeft = true;
+        unsigned tbase = 0x80000000u;
+        __syncthreads();
+        if (tid == 0) { s_near = 0; s_far = nFar; s_nextW = 0; }
+        __syncthreads();
+        auto nbrs = [&](int idx, int (&nb)[6]) {
+            int z, y, x;
+            dec3((size_t)idx, d.Z, d.Y, z, y, x);
+            nb[0] = x > 0 ? idx - sX : -1; nb[1] = y > 0 ? idx - sY : -1; nb[2] = z > 0 ? idx - 1 : -1;
+            nb[3] = z + 1 < d.Z ? idx + 1 : -1; nb[4] = y + 1 < d.Y ? idx + sY : -1; nb[5] = x + 1 < d.X ? idx + sX : -1;
+        };
+        auto putA = [&](int buf, int pos, unsigned long long key) { if (pos < WSP_CAP) sA[buf][pos] = key; else P.ga[buf][base + pos] = key; };
+        // a generation that outgrew the LDS moves to global memory as a whole; sorted either way
+        auto sortA = [&](int buf, int n) {
+            if (n <= WSP_CAP) {
+                ws_sort(n, [&](unsigned i) { return sA[buf][i]; }, [&](unsigned i, unsigned long long v) { sA[buf][i] = v; });
+            } else {
+                unsigned long long* G = P.ga[buf] + base;
+                for (int i = tid; i < WSP_CAP; i += WSP_NT) G[i] = sA[buf][i];
+                __syncthreads();
+                ws_sort(n, [&](unsigned i) { return G[i]; }, [&](unsigned i, unsigned long long v) { G[i] = v; });
+            }
+        };
+        while (true) {
+            if (nNear == 0) {
+                if (nFar == 0) break;
+                // ---- window: the highest FAR level and everything within delta of it become NEAR
+                if (tid == 0) { s_max = 0; s_near = 0; s_far = 0; }
+                __syncthreads();
+                int m = 0;
+                for (int k = tid; k < nFar; k += WSP_NT) m = max(m, P.bl[farBuf][farLeft ? base + k : base + cap - 1 - k]);
+                for (int sft = 32; sft >= 1; sft >>= 1) m = max(m, __shfl_xor(m, sft, 64));
+                if ((tid & 63) == 0) atomicMax(&s_max, m);
+                const int wmax = bcast(&s_max);
+                if (delta == 0) delta = max(1, wmax >> 6);
+                lo = wmax - delta;
+                const int db = farBuf ^ 1;
+                for (int k0 = 0; k0 < nFar; k0 += WSP_NT) {
+                    const int k = k0 + tid;
+                    const bool valid = k < nFar;
+                    const int src = farLeft ? base + k : base + cap - 1 - k;
+                    const int l = valid ? P.bl[farBuf][src] : 0;
+                    const unsigned t = valid ? P.bt[farBuf][src] : 0u;
+                    const int v = valid ? P.bv[farBuf][src] : 0;
+                    const bool near = valid && l >= lo;
+                    int sl = wave_slot(&s_near, near);
+                    if (near) { P.bl[db][base + sl] = l; P.bt[db][base + sl] = t; P.bv[db][base + sl] = v; }
+                    sl = wave_slot(&s_far, valid && !near);
+                    if (valid && !near) { const int dst = base + cap - 1 - sl; P.bl[db][dst] = l; P.bt[db][dst] = t; P.bv[db][dst] = v; }
+                }
+                __syncthreads();
+                nNear = s_near; nFar = s_far; nearBuf = farBuf = db; farLeft = false; W = wmax;
+                __syncthreads();
+            }
+            // ---- level W: its elements leave NEAR and form the first generation
+            if (tid == 0) { s_nA2 = 0; s_near = 0; s_nextW = 0; }
+            __syncthreads();
+            {
+                const int nb2 = nearBuf ^ 1;
+                int m = 0;
+                for (int k0 = 0; k0 < nNear; k0 += WSP_NT) {
+                    const int k = k0 + tid;
+                    const bool valid = k < nNear;
+                    const int l = valid ? P.bl[nearBuf][base + k] : 0;
+                    const unsigned t = valid ? P.bt[nearBuf][base + k] : 0u;
+                    const int v = valid ? P.bv[nearBuf][base + k] : 0;
+                    const bool isA = valid && l == W;
+                    int sl = wave_slot(&s_nA2, isA);
+                    if (isA) putA(cur, sl, ((unsigned long long)t << 32) | (unsigned)v);
+                    const bool keep = valid && !isA;
+                    sl = wave_slot(&s_near, keep);
+                    if (keep) { P.bl[nb2][base + sl] = l; P.bt[nb2][base + sl] = t; P.bv[nb2][base + sl] = v; m = max(m, l); }
+                }
+                for (int sft = 32; sft >= 1; sft >>= 1) m = max(m, __shfl_xor(m, sft, 64));
+                if ((tid & 63) == 0 && m > 0) atomicMax(&s_nextW, m);
+                __syncthreads();
+                nA = s_nA2; nearBuf = nb2;
+                __syncthreads();
+            }
+            sortA(cur, nA);
+            // ---- generations of level W
+            while (nA > 0) {
+                const bool ldsA = nA <= WSP_CAP;
+                const unsigned long long* GA = P.ga[cur] + base;
+                auto voxA = [&](unsigned i) -> int { return (int)(unsigned)(ldsA ? sA[cur][i] : GA[i]); };
+                if (tid == 0) { s_nA2 = 0; s_nCL = 0; s_tail = 0; s_dirty = 0; }
+                __syncthreads();
+                // claims of the generation's elements: above W -> cascade seeds (queue wl), else -> cl
+                for (int i0 = 0; i0 < nA; i0 += WSP_NT) {
+                    const int i = i0 + tid;
+                    const bool valid = i < nA;
+                    int nb[6];
+                    nbrs(valid ? voxA(i) : 0, nb);
+                    int cq[6], oq[6], gq[6];
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) {
+                        const int q = (valid && nb[e] >= 0) ? nb[e] : 0;
+                        cq[e] = comp[q]; oq[e] = ld_agent(&out[q]); gq[e] = g[q];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) {
+                        const int q = nb[e];
+                        const bool cand = valid && q >= 0 && cq[e] == c && oq[e] == 0;
+                        const unsigned old = cand ? atomicMin(&P.claim[q], (unsigned)i) : 0u;
+                        const bool first = cand && old == WSP_FREE, up = gq[e] > W;
+                        int sl = wave_slot(&s_tail, first && up);
+                        if (first && up) P.wl[base + sl] = q;
+                        sl = wave_slot(&s_nCL, first && !up);
+                        if (first && !up) P.cl[base + sl] = q;
+                    }
+                }
+                int tail = bcast(&s_tail);
+                if (tail > 0) {
+                    // cascade regions: breadth-first growth, the owner (smallest block) travels along
+                    int head = 0;
+                    while (head < tail) {
+                        for (int k0 = head; k0 < tail; k0 += WSP_NT) {
+                            const int k = k0 + tid;
+                            const bool valid = k < tail;
+                            const int r = valid ? P.wl[base + k] : 0;
+                            const unsigned o = valid ? ld_agent(&P.claim[r]) : 0u;
+                            int nb[6];
+                            nbrs(r, nb);
+                            int cq[6], oq[6], gq[6];
+#pragma unroll
+                            for (int e = 0; e < 6; ++e) {
+                                const int q = (valid && nb[e] >= 0) ? nb[e] : 0;
+                                cq[e] = comp[q]; oq[e] = ld_agent(&out[q]); gq[e] = g[q];
+                            }
+#pragma unroll
+                            for (int e = 0; e < 6; ++e) {
+                                const int q = nb[e];
+                                const bool cand = valid && q >= 0 && cq[e] == c && oq[e] == 0 && gq[e] > W;
+                                const unsigned old = cand ? atomicMin(&P.claim[q], o) : 0u;
+                                const bool first = cand && old == WSP_FREE;
+                                if (cand && !first && old > o) s_dirty = 1;
+                                const int sl = wave_slot(&s_tail, first);
+                                if (first) P.wl[base + sl] = q;
+                            }
+                        }
+                        head = tail;
+                        tail = bcast(&s_tail);
+                    }
+                    // two blocks met inside one region: relax until every voxel of it carries the smaller one
+                    while (bcast(&s_dirty)) {
+                        if (tid == 0) s_dirty = 0;
+                        __syncthreads();
+                        for (int k = tid; k < tail; k += WSP_NT) {
+                            const int r = P.wl[base + k];
+                            const unsigned o = ld_agent(&P.claim[r]);
+                            int nb[6];
+                            nbrs(r, nb);
+#pragma unroll
+                            for (int e = 0; e < 6; ++e) {
+                                const int q = nb[e];
+                                if (q >= 0 && comp[q] == c && ld_agent(&out[q]) == 0 && g[q] > W && atomicMin(&P.claim[q], o) > o) s_dirty = 1;
+                            }
+                        }
+                    }
+                    // the regions' unlabelled rim at or below W
+                    for (int k0 = 0; k0 < tail; k0 += WSP_NT) {
+                        const int k = k0 + tid;
+                        const bool valid = k < tail;
+                        const int r = valid ? P.wl[base + k] : 0;
+                        const unsigned o = valid ? ld_agent(&P.claim[r]) : 0u;
+                        int nb[6];
+                        nbrs(r, nb);
+#pragma unroll
+                        for (int e = 0; e < 6; ++e) {
+                            const int q = nb[e];
+                            const bool cand = valid && q >= 0 && comp[q] == c && ld_agent(&out[q]) == 0 && g[q] <= W;
+                            const unsigned old = cand ? atomicMin(&P.claim[q], o) : 0u;
+                            const bool first = cand && old == WSP_FREE;
+                            const int sl = wave_slot(&s_nCL, first);
+                            if (first) P.cl[base + sl] = q;
+                        }
+                    }
+                }
+                const int nCL = bcast(&s_nCL);
+                // labels; pushes: level W -> next generation, lower levels -> the bags
+                for (int k = tid; k < tail; k += WSP_NT) {
+                    const int r = P.wl[base + k];
+                    out[r] = ld_agent(&out[voxA(ld_agent(&P.claim[r]))]);
+                }
+                for (int k0 = 0; k0 < nCL; k0 += WSP_NT) {
+                    const int k = k0 + tid;
+                    const bool valid = k < nCL;
+                    const int q = valid ? P.cl[base + k] : 0;
+                    const unsigned w = valid ? ld_agent(&P.claim[q]) : 0u;
+                    const int lq = valid ? g[q] : 0;
+                    if (valid) out[q] = ld_agent(&out[voxA(w)]);
+                    const unsigned t = tbase + w;
+                    const bool toA = valid && lq == W, toN = valid && lq < W && lq >= lo, toF = valid && lq < lo;
+                    int sl = wave_slot(&s_nA2, toA);
+                    if (toA) putA(cur ^ 1, sl, ((unsigned long long)t << 32) | (unsigned)q);
+                    sl = wave_slot(&s_near, toN);
+                    if (toN) { P.bl[nearBuf][base + sl] = lq; P.bt[nearBuf][base + sl] = t; P.bv[nearBuf][base + sl] = q; atomicMax(&s_nextW, lq); }
+                    sl = wave_slot(&s_far, toF);
+                    if (toF) { const int dst = base + cap - 1 - sl; P.bl[farBuf][dst] = lq; P.bt[farBuf][dst] = t; P.bv[farBuf][dst] = q; }
+                }
+                tbase += (unsigned)nA;
+                nA = bcast(&s_nA2);
+                cur ^= 1;
+                sortA(cur, nA);
+            }
+            __syncthreads();
+            nNear = s_near; nFar = s_far; W = s_nextW;
+            __syncthreads();
         }
     }
 }
@@ -711,7 +1025,7 @@ int cut_of(double threshold) {
 
 // workspace of the watershed branch: the plain layout + a copy of the mask bits, three more int32 volumes (markers, mask
 // components, squared distances), per-id tables (a volume of n voxels has at most n/2 + 1 six-connected components) and the heap arena
-struct WsLayout2 { WsLayout w; size_t mbits, mk, comp, g, tab[9], hkey, hidx, scal, total; size_t T; };
+struct WsLayout2 { WsLayout w; size_t mbits, mk, comp, g, tab[9], bag[6], ga[2], cl, wl, scal, total; size_t T; };
 WsLayout2 ws_layout2(int X, int Y, int Z, int P) {
     WsLayout2 l{};
     l.w = ws_layout(X, Y, Z, P);
@@ -724,11 +1038,67 @@ WsLayout2 ws_layout2(int X, int Y, int Z, int P) {
     l.comp = cur; cur += rup256(nvox * 4);
     l.g = cur; cur += rup256(nvox * 4);
     for (int i = 0; i < 9; ++i) { l.tab[i] = cur; cur += rup256(l.T * 4); }
-    l.hkey = cur; cur += rup256(nvox * 8);
-    l.hidx = cur; cur += rup256(nvox * 4);
+    for (int i = 0; i < 6; ++i) { l.bag[i] = cur; cur += rup256(nvox * 4); }      // the flood's pool: 48 bytes per voxel of a
+    for (int i = 0; i < 2; ++i) { l.ga[i] = cur; cur += rup256(nvox * 8); }       // multi-marker component, sized for the worst case
+    l.cl = cur; cur += rup256(nvox * 4);
+    l.wl = cur; cur += rup256(nvox * 4);
     l.scal = cur; cur += 256;
     l.total = cur;
     return l;
+}
+
+// pointers into the watershed workspace
+struct WsBufs { int *rank, *blockcnt, *comp, *mn, *mx, *off, *hcnt, *scal; size_t T; WsPool pool; };
+WsBufs ws_bufs(char* wb, const WsLayout2& l) {
+    WsBufs b{};
+    b.rank = reinterpret_cast<int*>(wb + l.w.rank);
+    b.blockcnt = reinterpret_cast<int*>(wb + l.w.blockcnt);
+    b.comp = reinterpret_cast<int*>(wb + l.comp);
+    b.mn = reinterpret_cast<int*>(wb + l.tab[5]); b.mx = reinterpret_cast<int*>(wb + l.tab[6]);
+    b.off = reinterpret_cast<int*>(wb + l.tab[7]); b.hcnt = reinterpret_cast<int*>(wb + l.tab[8]);
+    b.scal = reinterpret_cast<int*>(wb + l.scal);      // [0] N seeds, [1] NC mask components, [2] deleted seeds, [3] J, [4] pool total
+    b.T = l.T;
+    for (int i = 0; i < 2; ++i) {
+        b.pool.bl[i] = reinterpret_cast<int*>(wb + l.bag[3 * i]);
+        b.pool.bt[i] = reinterpret_cast<unsigned*>(wb + l.bag[3 * i + 1]);
+        b.pool.bv[i] = reinterpret_cast<int*>(wb + l.bag[3 * i + 2]);
+        b.pool.ga[i] = reinterpret_cast<unsigned long long*>(wb + l.ga[i]);
+    }
+    b.pool.cl = reinterpret_cast<int*>(wb + l.cl);
+    b.pool.wl = reinterpret_cast<int*>(wb + l.wl);
+    b.pool.claim = reinterpret_cast<unsigned*>(b.rank);      // free once the distance transform and the labelling are done
+    return b;
+}
+// skimage.segmentation.watershed(-distance, markers, mask) (:351) given the mask bits M, the marker volume mk and the squared
+// distances g: mask components, then the flood of every component that holds several markers
+void flood_stage(hipStream_t s, const uint32_t* M, const Dom& d, const int* mk, const int* g, const WsBufs& B, int32_t* labels_dev,
+                 int32_t* max_label_dev, uint8_t* mask_out_dev) {
+    const size_t nvox = (size_t)d.X * d.Y * d.Z;
+    const int gt = grid_for(B.T);
+    int *rank = B.rank, *blockcnt = B.blockcnt, *comp = B.comp, *mn = B.mn, *mx = B.mx, *off = B.off, *hcnt = B.hcnt, *scal = B.scal;
+    const WsPool& pool = B.pool;
+    struct { size_t T; } l{B.T};
+    run_cc(s, M, d, comp, rank, blockcnt, scal + 1, mask_out_dev);
+    hipLaunchKernelGGL(k_fill_int, dim3(gt), dim3(256), 0, s, mn, l.T, 0x7fffffff);
+    hipLaunchKernelGGL(k_fill_int, dim3(gt), dim3(256), 0, s, mx, l.T, 0);
+    hipLaunchKernelGGL(k_fill_int, dim3(gt), dim3(256), 0, s, off, l.T, 0);
+    hipLaunchKernelGGL(k_fill_int, dim3(gt), dim3(256), 0, s, hcnt, l.T, 0);
+    hipLaunchKernelGGL(k_comp_markers, dim3(grid_for(nvox)), dim3(256), 0, s, comp, mk, nvox, mn, mx);
+    hipLaunchKernelGGL(k_comp_sizes, dim3(grid_for(nvox)), dim3(256), 0, s, comp, nvox, mn, mx, off);
+    hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, s, off, scal + 1, 1, scal + 4);
+    // watershed (:351): start state + queued markers, then the flood of every multi-marker component (level-synchronous, one
+    // workgroup per component; SD_WS_SEQUENTIAL=1 selects the sequential restatement it is cross-checked with)
+    const bool sequential = getenv("SD_WS_SEQUENTIAL") != nullptr;
+    if (sequential) {
+        hipLaunchKernelGGL(k_ws_init_seq, dim3(grid_for(nvox)), dim3(256), 0, s, comp, mk, g, nvox, mn, mx, off, hcnt, pool.ga[0], pool.cl, labels_dev);
+        hipLaunchKernelGGL(k_ws_flood_seq, dim3(4096), dim3(64), 0, s, comp, g, d, scal + 1, mn, mx, off, hcnt, pool.ga[0], pool.cl, labels_dev);
+    } else {
+        hipLaunchKernelGGL(k_fill_int, dim3(grid_for(nvox)), dim3(256), 0, s, rank, nvox, -1);
+        hipLaunchKernelGGL(k_ws_init, dim3(grid_for(nvox)), dim3(256), 0, s, comp, mk, g, d, nvox, mn, mx, off, hcnt, pool, labels_dev);
+        hipLaunchKernelGGL(k_ws_flood, dim3(2048), dim3(WSP_NT), 0, s, comp, g, d, scal + 1, mn, mx, off, scal + 4, hcnt, pool, labels_dev);
+    }
+    hipLaunchKernelGGL(k_fill_int, dim3(1), dim3(256), 0, s, max_label_dev, (size_t)1, 0);
+    hipLaunchKernelGGL(k_max_label, dim3(grid_for(nvox, 1024)), dim3(256), 0, s, labels_dev, nvox, max_label_dev);
 }
 }  // namespace
 
@@ -794,18 +1164,14 @@ int sd_object_segmentation_watershed(const uint8_t* prob_dev, int X, int Y, int 
     uint32_t* A = reinterpret_cast<uint32_t*>(wb + l.w.a);
     uint32_t* B = reinterpret_cast<uint32_t*>(wb + l.w.b);
     uint32_t* M = reinterpret_cast<uint32_t*>(wb + l.mbits);
-    int* rank = reinterpret_cast<int*>(wb + l.w.rank);
-    int* blockcnt = reinterpret_cast<int*>(wb + l.w.blockcnt);
+    const WsBufs B2 = ws_bufs(wb, l);
+    int *rank = B2.rank, *blockcnt = B2.blockcnt, *scal = B2.scal;
     int* bbox = reinterpret_cast<int*>(wb + l.w.bbox);
     int* mk = reinterpret_cast<int*>(wb + l.mk);
-    int* comp = reinterpret_cast<int*>(wb + l.comp);
     int* g = reinterpret_cast<int*>(wb + l.g);
-    int* tab[9];
-    for (int i = 0; i < 9; ++i) tab[i] = reinterpret_cast<int*>(wb + l.tab[i]);
-    int *cnt = tab[0], *rd = tab[1], *D = tab[2], *K = tab[3], *map = tab[4], *mn = tab[5], *mx = tab[6], *off = tab[7], *hcnt = tab[8];
-    unsigned long long* hkey = reinterpret_cast<unsigned long long*>(wb + l.hkey);
-    int* hidx = reinterpret_cast<int*>(wb + l.hidx);
-    int* scal = reinterpret_cast<int*>(wb + l.scal);      // [0] N seeds, [1] NC mask components, [2] deleted seeds, [3] J, [4] heap total
+    int* tab[5];
+    for (int i = 0; i < 5; ++i) tab[i] = reinterpret_cast<int*>(wb + l.tab[i]);
+    int *cnt = tab[0], *rd = tab[1], *D = tab[2], *K = tab[3], *map = tab[4];
     const Dom d = make_dom(X, Y, Z, P);
     const size_t pwords = (size_t)d.PX * d.PY * d.PZW, nvox = (size_t)X * Y * Z;
     const int gt = grid_for(l.T);
@@ -835,20 +1201,24 @@ int sd_object_segmentation_watershed(const uint8_t* prob_dev, int X, int Y, int 
     hipLaunchKernelGGL(k_edt_axis, dim3(grid_for(nvox)), dim3(256), 0, s, g, rank, d, 1, (int)pixel_pitch_xyz[1]);
     hipLaunchKernelGGL(k_edt_axis, dim3(grid_for(nvox)), dim3(256), 0, s, rank, g, d, 2, (int)pixel_pitch_xyz[0]);
     if (distance_out_dev) hipLaunchKernelGGL(k_sqrt_out, dim3(grid_for(nvox)), dim3(256), 0, s, g, nvox, distance_out_dev);
-    run_cc(s, M, d, comp, rank, blockcnt, scal + 1, mask_out_dev);
-    hipLaunchKernelGGL(k_fill_int, dim3(gt), dim3(256), 0, s, mn, l.T, 0x7fffffff);
-    hipLaunchKernelGGL(k_fill_int, dim3(gt), dim3(256), 0, s, mx, l.T, 0);
-    hipLaunchKernelGGL(k_fill_int, dim3(gt), dim3(256), 0, s, off, l.T, 0);
-    hipLaunchKernelGGL(k_fill_int, dim3(gt), dim3(256), 0, s, hcnt, l.T, 0);
-    hipLaunchKernelGGL(k_comp_markers, dim3(grid_for(nvox)), dim3(256), 0, s, comp, mk, nvox, mn, mx);
-    hipLaunchKernelGGL(k_comp_sizes, dim3(grid_for(nvox)), dim3(256), 0, s, comp, nvox, mn, mx, off);
-    hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, s, off, scal + 1, 1, scal + 4);
-    // watershed (:351): start state + marker heaps, then one sequential priority flood per multi-marker component
-    hipLaunchKernelGGL(k_ws_init, dim3(grid_for(nvox)), dim3(256), 0, s, comp, mk, g, nvox, mn, mx, off, hcnt, hkey, hidx, labels_dev);
-    hipLaunchKernelGGL(k_ws_flood, dim3(4096), dim3(64), 0, s, comp, g, d, scal + 1, mn, mx, off, hcnt, hkey, hidx, labels_dev);
-    hipLaunchKernelGGL(k_fill_int, dim3(1), dim3(256), 0, s, max_label_dev, (size_t)1, 0);
-    hipLaunchKernelGGL(k_max_label, dim3(grid_for(nvox, 1024)), dim3(256), 0, s, labels_dev, nvox, max_label_dev);
+    flood_stage(s, M, d, mk, g, B2, labels_dev, max_label_dev, mask_out_dev);
     return hipGetLastError() == hipSuccess ? SD_OK : sd_fail_msg(SD_ERR_HIP, "sd_object_segmentation_watershed: launch failed");
+}
+
+int sd_marker_flood(const int32_t* d2_dev, const int32_t* markers_dev, const uint8_t* mask_dev, int X, int Y, int Z,
+                    int32_t* labels_dev, int32_t* max_label_dev, void* ws, size_t ws_bytes, void* stream) {
+    if (!d2_dev || !markers_dev || !mask_dev || !labels_dev || !max_label_dev || !ws || X <= 0 || Y <= 0 || Z <= 0)
+        return sd_fail_msg(SD_ERR_INVALID, "sd_marker_flood: bad argument");
+    if ((size_t)X * Y * Z >= (1ull << 31)) return sd_fail_msg(SD_ERR_INVALID, "sd_marker_flood: volume must have < 2^31 voxels");
+    const WsLayout2 l = ws_layout2(X, Y, Z, 0);
+    if (ws_bytes < l.total) return sd_fail_msg(SD_ERR_NOMEM, "sd_marker_flood: workspace too small");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    char* const wb = reinterpret_cast<char*>(ws);
+    const Dom d = make_dom(X, Y, Z, 0);
+    uint32_t* M = reinterpret_cast<uint32_t*>(wb + l.mbits);
+    hipLaunchKernelGGL(k_threshold_bits, dim3(grid_for((size_t)d.PX * d.PY * d.PZW)), dim3(256), 0, s, mask_dev, 1, d, M);
+    flood_stage(s, M, d, markers_dev, d2_dev, ws_bufs(wb, l), labels_dev, max_label_dev, nullptr);
+    return hipGetLastError() == hipSuccess ? SD_OK : sd_fail_msg(SD_ERR_HIP, "sd_marker_flood: launch failed");
 }
 
 }  // extern "C"

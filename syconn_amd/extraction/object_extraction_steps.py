@@ -124,6 +124,34 @@ def object_segmentation_first_stage(prob, threshold: float, morph_ops: Sequence[
     return (labels.cpu().numpy(), int(max_label.item())) + tuple(e.cpu().numpy() for e in extra)
 
 
+def marker_flood(d2, markers, mask, device=None, return_device: bool = False):
+    """``skimage.segmentation.watershed(-distance, markers, mask=mask)`` as `_object_segmentation_thread` calls it
+    (object_extraction_steps.py:351) for ``distance ** 2 == d2`` (int32 >= 0): (x, y, z) arrays or device tensors -> int32 labels
+    and the largest label (`sd_marker_flood`)."""
+    lib = L.load()
+    if not torch.cuda.is_available():
+        raise RuntimeError('syconn_amd: no MI355X visible to PyTorch-ROCm; this package has no CPU fallback')
+    device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    L.check(lib.sd_init(device.index or 0), 'sd_init')
+
+    def dev(a, dt):
+        t = torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a
+        return t.to(device=device, dtype=dt).contiguous()
+    g, mk, m = dev(d2, torch.int32), dev(markers, torch.int32), dev(mask, torch.uint8)
+    if g.dim() != 3 or g.shape != mk.shape or g.shape != m.shape:
+        raise ValueError('expected three 3D (x, y, z) volumes of one shape')
+    X, Y, Z = (int(v) for v in g.shape)
+    labels = torch.empty((X, Y, Z), dtype=torch.int32, device=device)
+    max_label = torch.zeros(1, dtype=torch.int32, device=device)
+    ws_bytes = lib.sd_objseg_watershed_workspace_bytes(X, Y, Z, 0)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+    L.check(lib.sd_marker_flood(g.data_ptr(), mk.data_ptr(), m.data_ptr(), X, Y, Z, labels.data_ptr(), max_label.data_ptr(),
+                                ws.data_ptr(), ws_bytes, torch.cuda.current_stream(device).cuda_stream), 'sd_marker_flood')
+    if return_device:
+        return labels, max_label
+    return labels.cpu().numpy(), int(max_label.item())
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # chunk driver (thin: no job machinery, no h5 files)
 def auto_overlap(morph_ops: dict, scaling, sigmas=None) -> np.ndarray:

@@ -297,3 +297,88 @@ def test_gpu_chunk_driver_kd_to_labels_to_properties(gpu, tmp_path):
             assert props[(nb, name)] == find_object_properties_np(want.astype(np.uint32))
             n_obj += want_max
     assert n_obj > 8
+
+
+# ---- the marker flood on its own (sd_marker_flood: level-synchronous form, csrc/sd_objseg.hip::k_ws_flood) -------------------------------
+def _flood_case(rng, sh, kind, n_mk):
+    mask = rng.random(sh) < rng.uniform(0.5, 1.0)
+    if kind == 'ties':                                          # few distinct levels: plateaus, first-in first-out decides
+        d2 = rng.integers(1, 4, sh)
+    elif kind == 'rough':                                       # rough landscape: most pushes go uphill (cascades)
+        d2 = rng.integers(0, 50, sh)
+    elif kind == 'flat':
+        d2 = np.ones(sh, np.int64)
+    else:                                                       # what the product feeds it: an exact squared distance transform
+        d2 = np.rint(ndimage.distance_transform_edt(mask, sampling=(1, 1, 2)) ** 2)
+    d2 = np.where(mask, d2, 0).astype(np.int32)
+    markers = np.zeros(sh, np.int32)
+    pts = np.flatnonzero(mask.ravel())
+    for lab, p in enumerate(rng.choice(pts, min(n_mk, pts.size), replace=False), start=1):
+        markers.ravel()[p] = lab
+        for q in (p + 1, p + sh[2]):                            # some markers of several voxels
+            if lab % 2 and q < mask.size and mask.ravel()[q] and markers.ravel()[q] == 0:
+                markers.ravel()[q] = lab
+    return d2, markers, mask.astype(np.uint8)
+
+
+@pytest.mark.gpu
+def test_gpu_marker_flood_equals_sequential_restatement(gpu):
+    """random landscapes (plateaus, uphill cascades, distance transforms; 2..40 markers, ragged masks): the level-synchronous
+    device flood labels every voxel like the sequential priority flood of the oracle"""
+    from oracle.objseg_ref import watershed_ref
+    from syconn_amd.extraction.object_extraction_steps import marker_flood
+    rng = np.random.default_rng(11)
+    n = 0
+    for case in range(90):
+        sh = tuple(int(v) for v in rng.integers(2, 15, 3)) if case < 75 else tuple(int(v) for v in rng.integers(20, 41, 3))
+        kind = ('ties', 'rough', 'edt')[case % 3]
+        d2, markers, mask = _flood_case(rng, sh, kind, int(rng.integers(2, 7)) if case < 75 else 40)
+        want = watershed_ref(d2.astype(np.int64), markers, mask)
+        got, mx = marker_flood(d2, markers, mask)
+        assert np.array_equal(got, want), (case, sh, kind, int((got != want).sum()))
+        assert mx == want.max()
+        n += int((want > 0).sum() - (markers * (mask > 0) > 0).sum())
+    assert n > 50000                                            # voxels the floods had to decide
+
+
+@pytest.mark.gpu
+def test_gpu_marker_flood_large_generations(gpu):
+    """one level, one mask component, five markers in a 56^3 block: generations are whole breadth-first shells (beyond the 2048
+    elements a generation may hold in LDS -> the global-memory sort), ties decided by queue order only"""
+    from oracle.objseg_ref import watershed_ref
+    from syconn_amd.extraction.object_extraction_steps import marker_flood
+    rng = np.random.default_rng(3)
+    d2, markers, mask = _flood_case(rng, (56, 56, 56), 'flat', 5)
+    mask[:] = 1
+    d2[:] = 1
+    want = watershed_ref(d2.astype(np.int64), markers, mask)
+    got, mx = marker_flood(d2, markers, mask)
+    assert mx == 5 and np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_gpu_watershed_level_synchronous_equals_sequential_kernel(gpu, monkeypatch):
+    """the product path against the sequential device restatement (SD_WS_SEQUENTIAL=1) on volumes the Python oracle is too slow
+    for: 192^3 of touching ellipsoids (many mask components with 2..6 markers, deleted seeds -> cascades) and a smooth random
+    field (few huge components)"""
+    from syconn_amd.extraction.object_extraction_steps import object_segmentation_first_stage
+    n = 192
+    sph = np.zeros((n, n, n), np.uint8)
+    r2 = np.random.default_rng(5)
+    for _ in range(400):
+        c = r2.integers(12, n - 12, 3)
+        r = int(r2.integers(4, 12))
+        for cc in (c, np.clip(c + r2.integers(-r, r + 1, 3) * 1.4, 12, n - 13).astype(int))[:1 + (r2.random() < 0.5)]:
+            lo, hi = np.maximum(cc - r, 0), np.minimum(cc + r + 1, n)
+            g = np.ogrid[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
+            sph[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]][((g[0] - cc[0]) ** 2 + (g[1] - cc[1]) ** 2 + ((g[2] - cc[2]) * 1.6) ** 2) <= r * r] = 255
+    field, thr = _blobs((n, n, n), 3, 3.0, 0.7)
+    ops = ['binary_opening', 'binary_closing', 'binary_erosion']
+    for prob, t, o, ms in ((sph, 127.5, ops, 10), (sph, 127.5, ops + ['binary_erosion'] * 2, 40), (field, thr, ops, 10)):
+        monkeypatch.delenv('SD_WS_SEQUENTIAL', raising=False)
+        lab, mx, mk = object_segmentation_first_stage(prob, t, o, (10, 10, 20), min_seed_vx=ms, return_markers=True)
+        monkeypatch.setenv('SD_WS_SEQUENTIAL', '1')
+        want, wmx = object_segmentation_first_stage(prob, t, o, (10, 10, 20), min_seed_vx=ms)
+        monkeypatch.delenv('SD_WS_SEQUENTIAL')
+        assert mx == wmx and mx > 50 and np.array_equal(lab, want)
+        assert int(((lab > 0) & (mk == 0)).sum()) > 100000

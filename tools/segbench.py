@@ -69,6 +69,12 @@ def main():
     lab_ws, mx_ws = object_segmentation_first_stage(p_dev, thr, ws_ops, min_seed_vx=10)
     out['objseg_watershed'] = {'ops': ws_ops, 'min_seed_vx': 10, 'labels': mx_ws, 'gpu_ms_device_resident': t_ws * 1e3,
                                'gpu_Mvox_s': n ** 3 / t_ws / 1e6, 'labelled_voxels': int((lab_ws > 0).sum())}
+    os.environ['SD_WS_SEQUENTIAL'] = '1'                         # the sequential device restatement: cross-check + its time
+    t_seq = sync_time(lambda: object_segmentation_first_stage(p_dev, thr, ws_ops, return_device=True, min_seed_vx=10), reps=1)
+    lab_seq, mx_seq = object_segmentation_first_stage(p_dev, thr, ws_ops, min_seed_vx=10)
+    del os.environ['SD_WS_SEQUENTIAL']
+    assert mx_seq == mx_ws and np.array_equal(lab_seq, lab_ws)
+    out['objseg_watershed']['gpu_ms_sequential_flood_kernel'] = t_seq * 1e3
 
     # the same branch on an organelle-like volume: ~3000 separate ellipsoids (radius 5-14 voxels), about a third of them touching
     # a neighbour -- many small mask components, few markers each (what thresholded mi / vc / sj maps look like)
@@ -91,8 +97,14 @@ def main():
     t_ws2 = sync_time(lambda: object_segmentation_first_stage(s_dev2, 127.5, ws_ops, return_device=True, min_seed_vx=10), reps=3)
     lab2, mx2 = object_segmentation_first_stage(s_dev2, 127.5, ws_ops, min_seed_vx=10)
     plain2, pmx2 = object_segmentation_first_stage(s_dev2, 127.5, ws_ops[:2])
+    os.environ['SD_WS_SEQUENTIAL'] = '1'
+    t_seq2 = sync_time(lambda: object_segmentation_first_stage(s_dev2, 127.5, ws_ops, return_device=True, min_seed_vx=10), reps=1)
+    lab2s, mx2s = object_segmentation_first_stage(s_dev2, 127.5, ws_ops, min_seed_vx=10)
+    del os.environ['SD_WS_SEQUENTIAL']
+    assert mx2s == mx2 and np.array_equal(lab2s, lab2)
     out['objseg_watershed_organelle_like'] = {'ops': ws_ops, 'min_seed_vx': 10, 'mask_components_after_opening_closing': pmx2,
                                               'labels': mx2, 'gpu_ms_device_resident': t_ws2 * 1e3,
+                                              'gpu_ms_sequential_flood_kernel': t_seq2 * 1e3,
                                               'gpu_Mvox_s': n ** 3 / t_ws2 / 1e6, 'labelled_voxels': int((lab2 > 0).sum())}
 
     # ---- label-volume statistics ---------------------------------------------------------------------------------------
