@@ -617,9 +617,10 @@ __global__ __launch_bounds__(64) void k_ws_flood_seq(const int* comp, const int*
 // One workgroup per multi-marker mask component.  Queued elements wait in two unordered bags per component -- NEAR (level >=
 // lo) and FAR (below), so that the per-level pass only touches the levels about to be popped --, a generation lives sorted by
 // (T, voxel) in LDS (global memory beyond WSP_CAP elements).
-constexpr int WSP_NT = 256;
-constexpr int WSP_CAP = 2048;
+constexpr int WSP_THREADS = 1024;      // 256: 13.8 / 30.7 ms, 512: 12.1 / 21.8, 1024: 11.5 / 20.3 ms (organelle-like / giant components, whole branch, 512^3)
+constexpr int WSP_CAP = 8192;
 constexpr unsigned WSP_FREE = 0xffffffffu;
+constexpr int WS_OPEN = -1;            // label volume during the flood: voxel of a multi-marker component, not labelled yet
 struct WsPool {
     int* bl[2]; unsigned* bt[2]; int* bv[2];      // bags: level, stamp, voxel (NEAR from the left end of a component's slice, FAR from the right)
     unsigned long long* ga[2];                    // generations beyond the LDS capacity
@@ -639,18 +640,33 @@ __device__ __forceinline__ int wave_slot(int* counter, bool pred) {
     return pred ? b + __builtin_popcountll(m & ((1ull << lane) - 1ull)) : -1;
 }
 __device__ __forceinline__ int bcast(const int* p) { __syncthreads(); const int v = *p; __syncthreads(); return v; }
-// ascending bitonic network for any n (positions >= n count as +infinity and never move); keys are unique
-template <class Get, class Put>
+// ascending bitonic network for any n (positions >= n count as +infinity and never move); keys are unique.  A step is a set
+// of disjoint pairs: thread t takes the pairs t, t + NT, ... (four at a time: the loads of a batch are independent)
+template <int WSP_NT, class Get, class Put>
 __device__ __forceinline__ void ws_sort(int n, Get get, Put put) {
-    for (unsigned long long k = 2; (k >> 1) < (unsigned long long)n; k <<= 1) {
+    if (n < 2) return;
+    unsigned np2 = 2;
+    while (np2 < (unsigned)n) np2 <<= 1;
+    const unsigned half = np2 >> 1;
+    for (unsigned k = 2; k <= np2; k <<= 1) {
         bool flip = true;
-        for (unsigned j = (unsigned)(k >> 1); j > 0; j >>= 1) {
-            for (unsigned i = threadIdx.x; i < (unsigned)n; i += WSP_NT) {
-                const unsigned p = flip ? (i ^ (unsigned)(k - 1)) : (i ^ j);
-                if (p > i && p < (unsigned)n) {
-                    const unsigned long long a = get(i), b = get(p);
-                    if (a > b) { put(i, b); put(p, a); }
+        for (unsigned j = k >> 1; j > 0; j >>= 1) {
+            const unsigned lj = 31u - (unsigned)__builtin_clz(j);
+            for (unsigned t0 = threadIdx.x; t0 < half; t0 += 4 * WSP_NT) {
+                unsigned ii[4], pp[4];
+                unsigned long long a[4], b[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned t = t0 + u * WSP_NT;
+                    const unsigned i = ((t >> lj) << (lj + 1)) | (t & (j - 1));
+                    const unsigned pr = flip ? (i ^ (k - 1)) : (i + j);
+                    ii[u] = i; pp[u] = pr; ok[u] = t < half && pr < (unsigned)n;
+                    if (ok[u]) { a[u] = get(i); b[u] = get(pr); }
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (ok[u] && a[u] > b[u]) { put(ii[u], b[u]); put(pp[u], a[u]); }
             }
             flip = false;
             __syncthreads();
@@ -668,7 +684,8 @@ __global__ __launch_bounds__(256) void k_ws_init(const int* comp, const int* mk,
             if (mx[c] == mn[c]) o = mx[c];
             else {
                 o = mk[i];
-                if (o > 0) {
+                if (o <= 0) o = WS_OPEN;
+                else {
                     int z, y, x;
                     dec3(i, d.Z, d.Y, z, y, x);
                     const int idx = (int)i;
@@ -676,7 +693,7 @@ __global__ __launch_bounds__(256) void k_ws_init(const int* comp, const int* mk,
                                        z + 1 < d.Z ? idx + 1 : -1, y + 1 < d.Y ? idx + sY : -1, x + 1 < d.X ? idx + sX : -1};
                     bool open = false;
 #pragma unroll
-                    for (int e = 0; e < 6; ++e) open |= nb[e] >= 0 && comp[nb[e]] == c && mk[nb[e]] == 0;
+                    for (int e = 0; e < 6; ++e) open |= nb[e] >= 0 && comp[nb[e]] == c && mk[nb[e]] <= 0;
                     if (open) {
                         const int slot = off[c] + atomicAdd(&hcnt[c], 1);
                         P.bl[0][slot] = g[i]; P.bt[0][slot] = (unsigned)idx; P.bv[0][slot] = idx;
@@ -687,18 +704,30 @@ __global__ __launch_bounds__(256) void k_ws_init(const int* comp, const int* mk,
         out[i] = o;
     }
 }
+#ifdef SD_WS_TIMING
+__device__ unsigned long long g_ws_dbg[2048][16];
+#define WS_T(slot) do { if (threadIdx.x == 0) { const unsigned long long _n = wall_clock64(); g_ws_dbg[blockIdx.x][slot] += _n - t_last; t_last = _n; } } while (0)
+#define WS_C(slot, v) do { if (threadIdx.x == 0) g_ws_dbg[blockIdx.x][slot] += (v); } while (0)
+#else
+#define WS_T(slot) do {} while (0)
+#define WS_C(slot, v) do {} while (0)
+#endif
+template <int WSP_NT>
 __global__ __launch_bounds__(WSP_NT) void k_ws_flood(const int* __restrict__ comp, const int* __restrict__ g, Dom d, const int* NC,
                                                      const int* mn, const int* mx, const int* off, const int* off_total,
                                                      const int* hcnt, WsPool P, int* out) {
-    __shared__ unsigned long long sA[2][WSP_CAP];
+    __shared__ unsigned long long sA[WSP_CAP];
     __shared__ int s_nA2, s_nCL, s_tail, s_dirty, s_near, s_far, s_nextW, s_max;
     const int tid = threadIdx.x, nc = *NC;
     const int sY = d.Z, sX = d.Z * d.Y;
+#ifdef SD_WS_TIMING
+    unsigned long long t_last = wall_clock64();
+#endif
     for (int c = 1 + blockIdx.x; c <= nc; c += gridDim.x) {
         if (!(mx[c] > mn[c])) continue;
         const int base = off[c];
         const int cap = (c < nc ? off[c + 1] : *off_total) - base;
-        int nNear = 0, nFar = hcnt[c], nearBuf = 0, farBuf = 0, lo = 0, delta = 0, W = 0, cur = 0, nA = 0;
+        int nNear = 0, nFar = hcnt[c], nearBuf = 0, farBuf = 0, lo = 0, delta = 0, W = 0, nA = 0;
         bool farLeft = true;
         unsigned tbase = 0x80000000u;
         __syncthreads();
@@ -710,16 +739,18 @@ __global__ __launch_bounds__(WSP_NT) void k_ws_flood(const int* __restrict__ com
             nb[0] = x > 0 ? idx - sX : -1; nb[1] = y > 0 ? idx - sY : -1; nb[2] = z > 0 ? idx - 1 : -1;
             nb[3] = z + 1 < d.Z ? idx + 1 : -1; nb[4] = y + 1 < d.Y ? idx + sY : -1; nb[5] = x + 1 < d.X ? idx + sX : -1;
         };
-        auto putA = [&](int buf, int pos, unsigned long long key) { if (pos < WSP_CAP) sA[buf][pos] = key; else P.ga[buf][base + pos] = key; };
-        // a generation that outgrew the LDS moves to global memory as a whole; sorted either way
-        auto sortA = [&](int buf, int n) {
+        // a generation is collected in global memory (any order) and then sorted: in LDS if it fits, in place otherwise
+        unsigned long long* const GA = P.ga[0] + base;
+        unsigned long long* const GB = P.ga[1] + base;      // an over-long generation is read from here while GA collects the next
+        auto sortA = [&](int n) {
             if (n <= WSP_CAP) {
-                ws_sort(n, [&](unsigned i) { return sA[buf][i]; }, [&](unsigned i, unsigned long long v) { sA[buf][i] = v; });
-            } else {
-                unsigned long long* G = P.ga[buf] + base;
-                for (int i = tid; i < WSP_CAP; i += WSP_NT) G[i] = sA[buf][i];
+                for (int i = tid; i < n; i += WSP_NT) sA[i] = GA[i];
                 __syncthreads();
-                ws_sort(n, [&](unsigned i) { return G[i]; }, [&](unsigned i, unsigned long long v) { G[i] = v; });
+                ws_sort<WSP_NT>(n, [&](unsigned i) { return sA[i]; }, [&](unsigned i, unsigned long long v) { sA[i] = v; });
+            } else {
+                ws_sort<WSP_NT>(n, [&](unsigned i) { return GA[i]; }, [&](unsigned i, unsigned long long v) { GA[i] = v; });
+                for (int i = tid; i < n; i += WSP_NT) GB[i] = GA[i];
+                __syncthreads();
             }
         };
         while (true) {
@@ -752,6 +783,7 @@ __global__ __launch_bounds__(WSP_NT) void k_ws_flood(const int* __restrict__ com
                 __syncthreads();
                 nNear = s_near; nFar = s_far; nearBuf = farBuf = db; farLeft = false; W = wmax;
                 __syncthreads();
+                WS_T(0); WS_C(6, 1);
             }
             // ---- level W: its elements leave NEAR and form the first generation
             if (tid == 0) { s_nA2 = 0; s_near = 0; s_nextW = 0; }
@@ -767,7 +799,7 @@ __global__ __launch_bounds__(WSP_NT) void k_ws_flood(const int* __restrict__ com
                     const int v = valid ? P.bv[nearBuf][base + k] : 0;
                     const bool isA = valid && l == W;
                     int sl = wave_slot(&s_nA2, isA);
-                    if (isA) putA(cur, sl, ((unsigned long long)t << 32) | (unsigned)v);
+                    if (isA) GA[sl] = ((unsigned long long)t << 32) | (unsigned)v;
                     const bool keep = valid && !isA;
                     sl = wave_slot(&s_near, keep);
                     if (keep) { P.bl[nb2][base + sl] = l; P.bt[nb2][base + sl] = t; P.bv[nb2][base + sl] = v; m = max(m, l); }
@@ -778,40 +810,55 @@ __global__ __launch_bounds__(WSP_NT) void k_ws_flood(const int* __restrict__ com
                 nA = s_nA2; nearBuf = nb2;
                 __syncthreads();
             }
-            sortA(cur, nA);
+            sortA(nA);
+            WS_T(1); WS_C(7, 1);
             // ---- generations of level W
             while (nA > 0) {
                 const bool ldsA = nA <= WSP_CAP;
-                const unsigned long long* GA = P.ga[cur] + base;
-                auto voxA = [&](unsigned i) -> int { return (int)(unsigned)(ldsA ? sA[cur][i] : GA[i]); };
+                auto voxA = [&](unsigned i) -> int { return (int)(unsigned)(ldsA ? sA[i] : GB[i]); };
                 if (tid == 0) { s_nA2 = 0; s_nCL = 0; s_tail = 0; s_dirty = 0; }
                 __syncthreads();
-                // claims of the generation's elements: above W -> cascade seeds (queue wl), else -> cl
+                // claims of the generation's elements (WS_OPEN marks the voxels the flood may still label: no mask / component test)
                 for (int i0 = 0; i0 < nA; i0 += WSP_NT) {
                     const int i = i0 + tid;
                     const bool valid = i < nA;
                     int nb[6];
                     nbrs(valid ? voxA(i) : 0, nb);
-                    int cq[6], oq[6], gq[6];
+                    int oq[6];
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) oq[e] = (valid && nb[e] >= 0) ? ld_agent(&out[nb[e]]) : 0;
+                    unsigned oldv[6];
+#ifdef SD_WS_TIMING
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); WS_T(12);
+#endif
+#pragma unroll
+                    for (int e = 0; e < 6; ++e)        // all claims in flight before the first result is needed
+                        oldv[e] = oq[e] == WS_OPEN ? atomicMin(&P.claim[nb[e]], (unsigned)i) : 0u;
+#ifdef SD_WS_TIMING
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); WS_T(13);
+#endif
 #pragma unroll
                     for (int e = 0; e < 6; ++e) {
-                        const int q = (valid && nb[e] >= 0) ? nb[e] : 0;
-                        cq[e] = comp[q]; oq[e] = ld_agent(&out[q]); gq[e] = g[q];
+                        const bool first = oq[e] == WS_OPEN && oldv[e] == WSP_FREE;
+                        const int sl = wave_slot(&s_nCL, first);
+                        if (first) P.cl[base + sl] = nb[e];
                     }
-#pragma unroll
-                    for (int e = 0; e < 6; ++e) {
-                        const int q = nb[e];
-                        const bool cand = valid && q >= 0 && cq[e] == c && oq[e] == 0;
-                        const unsigned old = cand ? atomicMin(&P.claim[q], (unsigned)i) : 0u;
-                        const bool first = cand && old == WSP_FREE, up = gq[e] > W;
-                        int sl = wave_slot(&s_tail, first && up);
-                        if (first && up) P.wl[base + sl] = q;
-                        sl = wave_slot(&s_nCL, first && !up);
-                        if (first && !up) P.cl[base + sl] = q;
-                    }
+                    WS_T(14);
+                }
+                // the claimed voxels above W are cascade seeds: they move to the queue wl
+                const int nCL0 = bcast(&s_nCL);
+                for (int k0 = 0; k0 < nCL0; k0 += WSP_NT) {
+                    const int k = k0 + tid;
+                    const bool valid = k < nCL0;
+                    const int q = valid ? P.cl[base + k] : 0;
+                    const bool up = valid && g[q] > W;
+                    const int sl = wave_slot(&s_tail, up);
+                    if (up) { P.wl[base + sl] = q; P.cl[base + k] = -1; }
                 }
                 int tail = bcast(&s_tail);
+                WS_T(2); WS_C(8, 1); WS_C(9, nA);
                 if (tail > 0) {
+                    WS_C(10, 1);
                     // cascade regions: breadth-first growth, the owner (smallest block) travels along
                     int head = 0;
                     while (head < tail) {
@@ -822,16 +869,16 @@ __global__ __launch_bounds__(WSP_NT) void k_ws_flood(const int* __restrict__ com
                             const unsigned o = valid ? ld_agent(&P.claim[r]) : 0u;
                             int nb[6];
                             nbrs(r, nb);
-                            int cq[6], oq[6], gq[6];
+                            int oq[6], gq[6];
 #pragma unroll
                             for (int e = 0; e < 6; ++e) {
                                 const int q = (valid && nb[e] >= 0) ? nb[e] : 0;
-                                cq[e] = comp[q]; oq[e] = ld_agent(&out[q]); gq[e] = g[q];
+                                oq[e] = ld_agent(&out[q]); gq[e] = g[q];
                             }
 #pragma unroll
                             for (int e = 0; e < 6; ++e) {
                                 const int q = nb[e];
-                                const bool cand = valid && q >= 0 && cq[e] == c && oq[e] == 0 && gq[e] > W;
+                                const bool cand = valid && q >= 0 && oq[e] == WS_OPEN && gq[e] > W;
                                 const unsigned old = cand ? atomicMin(&P.claim[q], o) : 0u;
                                 const bool first = cand && old == WSP_FREE;
                                 if (cand && !first && old > o) s_dirty = 1;
@@ -854,7 +901,7 @@ __global__ __launch_bounds__(WSP_NT) void k_ws_flood(const int* __restrict__ com
 #pragma unroll
                             for (int e = 0; e < 6; ++e) {
                                 const int q = nb[e];
-                                if (q >= 0 && comp[q] == c && ld_agent(&out[q]) == 0 && g[q] > W && atomicMin(&P.claim[q], o) > o) s_dirty = 1;
+                                if (q >= 0 && ld_agent(&out[q]) == WS_OPEN && g[q] > W && atomicMin(&P.claim[q], o) > o) s_dirty = 1;
                             }
                         }
                     }
@@ -869,7 +916,7 @@ __global__ __launch_bounds__(WSP_NT) void k_ws_flood(const int* __restrict__ com
 #pragma unroll
                         for (int e = 0; e < 6; ++e) {
                             const int q = nb[e];
-                            const bool cand = valid && q >= 0 && comp[q] == c && ld_agent(&out[q]) == 0 && g[q] <= W;
+                            const bool cand = valid && q >= 0 && ld_agent(&out[q]) == WS_OPEN && g[q] <= W;
                             const unsigned old = cand ? atomicMin(&P.claim[q], o) : 0u;
                             const bool first = cand && old == WSP_FREE;
                             const int sl = wave_slot(&s_nCL, first);
@@ -878,6 +925,7 @@ __global__ __launch_bounds__(WSP_NT) void k_ws_flood(const int* __restrict__ com
                     }
                 }
                 const int nCL = bcast(&s_nCL);
+                WS_T(3); WS_C(11, nCL);
                 // labels; pushes: level W -> next generation, lower levels -> the bags
                 for (int k = tid; k < tail; k += WSP_NT) {
                     const int r = P.wl[base + k];
@@ -885,15 +933,17 @@ __global__ __launch_bounds__(WSP_NT) void k_ws_flood(const int* __restrict__ com
                 }
                 for (int k0 = 0; k0 < nCL; k0 += WSP_NT) {
                     const int k = k0 + tid;
-                    const bool valid = k < nCL;
-                    const int q = valid ? P.cl[base + k] : 0;
+                    
+                    const int qq = k < nCL ? P.cl[base + k] : -1;
+                    const bool valid = qq >= 0;
+                    const int q = valid ? qq : 0;
                     const unsigned w = valid ? ld_agent(&P.claim[q]) : 0u;
                     const int lq = valid ? g[q] : 0;
                     if (valid) out[q] = ld_agent(&out[voxA(w)]);
                     const unsigned t = tbase + w;
                     const bool toA = valid && lq == W, toN = valid && lq < W && lq >= lo, toF = valid && lq < lo;
                     int sl = wave_slot(&s_nA2, toA);
-                    if (toA) putA(cur ^ 1, sl, ((unsigned long long)t << 32) | (unsigned)q);
+                    if (toA) GA[sl] = ((unsigned long long)t << 32) | (unsigned)q;
                     sl = wave_slot(&s_near, toN);
                     if (toN) { P.bl[nearBuf][base + sl] = lq; P.bt[nearBuf][base + sl] = t; P.bv[nearBuf][base + sl] = q; atomicMax(&s_nextW, lq); }
                     sl = wave_slot(&s_far, toF);
@@ -901,8 +951,9 @@ __global__ __launch_bounds__(WSP_NT) void k_ws_flood(const int* __restrict__ com
                 }
                 tbase += (unsigned)nA;
                 nA = bcast(&s_nA2);
-                cur ^= 1;
-                sortA(cur, nA);
+                WS_T(4);
+                sortA(nA);
+                WS_T(5);
             }
             __syncthreads();
             nNear = s_near; nFar = s_far; W = s_nextW;
@@ -1095,7 +1146,7 @@ void flood_stage(hipStream_t s, const uint32_t* M, const Dom& d, const int* mk, 
     } else {
         hipLaunchKernelGGL(k_fill_int, dim3(grid_for(nvox)), dim3(256), 0, s, rank, nvox, -1);
         hipLaunchKernelGGL(k_ws_init, dim3(grid_for(nvox)), dim3(256), 0, s, comp, mk, g, d, nvox, mn, mx, off, hcnt, pool, labels_dev);
-        hipLaunchKernelGGL(k_ws_flood, dim3(2048), dim3(WSP_NT), 0, s, comp, g, d, scal + 1, mn, mx, off, scal + 4, hcnt, pool, labels_dev);
+        hipLaunchKernelGGL(k_ws_flood<WSP_THREADS>, dim3(2048), dim3(WSP_THREADS), 0, s, comp, g, d, scal + 1, mn, mx, off, scal + 4, hcnt, pool, labels_dev);
     }
     hipLaunchKernelGGL(k_fill_int, dim3(1), dim3(256), 0, s, max_label_dev, (size_t)1, 0);
     hipLaunchKernelGGL(k_max_label, dim3(grid_for(nvox, 1024)), dim3(256), 0, s, labels_dev, nvox, max_label_dev);
@@ -1220,5 +1271,14 @@ int sd_marker_flood(const int32_t* d2_dev, const int32_t* markers_dev, const uin
     flood_stage(s, M, d, markers_dev, d2_dev, ws_bufs(wb, l), labels_dev, max_label_dev, nullptr);
     return hipGetLastError() == hipSuccess ? SD_OK : sd_fail_msg(SD_ERR_HIP, "sd_marker_flood: launch failed");
 }
+
+#ifdef SD_WS_TIMING
+int sd_debug_ws_timing(unsigned long long* host_out, int reset) {      // [2048][16]
+    hipDeviceSynchronize();
+    if (host_out) hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ws_dbg), sizeof(unsigned long long) * 2048 * 16);
+    if (reset) { static unsigned long long z[2048 * 16]; hipMemcpyToSymbol(HIP_SYMBOL(g_ws_dbg), z, sizeof(z)); }
+    return 0;
+}
+#endif
 
 }  // extern "C"
