@@ -314,11 +314,31 @@ __global__ __launch_bounds__(256) void k_cc_rank(const uint32_t* A, Dom d, size_
     for (int k = 0; k < SCAN_PER_THREAD; ++k)
         if (root[k]) rank[base + k] = ++off;
 }
-__global__ __launch_bounds__(256) void k_cc_relabel(const uint32_t* A, Dom d, size_t total, int* L, const int* rank) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        int z, y, x;
-        dec3(i, d.Z, d.Y, z, y, x);
-        L[i] = fg(A, d, x, y, z) ? rank[L[i]] : 0;      // rank[] is a separate buffer: roots read here are never overwritten
+// cnt[key] += 1 for every lane with key > 0, aggregated over runs of equal keys in consecutive lanes (voxels of one object sit
+// next to each other: one atomic per run instead of one per voxel; all 64 lanes must call)
+__device__ __forceinline__ void count_runs(int key, int* cnt) {
+    const int lane = threadIdx.x & 63;
+    const int prev = __shfl_up(key, 1, 64);
+    const bool head = lane == 0 || key != prev;
+    const unsigned long long heads = __ballot(head);
+    if (head && key > 0) {
+        const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+        const int len = above ? (__builtin_ctzll(above) + 1) : (64 - lane);
+        atomicAdd(&cnt[key], len);
+    }
+}
+// (cnt != nullptr: cnt[label] += voxels, one atomic per run of equal labels in a wave)
+__global__ __launch_bounds__(256) void k_cc_relabel(const uint32_t* A, Dom d, size_t total, int* L, const int* rank, int* cnt) {
+    const size_t n64 = (total + 63) / 64 * 64;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n64; i += (size_t)gridDim.x * 256) {
+        int l = 0;
+        if (i < total) {
+            int z, y, x;
+            dec3(i, d.Z, d.Y, z, y, x);
+            l = fg(A, d, x, y, z) ? rank[L[i]] : 0;      // rank[] is a separate buffer: roots read here are never overwritten
+            L[i] = l;
+        }
+        if (cnt) count_runs(l, cnt);
     }
 }
 
@@ -351,25 +371,6 @@ __global__ __launch_bounds__(1024) void k_scan_excl(int* v, const int* n_ptr, in
 }
 __global__ __launch_bounds__(256) void k_fill_int(int* p, size_t n, int v) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
-}
-// cnt[key] += 1 for every lane with key > 0, aggregated over runs of equal keys in consecutive lanes (voxels of one object sit
-// next to each other: one atomic per run instead of one per voxel; all 64 lanes must call)
-__device__ __forceinline__ void count_runs(int key, int* cnt) {
-    const int lane = threadIdx.x & 63;
-    const int prev = __shfl_up(key, 1, 64);
-    const bool head = lane == 0 || key != prev;
-    const unsigned long long heads = __ballot(head);
-    if (head && key > 0) {
-        const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
-        const int len = above ? (__builtin_ctzll(above) + 1) : (64 - lane);
-        atomicAdd(&cnt[key], len);
-    }
-}
-// cnt[label] += 1 over the volume (label > 0)
-__global__ __launch_bounds__(256) void k_count_labels(const int* L, size_t total, int* cnt) {
-    const size_t n64 = (total + 63) / 64 * 64;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n64; i += (size_t)gridDim.x * 256)
-        count_runs(i < total ? L[i] : 0, cnt);
 }
 // min_seed_vx filter, step 1: del[i] = 1 where the seed with id i (1..N) has fewer than min_size voxels (:325-329)
 __global__ __launch_bounds__(256) void k_seed_flags(const int* cnt, const int* N, int min_size, int* del) {
@@ -406,8 +407,11 @@ __global__ __launch_bounds__(256) void k_seed_map(const int* cnt, const int* rd,
         map[i] = v;
     }
 }
-__global__ __launch_bounds__(256) void k_apply_map(int* L, size_t total, const int* map) {      // relabel_vol (block_processing_C.pyx:161-169)
+__global__ __launch_bounds__(256) void k_apply_map(const uint32_t* S, Dom d, int* L, size_t total, const int* map) {      // relabel_vol (block_processing_C.pyx:161-169)
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        int z, y, x;
+        dec3(i, d.Z, d.Y, z, y, x);
+        if (!fg(S, d, x, y, z)) continue;      // S = the bits the seeds were labelled from: ids are nonzero only there
         const int l = L[i];
         if (l > 0) L[i] = map[l];
     }
@@ -419,7 +423,7 @@ __global__ __launch_bounds__(256) void k_apply_map(int* L, size_t total, const i
 // lower envelope of parabolas along y and along x, searched outwards from the voxel itself -- a candidate at offset k cannot
 // beat the current best once (pitch * k)^2 >= best, so the search stops after about distance / pitch steps.
 constexpr int EDT_INF = 0x3f000000;
-__global__ __launch_bounds__(256) void k_edt_z(const uint32_t* A, Dom d, int pz, int* g) {
+__global__ __launch_bounds__(256) void k_edt_z(const uint32_t* A, Dom d, int pz, int* g, int* g2) {
     // one thread per voxel (coalesced stores): the nearest background voxel of the z-row below and above is read off the mask
     // words -- bits outside the volume's own z range (the morphology padding) do not count as background
     const size_t total = (size_t)d.X * d.Y * d.Z;
@@ -447,27 +451,38 @@ __global__ __launch_bounds__(256) void k_edt_z(const uint32_t* A, Dom d, int pz,
             }
             if (dist < 0) best = EDT_INF;
             else { const long t = (long)pz * dist; best = (int)min(t * t, (long)EDT_INF); }
-        }
+        } else g2[i] = 0;      // the axis passes below skip background voxels: both buffers hold 0 there from here on
         g[i] = best;
     }
 }
-// one axis pass: out[i] = min over k of in[i + k * stride] + (pitch * k)^2 along an axis of extent n (position c)
-__global__ __launch_bounds__(256) void k_edt_axis(const int* in, int* out, Dom d, int axis, int pitch) {
+// one axis pass: out[i] = min over k of in[i + k * stride] + (pitch * k)^2 along an axis of extent n (position c), foreground
+// voxels only (read off the mask bits: a wave of background voxels costs two word loads)
+__global__ __launch_bounds__(256) void k_edt_axis(const uint32_t* A, const int* in, int* out, Dom d, int axis, int pitch) {
     const size_t total = (size_t)d.X * d.Y * d.Z;
     const size_t stride = axis == 1 ? (size_t)d.Z : (size_t)d.Z * d.Y;
     const int n = axis == 1 ? d.Y : d.X;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        int z, y, x;
+        dec3(i, d.Z, d.Y, z, y, x);
+        if (!fg(A, d, x, y, z)) continue;
         int best = in[i];
-        if (best != 0) {
-            int z, y, x;
-            dec3(i, d.Z, d.Y, z, y, x);
-            const int c = axis == 1 ? y : x;
-            for (int k = 1; k < n; ++k) {
-                const long pk = (long)pitch * k, q = pk * pk;
-                if (q >= (long)best) break;
-                if (c - k < 0 && c + k >= n) break;
-                if (c - k >= 0) best = (int)min((long)best, (long)in[i - (size_t)k * stride] + q);
-                if (c + k < n) best = (int)min((long)best, (long)in[i + (size_t)k * stride] + q);
+        const int c = axis == 1 ? y : x;
+        // (a candidate at offset k cannot win once (pitch k)^2 >= best; four offsets per round with their loads in flight
+        // together -- the chain of dependent loads was what bounded this pass; evaluating a few candidates too many is harmless)
+        for (int k0 = 1; k0 < n; k0 += 4) {
+            const long p0 = (long)pitch * k0;
+            if (p0 * p0 >= (long)best || (c - k0 < 0 && c + k0 >= n)) break;
+            int lo[4], hi[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u;
+                lo[u] = c - k >= 0 ? in[i - (size_t)k * stride] : EDT_INF;
+                hi[u] = c + k < n ? in[i + (size_t)k * stride] : EDT_INF;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long pk = (long)pitch * (k0 + u), q = pk * pk;
+                best = (int)min((long)best, min((long)lo[u], (long)hi[u]) + q);
             }
         }
         out[i] = best;
@@ -475,23 +490,31 @@ __global__ __launch_bounds__(256) void k_edt_axis(const int* in, int* out, Dom d
 }
 
 // per mask component: smallest and largest marker id found inside it (mn = INT_MAX, mx = 0: none)
-__global__ __launch_bounds__(256) void k_comp_markers(const int* comp, const int* mk, size_t total, int* mn, int* mx) {
+__global__ __launch_bounds__(256) void k_comp_markers(const uint32_t* S, Dom d, const int* comp, const int* mk, size_t total, int* mn, int* mx,
+                                                      int* max_label) {
+    int top = 0;      // largest marker inside the mask = largest label of the flood's result
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        if (S) {              // markers are nonzero only where these bits are set (the volume the seeds were labelled from)
+            int z, y, x;
+            dec3(i, d.Z, d.Y, z, y, x);
+            if (!fg(S, d, x, y, z)) continue;
+        }
         const int m = mk[i];
         if (m > 0) {          // (plain reads first: after the first few voxels of a component almost no atomic is needed)
             const int c = comp[i];
+            if (c > 0) top = max(top, m);
             if (m < __hip_atomic_load(&mn[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&mn[c], m);
             if (m > __hip_atomic_load(&mx[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&mx[c], m);
         }
     }
+    for (int sft = 32; sft >= 1; sft >>= 1) top = max(top, __shfl_xor(top, sft, 64));
+    if ((threadIdx.x & 63) == 0 && top > 0) atomicMax(max_label, top);
 }
-// heap capacity of a component that holds several markers = its voxel count (every voxel is pushed at most once)
-__global__ __launch_bounds__(256) void k_comp_sizes(const int* comp, size_t total, const int* mn, const int* mx, int* sz) {
-    const size_t n64 = (total + 63) / 64 * 64;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n64; i += (size_t)gridDim.x * 256) {
-        const int c = i < total ? comp[i] : 0;
-        count_runs((c > 0 && mx[c] > mn[c]) ? c : 0, sz);
-    }
+// pool capacity of a component = its voxel count (counted by the labelling pass) if it holds several markers, else 0
+__global__ __launch_bounds__(256) void k_comp_keep_multi(const int* NC, const int* mn, const int* mx, int* sz) {
+    const int nc = *NC;
+    for (int c = blockIdx.x * 256 + threadIdx.x; c <= nc; c += gridDim.x * 256)
+        if (!(mx[c] > mn[c])) sz[c] = 0;
 }
 // out = the flood's start state: background 0; a component without markers 0; with ONE marker that marker everywhere (the
 // flood cannot leave the mask component and nothing competes); with several markers the markers themselves, which are also
@@ -674,11 +697,13 @@ __device__ __forceinline__ void ws_sort(int n, Get get, Put put) {
     }
 }
 // start state as k_ws_init_seq; the marker voxels that can push anything enter the component's bag (left-aligned, buffer 0)
-__global__ __launch_bounds__(256) void k_ws_init(const int* comp, const int* mk, const int* g, Dom d, size_t total, const int* mn,
-                                                 const int* mx, const int* off, int* hcnt, WsPool P, int* out) {
+__global__ __launch_bounds__(256) void k_ws_init(const uint32_t* M, const int* comp, const int* mk, const int* g, Dom d, size_t total,
+                                                 const int* mn, const int* mx, const int* off, int* hcnt, WsPool P, int* out) {
     const int sY = d.Z, sX = d.Z * d.Y;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c = comp[i];
+        int z, y, x;
+        dec3(i, d.Z, d.Y, z, y, x);
+        const int c = fg(M, d, x, y, z) ? comp[i] : 0;
         int o = 0;
         if (c > 0 && mx[c] > 0) {
             if (mx[c] == mn[c]) o = mx[c];
@@ -686,8 +711,6 @@ __global__ __launch_bounds__(256) void k_ws_init(const int* comp, const int* mk,
                 o = mk[i];
                 if (o <= 0) o = WS_OPEN;
                 else {
-                    int z, y, x;
-                    dec3(i, d.Z, d.Y, z, y, x);
                     const int idx = (int)i;
                     const int nb[6] = {x > 0 ? idx - sX : -1, y > 0 ? idx - sY : -1, z > 0 ? idx - 1 : -1,
                                        z + 1 < d.Z ? idx + 1 : -1, y + 1 < d.Y ? idx + sY : -1, x + 1 < d.X ? idx + sX : -1};
@@ -961,12 +984,6 @@ __global__ __launch_bounds__(WSP_NT) void k_ws_flood(const int* __restrict__ com
         }
     }
 }
-__global__ __launch_bounds__(256) void k_max_label(const int* L, size_t total, int* mx) {
-    int m = 0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) m = max(m, L[i]);
-    for (int s = 32; s >= 1; s >>= 1) m = max(m, __shfl_xor(m, s, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(mx, m);
-}
 // squared distances -> float32 distances (what vigra returns), optional output
 __global__ __launch_bounds__(256) void k_sqrt_out(const int* g, size_t total, float* out) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) out[i] = sqrtf((float)g[i]);
@@ -1058,7 +1075,8 @@ void run_morph(hipStream_t s, uint32_t*& A, uint32_t*& B, const Dom& d, int* bbo
     }
 }
 // scipy.ndimage.label of the bit-packed volume A into L (ids 1..N in raster order of the first voxel), N -> *max_label_dev
-void run_cc(hipStream_t s, const uint32_t* A, const Dom& d, int* L, int* rank, int* blockcnt, int* max_label_dev, uint8_t* mask_out) {
+void run_cc(hipStream_t s, const uint32_t* A, const Dom& d, int* L, int* rank, int* blockcnt, int* max_label_dev, uint8_t* mask_out,
+            int* cnt = nullptr) {      // cnt (zeroed by the caller): voxels per label
     const size_t nvox = (size_t)d.X * d.Y * d.Z;
     hipLaunchKernelGGL(k_cc_init_runs, dim3(grid_for(nvox)), dim3(256), 0, s, A, d, L, mask_out);
     hipLaunchKernelGGL(k_cc_merge_runs, dim3(grid_for((size_t)d.X * d.Y * d.PZW)), dim3(256), 0, s, A, d, L);
@@ -1066,7 +1084,7 @@ void run_cc(hipStream_t s, const uint32_t* A, const Dom& d, int* L, int* rank, i
     hipLaunchKernelGGL(k_cc_compress_count, dim3(nblk), dim3(256), 0, s, A, d, nvox, L, blockcnt);
     hipLaunchKernelGGL(k_cc_scan_blocks, dim3(1), dim3(1024), 0, s, blockcnt, nblk, max_label_dev);
     hipLaunchKernelGGL(k_cc_rank, dim3(nblk), dim3(256), 0, s, A, d, nvox, L, blockcnt, rank);
-    hipLaunchKernelGGL(k_cc_relabel, dim3(grid_for(nvox)), dim3(256), 0, s, A, d, nvox, L, rank);
+    hipLaunchKernelGGL(k_cc_relabel, dim3(grid_for(nvox)), dim3(256), 0, s, A, d, nvox, L, rank, cnt);
 }
 int cut_of(double threshold) {
     // (uint8 p > t) <=> p >= floor(t) + 1; threshold 0 means "already a 0/1 mask" (object_extraction_steps.py:316): cut 1
@@ -1122,20 +1140,21 @@ WsBufs ws_bufs(char* wb, const WsLayout2& l) {
 }
 // skimage.segmentation.watershed(-distance, markers, mask) (:351) given the mask bits M, the marker volume mk and the squared
 // distances g: mask components, then the flood of every component that holds several markers
-void flood_stage(hipStream_t s, const uint32_t* M, const Dom& d, const int* mk, const int* g, const WsBufs& B, int32_t* labels_dev,
-                 int32_t* max_label_dev, uint8_t* mask_out_dev) {
+void flood_stage(hipStream_t s, const uint32_t* M, const uint32_t* seed_bits, const Dom& d, const int* mk, const int* g, const WsBufs& B,
+                 int32_t* labels_dev, int32_t* max_label_dev, uint8_t* mask_out_dev) {      // seed_bits: optional superset of {mk != 0}
     const size_t nvox = (size_t)d.X * d.Y * d.Z;
     const int gt = grid_for(B.T);
     int *rank = B.rank, *blockcnt = B.blockcnt, *comp = B.comp, *mn = B.mn, *mx = B.mx, *off = B.off, *hcnt = B.hcnt, *scal = B.scal;
     const WsPool& pool = B.pool;
     struct { size_t T; } l{B.T};
-    run_cc(s, M, d, comp, rank, blockcnt, scal + 1, mask_out_dev);
+    hipLaunchKernelGGL(k_fill_int, dim3(gt), dim3(256), 0, s, off, l.T, 0);
+    run_cc(s, M, d, comp, rank, blockcnt, scal + 1, mask_out_dev, off);      // off[c] = voxels of component c
     hipLaunchKernelGGL(k_fill_int, dim3(gt), dim3(256), 0, s, mn, l.T, 0x7fffffff);
     hipLaunchKernelGGL(k_fill_int, dim3(gt), dim3(256), 0, s, mx, l.T, 0);
-    hipLaunchKernelGGL(k_fill_int, dim3(gt), dim3(256), 0, s, off, l.T, 0);
     hipLaunchKernelGGL(k_fill_int, dim3(gt), dim3(256), 0, s, hcnt, l.T, 0);
-    hipLaunchKernelGGL(k_comp_markers, dim3(grid_for(nvox)), dim3(256), 0, s, comp, mk, nvox, mn, mx);
-    hipLaunchKernelGGL(k_comp_sizes, dim3(grid_for(nvox)), dim3(256), 0, s, comp, nvox, mn, mx, off);
+    hipLaunchKernelGGL(k_fill_int, dim3(1), dim3(256), 0, s, max_label_dev, (size_t)1, 0);
+    hipLaunchKernelGGL(k_comp_markers, dim3(grid_for(nvox)), dim3(256), 0, s, seed_bits, d, comp, mk, nvox, mn, mx, max_label_dev);
+    hipLaunchKernelGGL(k_comp_keep_multi, dim3(gt), dim3(256), 0, s, scal + 1, mn, mx, off);
     hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, s, off, scal + 1, 1, scal + 4);
     // watershed (:351): start state + queued markers, then the flood of every multi-marker component (level-synchronous, one
     // workgroup per component; SD_WS_SEQUENTIAL=1 selects the sequential restatement it is cross-checked with)
@@ -1145,11 +1164,9 @@ void flood_stage(hipStream_t s, const uint32_t* M, const Dom& d, const int* mk, 
         hipLaunchKernelGGL(k_ws_flood_seq, dim3(4096), dim3(64), 0, s, comp, g, d, scal + 1, mn, mx, off, hcnt, pool.ga[0], pool.cl, labels_dev);
     } else {
         hipLaunchKernelGGL(k_fill_int, dim3(grid_for(nvox)), dim3(256), 0, s, rank, nvox, -1);
-        hipLaunchKernelGGL(k_ws_init, dim3(grid_for(nvox)), dim3(256), 0, s, comp, mk, g, d, nvox, mn, mx, off, hcnt, pool, labels_dev);
+        hipLaunchKernelGGL(k_ws_init, dim3(grid_for(nvox)), dim3(256), 0, s, M, comp, mk, g, d, nvox, mn, mx, off, hcnt, pool, labels_dev);
         hipLaunchKernelGGL(k_ws_flood<WSP_THREADS>, dim3(2048), dim3(WSP_THREADS), 0, s, comp, g, d, scal + 1, mn, mx, off, scal + 4, hcnt, pool, labels_dev);
     }
-    hipLaunchKernelGGL(k_fill_int, dim3(1), dim3(256), 0, s, max_label_dev, (size_t)1, 0);
-    hipLaunchKernelGGL(k_max_label, dim3(grid_for(nvox, 1024)), dim3(256), 0, s, labels_dev, nvox, max_label_dev);
 }
 }  // namespace
 
@@ -1233,26 +1250,25 @@ int sd_object_segmentation_watershed(const uint8_t* prob_dev, int X, int Y, int 
     if (hipMemcpyAsync(M, A, pwords * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return sd_fail_msg(SD_ERR_HIP, "sd_object_segmentation_watershed: copy failed");
     // markers: the erosions (and whatever follows them), scipy.ndimage.label (:323-327)
     run_morph(s, A, B, d, bbox, seed_ops, seed_iterations, n_seed_ops, o);
-    run_cc(s, A, d, mk, rank, blockcnt, scal + 0, nullptr);
+    if (min_seed_vx > 1) hipLaunchKernelGGL(k_fill_int, dim3(gt), dim3(256), 0, s, cnt, l.T, 0);
+    run_cc(s, A, d, mk, rank, blockcnt, scal + 0, nullptr, min_seed_vx > 1 ? cnt : nullptr);      // cnt[id] = voxels of seed id
     if (min_seed_vx > 1) {      // :330-347: drop seeds smaller than min_seed_vx, fill the holes in the id space from the top
-        hipLaunchKernelGGL(k_fill_int, dim3(gt), dim3(256), 0, s, cnt, l.T, 0);
         hipLaunchKernelGGL(k_fill_int, dim3(1), dim3(256), 0, s, scal + 3, (size_t)1, 0x7fffffff);
-        hipLaunchKernelGGL(k_count_labels, dim3(grid_for(nvox)), dim3(256), 0, s, mk, nvox, cnt);
         hipLaunchKernelGGL(k_seed_flags, dim3(gt), dim3(256), 0, s, cnt, scal + 0, min_seed_vx, rd);
         hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, s, rd, scal + 0, 1, scal + 2);
         hipLaunchKernelGGL(k_seed_lists, dim3(gt), dim3(256), 0, s, cnt, rd, scal + 0, min_seed_vx, D, K);
         hipLaunchKernelGGL(k_seed_prefix, dim3(gt), dim3(256), 0, s, D, K, scal + 0, scal + 2, scal + 3);
         hipLaunchKernelGGL(k_seed_map, dim3(gt), dim3(256), 0, s, cnt, rd, D, scal + 0, scal + 2, scal + 3, min_seed_vx, map);
-        hipLaunchKernelGGL(k_apply_map, dim3(grid_for(nvox)), dim3(256), 0, s, mk, nvox, map);
+        hipLaunchKernelGGL(k_apply_map, dim3(grid_for(nvox)), dim3(256), 0, s, A, d, mk, nvox, map);
     }
     if (markers_out_dev && hipMemcpyAsync(markers_out_dev, mk, nvox * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
         return sd_fail_msg(SD_ERR_HIP, "sd_object_segmentation_watershed: copy failed");
     // distance transform of tmp_data (:349-350) and its connected components (the flood never leaves one)
-    hipLaunchKernelGGL(k_edt_z, dim3(grid_for(nvox)), dim3(256), 0, s, M, d, (int)pixel_pitch_xyz[2], g);
-    hipLaunchKernelGGL(k_edt_axis, dim3(grid_for(nvox)), dim3(256), 0, s, g, rank, d, 1, (int)pixel_pitch_xyz[1]);
-    hipLaunchKernelGGL(k_edt_axis, dim3(grid_for(nvox)), dim3(256), 0, s, rank, g, d, 2, (int)pixel_pitch_xyz[0]);
+    hipLaunchKernelGGL(k_edt_z, dim3(grid_for(nvox)), dim3(256), 0, s, M, d, (int)pixel_pitch_xyz[2], g, rank);
+    hipLaunchKernelGGL(k_edt_axis, dim3(grid_for(nvox)), dim3(256), 0, s, M, g, rank, d, 1, (int)pixel_pitch_xyz[1]);
+    hipLaunchKernelGGL(k_edt_axis, dim3(grid_for(nvox)), dim3(256), 0, s, M, rank, g, d, 2, (int)pixel_pitch_xyz[0]);
     if (distance_out_dev) hipLaunchKernelGGL(k_sqrt_out, dim3(grid_for(nvox)), dim3(256), 0, s, g, nvox, distance_out_dev);
-    flood_stage(s, M, d, mk, g, B2, labels_dev, max_label_dev, mask_out_dev);
+    flood_stage(s, M, A, d, mk, g, B2, labels_dev, max_label_dev, mask_out_dev);
     return hipGetLastError() == hipSuccess ? SD_OK : sd_fail_msg(SD_ERR_HIP, "sd_object_segmentation_watershed: launch failed");
 }
 
@@ -1268,7 +1284,7 @@ int sd_marker_flood(const int32_t* d2_dev, const int32_t* markers_dev, const uin
     const Dom d = make_dom(X, Y, Z, 0);
     uint32_t* M = reinterpret_cast<uint32_t*>(wb + l.mbits);
     hipLaunchKernelGGL(k_threshold_bits, dim3(grid_for((size_t)d.PX * d.PY * d.PZW)), dim3(256), 0, s, mask_dev, 1, d, M);
-    flood_stage(s, M, d, markers_dev, d2_dev, ws_bufs(wb, l), labels_dev, max_label_dev, nullptr);
+    flood_stage(s, M, nullptr, d, markers_dev, d2_dev, ws_bufs(wb, l), labels_dev, max_label_dev, nullptr);
     return hipGetLastError() == hipSuccess ? SD_OK : sd_fail_msg(SD_ERR_HIP, "sd_marker_flood: launch failed");
 }
 
