@@ -343,17 +343,17 @@ def test_gpu_marker_flood_equals_sequential_restatement(gpu):
 
 @pytest.mark.gpu
 def test_gpu_marker_flood_large_generations(gpu):
-    """one level, one mask component, five markers in a 56^3 block: generations are whole breadth-first shells (beyond the 2048
-    elements a generation may hold in LDS -> the global-memory sort), ties decided by queue order only"""
+    """one level, one mask component, three markers in a 40 x 150 x 150 block: generations are whole breadth-first shells (beyond the
+    8192 elements a generation may hold in LDS -> the global-memory sort), ties decided by queue order only"""
     from oracle.objseg_ref import watershed_ref
     from syconn_amd.extraction.object_extraction_steps import marker_flood
     rng = np.random.default_rng(3)
-    d2, markers, mask = _flood_case(rng, (56, 56, 56), 'flat', 5)
+    d2, markers, mask = _flood_case(rng, (40, 150, 150), 'flat', 3)      # shells of > 8192 voxels
     mask[:] = 1
     d2[:] = 1
     want = watershed_ref(d2.astype(np.int64), markers, mask)
     got, mx = marker_flood(d2, markers, mask)
-    assert mx == 5 and np.array_equal(got, want)
+    assert mx == 3 and np.array_equal(got, want)
 
 
 @pytest.mark.gpu
@@ -382,3 +382,22 @@ def test_gpu_watershed_level_synchronous_equals_sequential_kernel(gpu, monkeypat
         monkeypatch.delenv('SD_WS_SEQUENTIAL')
         assert mx == wmx and mx > 50 and np.array_equal(lab, want)
         assert int(((lab > 0) & (mk == 0)).sum()) > 100000
+
+
+def test_level_synchronous_formulation_equals_sequential_flood():
+    """CPU: the formulation the device flood implements (generations of one level claimed at once, cascades by min-propagation,
+    pushes ordered by block only -- tools/experiments/ws_levelsync_proto.py, in-block order shuffled) against the sequential
+    restatement of skimage's priority flood on tie-heavy, cascade-heavy and distance-transform landscapes"""
+    import importlib.util
+    from oracle.objseg_ref import watershed_ref
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'experiments', 'ws_levelsync_proto.py')
+    spec = importlib.util.spec_from_file_location('ws_levelsync_proto', path)
+    proto = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(proto)
+    rng = np.random.default_rng(21)
+    for case in range(45):
+        sh = tuple(int(v) for v in rng.integers(3, 11, 3))
+        d2, markers, mask = _flood_case(rng, sh, ('ties', 'rough', 'edt')[case % 3], int(rng.integers(2, 6)))
+        want = watershed_ref(d2.astype(np.int64), markers, mask)
+        got = proto.flood_levelsync(d2.astype(np.int64), markers, mask, rng)
+        assert np.array_equal(got, want), (case, sh)
