@@ -956,7 +956,6 @@ __global__ __launch_bounds__(WSP_NT) void k_ws_flood(const int* __restrict__ com
                 }
                 for (int k0 = 0; k0 < nCL; k0 += WSP_NT) {
                     const int k = k0 + tid;
-                    
                     const int qq = k < nCL ? P.cl[base + k] : -1;
                     const bool valid = qq >= 0;
                     const int q = valid ? qq : 0;
