@@ -407,13 +407,17 @@ __global__ __launch_bounds__(256) void k_seed_map(const int* cnt, const int* rd,
         map[i] = v;
     }
 }
-__global__ __launch_bounds__(256) void k_apply_map(const uint32_t* S, Dom d, int* L, size_t total, const int* map) {      // relabel_vol (block_processing_C.pyx:161-169)
+__global__ __launch_bounds__(256) void k_apply_map(uint32_t* S, Dom d, int* L, size_t total, const int* map) {      // relabel_vol (block_processing_C.pyx:161-169)
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         int z, y, x;
         dec3(i, d.Z, d.Y, z, y, x);
         if (!fg(S, d, x, y, z)) continue;      // S = the bits the seeds were labelled from: ids are nonzero only there
         const int l = L[i];
-        if (l > 0) L[i] = map[l];
+        if (l > 0) {
+            const int t = map[l];
+            L[i] = t;
+            if (t == 0) atomicAnd(&S[widx(d, x + d.P, y + d.P, (z + d.P) >> 5)], ~(1u << ((z + d.P) & 31)));      // S stays == {id > 0}
+        }
     }
 }
 
@@ -697,7 +701,7 @@ __device__ __forceinline__ void ws_sort(int n, Get get, Put put) {
     }
 }
 // start state as k_ws_init_seq; the marker voxels that can push anything enter the component's bag (left-aligned, buffer 0)
-__global__ __launch_bounds__(256) void k_ws_init(const uint32_t* M, const int* comp, const int* mk, const int* g, Dom d, size_t total,
+__global__ __launch_bounds__(256) void k_ws_init(const uint32_t* M, const uint32_t* S, const int* comp, const int* mk, const int* g, Dom d, size_t total,
                                                  const int* mn, const int* mx, const int* off, int* hcnt, WsPool P, int* out) {
     const int sY = d.Z, sX = d.Z * d.Y;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -715,8 +719,15 @@ __global__ __launch_bounds__(256) void k_ws_init(const uint32_t* M, const int* c
                     const int nb[6] = {x > 0 ? idx - sX : -1, y > 0 ? idx - sY : -1, z > 0 ? idx - 1 : -1,
                                        z + 1 < d.Z ? idx + 1 : -1, y + 1 < d.Y ? idx + sY : -1, x + 1 < d.X ? idx + sX : -1};
                     bool open = false;
+                    if (S) {      // S == {marker > 0} exactly: a neighbour inside the mask (hence inside this component) without a marker
+                        const int ex[6] = {-1, 0, 0, 0, 0, 1}, ey[6] = {0, -1, 0, 0, 1, 0}, ez[6] = {0, 0, -1, 1, 0, 0};
 #pragma unroll
-                    for (int e = 0; e < 6; ++e) open |= nb[e] >= 0 && comp[nb[e]] == c && mk[nb[e]] <= 0;
+                        for (int e = 0; e < 6; ++e)
+                            open |= nb[e] >= 0 && fg(M, d, x + ex[e], y + ey[e], z + ez[e]) && !fg(S, d, x + ex[e], y + ey[e], z + ez[e]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 6; ++e) open |= nb[e] >= 0 && comp[nb[e]] == c && mk[nb[e]] <= 0;
+                    }
                     if (open) {
                         const int slot = off[c] + atomicAdd(&hcnt[c], 1);
                         P.bl[0][slot] = g[i]; P.bt[0][slot] = (unsigned)idx; P.bv[0][slot] = idx;
@@ -1140,7 +1151,7 @@ WsBufs ws_bufs(char* wb, const WsLayout2& l) {
 // skimage.segmentation.watershed(-distance, markers, mask) (:351) given the mask bits M, the marker volume mk and the squared
 // distances g: mask components, then the flood of every component that holds several markers
 void flood_stage(hipStream_t s, const uint32_t* M, const uint32_t* seed_bits, const Dom& d, const int* mk, const int* g, const WsBufs& B,
-                 int32_t* labels_dev, int32_t* max_label_dev, uint8_t* mask_out_dev) {      // seed_bits: optional superset of {mk != 0}
+                 int32_t* labels_dev, int32_t* max_label_dev, uint8_t* mask_out_dev) {      // seed_bits: optional, == {mk > 0}
     const size_t nvox = (size_t)d.X * d.Y * d.Z;
     const int gt = grid_for(B.T);
     int *rank = B.rank, *blockcnt = B.blockcnt, *comp = B.comp, *mn = B.mn, *mx = B.mx, *off = B.off, *hcnt = B.hcnt, *scal = B.scal;
@@ -1163,7 +1174,7 @@ void flood_stage(hipStream_t s, const uint32_t* M, const uint32_t* seed_bits, co
         hipLaunchKernelGGL(k_ws_flood_seq, dim3(4096), dim3(64), 0, s, comp, g, d, scal + 1, mn, mx, off, hcnt, pool.ga[0], pool.cl, labels_dev);
     } else {
         hipLaunchKernelGGL(k_fill_int, dim3(grid_for(nvox)), dim3(256), 0, s, rank, nvox, -1);
-        hipLaunchKernelGGL(k_ws_init, dim3(grid_for(nvox)), dim3(256), 0, s, M, comp, mk, g, d, nvox, mn, mx, off, hcnt, pool, labels_dev);
+        hipLaunchKernelGGL(k_ws_init, dim3(grid_for(nvox)), dim3(256), 0, s, M, seed_bits, comp, mk, g, d, nvox, mn, mx, off, hcnt, pool, labels_dev);
         hipLaunchKernelGGL(k_ws_flood<WSP_THREADS>, dim3(2048), dim3(WSP_THREADS), 0, s, comp, g, d, scal + 1, mn, mx, off, scal + 4, hcnt, pool, labels_dev);
     }
 }
