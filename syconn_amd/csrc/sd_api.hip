@@ -57,8 +57,11 @@ struct Op {
     int fuse_final = -1;   // index of the final 1x1x1 op computed in this conv's epilogue
     int fuse_first = -1;   // conv: index of the first (cin = 1) convolution whose output (this conv's src0) it computes itself
     int fuse_gn = -1;      // conv: index of the GroupNorm op whose statistics this conv's epilogue accumulates
+    int fuse_pool_raw = -1;   // conv with fuse_gn: index of the MaxPool op (behind that GroupNorm) whose RAW pooling this conv's epilogue does
+    size_t pooldir_off = 0;   //   its per-channel direction masks (gamma < 0: minimum) in the blob
     bool stats_done = false;   // groupnorm: statistics come from the producing conv
     int gn_pool = -1;          // groupnorm: index of the MaxPool op fused into the apply pass
+    bool pool_in_conv = false;   // groupnorm (deferred, with gn_pool): the producing conv pools the RAW tensor, its readers apply the table
     bool gn_defer = false;       // groupnorm: statistics -> scale / shift only; every consumer of the buffer applies them itself
     size_t fwfrag_off = 0;             // fused final 1x1x1: hi/lo MFMA weight fragments
     bool skipped = false;  // op is executed inside its producer
@@ -191,6 +194,7 @@ size_t plan_workspace(const sd_model* m, const std::vector<Dims>& dims, std::vec
         // outputs of ops executed inside this op's launch are written NOW, not at their own position in the plan
         if (op.fuse_pool >= 0) touch_w(m->ops[op.fuse_pool].d.dst, i);
         if (op.gn_pool >= 0) touch_w(m->ops[op.gn_pool].d.dst, i);
+        if (op.fuse_pool_raw >= 0) touch_w(m->ops[op.fuse_pool_raw].d.dst, i);
         // a first convolution computed inside its consumer may also run as its own launch (decided per launch)
     }
     std::vector<int> order;
@@ -514,6 +518,7 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
                         ok = upconv_rows_kernel(m->bufCp[b] / SD_CHUNK, rup(r.d.cout, SD_CHUNK));
                     else if (r.d.kind == SD_OP_FINAL) ok = true;
                     else if (r.d.kind == SD_OP_POOL) ok = (g.gn_pool == (int)k);
+                    else if (r.d.kind == SD_OP_GROUPNORM && r.d.src0 != b) ok = !getenv("SD_GN_SKIP_NOT_DEFERRED");      // src1 of a GroupNorm only lends its extents (crop region)
                     else ok = false;                                                     // another GroupNorm etc.
                 }
                 if (ok && any) { g.gn_defer = true; m->buf_gn[b] = (int)i; }
@@ -532,6 +537,43 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
             if (nx.d.kind == SD_OP_GROUPNORM && nx.d.src0 == c.d.dst && nx.d.src1 < 0 && !getenv("SD_NO_GN_FUSE")) {
                 c.fuse_gn = (int)(i + 1);
                 nx.stats_done = true;
+                // ... and if that GroupNorm is deferred and feeds a pooling, this conv also pools its RAW output (per channel the
+                // window's maximum or, for gamma < 0, minimum: relu(a x + b) is monotone in x) and the readers of the pooled tensor
+                // apply the scale / shift table like the readers of the full-resolution one: the apply + pool pass disappears.
+                // Needs the deferred-input kernel form (MODE 2 carries the epilogue) and deferral-capable readers.
+                if (nx.gn_defer && nx.gn_pool == (int)i + 2 && !getenv("SD_NO_GN_POOL_RAW")) {
+                    const Op& po = m->ops[i + 2];
+                    const int pb = po.d.dst;
+                    bool ok = (c.d.kz == 3) == (po.d.kz == 2) && m->bufCp[pb] <= 256 &&
+                              (m->buf_gn[c.d.src0] >= 0 || (c.d.src1 >= 0 && m->buf_gn[c.d.src1] >= 0));
+                    for (size_t k = i + 3; k < m->ops.size() && ok; ++k) {
+                        const Op& r = m->ops[k];
+                        if (r.d.src0 != pb && r.d.src1 != pb) continue;
+                        if (r.d.kind == SD_OP_CONV) ok = !r.first;
+                        else if (r.d.kind == SD_OP_UPCONV) ok = upconv_rows_kernel(m->bufCp[pb] / SD_CHUNK, rup(r.d.cout, SD_CHUNK));
+                        else ok = r.d.kind == SD_OP_FINAL || (r.d.kind == SD_OP_GROUPNORM && r.d.src0 != pb);
+                    }
+                    if (ok) {
+                        c.fuse_pool_raw = (int)i + 2;
+                        nx.pool_in_conv = true;
+                        m->buf_gn[pb] = (int)i + 1;
+                        m->gn_tab_off[pb] = m->gn_tab_off[nx.d.src0];      // one table for the tensor and its pooled version
+                        const int ntile = c.NT * c.NB;
+                        c.pooldir_off = blob_alloc((size_t)ntile * 2 * 8 * 4);
+                        uint32_t* dq = reinterpret_cast<uint32_t*>(blob.data() + c.pooldir_off);
+                        // register r = 4 s + t of lane half h holds the channels 32 tile + 16 s + 8 (t >> 1) + 4 h + 2 (t & 1) + {0, 1}
+                        for (int tile = 0; tile < ntile; ++tile)
+                            for (int h = 0; h < 2; ++h)
+                                for (int r = 0; r < 8; ++r) {
+                                    uint32_t w = 0;
+                                    for (int e = 0; e < 2; ++e) {
+                                        const int ch = 32 * tile + 16 * (r >> 2) + 8 * ((r & 3) >> 1) + 4 * h + 2 * (r & 1) + e;
+                                        if (ch < m->bufC[nx.d.src0] && W[nx.d.gamma_off + ch] < 0.f) w |= 0xffffu << (16 * e);
+                                    }
+                                    dq[(tile * 2 + h) * 8 + r] = w;
+                                }
+                    }
+                }
                 continue;
             }
             // (the fused pooling maximum works on the packed, rounded outputs as integers: exact behind a ReLU only)
@@ -828,6 +870,12 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
                 if (op.fuse_gn >= 0) {      // (scratch is zero: see the start of the forward pass and k_gn_finalize)
                     p.gn_sums = reinterpret_cast<double*>(wsb); p.gn_C = p.Cd;
                 }
+                if (op.fuse_pool_raw >= 0) {
+                    const sd_op_desc& pd = m->ops[op.fuse_pool_raw].d;
+                    p.pool_dst = bufp(pd.dst); p.pH = m->dims[pd.dst].h; p.pW = m->dims[pd.dst].w;
+                    p.Pp = (size_t)m->dims[pd.dst].d * p.pH * p.pW;
+                    p.pool_dir = reinterpret_cast<const unsigned*>(m->dev_blob + op.pooldir_off);
+                }
                 p.nbx = (o.w + SD_BX - 1) / SD_BX; p.nby = (o.h + BY - 1) / BY; p.nbz = (o.d + BZ - 1) / BZ;
                 auto gn_of = [&](int b, const float*& tab, int& relu) {
                     if (b > 0 && m->buf_gn[b] >= 0) {
@@ -924,9 +972,9 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
             p.scale_shift = reinterpret_cast<float*>(op.gn_defer ? wsb + m->gn_tab_off[d.src0] : wsb + SD_GN_SCALE_OFF);
             p.relu = d.relu;
             p.batch = N; p.tstride = tstride; p.skip_stats = op.stats_done ? 1 : 0;
-            p.skip_apply = (op.gn_defer && op.gn_pool < 0) ? 1 : 0;
+            p.skip_apply = (op.gn_defer && (op.gn_pool < 0 || op.pool_in_conv)) ? 1 : 0;
             p.no_inplace = op.gn_defer ? 1 : 0;
-            if (op.gn_pool >= 0) {
+            if (op.gn_pool >= 0 && !op.pool_in_conv) {
                 const sd_op_desc& pd = m->ops[op.gn_pool].d;
                 const Dims po = m->dims[pd.dst];
                 p.pool_dst = bufp(pd.dst); p.pkz = pd.kz; p.pD = po.d; p.pH = po.h; p.pW = po.w;

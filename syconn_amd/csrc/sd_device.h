@@ -92,6 +92,21 @@ __device__ __forceinline__ void swap32x4(unsigned& a0, unsigned& b0, unsigned& a
                  "v_permlane32_swap_b32 %4, %5\n\tv_permlane32_swap_b32 %6, %7\n\ts_nop 1"
                  : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3));
 }
+// Pooling of RAW (signed, not yet normalised) packed 16-bit floats behind a deferred GroupNorm: y = relu(a x + b) is monotone in
+// x -- rising for a >= 0, falling for a < 0 (the sign of a is the sign of gamma) --, so max over the window of y is y at the
+// window's largest (smallest) x.  A packed pair becomes a pair of SIGNED 16-bit keys (pk_max16 is v_pk_max_i16) whose order is
+// the float order (sign-magnitude -> two's complement: negative floats flip their magnitude bits), complemented where the minimum
+// is wanted; PK_KEY_LOWEST is below every key (voxels beyond the volume).  The same function maps back.
+constexpr unsigned PK_KEY_LOWEST = 0x80008000u;
+__device__ __forceinline__ unsigned pk_order_key(unsigned u, unsigned dir) {
+    const unsigned neg = ((u >> 15) & 0x00010001u) * 0xffffu;
+    return u ^ (neg & 0x7fff7fffu) ^ dir;
+}
+__device__ __forceinline__ unsigned pk_order_unkey(unsigned k, unsigned dir) {
+    const unsigned v = k ^ dir;
+    const unsigned neg = ((v >> 15) & 0x00010001u) * 0xffffu;
+    return v ^ (neg & 0x7fff7fffu);
+}
 // packed-pair max over the 2x2 (y,x) pooling window: lane^1 by DPP, lane^16 by one batched v_permlane16_swap of
 // the eight registers of an accumulator tile; result valid in all four lanes
 __device__ __forceinline__ void pool_xy_pk8(unsigned (&m)[8]) {
@@ -109,6 +124,28 @@ __device__ __forceinline__ void pool_xy_pk8(unsigned (&m)[8]) {
                    "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
 #pragma unroll
     for (int k = 0; k < 8; ++k) m[k] = pk_max16(m[k], b[k]);
+}
+// the same window maximum for packed fp16 pairs compared AS FLOATS (one v_pk_max_f16 per step; raw pooling of the fp16 plans)
+__device__ __forceinline__ unsigned pk_fmax_f16(unsigned a, unsigned b) {
+    unsigned r;
+    asm volatile("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void pool_xy_pk8_f16(unsigned (&m)[8]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        m[k] = pk_fmax_f16(m[k], (unsigned)__builtin_amdgcn_update_dpp(0, (int)m[k], 0xB1, 0xF, 0xF, true));
+    unsigned b[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) b[k] = m[k];
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %8\n\tv_permlane16_swap_b32 %1, %9\n\t"
+                 "v_permlane16_swap_b32 %2, %10\n\tv_permlane16_swap_b32 %3, %11\n\t"
+                 "v_permlane16_swap_b32 %4, %12\n\tv_permlane16_swap_b32 %5, %13\n\t"
+                 "v_permlane16_swap_b32 %6, %14\n\tv_permlane16_swap_b32 %7, %15\n\ts_nop 1"
+                 : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7]),
+                   "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[k] = pk_fmax_f16(m[k], b[k]);
 }
 __device__ __forceinline__ float max_xor1(float m) {       // max with lane^1 (DPP quad_perm [1,0,3,2])
     return fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0xB1, 0xF,

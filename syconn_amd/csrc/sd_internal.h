@@ -43,6 +43,8 @@ struct ConvParams {
     const void* zero;  // >= 16 zero bytes (DMA source of out-of-volume halo voxels)
     int store_main;    // write dst (0 when only the fused final output is needed)
     void* pool_dst;    // fused MaxPool(ceil): pooled tensor (same channel stride), or nullptr
+    const unsigned* pool_dir;  // with pool_dst behind a fused-statistics GroupNorm conv (raw outputs): per (32-column tile, lane half,
+                               // register) a mask of 0xffff halves where the channel's gamma < 0 (pool the MINIMUM there), else nullptr
     int pH, pW;        // y/x extents of the pooled tensor
     const void* final_wfrag; // fused conv_final: hi/lo weight fragments [NT][2 k-steps][2][64 lanes][8] of T, or nullptr
     const float* final_b;

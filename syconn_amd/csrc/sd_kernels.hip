@@ -1036,12 +1036,39 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 unsigned m[8];
+                if (GN && p.pool_dir) {      // raw outputs, GroupNorm apply deferred to the readers: pool in the order of the floats
+                    const unsigned* const dq = p.pool_dir + ((size_t)(nb * NT + j) * 2 + half) * 8;
+                    unsigned dk[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    m[k] = valid[i] ? pk[i][j][k] : 0u;
-                    if (KZ == 3) m[k] = pk_max16(m[k], valid[i | 1] ? pk[i | 1][j][k] : 0u);
+                    for (int k = 0; k < 8; ++k) dk[k] = dq[k];
+                    if constexpr (std::is_same<T, f16_t>::value) {      // fp16 has a packed float maximum: negate where the minimum is wanted
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const unsigned flip = dk[k] & 0x80008000u;
+                            m[k] = valid[i] ? (pk[i][j][k] ^ flip) : 0xfc00fc00u;      // (-inf, -inf)
+                            if (KZ == 3) m[k] = pk_fmax_f16(m[k], valid[i | 1] ? (pk[i | 1][j][k] ^ flip) : 0xfc00fc00u);
+                        }
+                        pool_xy_pk8_f16(m);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) m[k] ^= dk[k] & 0x80008000u;
+                    } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        m[k] = valid[i] ? pk_order_key(pk[i][j][k], dk[k]) : PK_KEY_LOWEST;
+                        if (KZ == 3) m[k] = pk_max16(m[k], valid[i | 1] ? pk_order_key(pk[i | 1][j][k], dk[k]) : PK_KEY_LOWEST);
+                    }
+                    pool_xy_pk8(m);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) m[k] = pk_order_unkey(m[k], dk[k]);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        m[k] = valid[i] ? pk[i][j][k] : 0u;
+                        if (KZ == 3) m[k] = pk_max16(m[k], valid[i | 1] ? pk[i | 1][j][k] : 0u);
+                    }
+                    pool_xy_pk8(m);
                 }
-                pool_xy_pk8(m);
                 store_tile_rows_pk<T>(m, pdst, p.Pp, po, writer && valid[i], (nb * NT + j) * 32, half, p.Cd);
             }
         }

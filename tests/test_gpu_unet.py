@@ -467,3 +467,41 @@ def test_fused_level0_decoder_label_rules(gpu):
         got = dm.forward_labels_batch(x, ids, thr)
         assert torch.equal(got, want), (ids, thr)
     assert len(torch.unique(dm.forward_labels_batch(x, (4, 2, 1, 3), (40.0, 60.5, 30.0, 80.0)))) >= 3
+
+
+@pytest.mark.parametrize('act', ['f16', 'bf16'])
+def test_groupnorm_raw_pooling_in_conv_epilogue_is_bit_identical(gpu, monkeypatch, act):
+    """GroupNorm + ReLU + MaxPool behind a convolution: the conv's epilogue pools its RAW output -- per channel the window's
+    maximum, or its minimum where gamma < 0 (relu(a x + b) is monotone in x) -- and the next level applies scale / shift on
+    load, so the apply + pool pass over the tensor disappears.  Half of all GroupNorm weights negative here: logits,
+    probabilities and labels must equal the plan with separate apply passes (SD_NO_GN_DEFER) and the plan that only lacks
+    this fusion (SD_NO_GN_POOL_RAW) bit for bit; and stay within the fp32 oracle's tolerance."""
+    from syconn_amd import _lib as L
+    from syconn_amd.cnn import random_state_dict
+    from syconn_amd.engine import DenseModel
+    sd = random_state_dict('mivcsj', seed=9, final_scale=5.0)
+    g = torch.Generator().manual_seed(1)
+    for k in sd:
+        if '.norm' in k and k.endswith('.weight'):
+            sd[k] = sd[k] * (torch.randint(0, 2, sd[k].shape, generator=g) * 2 - 1).to(sd[k].dtype)
+    monkeypatch.setenv('SD_NO_GN_DEFER', '1')
+    plain = DenseModel(sd, act_dtype=act, device=gpu)
+    monkeypatch.delenv('SD_NO_GN_DEFER')
+    monkeypatch.setenv('SD_NO_GN_POOL_RAW', '1')
+    nofuse = DenseModel(sd, act_dtype=act, device=gpu)
+    monkeypatch.delenv('SD_NO_GN_POOL_RAW')
+    fused = DenseModel(sd, act_dtype=act, device=gpu)
+    for shape in ((2, 16, 32, 48), (3, 13, 37, 43), (1, 32, 112, 144)):
+        x = _input(shape, 5).to(gpu)
+        for kind in (L.SD_OUT_LOGITS_F32, L.SD_OUT_PROBS_U8):
+            a = plain.forward_batch(x, kind).clone()
+            n0 = nofuse.forward_batch(x, kind, slot=1).clone()
+            b = fused.forward_batch(x, kind, slot=1)
+            assert torch.equal(a, b) and torch.equal(n0, b), (act, shape, kind)
+    # ... and the fp32 oracle agrees within the usual tolerance (negative gammas go through the minimum path)
+    model = build_unet('mivcsj', seed=9)
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            if '.norm' in k and k.endswith('.weight'):
+                v.mul_((torch.randint(0, 2, v.shape, generator=g) * 2 - 1).to(v.dtype))
+    _run_case(gpu, model, (12, 35, 41), act)
