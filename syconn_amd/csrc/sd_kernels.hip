@@ -1880,10 +1880,42 @@ __global__ __launch_bounds__(256) void k_gn_apply_pool(const GnParams p) {
 }
 
 __global__ void k_gn_finalize(const GnParams p) {
-    const double* const sums = reinterpret_cast<const double*>(reinterpret_cast<const char*>(p.sums) + blockIdx.z * p.tstride);
+    double* const sums = reinterpret_cast<double*>(reinterpret_cast<char*>(p.sums) + blockIdx.z * p.tstride);
     float* const scale_shift = reinterpret_cast<float*>(reinterpret_cast<char*>(p.scale_shift) + blockIdx.z * p.tstride);
     const int cpg = p.cout / p.groups;
     const double n = (double)p.D * p.H * p.W * cpg;
+    // one load per channel and statistic into LDS (the per-thread loops over a group's channels in global memory were a chain of
+    // up to 192 dependent loads: 9 us per launch, 22 launches per forward of the 5-block net), the scratch is zeroed for the next
+    // GroupNorm of this forward pass on the way (sd_forward_batch zeroes it once at the start)
+    __shared__ double ls[2 * 1024];      // plans refuse GroupNorm over more channels (MODEL_FAIL "too many channels": C <= 2560 > 1024 handled below)
+    __shared__ double gmean[256], grstd[256];
+    const bool fits = p.C <= 1024 && p.groups <= 256;
+    if (fits) {
+        for (int c = threadIdx.x; c < 2 * p.C; c += blockDim.x) { ls[c] = sums[c]; sums[c] = 0.0; }
+        __syncthreads();
+        for (int g = threadIdx.x; g < p.groups; g += blockDim.x) {
+            double s = 0.0, ss = 0.0;
+            for (int k = g * cpg; k < (g + 1) * cpg; ++k) { s += ls[k]; ss += ls[p.C + k]; }      // same order as before
+            const double mean = s / n;
+            double var = ss / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            gmean[g] = mean;
+            grstd[g] = 1.0 / sqrt(var + (double)p.eps);
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+            float sc = 0.f, sh = 0.f;
+            if (c < p.cout) {
+                const int g = c / cpg;
+                const double mean = gmean[g], rstd = grstd[g];
+                sc = (float)(rstd * (double)p.gamma[c]);
+                sh = (float)((double)p.beta[c] - mean * rstd * (double)p.gamma[c]);
+            }
+            scale_shift[c] = sc;
+            scale_shift[p.C + c] = sh;
+        }
+        return;
+    }
     for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
         float sc = 0.f, sh = 0.f;
         if (c < p.cout) {
@@ -1900,11 +1932,8 @@ __global__ void k_gn_finalize(const GnParams p) {
         scale_shift[c] = sc;
         scale_shift[p.C + c] = sh;
     }
-    // leave the statistics scratch zeroed for the next GroupNorm of this forward pass (sd_forward_batch zeroes it once at the
-    // start): one memset per tile and GroupNorm op was 3.6 % of the kernel time of the 5-block GroupNorm net
     __syncthreads();
-    double* const zs = reinterpret_cast<double*>(reinterpret_cast<char*>(p.sums) + blockIdx.z * p.tstride);
-    for (int c = threadIdx.x; c < 2 * p.C; c += blockDim.x) zs[c] = 0.0;
+    for (int c = threadIdx.x; c < 2 * p.C; c += blockDim.x) sums[c] = 0.0;
 }
 
 // zero the first `nbytes` (multiple of 16) of every tile's workspace: GroupNorm statistics scratch at the start of a forward pass
