@@ -51,3 +51,12 @@ def test_fails_loudly_without_gpu():
     assert lib.sd_init(0) == _lib.SD_ERR_NODEVICE
     with pytest.raises(RuntimeError):
         _lib.check(lib.sd_init(0), 'sd_init')
+    # the post-inference entry points likewise
+    import numpy as np
+    from syconn_amd.extraction.find_object_properties import find_object_properties
+    from syconn_amd.extraction.object_extraction_steps import marker_flood, object_segmentation_first_stage
+    z = np.zeros((4, 4, 4), np.uint8)
+    for call in (lambda: object_segmentation_first_stage(z, 1.0, ['binary_erosion']), lambda: marker_flood(z, z, z),
+                 lambda: find_object_properties(z.astype(np.uint64))):
+        with pytest.raises(RuntimeError):
+            call()
