@@ -1,5 +1,5 @@
 """Per-layer table of one launch set (GPU box): time per tile, algorithmic GFLOP and MB per tile, achieved PFLOP/s and TB/s --
-the table DESIGN.md section 5 quotes for the three judged models.  usage: layer_table.py <arch> <act> [tiles=8] [edge=128]"""
+the table DESIGN.md section 5 quotes for the three judged models.  usage: layer_table.py <arch> <act> [tiles=8] [edge=128 | DxHxW]"""
 import os
 import sys
 
@@ -14,9 +14,9 @@ from syconn_amd.engine import DenseModel                                # noqa: 
 arch = sys.argv[1] if len(sys.argv) > 1 else 'semseg_spine'
 act = sys.argv[2] if len(sys.argv) > 2 else 'bf16'
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 8
-n = int(sys.argv[4]) if len(sys.argv) > 4 else 128
+shape = tuple(int(v) for v in sys.argv[4].split('x')) if len(sys.argv) > 4 and 'x' in sys.argv[4] else (int(sys.argv[4]) if len(sys.argv) > 4 else 128,) * 3
 dm = DenseModel(random_state_dict(arch, seed=0, final_scale=8.0), act, torch.device('cuda', 0))
-x = torch.randint(0, 256, (B, n, n, n), dtype=torch.uint8, device='cuda')
+x = torch.randint(0, 256, (B, *shape), dtype=torch.uint8, device='cuda')
 ids, thr = list(range(1, dm.out_channels)), [127.5] * (dm.out_channels - 1)
 for _ in range(3):
     dm.forward_labels_batch(x, ids, thr)
@@ -26,7 +26,8 @@ for _ in range(5):
     dm.forward_labels_batch(x, ids, thr)
 us = sum(dm.profile_read(k) for k in range(5)) / 5 / B * 1e3
 # shapes per buffer
-dims = {0: (n, n, n)}
+dims = {0: shape}
+shape_s = 'x'.join(map(str, shape))
 chans = {0: 1}
 rows = []
 names = {1: 'conv', 2: 'pool', 3: 'upconv', 4: 'groupnorm', 5: 'final'}
@@ -61,7 +62,7 @@ for i, o in enumerate(dm.ops):
         by = w * o.cin0 * np.prod(a) + np.prod(a)
         what = f'final {o.cin0} -> {o.cout} + softmax + labels'
     rows.append((i, what, us[i], fl / 1e9, by / 1e6))
-print(f'| op | layer ({arch}, {act}, {B} x {n}^3 per launch set) | us / tile | GFLOP | PFLOP/s | MB (algorithmic) | TB/s |')
+print(f'| op | layer ({arch}, {act}, {B} x {shape_s} per launch set) | us / tile | GFLOP | PFLOP/s | MB (algorithmic) | TB/s |')
 print('|---|---|---|---|---|---|---|')
 for i, what, t, gf, mb in rows:
     if t < 1.0:
