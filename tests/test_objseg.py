@@ -401,3 +401,31 @@ def test_level_synchronous_formulation_equals_sequential_flood():
         want = watershed_ref(d2.astype(np.int64), markers, mask)
         got = proto.flood_levelsync(d2.astype(np.int64), markers, mask, rng)
         assert np.array_equal(got, want), (case, sh)
+
+
+@pytest.mark.gpu
+def test_gpu_watershed_branch_random_configurations(gpu):
+    """40 random small configurations of the watershed branch -- operation lists with 1..4 erosions behind random openings /
+    closings / dilations, min_seed_vx 0..40, isotropic and anisotropic pitches, ragged shapes: mask, markers, labels and label
+    count equal the oracle's bit for bit"""
+    from oracle.objseg_ref import object_segmentation_watershed_ref
+    from syconn_amd.extraction.object_extraction_steps import object_segmentation_first_stage
+    rng = np.random.default_rng(2024)
+    pre_choices = ([], ['binary_opening'], ['binary_closing'], ['binary_opening', 'binary_closing'], ['binary_dilation'],
+                   ['binary_closing', 'binary_closing'])
+    flooded = 0
+    for case in range(40):
+        shape = tuple(int(v) for v in rng.integers(6, 49, 3))
+        prob, thr = _blobs(shape, 100 + case, float(rng.uniform(1.2, 3.0)), float(rng.uniform(0.45, 0.75)))
+        ops = list(pre_choices[int(rng.integers(len(pre_choices)))]) + ['binary_erosion'] * int(rng.integers(1, 5))
+        if rng.random() < 0.25:
+            ops += ['binary_dilation']                          # operations after the erosions act on the seeds
+        scaling = [(10, 10, 20), (10, 10, 10), (9, 9, 20), (4, 4, 35)][int(rng.integers(4))]
+        min_seed = int(rng.integers(0, 41))
+        want, want_max, tmp, markers = object_segmentation_watershed_ref(prob, thr, ops, scaling, min_seed)
+        lab, mx, m, mk = object_segmentation_first_stage(prob, thr, ops, scaling, return_mask=True, min_seed_vx=min_seed,
+                                                         return_markers=True)
+        assert np.array_equal(m, tmp) and np.array_equal(mk.astype(np.uint32), markers), (case, shape, ops, scaling, min_seed)
+        assert mx == want_max and np.array_equal(lab, want), (case, shape, ops, scaling, min_seed)
+        flooded += int(((want > 0) & (markers == 0)).sum())
+    assert flooded > 20000
