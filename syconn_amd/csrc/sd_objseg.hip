@@ -263,29 +263,31 @@ __global__ __launch_bounds__(256) void k_cc_compress_count(const uint32_t* A, Do
     __syncthreads();
     if (threadIdx.x == 0) blockcnt[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
-// exclusive scan of blockcnt[0..n) in place, total -> *max_label (one workgroup)
+// exclusive scan of blockcnt[0..n) in place, total -> *max_label (one workgroup): each of the 16 waves scans a contiguous
+// sixteenth of the array 64 entries at a time (coalesced loads, wave scan by shuffles, running carry), the wave totals are
+// scanned in LDS and added in a second coalesced sweep (the round-per-1024-entries Hillis-Steele form took 0.11 ms for the 65 k
+// blocks of a 512^3 volume: 64 rounds x 20 barriers)
 __global__ __launch_bounds__(1024) void k_cc_scan_blocks(int* blockcnt, int n, int* max_label) {
-    __shared__ int part[1024];
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int v = i < n ? blockcnt[i] : 0;
-        part[threadIdx.x] = v;
-        __syncthreads();
-        for (int s = 1; s < 1024; s <<= 1) {                  // Hillis-Steele inclusive scan
-            const int t = threadIdx.x >= s ? part[threadIdx.x - s] : 0;
-            __syncthreads();
-            part[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (i < n) blockcnt[i] = carry + part[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry += part[1023];
-        __syncthreads();
+    __shared__ int wtot[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per = ((n + 15) / 16 + 63) / 64 * 64;            // entries per wave, a multiple of 64
+    const int lo = min(n, wave * per), hi = min(n, lo + per);
+    int carry = 0;
+    for (int i0 = lo; i0 < hi; i0 += 64) {
+        const int i = i0 + lane;
+        const int v = i < hi ? blockcnt[i] : 0;
+        int incl = v;
+        for (int s = 1; s < 64; s <<= 1) { const int t = __shfl_up(incl, s, 64); if (lane >= s) incl += t; }
+        if (i < hi) blockcnt[i] = carry + incl - v;
+        carry += __shfl(incl, 63, 64);
     }
-    if (threadIdx.x == 0) *max_label = carry;
+    if (lane == 0) wtot[wave] = carry;
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < wave; ++w) off += wtot[w];
+    if (off)
+        for (int i = lo + lane; i < hi; i += 64) blockcnt[i] += off;
+    if (threadIdx.x == 1023) *max_label = off + carry;
 }
 // rank[root] = 1 + number of roots with a smaller raster index
 __global__ __launch_bounds__(256) void k_cc_rank(const uint32_t* A, Dom d, size_t total, const int* L, const int* blockcnt, int* rank) {
