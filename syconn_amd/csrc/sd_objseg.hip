@@ -178,38 +178,62 @@ __device__ __forceinline__ bool fg(const uint32_t* A, const Dom& d, int x, int y
     return (A[widx(d, x + d.P, y + d.P, pz >> 5)] >> (pz & 31)) & 1u;
 }
 
-// L[i] = linear index of the first voxel of i's z-run for FOREGROUND voxels (background entries stay unwritten: the passes
-// below read the 1/8 byte-per-voxel bit mask first and touch the 4 byte-per-voxel label only where it is set -- at 5-20 %
-// foreground that removes most of the label traffic of the five passes); optional byte mask output.
-// One thread = one voxel; the run start is read off the mask words (scan back over all-ones words).
-__global__ __launch_bounds__(256) void k_cc_init_runs(const uint32_t* A, Dom d, int* L, uint8_t* mask_out) {
+// The labelling works on z-RUNS, not voxels: the union-find lives at the first voxel of every run (its HEAD, read off the mask
+// words: a set bit whose lower neighbour is clear), all passes up to the last one are one thread per mask WORD and touch the 4-byte
+// arrays only at heads (a 512^3 volume with 8 % foreground has 0.7 M runs but 10 M foreground voxels); only the final relabel is a
+// pass over the voxels.
+// padded z of the first voxel of the run that contains bit b of word zw of `row` (padding bits are 0; without padding the scan
+// stops at word 0)
+__device__ __forceinline__ int run_start_pz(const uint32_t* row, int zw, int b) {
+    uint32_t zeros = ~row[zw] & (b ? ((1u << b) - 1u) : 0u);
+    while (!zeros && zw > 0) { --zw; zeros = ~row[zw]; }
+    return zeros ? (zw * 32 + 32 - __builtin_clz(zeros)) : 0;
+}
+// voxels of the run that starts at padded z `pz`
+__device__ __forceinline__ int run_length(const uint32_t* row, int nwords, int pz) {
+    int zw = pz >> 5, avail = 32 - (pz & 31), len = 0;
+    uint32_t w = row[zw] >> (pz & 31);
+    while (true) {
+        const uint32_t inv = ~w;
+        const int n = min(inv ? __builtin_ctz(inv) : 32, avail);
+        len += n;
+        if (n < avail || ++zw >= nwords) break;
+        w = row[zw]; avail = 32;
+    }
+    return len;
+}
+// heads of the runs that start inside word zw (valid z range only)
+__device__ __forceinline__ uint32_t run_heads(const uint32_t* row, int zw, int vlo, int vhi) {
+    const uint32_t w = row[zw] & zmask(zw, vlo, vhi);
+    const uint32_t below = zw > 0 ? ((row[zw - 1] & zmask(zw - 1, vlo, vhi)) >> 31) : 0u;
+    return w & ~((w << 1) | below);
+}
+// L[head] = head for every run
+__global__ __launch_bounds__(256) void k_cc_init_heads(const uint32_t* A, Dom d, int* L) {
+    const size_t total = (size_t)d.X * d.Y * d.PZW;
+    const int vlo = d.P, vhi = d.P + d.Z;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+        int zw, y, x;
+        dec3(t, d.PZW, d.Y, zw, y, x);
+        if (!zmask(zw, vlo, vhi)) continue;
+        uint32_t h = run_heads(A + widx(d, x + d.P, y + d.P, 0), zw, vlo, vhi);
+        const int ibase = (int)(((size_t)x * d.Y + y) * d.Z) + zw * 32 - d.P;      // linear voxel index of bit 0 of this word
+        while (h) { const int bit = __builtin_ctz(h); h &= h - 1; L[ibase + bit] = ibase + bit; }
+    }
+}
+// optional byte mask of the labelled volume
+__global__ __launch_bounds__(256) void k_mask_bytes(const uint32_t* A, Dom d, uint8_t* mask_out) {
     const size_t total = (size_t)d.X * d.Y * d.Z;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         int z, y, x;
         dec3(i, d.Z, d.Y, z, y, x);
-        const uint32_t* row = A + widx(d, x + d.P, y + d.P, 0);
-        const int pz = z + d.P;
-        int zw = pz >> 5;
-        const int b = pz & 31;
-        uint32_t w = row[zw];
-        const bool f = (w >> b) & 1u;
-        int lab = -1;
-        if (f) {
-            // highest zero bit strictly below b in this word, else continue in the words below (padding bits are 0, and
-            // bits of z < 0 do not exist for P == 0: the loop stops at word 0)
-            uint32_t zeros = ~w & (b ? ((1u << b) - 1u) : 0u);
-            while (!zeros && zw > 0) { --zw; zeros = ~row[zw]; }
-            const int start_pz = zeros ? (zw * 32 + 32 - __builtin_clz(zeros)) : 0;
-            lab = (int)(i - (size_t)(pz - max(start_pz, d.P)));
-        }
-        if (f) L[i] = lab;                  // background entries of L are never read (every later pass asks the bit mask first)
-        if (mask_out) mask_out[i] = f ? 1 : 0;
+        mask_out[i] = fg(A, d, x, y, z) ? 1 : 0;
     }
 }
 // unions across y and x, one thread per MASK WORD (32 voxels of a z-row): where this row and a neighbouring row are both
-// foreground they touch along a z-interval; one union per interval suffices (each side of it lies inside one z-run), issued at
-// the interval's first voxel = the set bits of  adj & ~(adj << 1 | carry from the word below)  -- a few bit operations per 32
-// voxels instead of a coordinate decode and five mask probes per voxel.
+// foreground they touch along a z-interval; one union per interval suffices (each side of it lies inside one z-run), issued
+// between the heads of the two runs at the interval's first voxel = the set bits of
+// adj & ~(adj << 1 | carry from the word below)  -- a few bit operations per 32 voxels.
 __global__ __launch_bounds__(256) void k_cc_merge_runs(const uint32_t* A, Dom d, int* L) {
     const size_t total = (size_t)d.X * d.Y * d.PZW;
     const int vlo = d.P, vhi = d.P + d.Z;
@@ -222,7 +246,7 @@ __global__ __launch_bounds__(256) void k_cc_merge_runs(const uint32_t* A, Dom d,
         const uint32_t w = row[zw] & vm;
         if (!w) continue;
         const uint32_t wlow = zw > 0 ? (row[zw - 1] & zmask(zw - 1, vlo, vhi)) : 0u;
-        const int ibase = (int)(((size_t)x * d.Y + y) * d.Z) + zw * 32 - d.P;      // linear voxel index of bit 0 of this word
+        const int rbase = (int)(((size_t)x * d.Y + y) * d.Z) - d.P;                 // voxel index of padded z = 0 of this row
 #pragma unroll
         for (int dir = 0; dir < 2; ++dir) {
             if (dir == 0 ? y == 0 : x == 0) continue;
@@ -235,28 +259,36 @@ __global__ __launch_bounds__(256) void k_cc_merge_runs(const uint32_t* A, Dom d,
             while (starts) {
                 const int bit = __builtin_ctz(starts);
                 starts &= starts - 1;
-                cc_union(L, ibase + bit, ibase + bit - noff);
+                const int ha = max(run_start_pz(row, zw, bit), d.P), hb = max(run_start_pz(nrow, zw, bit), d.P);
+                cc_union(L, rbase + ha, rbase - noff + hb);
             }
         }
     }
 }
-constexpr int SCAN_PER_THREAD = 8, SCAN_BLOCK = 256 * SCAN_PER_THREAD;
-// path compression (L[i] = root of i) fused with the count of roots per block of SCAN_BLOCK voxels (a root is a foreground
-// voxel with L[i] == i: fixed once the merges are done, so it can be counted while other blocks still compress)
-__global__ __launch_bounds__(256) void k_cc_compress_count(const uint32_t* A, Dom d, size_t total, int* L, int* blockcnt) {
+constexpr int SCAN_PER_THREAD = 8, SCAN_BLOCK = 256 * SCAN_PER_THREAD;      // mask words per thread / per workgroup of the ranking passes
+// path compression of the run heads (L[head] = root) fused with the count of roots per block of SCAN_BLOCK mask words (a root is
+// a head with L[head] == head: fixed once the merges are done, so it can be counted while other blocks still compress)
+__global__ __launch_bounds__(256) void k_cc_compress_count(const uint32_t* A, Dom d, size_t nwords, int* L, int* blockcnt) {
     __shared__ int red[4];
+    const int vlo = d.P, vhi = d.P + d.Z;
     const size_t base = (size_t)blockIdx.x * SCAN_BLOCK + threadIdx.x;
     int c = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_PER_THREAD; ++k) {
-        const size_t i = base + (size_t)k * 256;           // consecutive threads = consecutive voxels
-        if (i >= total) continue;
-        int z, y, x;
-        dec3(i, d.Z, d.Y, z, y, x);
-        if (!fg(A, d, x, y, z)) continue;
-        const int r = cc_find(L, (int)i);
-        L[i] = r;
-        c += r == (int)i ? 1 : 0;
+        const size_t t = base + (size_t)k * 256;           // consecutive threads = consecutive words
+        if (t >= nwords) continue;
+        int zw, y, x;
+        dec3(t, d.PZW, d.Y, zw, y, x);
+        if (!zmask(zw, vlo, vhi)) continue;
+        uint32_t h = run_heads(A + widx(d, x + d.P, y + d.P, 0), zw, vlo, vhi);
+        const int ibase = (int)(((size_t)x * d.Y + y) * d.Z) + zw * 32 - d.P;
+        while (h) {
+            const int i = ibase + __builtin_ctz(h);
+            h &= h - 1;
+            const int r = cc_find(L, i);
+            L[i] = r;
+            c += r == i ? 1 : 0;
+        }
     }
     for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
@@ -289,22 +321,32 @@ __global__ __launch_bounds__(1024) void k_cc_scan_blocks(int* blockcnt, int n, i
         for (int i = lo + lane; i < hi; i += 64) blockcnt[i] += off;
     if (threadIdx.x == 1023) *max_label = off + carry;
 }
-// rank[root] = 1 + number of roots with a smaller raster index
-__global__ __launch_bounds__(256) void k_cc_rank(const uint32_t* A, Dom d, size_t total, const int* L, const int* blockcnt, int* rank) {
+// rank[root] = 1 + number of roots with a smaller raster index (words in raster order, bits ascending = voxels in raster order)
+__global__ __launch_bounds__(256) void k_cc_rank(const uint32_t* A, Dom d, size_t nwords, const int* L, const int* blockcnt, int* rank) {
     __shared__ int wsum[4];
+    const int vlo = d.P, vhi = d.P + d.Z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t base = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * SCAN_PER_THREAD;
-    bool root[SCAN_PER_THREAD];
+    const size_t base = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * SCAN_PER_THREAD;      // consecutive words per thread
+    uint32_t roots[SCAN_PER_THREAD];
+    int ib[SCAN_PER_THREAD];
     int c = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_PER_THREAD; ++k) {
-        root[k] = false;
-        if (base + k < total) {
-            int z, y, x;
-            dec3(base + k, d.Z, d.Y, z, y, x);
-            root[k] = fg(A, d, x, y, z) && L[base + k] == (int)(base + k);
+        roots[k] = 0u; ib[k] = 0;
+        if (base + k < nwords) {
+            int zw, y, x;
+            dec3(base + k, d.PZW, d.Y, zw, y, x);
+            if (zmask(zw, vlo, vhi)) {
+                uint32_t h = run_heads(A + widx(d, x + d.P, y + d.P, 0), zw, vlo, vhi);
+                ib[k] = (int)(((size_t)x * d.Y + y) * d.Z) + zw * 32 - d.P;
+                while (h) {
+                    const int bit = __builtin_ctz(h);
+                    h &= h - 1;
+                    if (L[ib[k] + bit] == ib[k] + bit) roots[k] |= 1u << bit;
+                }
+            }
         }
-        c += root[k];
+        c += __builtin_popcount(roots[k]);
     }
     int incl = c;                                             // inclusive scan over the wave's lanes
     for (int s = 1; s < 64; s <<= 1) { const int t = __shfl_up(incl, s, 64); if (lane >= s) incl += t; }
@@ -313,8 +355,10 @@ __global__ __launch_bounds__(256) void k_cc_rank(const uint32_t* A, Dom d, size_
     int off = blockcnt[blockIdx.x] + incl - c;
     for (int w = 0; w < wave; ++w) off += wsum[w];
 #pragma unroll
-    for (int k = 0; k < SCAN_PER_THREAD; ++k)
-        if (root[k]) rank[base + k] = ++off;
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+        uint32_t r = roots[k];
+        while (r) { const int bit = __builtin_ctz(r); r &= r - 1; rank[ib[k] + bit] = ++off; }
+    }
 }
 // cnt[key] += 1 for every lane with key > 0, aggregated over runs of equal keys in consecutive lanes (voxels of one object sit
 // next to each other: one atomic per run instead of one per voxel; all 64 lanes must call)
@@ -329,18 +373,58 @@ __device__ __forceinline__ void count_runs(int key, int* cnt) {
         atomicAdd(&cnt[key], len);
     }
 }
-// (cnt != nullptr: cnt[label] += voxels, one atomic per run of equal labels in a wave)
-__global__ __launch_bounds__(256) void k_cc_relabel(const uint32_t* A, Dom d, size_t total, int* L, const int* rank, int* cnt) {
-    const size_t n64 = (total + 63) / 64 * 64;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n64; i += (size_t)gridDim.x * 256) {
-        int l = 0;
-        if (i < total) {
-            int z, y, x;
-            dec3(i, d.Z, d.Y, z, y, x);
-            l = fg(A, d, x, y, z) ? rank[L[i]] : 0;      // rank[] is a separate buffer: roots read here are never overwritten
-            L[i] = l;
+// rank[head] = final label of every run (roots have theirs); cnt != nullptr: cnt[label] += voxels of the run -- aggregated per
+// workgroup in a small LDS table first (the runs of one component sit next to each other: 0.7 M global atomics onto a few
+// thousand addresses took 0.35 ms per 512^3)
+__global__ __launch_bounds__(256) void k_cc_head_labels(const uint32_t* A, Dom d, const int* L, int* rank, int* cnt) {
+    constexpr int SLOTS = 512;
+    __shared__ int skey[SLOTS], sval[SLOTS];
+    if (cnt) {
+        for (int i = threadIdx.x; i < SLOTS; i += 256) { skey[i] = 0; sval[i] = 0; }
+        __syncthreads();
+    }
+    const size_t total = (size_t)d.X * d.Y * d.PZW;
+    const int vlo = d.P, vhi = d.P + d.Z;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+        int zw, y, x;
+        dec3(t, d.PZW, d.Y, zw, y, x);
+        if (!zmask(zw, vlo, vhi)) continue;
+        const uint32_t* row = A + widx(d, x + d.P, y + d.P, 0);
+        uint32_t h = run_heads(row, zw, vlo, vhi);
+        const int ibase = (int)(((size_t)x * d.Y + y) * d.Z) + zw * 32 - d.P;
+        while (h) {
+            const int bit = __builtin_ctz(h);
+            h &= h - 1;
+            const int i = ibase + bit, r = L[i];
+            const int lab = rank[r];                          // a root's entry: written by k_cc_rank only
+            if (r != i) rank[i] = lab;
+            if (cnt) {
+                const int len = run_length(row, d.PZW, zw * 32 + bit);
+                int slot = (int)(((unsigned)lab * 2654435761u) >> 23), tries = 0;      // labels are >= 1: key 0 = empty
+                for (; tries < 8; ++tries, slot = (slot + 1) & (SLOTS - 1)) {
+                    const int k = atomicCAS(&skey[slot], 0, lab);
+                    if (k == 0 || k == lab) { atomicAdd(&sval[slot], len); break; }
+                }
+                if (tries == 8) atomicAdd(&cnt[lab], len);
+            }
         }
-        if (cnt) count_runs(l, cnt);
+    }
+    if (cnt) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < SLOTS; i += 256)
+            if (skey[i]) atomicAdd(&cnt[skey[i]], sval[i]);
+    }
+}
+// the only pass over the voxels: label of the voxel's run, 0 for background
+__global__ __launch_bounds__(256) void k_cc_relabel(const uint32_t* A, Dom d, size_t total, int* L, const int* rank) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        int z, y, x;
+        dec3(i, d.Z, d.Y, z, y, x);
+        const uint32_t* row = A + widx(d, x + d.P, y + d.P, 0);
+        const int pz = z + d.P;
+        int l = 0;
+        if ((row[pz >> 5] >> (pz & 31)) & 1u) l = rank[(int)i - (pz - max(run_start_pz(row, pz >> 5, pz & 31), d.P))];
+        L[i] = l;
     }
 }
 
@@ -1089,14 +1173,16 @@ void run_morph(hipStream_t s, uint32_t*& A, uint32_t*& B, const Dom& d, int* bbo
 // scipy.ndimage.label of the bit-packed volume A into L (ids 1..N in raster order of the first voxel), N -> *max_label_dev
 void run_cc(hipStream_t s, const uint32_t* A, const Dom& d, int* L, int* rank, int* blockcnt, int* max_label_dev, uint8_t* mask_out,
             int* cnt = nullptr) {      // cnt (zeroed by the caller): voxels per label
-    const size_t nvox = (size_t)d.X * d.Y * d.Z;
-    hipLaunchKernelGGL(k_cc_init_runs, dim3(grid_for(nvox)), dim3(256), 0, s, A, d, L, mask_out);
-    hipLaunchKernelGGL(k_cc_merge_runs, dim3(grid_for((size_t)d.X * d.Y * d.PZW)), dim3(256), 0, s, A, d, L);
-    const int nblk = (int)((nvox + SCAN_BLOCK - 1) / SCAN_BLOCK);
-    hipLaunchKernelGGL(k_cc_compress_count, dim3(nblk), dim3(256), 0, s, A, d, nvox, L, blockcnt);
+    const size_t nvox = (size_t)d.X * d.Y * d.Z, nwords = (size_t)d.X * d.Y * d.PZW;
+    hipLaunchKernelGGL(k_cc_init_heads, dim3(grid_for(nwords)), dim3(256), 0, s, A, d, L);
+    if (mask_out) hipLaunchKernelGGL(k_mask_bytes, dim3(grid_for(nvox)), dim3(256), 0, s, A, d, mask_out);
+    hipLaunchKernelGGL(k_cc_merge_runs, dim3(grid_for(nwords)), dim3(256), 0, s, A, d, L);
+    const int nblk = (int)((nwords + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    hipLaunchKernelGGL(k_cc_compress_count, dim3(nblk), dim3(256), 0, s, A, d, nwords, L, blockcnt);
     hipLaunchKernelGGL(k_cc_scan_blocks, dim3(1), dim3(1024), 0, s, blockcnt, nblk, max_label_dev);
-    hipLaunchKernelGGL(k_cc_rank, dim3(nblk), dim3(256), 0, s, A, d, nvox, L, blockcnt, rank);
-    hipLaunchKernelGGL(k_cc_relabel, dim3(grid_for(nvox)), dim3(256), 0, s, A, d, nvox, L, rank, cnt);
+    hipLaunchKernelGGL(k_cc_rank, dim3(nblk), dim3(256), 0, s, A, d, nwords, L, blockcnt, rank);
+    hipLaunchKernelGGL(k_cc_head_labels, dim3(grid_for(nwords)), dim3(256), 0, s, A, d, L, rank, cnt);
+    hipLaunchKernelGGL(k_cc_relabel, dim3(grid_for(nvox)), dim3(256), 0, s, A, d, nvox, L, rank);
 }
 int cut_of(double threshold) {
     // (uint8 p > t) <=> p >= floor(t) + 1; threshold 0 means "already a 0/1 mask" (object_extraction_steps.py:316): cut 1
