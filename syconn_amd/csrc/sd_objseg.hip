@@ -415,16 +415,24 @@ __global__ __launch_bounds__(256) void k_cc_head_labels(const uint32_t* A, Dom d
             if (skey[i]) atomicAdd(&cnt[skey[i]], sval[i]);
     }
 }
-// the only pass over the voxels: label of the voxel's run, 0 for background
-__global__ __launch_bounds__(256) void k_cc_relabel(const uint32_t* A, Dom d, size_t total, int* L, const int* rank) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        int z, y, x;
-        dec3(i, d.Z, d.Y, z, y, x);
+// the label volume: zero-filled by a memset, then every run writes its label over its voxels (one thread per mask word, the
+// runs that START in it)
+__global__ __launch_bounds__(256) void k_cc_fill_runs(const uint32_t* A, Dom d, int* L, const int* rank) {
+    const size_t total = (size_t)d.X * d.Y * d.PZW;
+    const int vlo = d.P, vhi = d.P + d.Z;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+        int zw, y, x;
+        dec3(t, d.PZW, d.Y, zw, y, x);
+        if (!zmask(zw, vlo, vhi)) continue;
         const uint32_t* row = A + widx(d, x + d.P, y + d.P, 0);
-        const int pz = z + d.P;
-        int l = 0;
-        if ((row[pz >> 5] >> (pz & 31)) & 1u) l = rank[(int)i - (pz - max(run_start_pz(row, pz >> 5, pz & 31), d.P))];
-        L[i] = l;
+        uint32_t h = run_heads(row, zw, vlo, vhi);
+        const int ibase = (int)(((size_t)x * d.Y + y) * d.Z) + zw * 32 - d.P;
+        while (h) {
+            const int bit = __builtin_ctz(h);
+            h &= h - 1;
+            const int i = ibase + bit, lab = rank[i], len = run_length(row, d.PZW, zw * 32 + bit);
+            for (int k = 0; k < len; ++k) L[i + k] = lab;
+        }
     }
 }
 
@@ -1182,7 +1190,8 @@ void run_cc(hipStream_t s, const uint32_t* A, const Dom& d, int* L, int* rank, i
     hipLaunchKernelGGL(k_cc_scan_blocks, dim3(1), dim3(1024), 0, s, blockcnt, nblk, max_label_dev);
     hipLaunchKernelGGL(k_cc_rank, dim3(nblk), dim3(256), 0, s, A, d, nwords, L, blockcnt, rank);
     hipLaunchKernelGGL(k_cc_head_labels, dim3(grid_for(nwords)), dim3(256), 0, s, A, d, L, rank, cnt);
-    hipLaunchKernelGGL(k_cc_relabel, dim3(grid_for(nvox)), dim3(256), 0, s, A, d, nvox, L, rank);
+    hipMemsetAsync(L, 0, nvox * sizeof(int), s);      // (after the head passes: they use L as the union-find array)
+    hipLaunchKernelGGL(k_cc_fill_runs, dim3(grid_for(nwords)), dim3(256), 0, s, A, d, L, rank);
 }
 int cut_of(double threshold) {
     // (uint8 p > t) <=> p >= floor(t) + 1; threshold 0 means "already a 0/1 mask" (object_extraction_steps.py:316): cut 1
