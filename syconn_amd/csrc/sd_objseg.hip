@@ -373,6 +373,16 @@ __device__ __forceinline__ void count_runs(int key, int* cnt) {
         atomicAdd(&cnt[key], len);
     }
 }
+// slot of key k (>= 1; 0 = empty) in a small open-addressing table in LDS, inserting it if absent; -1 if the probe sequence is full
+template <int SLOTS>
+__device__ __forceinline__ int lds_slot(int* skey, int k) {
+    int slot = (int)(((unsigned)k * 2654435761u) >> 16) & (SLOTS - 1);
+    for (int tries = 0; tries < 8; ++tries, slot = (slot + 1) & (SLOTS - 1)) {
+        const int old = atomicCAS(&skey[slot], 0, k);
+        if (old == 0 || old == k) return slot;
+    }
+    return -1;
+}
 // rank[head] = final label of every run (roots have theirs); cnt != nullptr: cnt[label] += voxels of the run -- aggregated per
 // workgroup in a small LDS table first (the runs of one component sit next to each other: 0.7 M global atomics onto a few
 // thousand addresses took 0.35 ms per 512^3)
@@ -501,17 +511,53 @@ __global__ __launch_bounds__(256) void k_seed_map(const int* cnt, const int* rd,
         map[i] = v;
     }
 }
-__global__ __launch_bounds__(256) void k_apply_map(uint32_t* S, Dom d, int* L, size_t total, const int* map) {      // relabel_vol (block_processing_C.pyx:161-169)
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        int z, y, x;
-        dec3(i, d.Z, d.Y, z, y, x);
-        if (!fg(S, d, x, y, z)) continue;      // S = the bits the seeds were labelled from: ids are nonzero only there
-        const int l = L[i];
-        if (l > 0) {
-            const int t = map[l];
-            L[i] = t;
-            if (t == 0) atomicAnd(&S[widx(d, x + d.P, y + d.P, (z + d.P) >> 5)], ~(1u << ((z + d.P) & 31)));      // S stays == {id > 0}
+__global__ __launch_bounds__(256) void k_apply_map(const uint32_t* S, Dom d, int* L, const int* map) {      // relabel_vol (block_processing_C.pyx:161-169)
+    // one thread per word of S (the bits the seeds were labelled from): a z-run carries ONE id -- rewrite the runs whose id changes
+    const size_t total = (size_t)d.X * d.Y * d.PZW;
+    const int vlo = d.P, vhi = d.P + d.Z;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+        int zw, y, x;
+        dec3(t, d.PZW, d.Y, zw, y, x);
+        if (!zmask(zw, vlo, vhi)) continue;
+        const uint32_t* row = S + widx(d, x + d.P, y + d.P, 0);
+        uint32_t h = run_heads(row, zw, vlo, vhi);
+        const int ibase = (int)(((size_t)x * d.Y + y) * d.Z) + zw * 32 - d.P;
+        while (h) {
+            const int bit = __builtin_ctz(h);
+            h &= h - 1;
+            const int i = ibase + bit, l = L[i], tl = l > 0 ? map[l] : l;
+            if (tl != l) {
+                const int len = run_length(row, d.PZW, zw * 32 + bit);
+                for (int k = 0; k < len; ++k) L[i + k] = tl;
+            }
         }
+    }
+}
+// ... and S follows: bits of deleted seeds are cleared (S == {id > 0} afterwards).  Every thread reads and writes its own word only:
+// any voxel of a run tells whether the run was deleted.
+__global__ __launch_bounds__(256) void k_seed_bits_sync(uint32_t* S, Dom d, const int* L) {
+    const size_t total = (size_t)d.X * d.Y * d.PZW;
+    const int vlo = d.P, vhi = d.P + d.Z;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+        int zw, y, x;
+        dec3(t, d.PZW, d.Y, zw, y, x);
+        const uint32_t vm = zmask(zw, vlo, vhi);
+        if (!vm) continue;
+        uint32_t* const wp = S + widx(d, x + d.P, y + d.P, zw);
+        const uint32_t w = *wp & vm;
+        if (!w) continue;
+        const int ibase = (int)(((size_t)x * d.Y + y) * d.Z) + zw * 32 - d.P;
+        uint32_t first = w & ~(w << 1), keep = *wp;      // first bit of every stretch of ones inside this word
+        while (first) {
+            const int bit = __builtin_ctz(first);
+            first &= first - 1;
+            if (L[ibase + bit] == 0) {
+                const uint32_t above = ~(w >> bit);                                   // zeros of the stretch's continuation
+                const int n = above ? __builtin_ctz(above) : 32 - bit;
+                keep &= ~((n >= 32 ? 0xffffffffu : ((1u << n) - 1u)) << bit);
+            }
+        }
+        if (keep != *wp) *wp = keep;
     }
 }
 
@@ -590,23 +636,48 @@ __global__ __launch_bounds__(256) void k_edt_axis(const uint32_t* A, const int* 
 // per mask component: smallest and largest marker id found inside it (mn = INT_MAX, mx = 0: none)
 __global__ __launch_bounds__(256) void k_comp_markers(const uint32_t* S, Dom d, const int* comp, const int* mk, size_t total, int* mn, int* mx,
                                                       int* max_label) {
-    int top = 0;      // largest marker inside the mask = largest label of the flood's result
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        if (S) {              // markers are nonzero only where these bits are set (the volume the seeds were labelled from)
-            int z, y, x;
-            dec3(i, d.Z, d.Y, z, y, x);
-            if (!fg(S, d, x, y, z)) continue;
+    // smallest / largest marker per component and the largest marker inside the mask (= largest label of the flood's result),
+    // aggregated per workgroup in LDS: the runs of one component are neighbours, global atomics on its two words serialise
+    constexpr int SLOTS = 512;
+    __shared__ int skey[SLOTS], smin[SLOTS], smax[SLOTS], stop;
+    for (int i = threadIdx.x; i < SLOTS; i += 256) { skey[i] = 0; smin[i] = 0x7fffffff; smax[i] = 0; }
+    if (threadIdx.x == 0) stop = 0;
+    __syncthreads();
+    int top = 0;
+    auto see = [&](int m, int c) {
+        if (c <= 0) return;
+        top = max(top, m);
+        const int slot = lds_slot<SLOTS>(skey, c);
+        if (slot >= 0) { atomicMin(&smin[slot], m); atomicMax(&smax[slot], m); }
+        else { atomicMin(&mn[c], m); atomicMax(&mx[c], m); }
+    };
+    if (S) {      // S == {marker > 0}, one marker and one mask component per z-run of S: one thread per word, the runs that start in it
+        const size_t nwords = (size_t)d.X * d.Y * d.PZW;
+        const int vlo = d.P, vhi = d.P + d.Z;
+        for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < nwords; t += (size_t)gridDim.x * 256) {
+            int zw, y, x;
+            dec3(t, d.PZW, d.Y, zw, y, x);
+            if (!zmask(zw, vlo, vhi)) continue;
+            uint32_t h = run_heads(S + widx(d, x + d.P, y + d.P, 0), zw, vlo, vhi);
+            const int ibase = (int)(((size_t)x * d.Y + y) * d.Z) + zw * 32 - d.P;
+            while (h) {
+                const int i = ibase + __builtin_ctz(h);
+                h &= h - 1;
+                const int m = mk[i];
+                if (m > 0) see(m, comp[i]);
+            }
         }
-        const int m = mk[i];
-        if (m > 0) {          // (plain reads first: after the first few voxels of a component almost no atomic is needed)
-            const int c = comp[i];
-            if (c > 0) top = max(top, m);
-            if (m < __hip_atomic_load(&mn[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&mn[c], m);
-            if (m > __hip_atomic_load(&mx[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&mx[c], m);
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+            const int m = mk[i];
+            if (m > 0) see(m, comp[i]);
         }
     }
-    for (int sft = 32; sft >= 1; sft >>= 1) top = max(top, __shfl_xor(top, sft, 64));
-    if ((threadIdx.x & 63) == 0 && top > 0) atomicMax(max_label, top);
+    if (top > 0) atomicMax(&stop, top);
+    __syncthreads();
+    for (int i = threadIdx.x; i < SLOTS; i += 256)
+        if (skey[i]) { atomicMin(&mn[skey[i]], smin[i]); atomicMax(&mx[skey[i]], smax[i]); }
+    if (threadIdx.x == 0 && stop > 0) atomicMax(max_label, stop);
 }
 // pool capacity of a component = its voxel count (counted by the labelling pass) if it holds several markers, else 0
 __global__ __launch_bounds__(256) void k_comp_keep_multi(const int* NC, const int* mn, const int* mx, int* sz) {
@@ -795,41 +866,102 @@ __device__ __forceinline__ void ws_sort(int n, Get get, Put put) {
     }
 }
 // start state as k_ws_init_seq; the marker voxels that can push anything enter the component's bag (left-aligned, buffer 0)
+constexpr int WI_WORDS = 4;      // mask words per thread of k_ws_init (a workgroup owns 1024 consecutive words)
 __global__ __launch_bounds__(256) void k_ws_init(const uint32_t* M, const uint32_t* S, const int* comp, const int* mk, const int* g, Dom d, size_t total,
                                                  const int* mn, const int* mx, const int* off, int* hcnt, WsPool P, int* out) {
+    // `out` is zero (memset); one thread per mask word, the z-runs that start in it: a run lies in one component.  The queued
+    // markers of a workgroup are collected in LDS and get their bag slots with ONE global atomic per component and workgroup
+    // (one per marker serialised on the component's counter: 1.3 M atomics onto a few hundred addresses per 512^3).
+    constexpr int SLOTS = 256, LIST = 3072;
+    __shared__ int skey[SLOTS], scnt[SLOTS], sbase[SLOTS];
+    __shared__ int lslot[LIST], lg[LIST], li[LIST];
+    __shared__ int nlist;
+    for (int i = threadIdx.x; i < SLOTS; i += 256) { skey[i] = 0; scnt[i] = 0; }
+    if (threadIdx.x == 0) nlist = 0;
+    __syncthreads();
     const int sY = d.Z, sX = d.Z * d.Y;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        int z, y, x;
-        dec3(i, d.Z, d.Y, z, y, x);
-        const int c = fg(M, d, x, y, z) ? comp[i] : 0;
-        int o = 0;
-        if (c > 0 && mx[c] > 0) {
-            if (mx[c] == mn[c]) o = mx[c];
+    const size_t nwords = (size_t)d.X * d.Y * d.PZW;
+    const int vlo = d.P, vhi = d.P + d.Z;
+#pragma unroll 1
+    for (int kw = 0; kw < WI_WORDS; ++kw) {
+        const size_t t = (size_t)blockIdx.x * (256 * WI_WORDS) + (size_t)kw * 256 + threadIdx.x;
+        if (t >= nwords) continue;
+        int zw, y, x;
+        dec3(t, d.PZW, d.Y, zw, y, x);
+        if (!zmask(zw, vlo, vhi)) continue;
+        const uint32_t* row = M + widx(d, x + d.P, y + d.P, 0);
+        uint32_t h = run_heads(row, zw, vlo, vhi);
+        const int ibase = (int)(((size_t)x * d.Y + y) * d.Z) + zw * 32 - d.P;
+        auto queue = [&](int c, int idx) {
+            const int slot = lds_slot<SLOTS>(skey, c);
+            const int pos = slot >= 0 ? atomicAdd(&nlist, 1) : LIST;
+            if (pos < LIST) { atomicAdd(&scnt[slot], 1); lslot[pos] = slot; lg[pos] = g[idx]; li[pos] = idx; }
             else {
-                o = mk[i];
-                if (o <= 0) o = WS_OPEN;
-                else {
-                    const int idx = (int)i;
-                    const int nb[6] = {x > 0 ? idx - sX : -1, y > 0 ? idx - sY : -1, z > 0 ? idx - 1 : -1,
-                                       z + 1 < d.Z ? idx + 1 : -1, y + 1 < d.Y ? idx + sY : -1, x + 1 < d.X ? idx + sX : -1};
-                    bool open = false;
-                    if (S) {      // S == {marker > 0} exactly: a neighbour inside the mask (hence inside this component) without a marker
-                        const int ex[6] = {-1, 0, 0, 0, 0, 1}, ey[6] = {0, -1, 0, 0, 1, 0}, ez[6] = {0, 0, -1, 1, 0, 0};
+                const int gs = off[c] + atomicAdd(&hcnt[c], 1);
+                P.bl[0][gs] = g[idx]; P.bt[0][gs] = (unsigned)idx; P.bv[0][gs] = idx;
+            }
+        };
+        while (h) {
+            const int bit = __builtin_ctz(h);
+            h &= h - 1;
+            const int i0 = ibase + bit, c = comp[i0];
+            if (c <= 0 || mx[c] <= 0) continue;
+            const int len = run_length(row, d.PZW, zw * 32 + bit), z0 = zw * 32 + bit - d.P;
+            if (mx[c] == mn[c]) {
+                const int o = mx[c];
+                for (int k = 0; k < len; ++k) out[i0 + k] = o;
+                continue;
+            }
+            for (int k = 0; k < len; ++k) {      // several markers: the markers themselves, WS_OPEN for the voxels the flood will label
+                const int o = mk[i0 + k];
+                out[i0 + k] = o > 0 ? o : WS_OPEN;
+            }
+            if (S) continue;                     // (the queue: word-wise below)
+            for (int k = 0; k < len; ++k) {      // arbitrary marker volumes (sd_marker_flood): neighbour tests on the label arrays
+                const int idx = i0 + k, z = z0 + k;
+                if (mk[idx] <= 0) continue;
+                const int nb[6] = {x > 0 ? idx - sX : -1, y > 0 ? idx - sY : -1, z > 0 ? idx - 1 : -1,
+                                   z + 1 < d.Z ? idx + 1 : -1, y + 1 < d.Y ? idx + sY : -1, x + 1 < d.X ? idx + sX : -1};
+                bool open = false;
 #pragma unroll
-                        for (int e = 0; e < 6; ++e)
-                            open |= nb[e] >= 0 && fg(M, d, x + ex[e], y + ey[e], z + ez[e]) && !fg(S, d, x + ex[e], y + ey[e], z + ez[e]);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 6; ++e) open |= nb[e] >= 0 && comp[nb[e]] == c && mk[nb[e]] <= 0;
-                    }
-                    if (open) {
-                        const int slot = off[c] + atomicAdd(&hcnt[c], 1);
-                        P.bl[0][slot] = g[i]; P.bt[0][slot] = (unsigned)idx; P.bv[0][slot] = idx;
-                    }
+                for (int e = 0; e < 6; ++e) open |= nb[e] >= 0 && comp[nb[e]] == c && mk[nb[e]] <= 0;
+                if (open) queue(c, idx);
+            }
+        }
+        if (S) {
+            // queued = marker voxels (S == {marker > 0} exactly) with a neighbour inside the mask (hence inside their component)
+            // that has no marker: U = M & ~S shifted along z and read from the four neighbouring rows -- bit operations per word
+            const uint32_t vm = zmask(zw, vlo, vhi);
+            const uint32_t* srow = S + widx(d, x + d.P, y + d.P, 0);
+            const uint32_t sw = srow[zw] & vm;
+            if (sw) {
+                auto U = [&](const uint32_t* mr, const uint32_t* sr, int w) -> uint32_t {
+                    return (w >= 0 && w < d.PZW) ? (mr[w] & ~sr[w] & zmask(w, vlo, vhi)) : 0u;
+                };
+                const uint32_t u0 = U(row, srow, zw);
+                uint32_t nbr = (u0 << 1) | (U(row, srow, zw - 1) >> 31) | (u0 >> 1) | (U(row, srow, zw + 1) << 31);
+                if (x > 0) nbr |= U(M + widx(d, x - 1 + d.P, y + d.P, 0), S + widx(d, x - 1 + d.P, y + d.P, 0), zw);
+                if (x + 1 < d.X) nbr |= U(M + widx(d, x + 1 + d.P, y + d.P, 0), S + widx(d, x + 1 + d.P, y + d.P, 0), zw);
+                if (y > 0) nbr |= U(M + widx(d, x + d.P, y - 1 + d.P, 0), S + widx(d, x + d.P, y - 1 + d.P, 0), zw);
+                if (y + 1 < d.Y) nbr |= U(M + widx(d, x + d.P, y + 1 + d.P, 0), S + widx(d, x + d.P, y + 1 + d.P, 0), zw);
+                uint32_t open = sw & nbr;
+                while (open) {
+                    const int b = __builtin_ctz(open);
+                    open &= open - 1;
+                    const int idx = ibase + b, c = comp[idx];
+                    if (c > 0 && mx[c] > mn[c]) queue(c, idx);
                 }
             }
         }
-        out[i] = o;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SLOTS; i += 256)
+        if (skey[i]) { sbase[i] = off[skey[i]] + atomicAdd(&hcnt[skey[i]], scnt[i]); scnt[i] = 0; }
+    __syncthreads();
+    const int n = min(nlist, LIST);
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int slot = lslot[i], gs = sbase[slot] + atomicAdd(&scnt[slot], 1);
+        P.bl[0][gs] = lg[i]; P.bt[0][gs] = (unsigned)li[i]; P.bv[0][gs] = li[i];
     }
 }
 #ifdef SD_WS_TIMING
@@ -1260,7 +1392,7 @@ void flood_stage(hipStream_t s, const uint32_t* M, const uint32_t* seed_bits, co
     hipLaunchKernelGGL(k_fill_int, dim3(gt), dim3(256), 0, s, mx, l.T, 0);
     hipLaunchKernelGGL(k_fill_int, dim3(gt), dim3(256), 0, s, hcnt, l.T, 0);
     hipLaunchKernelGGL(k_fill_int, dim3(1), dim3(256), 0, s, max_label_dev, (size_t)1, 0);
-    hipLaunchKernelGGL(k_comp_markers, dim3(grid_for(nvox)), dim3(256), 0, s, seed_bits, d, comp, mk, nvox, mn, mx, max_label_dev);
+    hipLaunchKernelGGL(k_comp_markers, dim3(grid_for(seed_bits ? (size_t)d.X * d.Y * d.PZW : nvox)), dim3(256), 0, s, seed_bits, d, comp, mk, nvox, mn, mx, max_label_dev);
     hipLaunchKernelGGL(k_comp_keep_multi, dim3(gt), dim3(256), 0, s, scal + 1, mn, mx, off);
     hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, s, off, scal + 1, 1, scal + 4);
     // watershed (:351): start state + queued markers, then the flood of every multi-marker component (level-synchronous, one
@@ -1271,7 +1403,8 @@ void flood_stage(hipStream_t s, const uint32_t* M, const uint32_t* seed_bits, co
         hipLaunchKernelGGL(k_ws_flood_seq, dim3(4096), dim3(64), 0, s, comp, g, d, scal + 1, mn, mx, off, hcnt, pool.ga[0], pool.cl, labels_dev);
     } else {
         hipLaunchKernelGGL(k_fill_int, dim3(grid_for(nvox)), dim3(256), 0, s, rank, nvox, -1);
-        hipLaunchKernelGGL(k_ws_init, dim3(grid_for(nvox)), dim3(256), 0, s, M, seed_bits, comp, mk, g, d, nvox, mn, mx, off, hcnt, pool, labels_dev);
+        hipMemsetAsync(labels_dev, 0, nvox * sizeof(int), s);
+        hipLaunchKernelGGL(k_ws_init, dim3((unsigned)(((size_t)d.X * d.Y * d.PZW + 256 * WI_WORDS - 1) / (256 * WI_WORDS))), dim3(256), 0, s, M, seed_bits, comp, mk, g, d, nvox, mn, mx, off, hcnt, pool, labels_dev);
         hipLaunchKernelGGL(k_ws_flood<WSP_THREADS>, dim3(2048), dim3(WSP_THREADS), 0, s, comp, g, d, scal + 1, mn, mx, off, scal + 4, hcnt, pool, labels_dev);
     }
 }
@@ -1366,7 +1499,8 @@ int sd_object_segmentation_watershed(const uint8_t* prob_dev, int X, int Y, int 
         hipLaunchKernelGGL(k_seed_lists, dim3(gt), dim3(256), 0, s, cnt, rd, scal + 0, min_seed_vx, D, K);
         hipLaunchKernelGGL(k_seed_prefix, dim3(gt), dim3(256), 0, s, D, K, scal + 0, scal + 2, scal + 3);
         hipLaunchKernelGGL(k_seed_map, dim3(gt), dim3(256), 0, s, cnt, rd, D, scal + 0, scal + 2, scal + 3, min_seed_vx, map);
-        hipLaunchKernelGGL(k_apply_map, dim3(grid_for(nvox)), dim3(256), 0, s, A, d, mk, nvox, map);
+        hipLaunchKernelGGL(k_apply_map, dim3(grid_for(pwords)), dim3(256), 0, s, A, d, mk, map);
+        hipLaunchKernelGGL(k_seed_bits_sync, dim3(grid_for(pwords)), dim3(256), 0, s, A, d, mk);
     }
     if (markers_out_dev && hipMemcpyAsync(markers_out_dev, mk, nvox * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
         return sd_fail_msg(SD_ERR_HIP, "sd_object_segmentation_watershed: copy failed");
