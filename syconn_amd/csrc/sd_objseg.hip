@@ -473,6 +473,12 @@ __global__ __launch_bounds__(1024) void k_scan_excl(int* v, const int* n_ptr, in
     }
     if (threadIdx.x == 0 && total_out) *total_out = carry;
 }
+// p[0 .. *n_ptr + extra) = v: the per-id tables are sized for the worst case (half the voxels) but used up to the id count, which
+// only the device knows
+__global__ __launch_bounds__(256) void k_fill_ids(int* p, const int* n_ptr, int extra, int v) {
+    const size_t n = (size_t)*n_ptr + extra;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
+}
 __global__ __launch_bounds__(256) void k_fill_int(int* p, size_t n, int v) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
 }
@@ -1312,7 +1318,7 @@ void run_morph(hipStream_t s, uint32_t*& A, uint32_t*& B, const Dom& d, int* bbo
 }
 // scipy.ndimage.label of the bit-packed volume A into L (ids 1..N in raster order of the first voxel), N -> *max_label_dev
 void run_cc(hipStream_t s, const uint32_t* A, const Dom& d, int* L, int* rank, int* blockcnt, int* max_label_dev, uint8_t* mask_out,
-            int* cnt = nullptr) {      // cnt (zeroed by the caller): voxels per label
+            int* cnt = nullptr) {      // cnt: voxels per label, entries 0 .. N + 1 (zeroed here, once N is known)
     const size_t nvox = (size_t)d.X * d.Y * d.Z, nwords = (size_t)d.X * d.Y * d.PZW;
     hipLaunchKernelGGL(k_cc_init_heads, dim3(grid_for(nwords)), dim3(256), 0, s, A, d, L);
     if (mask_out) hipLaunchKernelGGL(k_mask_bytes, dim3(grid_for(nvox)), dim3(256), 0, s, A, d, mask_out);
@@ -1321,8 +1327,9 @@ void run_cc(hipStream_t s, const uint32_t* A, const Dom& d, int* L, int* rank, i
     hipLaunchKernelGGL(k_cc_compress_count, dim3(nblk), dim3(256), 0, s, A, d, nwords, L, blockcnt);
     hipLaunchKernelGGL(k_cc_scan_blocks, dim3(1), dim3(1024), 0, s, blockcnt, nblk, max_label_dev);
     hipLaunchKernelGGL(k_cc_rank, dim3(nblk), dim3(256), 0, s, A, d, nwords, L, blockcnt, rank);
+    if (cnt) hipLaunchKernelGGL(k_fill_ids, dim3(1024), dim3(256), 0, s, cnt, max_label_dev, 2, 0);
     hipLaunchKernelGGL(k_cc_head_labels, dim3(grid_for(nwords)), dim3(256), 0, s, A, d, L, rank, cnt);
-    hipMemsetAsync(L, 0, nvox * sizeof(int), s);      // (after the head passes: they use L as the union-find array)
+    (void)hipMemsetAsync(L, 0, nvox * sizeof(int), s);      // (after the head passes: they use L as the union-find array)
     hipLaunchKernelGGL(k_cc_fill_runs, dim3(grid_for(nwords)), dim3(256), 0, s, A, d, L, rank);
 }
 int cut_of(double threshold) {
@@ -1385,12 +1392,10 @@ void flood_stage(hipStream_t s, const uint32_t* M, const uint32_t* seed_bits, co
     const int gt = grid_for(B.T);
     int *rank = B.rank, *blockcnt = B.blockcnt, *comp = B.comp, *mn = B.mn, *mx = B.mx, *off = B.off, *hcnt = B.hcnt, *scal = B.scal;
     const WsPool& pool = B.pool;
-    struct { size_t T; } l{B.T};
-    hipLaunchKernelGGL(k_fill_int, dim3(gt), dim3(256), 0, s, off, l.T, 0);
-    run_cc(s, M, d, comp, rank, blockcnt, scal + 1, mask_out_dev, off);      // off[c] = voxels of component c
-    hipLaunchKernelGGL(k_fill_int, dim3(gt), dim3(256), 0, s, mn, l.T, 0x7fffffff);
-    hipLaunchKernelGGL(k_fill_int, dim3(gt), dim3(256), 0, s, mx, l.T, 0);
-    hipLaunchKernelGGL(k_fill_int, dim3(gt), dim3(256), 0, s, hcnt, l.T, 0);
+    run_cc(s, M, d, comp, rank, blockcnt, scal + 1, mask_out_dev, off);      // off[c] = voxels of component c (entries 0 .. NC + 1)
+    hipLaunchKernelGGL(k_fill_ids, dim3(1024), dim3(256), 0, s, mn, scal + 1, 2, 0x7fffffff);
+    hipLaunchKernelGGL(k_fill_ids, dim3(1024), dim3(256), 0, s, mx, scal + 1, 2, 0);
+    hipLaunchKernelGGL(k_fill_ids, dim3(1024), dim3(256), 0, s, hcnt, scal + 1, 2, 0);
     hipLaunchKernelGGL(k_fill_int, dim3(1), dim3(256), 0, s, max_label_dev, (size_t)1, 0);
     hipLaunchKernelGGL(k_comp_markers, dim3(grid_for(seed_bits ? (size_t)d.X * d.Y * d.PZW : nvox)), dim3(256), 0, s, seed_bits, d, comp, mk, nvox, mn, mx, max_label_dev);
     hipLaunchKernelGGL(k_comp_keep_multi, dim3(gt), dim3(256), 0, s, scal + 1, mn, mx, off);
@@ -1403,7 +1408,7 @@ void flood_stage(hipStream_t s, const uint32_t* M, const uint32_t* seed_bits, co
         hipLaunchKernelGGL(k_ws_flood_seq, dim3(4096), dim3(64), 0, s, comp, g, d, scal + 1, mn, mx, off, hcnt, pool.ga[0], pool.cl, labels_dev);
     } else {
         hipLaunchKernelGGL(k_fill_int, dim3(grid_for(nvox)), dim3(256), 0, s, rank, nvox, -1);
-        hipMemsetAsync(labels_dev, 0, nvox * sizeof(int), s);
+        (void)hipMemsetAsync(labels_dev, 0, nvox * sizeof(int), s);
         hipLaunchKernelGGL(k_ws_init, dim3((unsigned)(((size_t)d.X * d.Y * d.PZW + 256 * WI_WORDS - 1) / (256 * WI_WORDS))), dim3(256), 0, s, M, seed_bits, comp, mk, g, d, nvox, mn, mx, off, hcnt, pool, labels_dev);
         hipLaunchKernelGGL(k_ws_flood<WSP_THREADS>, dim3(2048), dim3(WSP_THREADS), 0, s, comp, g, d, scal + 1, mn, mx, off, scal + 4, hcnt, pool, labels_dev);
     }
@@ -1490,7 +1495,6 @@ int sd_object_segmentation_watershed(const uint8_t* prob_dev, int X, int Y, int 
     if (hipMemcpyAsync(M, A, pwords * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return sd_fail_msg(SD_ERR_HIP, "sd_object_segmentation_watershed: copy failed");
     // markers: the erosions (and whatever follows them), scipy.ndimage.label (:323-327)
     run_morph(s, A, B, d, bbox, seed_ops, seed_iterations, n_seed_ops, o);
-    if (min_seed_vx > 1) hipLaunchKernelGGL(k_fill_int, dim3(gt), dim3(256), 0, s, cnt, l.T, 0);
     run_cc(s, A, d, mk, rank, blockcnt, scal + 0, nullptr, min_seed_vx > 1 ? cnt : nullptr);      // cnt[id] = voxels of seed id
     if (min_seed_vx > 1) {      // :330-347: drop seeds smaller than min_seed_vx, fill the holes in the id space from the top
         hipLaunchKernelGGL(k_fill_int, dim3(1), dim3(256), 0, s, scal + 3, (size_t)1, 0x7fffffff);
