@@ -573,36 +573,33 @@ __global__ __launch_bounds__(256) void k_seed_bits_sync(uint32_t* S, Dom d, cons
 // lower envelope of parabolas along y and along x, searched outwards from the voxel itself -- a candidate at offset k cannot
 // beat the current best once (pitch * k)^2 >= best, so the search stops after about distance / pitch steps.
 constexpr int EDT_INF = 0x3f000000;
-__global__ __launch_bounds__(256) void k_edt_z(const uint32_t* A, Dom d, int pz, int* g, int* g2) {
-    // one thread per voxel (coalesced stores): the nearest background voxel of the z-row below and above is read off the mask
-    // words -- bits outside the volume's own z range (the morphology padding) do not count as background
-    const size_t total = (size_t)d.X * d.Y * d.Z;
+__global__ __launch_bounds__(256) void k_edt_z(const uint32_t* A, Dom d, int pz, int* g) {
+    // g is zero (memset, like the second buffer of the axis passes); one thread per mask word, the z-runs that start in it: inside
+    // a run [s, e) the nearest background voxel of the row is s - 1 or e -- if that lies inside the volume (the array border
+    // is not background, and bits outside the volume's own z range, the morphology padding, do not count)
+    const size_t nwords = (size_t)d.X * d.Y * d.PZW;
     const int vlo = d.P, vhi = d.P + d.Z;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        int z, y, x;
-        dec3(i, d.Z, d.Y, z, y, x);
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < nwords; t += (size_t)gridDim.x * 256) {
+        int zw, y, x;
+        dec3(t, d.PZW, d.Y, zw, y, x);
+        if (!zmask(zw, vlo, vhi)) continue;
         const uint32_t* row = A + widx(d, x + d.P, y + d.P, 0);
-        const int pzv = z + d.P, zw = pzv >> 5, b = pzv & 31;
-        const uint32_t w = row[zw];
-        int best = 0;
-        if ((w >> b) & 1u) {
-            long dist = -1;
-            {   // downwards
-                uint32_t zeros = ~w & zmask(zw, vlo, vhi) & (b ? ((1u << b) - 1u) : 0u);
-                int k = zw;
-                while (!zeros && (k - 1) * 32 + 31 >= vlo && k > 0) { --k; zeros = ~row[k] & zmask(k, vlo, vhi); }
-                if (zeros) dist = pzv - (k * 32 + 31 - __builtin_clz(zeros));
+        uint32_t h = run_heads(row, zw, vlo, vhi);
+        const int ibase = (int)(((size_t)x * d.Y + y) * d.Z) + zw * 32 - d.P;
+        while (h) {
+            const int bit = __builtin_ctz(h);
+            h &= h - 1;
+            const int s0 = zw * 32 + bit - d.P, len = run_length(row, d.PZW, zw * 32 + bit), e0 = s0 + len;      // run = z in [s0, e0)
+            const bool below = s0 > 0, above = e0 < d.Z;
+            for (int k = 0; k < len; ++k) {
+                long dist = -1;
+                if (below) dist = k + 1;
+                if (above) dist = dist < 0 ? (long)(len - k) : min(dist, (long)(len - k));
+                int best = EDT_INF;
+                if (dist >= 0) { const long tt = (long)pz * dist; best = (int)min(tt * tt, (long)EDT_INF); }
+                g[ibase + bit + k] = best;
             }
-            {   // upwards
-                uint32_t zeros = ~w & zmask(zw, vlo, vhi) & (b == 31 ? 0u : ~((2u << b) - 1u));
-                int k = zw;
-                while (!zeros && (k + 1) * 32 < vhi && k + 1 < d.PZW) { ++k; zeros = ~row[k] & zmask(k, vlo, vhi); }
-                if (zeros) { const long up = (k * 32 + __builtin_ctz(zeros)) - pzv; dist = dist < 0 ? up : min(dist, up); }
-            }
-            if (dist < 0) best = EDT_INF;
-            else { const long t = (long)pz * dist; best = (int)min(t * t, (long)EDT_INF); }
-        } else g2[i] = 0;      // the axis passes below skip background voxels: both buffers hold 0 there from here on
-        g[i] = best;
+        }
     }
 }
 // one axis pass: out[i] = min over k of in[i + k * stride] + (pitch * k)^2 along an axis of extent n (position c), foreground
@@ -1509,7 +1506,9 @@ int sd_object_segmentation_watershed(const uint8_t* prob_dev, int X, int Y, int 
     if (markers_out_dev && hipMemcpyAsync(markers_out_dev, mk, nvox * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
         return sd_fail_msg(SD_ERR_HIP, "sd_object_segmentation_watershed: copy failed");
     // distance transform of tmp_data (:349-350) and its connected components (the flood never leaves one)
-    hipLaunchKernelGGL(k_edt_z, dim3(grid_for(nvox)), dim3(256), 0, s, M, d, (int)pixel_pitch_xyz[2], g, rank);
+    (void)hipMemsetAsync(g, 0, nvox * sizeof(int), s);          // the passes write foreground voxels only: both buffers are 0 elsewhere
+    (void)hipMemsetAsync(rank, 0, nvox * sizeof(int), s);
+    hipLaunchKernelGGL(k_edt_z, dim3(grid_for(pwords)), dim3(256), 0, s, M, d, (int)pixel_pitch_xyz[2], g);
     hipLaunchKernelGGL(k_edt_axis, dim3(grid_for(nvox)), dim3(256), 0, s, M, g, rank, d, 1, (int)pixel_pitch_xyz[1]);
     hipLaunchKernelGGL(k_edt_axis, dim3(grid_for(nvox)), dim3(256), 0, s, M, rank, g, d, 2, (int)pixel_pitch_xyz[0]);
     if (distance_out_dev) hipLaunchKernelGGL(k_sqrt_out, dim3(grid_for(nvox)), dim3(256), 0, s, g, nvox, distance_out_dev);
