@@ -573,10 +573,11 @@ __global__ __launch_bounds__(256) void k_seed_bits_sync(uint32_t* S, Dom d, cons
 // lower envelope of parabolas along y and along x, searched outwards from the voxel itself -- a candidate at offset k cannot
 // beat the current best once (pitch * k)^2 >= best, so the search stops after about distance / pitch steps.
 constexpr int EDT_INF = 0x3f000000;
-__global__ __launch_bounds__(256) void k_edt_z(const uint32_t* A, Dom d, int pz, int* g) {
+__global__ __launch_bounds__(256) void k_edt_z(const uint32_t* A, Dom d, int pz, int* g, const int* comp, const int* mn, const int* mx) {
     // g is zero (memset, like the second buffer of the axis passes); one thread per mask word, the z-runs that start in it: inside
     // a run [s, e) the nearest background voxel of the row is s - 1 or e -- if that lies inside the volume (the array border
-    // is not background, and bits outside the volume's own z range, the morphology padding, do not count)
+    // is not background, and bits outside the volume's own z range, the morphology padding, do not count).  comp != nullptr: only
+    // the runs of components with several markers (the others are never flooded; see k_edt_axis)
     const size_t nwords = (size_t)d.X * d.Y * d.PZW;
     const int vlo = d.P, vhi = d.P + d.Z;
     for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < nwords; t += (size_t)gridDim.x * 256) {
@@ -589,6 +590,7 @@ __global__ __launch_bounds__(256) void k_edt_z(const uint32_t* A, Dom d, int pz,
         while (h) {
             const int bit = __builtin_ctz(h);
             h &= h - 1;
+            if (comp) { const int c = comp[ibase + bit]; if (!(mx[c] > mn[c])) continue; }
             const int s0 = zw * 32 + bit - d.P, len = run_length(row, d.PZW, zw * 32 + bit), e0 = s0 + len;      // run = z in [s0, e0)
             const bool below = s0 > 0, above = e0 < d.Z;
             for (int k = 0; k < len; ++k) {
@@ -604,7 +606,11 @@ __global__ __launch_bounds__(256) void k_edt_z(const uint32_t* A, Dom d, int pz,
 }
 // one axis pass: out[i] = min over k of in[i + k * stride] + (pitch * k)^2 along an axis of extent n (position c), foreground
 // voxels only (read off the mask bits: a wave of background voxels costs two word loads)
-__global__ __launch_bounds__(256) void k_edt_axis(const uint32_t* A, const int* in, int* out, Dom d, int axis, int pitch) {
+// comp != nullptr: only voxels of components with several markers.  The others may hold ANY value >= 0 in `in`: a voxel u of
+// another component on v's line has a background voxel w between itself and v (else the two were connected), and w's candidate
+// (pitch k_w)^2 beats (pitch k_u)^2 + in[u] whatever in[u] >= 0 is.
+__global__ __launch_bounds__(256) void k_edt_axis(const uint32_t* A, const int* in, int* out, Dom d, int axis, int pitch, const int* comp,
+                                                  const int* mn, const int* mx) {
     const size_t total = (size_t)d.X * d.Y * d.Z;
     const size_t stride = axis == 1 ? (size_t)d.Z : (size_t)d.Z * d.Y;
     const int n = axis == 1 ? d.Y : d.X;
@@ -612,6 +618,7 @@ __global__ __launch_bounds__(256) void k_edt_axis(const uint32_t* A, const int* 
         int z, y, x;
         dec3(i, d.Z, d.Y, z, y, x);
         if (!fg(A, d, x, y, z)) continue;
+        if (comp) { const int cc = comp[i]; if (!(mx[cc] > mn[cc])) continue; }
         int best = in[i];
         const int c = axis == 1 ? y : x;
         // (a candidate at offset k cannot win once (pitch k)^2 >= best; four offsets per round with their loads in flight
@@ -1383,12 +1390,12 @@ WsBufs ws_bufs(char* wb, const WsLayout2& l) {
 }
 // skimage.segmentation.watershed(-distance, markers, mask) (:351) given the mask bits M, the marker volume mk and the squared
 // distances g: mask components, then the flood of every component that holds several markers
-void flood_stage(hipStream_t s, const uint32_t* M, const uint32_t* seed_bits, const Dom& d, const int* mk, const int* g, const WsBufs& B,
-                 int32_t* labels_dev, int32_t* max_label_dev, uint8_t* mask_out_dev) {      // seed_bits: optional, == {mk > 0}
+// ... part 1: the mask components (ids in B.comp, voxel counts, marker ranges, pool slices) and the result's largest label
+void flood_components(hipStream_t s, const uint32_t* M, const uint32_t* seed_bits, const Dom& d, const int* mk, const WsBufs& B,
+                      int32_t* max_label_dev, uint8_t* mask_out_dev) {      // seed_bits: optional, == {mk > 0}
     const size_t nvox = (size_t)d.X * d.Y * d.Z;
     const int gt = grid_for(B.T);
     int *rank = B.rank, *blockcnt = B.blockcnt, *comp = B.comp, *mn = B.mn, *mx = B.mx, *off = B.off, *hcnt = B.hcnt, *scal = B.scal;
-    const WsPool& pool = B.pool;
     run_cc(s, M, d, comp, rank, blockcnt, scal + 1, mask_out_dev, off);      // off[c] = voxels of component c (entries 0 .. NC + 1)
     hipLaunchKernelGGL(k_fill_ids, dim3(1024), dim3(256), 0, s, mn, scal + 1, 2, 0x7fffffff);
     hipLaunchKernelGGL(k_fill_ids, dim3(1024), dim3(256), 0, s, mx, scal + 1, 2, 0);
@@ -1397,8 +1404,14 @@ void flood_stage(hipStream_t s, const uint32_t* M, const uint32_t* seed_bits, co
     hipLaunchKernelGGL(k_comp_markers, dim3(grid_for(seed_bits ? (size_t)d.X * d.Y * d.PZW : nvox)), dim3(256), 0, s, seed_bits, d, comp, mk, nvox, mn, mx, max_label_dev);
     hipLaunchKernelGGL(k_comp_keep_multi, dim3(gt), dim3(256), 0, s, scal + 1, mn, mx, off);
     hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, s, off, scal + 1, 1, scal + 4);
-    // watershed (:351): start state + queued markers, then the flood of every multi-marker component (level-synchronous, one
-    // workgroup per component; SD_WS_SEQUENTIAL=1 selects the sequential restatement it is cross-checked with)
+}
+// ... part 2: start state + queued markers, then the flood of every multi-marker component (level-synchronous, one workgroup per
+// component; SD_WS_SEQUENTIAL=1 selects the sequential restatement it is cross-checked with); g = squared distances
+void flood_run(hipStream_t s, const uint32_t* M, const uint32_t* seed_bits, const Dom& d, const int* mk, const int* g, const WsBufs& B,
+               int32_t* labels_dev) {
+    const size_t nvox = (size_t)d.X * d.Y * d.Z;
+    int *rank = B.rank, *comp = B.comp, *mn = B.mn, *mx = B.mx, *off = B.off, *hcnt = B.hcnt, *scal = B.scal;
+    const WsPool& pool = B.pool;
     const bool sequential = getenv("SD_WS_SEQUENTIAL") != nullptr;
     if (sequential) {
         hipLaunchKernelGGL(k_ws_init_seq, dim3(grid_for(nvox)), dim3(256), 0, s, comp, mk, g, nvox, mn, mx, off, hcnt, pool.ga[0], pool.cl, labels_dev);
@@ -1505,14 +1518,17 @@ int sd_object_segmentation_watershed(const uint8_t* prob_dev, int X, int Y, int 
     }
     if (markers_out_dev && hipMemcpyAsync(markers_out_dev, mk, nvox * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
         return sd_fail_msg(SD_ERR_HIP, "sd_object_segmentation_watershed: copy failed");
-    // distance transform of tmp_data (:349-350) and its connected components (the flood never leaves one)
+    // the connected components of tmp_data (the flood never leaves one), then its distance transform (:349-350) -- in the components
+    // that hold several markers only, unless the caller wants the distances: nothing else is ever flooded
+    flood_components(s, M, A, d, mk, B2, max_label_dev, mask_out_dev);
+    const int* const ecomp = distance_out_dev ? nullptr : B2.comp;
     (void)hipMemsetAsync(g, 0, nvox * sizeof(int), s);          // the passes write foreground voxels only: both buffers are 0 elsewhere
     (void)hipMemsetAsync(rank, 0, nvox * sizeof(int), s);
-    hipLaunchKernelGGL(k_edt_z, dim3(grid_for(pwords)), dim3(256), 0, s, M, d, (int)pixel_pitch_xyz[2], g);
-    hipLaunchKernelGGL(k_edt_axis, dim3(grid_for(nvox)), dim3(256), 0, s, M, g, rank, d, 1, (int)pixel_pitch_xyz[1]);
-    hipLaunchKernelGGL(k_edt_axis, dim3(grid_for(nvox)), dim3(256), 0, s, M, rank, g, d, 2, (int)pixel_pitch_xyz[0]);
+    hipLaunchKernelGGL(k_edt_z, dim3(grid_for(pwords)), dim3(256), 0, s, M, d, (int)pixel_pitch_xyz[2], g, ecomp, B2.mn, B2.mx);
+    hipLaunchKernelGGL(k_edt_axis, dim3(grid_for(nvox)), dim3(256), 0, s, M, g, rank, d, 1, (int)pixel_pitch_xyz[1], ecomp, B2.mn, B2.mx);
+    hipLaunchKernelGGL(k_edt_axis, dim3(grid_for(nvox)), dim3(256), 0, s, M, rank, g, d, 2, (int)pixel_pitch_xyz[0], ecomp, B2.mn, B2.mx);
     if (distance_out_dev) hipLaunchKernelGGL(k_sqrt_out, dim3(grid_for(nvox)), dim3(256), 0, s, g, nvox, distance_out_dev);
-    flood_stage(s, M, A, d, mk, g, B2, labels_dev, max_label_dev, mask_out_dev);
+    flood_run(s, M, A, d, mk, g, B2, labels_dev);
     return hipGetLastError() == hipSuccess ? SD_OK : sd_fail_msg(SD_ERR_HIP, "sd_object_segmentation_watershed: launch failed");
 }
 
@@ -1528,7 +1544,9 @@ int sd_marker_flood(const int32_t* d2_dev, const int32_t* markers_dev, const uin
     const Dom d = make_dom(X, Y, Z, 0);
     uint32_t* M = reinterpret_cast<uint32_t*>(wb + l.mbits);
     hipLaunchKernelGGL(k_threshold_bits, dim3(grid_for((size_t)d.PX * d.PY * d.PZW)), dim3(256), 0, s, mask_dev, 1, d, M);
-    flood_stage(s, M, nullptr, d, markers_dev, d2_dev, ws_bufs(wb, l), labels_dev, max_label_dev, nullptr);
+    const WsBufs B = ws_bufs(wb, l);
+    flood_components(s, M, nullptr, d, markers_dev, B, max_label_dev, nullptr);
+    flood_run(s, M, nullptr, d, markers_dev, d2_dev, B, labels_dev);
     return hipGetLastError() == hipSuccess ? SD_OK : sd_fail_msg(SD_ERR_HIP, "sd_marker_flood: launch failed");
 }
 
