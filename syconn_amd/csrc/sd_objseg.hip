@@ -925,6 +925,7 @@ __global__ __launch_bounds__(256) void k_ws_init(const uint32_t* M, const uint32
             for (int k = 0; k < len; ++k) {      // several markers: the markers themselves, WS_OPEN for the voxels the flood will label
                 const int o = mk[i0 + k];
                 out[i0 + k] = o > 0 ? o : WS_OPEN;
+                if (o <= 0) P.claim[i0 + k] = WSP_FREE;      // (only these voxels are ever claimed)
             }
             if (S) continue;                     // (the queue: word-wise below)
             for (int k = 0; k < len; ++k) {      // arbitrary marker volumes (sd_marker_flood): neighbour tests on the label arrays
@@ -1410,14 +1411,13 @@ void flood_components(hipStream_t s, const uint32_t* M, const uint32_t* seed_bit
 void flood_run(hipStream_t s, const uint32_t* M, const uint32_t* seed_bits, const Dom& d, const int* mk, const int* g, const WsBufs& B,
                int32_t* labels_dev) {
     const size_t nvox = (size_t)d.X * d.Y * d.Z;
-    int *rank = B.rank, *comp = B.comp, *mn = B.mn, *mx = B.mx, *off = B.off, *hcnt = B.hcnt, *scal = B.scal;
+    int *comp = B.comp, *mn = B.mn, *mx = B.mx, *off = B.off, *hcnt = B.hcnt, *scal = B.scal;
     const WsPool& pool = B.pool;
     const bool sequential = getenv("SD_WS_SEQUENTIAL") != nullptr;
     if (sequential) {
         hipLaunchKernelGGL(k_ws_init_seq, dim3(grid_for(nvox)), dim3(256), 0, s, comp, mk, g, nvox, mn, mx, off, hcnt, pool.ga[0], pool.cl, labels_dev);
         hipLaunchKernelGGL(k_ws_flood_seq, dim3(4096), dim3(64), 0, s, comp, g, d, scal + 1, mn, mx, off, hcnt, pool.ga[0], pool.cl, labels_dev);
     } else {
-        hipLaunchKernelGGL(k_fill_int, dim3(grid_for(nvox)), dim3(256), 0, s, rank, nvox, -1);
         (void)hipMemsetAsync(labels_dev, 0, nvox * sizeof(int), s);
         hipLaunchKernelGGL(k_ws_init, dim3((unsigned)(((size_t)d.X * d.Y * d.PZW + 256 * WI_WORDS - 1) / (256 * WI_WORDS))), dim3(256), 0, s, M, seed_bits, comp, mk, g, d, nvox, mn, mx, off, hcnt, pool, labels_dev);
         hipLaunchKernelGGL(k_ws_flood<WSP_THREADS>, dim3(2048), dim3(WSP_THREADS), 0, s, comp, g, d, scal + 1, mn, mx, off, scal + 4, hcnt, pool, labels_dev);
