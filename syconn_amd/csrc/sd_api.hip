@@ -10,6 +10,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <thread>
+#include <atomic>
 
 namespace {
 
@@ -106,6 +108,17 @@ struct sd_model {
 
 namespace {
 
+// f(0) .. f(n - 1) on up to 16 host threads (independent items writing disjoint memory)
+template <class F>
+static void parallel_for(int n, F f) {
+    const int nt = std::max(1, std::min({n, 16, (int)std::thread::hardware_concurrency()}));
+    if (nt == 1) { for (int i = 0; i < n; ++i) f(i); return; }
+    std::atomic<int> next{0};
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t)
+        th.emplace_back([&] { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) f(i); });
+    for (auto& x : th) x.join();
+}
 constexpr size_t WS_SCRATCH = 65536;  // GroupNorm sums (double[2*C]) + scale/shift (float[2*C]) at workspace start
 
 // shape inference for an input tile; fills dims[] per buffer.
@@ -350,8 +363,10 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
                 op.bias_off = blob_alloc((size_t)op.NB * op.NT * 32 * 4 + 16);
                 uint16_t* wp = reinterpret_cast<uint16_t*>(blob.data() + op.wpack_off);
                 float* bp = reinterpret_cast<float*>(blob.data() + op.bias_off);
-                for (int nb = 0; nb < op.NB; ++nb)
-                    for (int c = 0; c < nchunks; ++c)
+                // (the packing of a 7.8 M-parameter net took 0.15 s on one core -- 15 % of a 1024 x 1024 x 256 file-system-mode job:
+                // the (block, chunk) groups are independent)
+                parallel_for(op.NB * nchunks, [&](int g0) {
+                    const int nb = g0 / nchunks, c = g0 % nchunks;
                         for (int kz = 0; kz < d.kz; ++kz)
                             for (int t9 = 0; t9 < 9; ++t9)
                                 for (int j = 0; j < op.NT; ++j)
@@ -371,6 +386,7 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
                                                 ((((((size_t)nb * nchunks + c) * d.kz + kz) * 9 + t9) * op.NT + j) * 64 + l) * 8 + e;
                                             wp[idx] = cvt(v, act_dtype);
                                         }
+                });
                 for (int n = 0; n < d.cout; ++n) bp[n] = W[d.b_off + n] * sc[n] + sh[n];
             }
             break;

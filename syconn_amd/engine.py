@@ -7,6 +7,8 @@ import ctypes as C
 from typing import Optional, Sequence
 
 import numpy as np
+import threading
+
 import torch
 
 from . import _lib as L
@@ -21,12 +23,19 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+_ready = threading.local()      # per thread (sd_init also selects the HIP device of the CALLING thread): the device sd_init last
+                                # succeeded for -- the check costs 0.14 ms and the tile helpers call this per tile
+
+
 def require_gpu(device_index: int = 0):
     """Fail loudly when the HIP path cannot run (no CPU fallback exists)."""
     lib = L.load()
+    if getattr(_ready, 'device', None) == int(device_index):
+        return lib
     if not torch.cuda.is_available():
         raise RuntimeError('syconn_amd: no MI355X visible to PyTorch-ROCm; this package has no CPU fallback')
     L.check(lib.sd_init(int(device_index)), 'sd_init')
+    _ready.device = int(device_index)
     return lib
 
 

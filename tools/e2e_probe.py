@@ -31,7 +31,9 @@ with tempfile.TemporaryDirectory(dir='/dev/shm' if os.path.isdir('/dev/shm') els
         for prm in params:
             import cProfile, pstats
             pr = cProfile.Profile(); t = time.perf_counter(); pr.enable(); P.dense_predictor(prm); pr.disable(); calls.append(time.perf_counter() - t)
-            if os.environ.get('E2E_PROFILE'): pstats.Stats(pr).sort_stats('cumulative').print_stats(28)
+            if os.environ.get('E2E_PROFILE'):
+                pstats.Stats(pr).sort_stats('cumulative').print_stats(28)
+                pstats.Stats(pr).print_callers('is_available')
         return tmp + '/out'
     bu.batchjob_script = inproc
     t0 = time.perf_counter()
