@@ -38,7 +38,8 @@ extern "C" {
 #define SD_ERR_NODEVICE (-4)
 
 /* element types of caller-visible buffers */
-enum sd_dtype { SD_U8 = 0, SD_F32 = 1, SD_BF16 = 2, SD_F16 = 3, SD_U64 = 4, SD_U32 = 5 };
+enum sd_dtype { SD_U8 = 0, SD_F32 = 1, SD_BF16 = 2, SD_F16 = 3, SD_U64 = 4, SD_U32 = 5,
+                SD_F16X2 = 6 /* only as act_dtype of sd_model_create: split-fp16 storage, see there */ };
 
 /* what sd_forward writes: raw logits (model(inp)), softmax(1) (Predictor(apply_softmax=True), prediction.py:779),
  * or floor(255*softmax) as uint8 (dense_predicton_helper, prediction.py:864-865) */
@@ -82,7 +83,11 @@ int sd_device_count(void);
 
 /* Build a model: validate the plan, fold BatchNorm, convert + pack weights into MFMA fragment order and upload
  * them.  Replaces torch.jit.load(model.pts).to(device) (prediction.py:777, 1061-1062).
- * act_dtype: SD_BF16 or SD_F16 (storage type of activations / MFMA operands; accumulation is fp32), or SD_F32 = the
+ * act_dtype: SD_BF16 or SD_F16 (storage type of activations / MFMA operands; accumulation is fp32); SD_F16X2 = the
+ * REFERENCE-PRECISION plan ON THE MATRIX CORES: every activation and weight is kept as two fp16 numbers hi + lo (22 mantissa
+ * bits; weights times a power of two per layer so that their lo parts stay normal) and every product is three fp16 MFMAs
+ * Wlo.Xhi + Whi.Xhi + Whi.Xlo accumulated in fp32 -- fp32-level logits (what the reference computes, prediction.py:777-779)
+ * at ~3x the cost of the SD_F16 plan; range-guarded like SD_F16 (sd_model_overflow); or SD_F32 = the
  * REFERENCE-PRECISION mode: fp32 storage and fp32 FMA arithmetic like the reference's own torch path (Predictor is built
  * without float16, prediction.py:777-779); planar activations, one plain launch per layer, ~25x slower than the bf16
  * plan -- for label-exactness checks against an fp32 implementation, not for throughput. */

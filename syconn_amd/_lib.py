@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 SD_OK, SD_ERR_INVALID, SD_ERR_NOMEM, SD_ERR_HIP, SD_ERR_NODEVICE = 0, -1, -2, -3, -4
-SD_U8, SD_F32, SD_BF16, SD_F16, SD_U64, SD_U32 = 0, 1, 2, 3, 4, 5
+SD_U8, SD_F32, SD_BF16, SD_F16, SD_U64, SD_U32, SD_F16X2 = 0, 1, 2, 3, 4, 5, 6
 SD_OUT_LOGITS_F32, SD_OUT_PROBS_F32, SD_OUT_PROBS_U8 = 0, 1, 2
 SD_OP_CONV, SD_OP_POOL, SD_OP_UPCONV, SD_OP_GROUPNORM, SD_OP_FINAL = 1, 2, 3, 4, 5
 SD_MOP_OPENING, SD_MOP_CLOSING, SD_MOP_DILATION, SD_MOP_EROSION = 1, 2, 3, 4

@@ -66,6 +66,7 @@ struct Op {
     bool pool_in_conv = false;   // groupnorm (deferred, with gn_pool): the producing conv pools the RAW tensor, its readers apply the table
     bool gn_defer = false;       // groupnorm: statistics -> scale / shift only; every consumer of the buffer applies them itself
     size_t fwfrag_off = 0;             // fused final 1x1x1: hi/lo MFMA weight fragments
+    float oscale = 1.f;                // split-fp16 plan: 2^-k, undoes the power of two the packed weights / bias of this layer carry
     bool skipped = false;  // op is executed inside its producer
     // up-convolution heading a fused level-0 decoder (sd_dec0.hip): indices of the merge conv and the second conv (whose
     // fuse_final names the final layer); those ops are `skipped` and their output buffers are never materialised
@@ -104,6 +105,7 @@ struct sd_model {
     std::vector<size_t> gn_tab_off;
     size_t ws_base = 65536;  // first byte of the activation buffers (behind the scratch and the tables)
     sd_f32_model* f32 = nullptr;   // act_dtype == SD_F32: the reference-precision plan (sd_f32.hip) serves every call
+    bool split = false;            // act_dtype == SD_F16X2 (sd_split.hip): every buffer holds 2 * Cp / 16 fp16 chunk planes [hi | lo]
 };
 
 namespace {
@@ -182,7 +184,7 @@ size_t plan_workspace(const sd_model* m, const std::vector<Dims>& dims, std::vec
     off.assign(nb, 0);
     const size_t WS_BASE = m->ws_base;      // statistics scratch + the scale / shift tables of deferred GroupNorm applies
     std::vector<size_t> bytes(nb, 0);
-    for (int b = 1; b < nb; ++b) bytes[b] = rup_sz((size_t)dims[b].d * dims[b].h * dims[b].w * m->bufCp[b] * 2, 256);
+    for (int b = 1; b < nb; ++b) bytes[b] = rup_sz((size_t)dims[b].d * dims[b].h * dims[b].w * m->bufCp[b] * (m->split ? 4 : 2), 256);
     if (!m->ws_reuse) {
         size_t cur = WS_BASE;
         for (int b = 1; b < nb; ++b) { off[b] = cur; cur += bytes[b]; }
@@ -262,10 +264,13 @@ int sd_debug_last_launch_count(const sd_model* m) { return m ? m->last_launches 
 int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_floats, int act_dtype,
                     sd_model** out) {
     if (!ops || n_ops <= 0 || !W || !out) return fail(SD_ERR_INVALID, "null argument");
-    if (act_dtype != SD_BF16 && act_dtype != SD_F16 && act_dtype != SD_F32)
-        return fail(SD_ERR_INVALID, "act_dtype must be SD_BF16, SD_F16 or SD_F32");
+    if (act_dtype != SD_BF16 && act_dtype != SD_F16 && act_dtype != SD_F32 && act_dtype != SD_F16X2)
+        return fail(SD_ERR_INVALID, "act_dtype must be SD_BF16, SD_F16, SD_F16X2 or SD_F32");
     sd_model* m = new sd_model();
     m->act_dtype = act_dtype;
+    const bool split = act_dtype == SD_F16X2;
+    m->split = split;
+    const int pack_dtype = split ? SD_F16 : act_dtype;      // element type of the packed MFMA weight fragments
     if (act_dtype == SD_F32) {       // reference-precision mode: its own plan, weights and kernels
         if (hipGetDevice(&m->device) != hipSuccess) { delete m; return fail(SD_ERR_NODEVICE, "no current HIP device"); }
         const int rc32 = f32_model_create(ops, n_ops, W, n_floats, &m->f32);
@@ -316,6 +321,20 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
             }
             return true;
         };
+        // split-fp16 plan: power of two 2^k that brings the largest folded weight of the layer into [2^14, 2^15) -- the lo parts
+        // of all weights that matter are then normal fp16 numbers (hi + lo carries 22+ bits); bias and epilogue follow (exact)
+        auto split_scale = [&](float maxabs) -> float {
+            if (!split || !(maxabs > 0.f) || !std::isfinite(maxabs)) return 1.f;
+            const int k = std::max(-60, std::min(60, 14 - std::ilogb(maxabs)));
+            return std::ldexp(1.f, k);
+        };
+        // element of virtual chunk `r` (0 .. 3n-1) of an n-chunk split input: planes [hi | hi | lo] meet weights [lo | hi | hi]
+        auto split_part = [&](float v, int r, int n) -> uint16_t {
+            const uint16_t hi = f2f16(v);
+            if (r >= n) return hi;
+            _Float16 h; std::memcpy(&h, &hi, 2);
+            return f2f16(v - (float)h);
+        };
         switch (d.kind) {
         case SD_OP_CONV: {
             if (d.ky != 3 || d.kx != 3 || (d.kz != 1 && d.kz != 3)) MODEL_FAIL("conv: only 3x3x3 and 1x3x3 kernels");
@@ -357,7 +376,15 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
                 static const bool no_nt3 = getenv("SD_NO_NT3") != nullptr;
                 op.NT = (ntile % 3 == 0 && !no_nt3) ? 3 : (ntile >= 2 ? 2 : 1);
                 op.NB = (ntile + op.NT - 1) / op.NT;
-                const int nchunks = nch0 + nch1;
+                const int nchunks = (nch0 + nch1) * (split ? 3 : 1);      // (split-fp16 plan: virtual chunks)
+                float wscale = 1.f;
+                if (split) {
+                    float mx = 0.f;
+                    for (int co = 0; co < d.cout; ++co)
+                        for (size_t k = 0; k < (size_t)cin * taps; ++k) mx = std::max(mx, std::fabs(w[(size_t)co * cin * taps + k] * sc[co]));
+                    wscale = split_scale(mx);
+                    op.oscale = 1.f / wscale;
+                }
                 const size_t gbytes = (size_t)9 * op.NT * 1024;
                 op.wpack_off = blob_alloc((size_t)op.NB * nchunks * d.kz * gbytes);
                 op.bias_off = blob_alloc((size_t)op.NB * op.NT * 32 * 4 + 16);
@@ -374,20 +401,20 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
                                         for (int e = 0; e < 8; ++e) {
                                             const int n = (nb * op.NT + j) * 32 + (l & 31);
                                             int ci;  // index into the concatenated weight input-channel axis
-                                            if (c < nch0) {
-                                                const int k = c * SD_CHUNK + (l >> 5) * 8 + e;
-                                                ci = k < d.cin0 ? k : -1;
-                                            } else {
-                                                const int k = (c - nch0) * SD_CHUNK + (l >> 5) * 8 + e;
-                                                ci = k < d.cin1 ? d.cin0 + k : -1;
+                                            const int m0 = split ? 3 : 1;
+                                            const bool s0 = c < nch0 * m0;
+                                            const int r = s0 ? c : c - nch0 * m0, nsrc = s0 ? nch0 : nch1;       // chunk within its source
+                                            {
+                                                const int k = (r % nsrc) * SD_CHUNK + (l >> 5) * 8 + e;
+                                                ci = s0 ? (k < d.cin0 ? k : -1) : (k < d.cin1 ? d.cin0 + k : -1);
                                             }
-                                            const float v = (n < d.cout && ci >= 0) ? wat(n, ci, kz, t9) : 0.f;
+                                            const float v = (n < d.cout && ci >= 0) ? wat(n, ci, kz, t9) * wscale : 0.f;
                                             const size_t idx =
                                                 ((((((size_t)nb * nchunks + c) * d.kz + kz) * 9 + t9) * op.NT + j) * 64 + l) * 8 + e;
-                                            wp[idx] = cvt(v, act_dtype);
+                                            wp[idx] = split ? split_part(v, r, nsrc) : cvt(v, act_dtype);
                                         }
                 });
-                for (int n = 0; n < d.cout; ++n) bp[n] = W[d.b_off + n] * sc[n] + sh[n];
+                for (int n = 0; n < d.cout; ++n) bp[n] = (W[d.b_off + n] * sc[n] + sh[n]) * wscale;
             }
             break;
         }
@@ -409,7 +436,17 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
             const int ntot = taps * Cd;
             op.NT = 2;
             op.NB = (ntot + 63) / 64;
-            const int nchunk = m->bufCp[d.src0] / SD_CHUNK;
+            const int nreal = m->bufCp[d.src0] / SD_CHUNK;
+            const int nchunk = nreal * (split ? 3 : 1);      // (split-fp16 plan: virtual chunks)
+            float wscale = 1.f;
+            if (split) {
+                float mx = 0.f;
+                for (int ci = 0; ci < d.cin0; ++ci)
+                    for (int co = 0; co < d.cout; ++co)
+                        for (int t = 0; t < taps; ++t) mx = std::max(mx, std::fabs(W[d.w_off + ((size_t)ci * d.cout + co) * taps + t] * sc[co]));
+                wscale = split_scale(mx);
+                op.oscale = 1.f / wscale;
+            }
             op.wpack_off = blob_alloc((size_t)op.NB * nchunk * 2 * 64 * 8 * 2);
             op.bias_off = blob_alloc((size_t)op.NB * 64 * 4 + 16);
             uint16_t* wp = reinterpret_cast<uint16_t*>(blob.data() + op.wpack_off);
@@ -422,15 +459,15 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
                             for (int e = 0; e < 8; ++e) {
                                 const int n = (nb * 2 + j) * 32 + (l & 31);
                                 const int tap = n / Cd, co = n % Cd;
-                                const int ci = c * SD_CHUNK + (l >> 5) * 8 + e;
+                                const int ci = (c % nreal) * SD_CHUNK + (l >> 5) * 8 + e;
                                 float v = 0.f;
                                 if (tap < taps && co < d.cout && ci < d.cin0)
-                                    v = w[((size_t)ci * d.cout + co) * taps + tap] * sc[co];
-                                wp[((((size_t)nb * nchunk + c) * 2 + j) * 64 + l) * 8 + e] = cvt(v, act_dtype);
+                                    v = w[((size_t)ci * d.cout + co) * taps + tap] * sc[co] * wscale;
+                                wp[((((size_t)nb * nchunk + c) * 2 + j) * 64 + l) * 8 + e] = split ? split_part(v, c, nreal) : cvt(v, act_dtype);
                             }
             for (int n = 0; n < ntot; ++n) {
                 const int co = n % Cd;
-                bp[n] = co < d.cout ? W[d.b_off + co] * sc[co] + sh[co] : 0.f;
+                bp[n] = co < d.cout ? (W[d.b_off + co] * sc[co] + sh[co]) * wscale : 0.f;
             }
             break;
         }
@@ -465,7 +502,7 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
                 op.aux_off = blob_alloc((size_t)nch * 2 * 64 * 8 * 2);
                 uint16_t* fp = reinterpret_cast<uint16_t*>(blob.data() + op.aux_off);
                 auto back = [&](uint16_t bits) -> float {
-                    if (act_dtype == SD_BF16) { uint32_t u = (uint32_t)bits << 16; float f; std::memcpy(&f, &u, 4); return f; }
+                    if (pack_dtype == SD_BF16) { uint32_t u = (uint32_t)bits << 16; float f; std::memcpy(&f, &u, 4); return f; }
                     _Float16 h; std::memcpy(&h, &bits, 2); return (float)h;
                 };
                 for (int c = 0; c < nch; ++c)
@@ -473,9 +510,9 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
                         for (int jj = 0; jj < 8; ++jj) {
                             const int co = l & 31, ch = c * SD_CHUNK + 8 * (l >> 5) + jj;
                             const float wv = (co < d.cout && ch < d.cin0) ? W[d.w_off + (size_t)co * d.cin0 + ch] : 0.f;
-                            const uint16_t hi = cvt(wv, act_dtype);
+                            const uint16_t hi = cvt(wv, pack_dtype);
                             fp[((size_t)(c * 2 + 0) * 64 + l) * 8 + jj] = hi;
-                            fp[((size_t)(c * 2 + 1) * 64 + l) * 8 + jj] = cvt(wv - back(hi), act_dtype);
+                            fp[((size_t)(c * 2 + 1) * 64 + l) * 8 + jj] = cvt(wv - back(hi), pack_dtype);
                         }
             }
             m->final_cout = d.cout;
@@ -489,8 +526,9 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
     m->buf_gn.assign(m->nbuf, -1);
     m->gn_tab_off.assign(m->nbuf, 0);
     m->ws_base = WS_SCRATCH;
-    // epilogue fusions (SD_NO_FUSE=1 keeps every layer a separate launch, for layer-wise debugging)
-    if (!getenv("SD_NO_FUSE")) {
+    // epilogue fusions (SD_NO_FUSE=1 keeps every layer a separate launch, for layer-wise debugging; the split-fp16 plan runs
+    // every op as its own launch)
+    if (!getenv("SD_NO_FUSE") && !split) {
         // first conv (1 -> 32, 1x3x3) -> conv (1x3x3) of one input: the second conv computes its halo of the first conv's
         // output on the fly (decided per launch: only the resident-weight form of the kernel can do it)
         for (size_t i = 0; i + 1 < m->ops.size(); ++i) {
@@ -716,7 +754,7 @@ int sd_profile_read(sd_model* m, int slot, float* ms, int n_ops) {
 int sd_model_overflow(sd_model* m, void* stream, int* flag_out) {
     if (!m || !flag_out) return fail(SD_ERR_INVALID, "null argument");
     *flag_out = 0;
-    if (m->f32 || m->act_dtype != SD_F16 || !m->dev_ovf) return SD_OK;       // only fp16 storage can overflow
+    if (m->f32 || (m->act_dtype != SD_F16 && m->act_dtype != SD_F16X2) || !m->dev_ovf) return SD_OK;       // only fp16 storage can overflow
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     HIP_TRY(hipMemcpyAsync(flag_out, m->dev_ovf, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -843,11 +881,13 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
                 ConvParams p{};
                 const Dims a = m->dims[d.src0];
                 p.src0 = bufp(d.src0); p.C0 = m->bufCp[d.src0]; p.H0 = a.h; p.W0 = a.w; p.P0 = (size_t)a.d * a.h * a.w;
-                p.nchunk0 = p.C0 / SD_CHUNK;
+                const int vmul = m->split ? 3 : 1;      // split-fp16 plan: virtual chunks [hi | hi | lo]
+                p.nchunk0 = p.C0 / SD_CHUNK * vmul;
+                p.oscale = op.oscale;
                 if (d.src1 >= 0) {
                     const Dims b = m->dims[d.src1];
                     p.src1 = bufp(d.src1); p.C1 = m->bufCp[d.src1]; p.H1 = b.h; p.W1 = b.w; p.P1 = (size_t)b.d * b.h * b.w;
-                    p.nchunk1 = p.C1 / SD_CHUNK;
+                    p.nchunk1 = p.C1 / SD_CHUNK * vmul;
                 }
                 p.dst = bufp(d.dst); p.Cd = m->bufCp[d.dst];
                 p.D = o.d; p.H = o.h; p.W = o.w; p.Pd = (size_t)o.d * o.h * o.w;
@@ -959,7 +999,8 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
             }
             UpconvParams p{};
             const Dims a = m->dims[d.src0];
-            p.src = bufp(d.src0); p.Cs = m->bufCp[d.src0]; p.nchunk = p.Cs / SD_CHUNK;
+            p.src = bufp(d.src0); p.Cs = m->bufCp[d.src0]; p.nchunk = p.Cs / SD_CHUNK * (m->split ? 3 : 1);
+            p.oscale = op.oscale;
             p.D = a.d; p.H = a.h; p.W = a.w;
             p.dst = bufp(d.dst); p.Cd = m->bufCp[d.dst]; p.kz = d.kz;
             p.Pd = (size_t)m->dims[d.dst].d * m->dims[d.dst].h * m->dims[d.dst].w;

@@ -40,6 +40,21 @@ template <> struct Act<f16_t> {
         return __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a, b}, t2));
     }
 };
+// split-fp16 plan: two fp32 values -> packed fp16 hi pair and packed fp16 lo pair, v = hi + lo up to 2^-24 |v| (lo normal) /
+// 2^-25 absolute (lo subnormal)
+__device__ __forceinline__ void split_pk(float a, float b, unsigned& hi, unsigned& lo) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    hi = Act<f16_t>::pack2(a, b);
+    const h2 h = __builtin_bit_cast(h2, hi);
+    lo = Act<f16_t>::pack2(a - (float)h[0], b - (float)h[1]);
+}
+// ... and back: the exact fp32 value of a (hi, lo) pair of packed fp16 pairs
+__device__ __forceinline__ void join_pk(unsigned hi, unsigned lo, float& a, float& b) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    const h2 h = __builtin_bit_cast(h2, hi), l = __builtin_bit_cast(h2, lo);
+    a = (float)h[0] + (float)l[0];
+    b = (float)h[1] + (float)l[1];
+}
 // max of two packed pairs of NON-NEGATIVE-or-any 16-bit floats against each other as signed 16-bit integers: for
 // sign-magnitude floats this is the float max whenever at most one operand is negative (ReLU: max(x, +0) is exact
 // for every x incl. -0; pooling: all operands are >= 0 after the ReLU).  One v_pk_max_i16 for two channels.

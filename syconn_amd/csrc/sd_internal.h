@@ -68,6 +68,7 @@ struct ConvParams {
     // per-tile [2*C] float tables (scale then shift; tile t at + t*tstride bytes) or nullptr when that input is final
     const float* gn0; const float* gn1; int gn_relu0, gn_relu1;
     int* ovf;          // fp16 range guard flag (sd_device.h: StoreGuard on every store, range_guard in the fused final layer)
+    float oscale;      // split-fp16 plan (k_conv_mfma<..., MODE 3>): 2^-k, undoes the power-of-two scale of the packed weights / bias
 };
 
 struct FirstParams {
@@ -98,6 +99,7 @@ struct UpconvParams {
     int batch; size_t tstride;
     const float* gn; int gn_relu;   // deferred GroupNorm apply of `src` ([2*Cs] floats per tile) or nullptr
     int* ovf;          // fp16 range guard flag (sd_device.h)
+    float oscale;      // split-fp16 plan: 2^-k of the packed weights / bias
 };
 
 struct PoolParams {
@@ -196,6 +198,13 @@ int launch_box_majority(const uint8_t* vol, int D, int H, int W, const int32_t* 
                         int cut, double thresh_majority, uint8_t* out, hipStream_t s);
 int launch_labels(const uint8_t* probs, size_t nvox, const LabelArgs& a, void* out, int out_u64, hipStream_t s);
 int launch_read_buffer(const void* buf, int act_dtype, int C, int Cs, int D, int H, int W, float* out, hipStream_t s);
+// split-fp16 plan (sd_split.hip; act_dtype SD_F16X2): a tensor of C (padded) channels = 2 * C / 16 fp16 chunk planes [hi | lo]
+int launch_conv_split(const ConvParams& p, int KZ, int NT, int NB, hipStream_t s);
+int launch_pool_split(const PoolParams& p, hipStream_t s);
+int launch_final_split(const FinalParams& p, hipStream_t s);
+int launch_groupnorm_split(const GnParams& p, hipStream_t s);
+int launch_gn_finalize(const GnParams& p, hipStream_t s);      // statistics scratch -> per-channel scale / shift (sd_kernels.hip)
+int launch_read_buffer_split(const void* buf, int C, int Cs, long nvox, float* out, hipStream_t s);
 
 // ---- reference-precision mode (sd_f32.hip): act_dtype = SD_F32, planar fp32 activations, plain FMA kernels ----------------
 struct sd_f32_model;

@@ -14,8 +14,10 @@ import torch
 from . import _lib as L
 from .plan import plan_from_model
 
-# 'f32': the reference-precision plan (csrc/sd_f32.hip: fp32 storage and arithmetic like the reference's torch path, slow)
+# 'f16x2': the reference-precision plan on the matrix cores (csrc/sd_split.hip: every value kept as fp16 hi + lo, three MFMA
+# passes per product, fp32-level logits at ~3x the cost of 'f16'); 'f32': fp32 storage and FMA arithmetic (csrc/sd_f32.hip, slow)
 _ACT = {'bf16': L.SD_BF16, 'bfloat16': L.SD_BF16, 'f16': L.SD_F16, 'fp16': L.SD_F16, 'float16': L.SD_F16,
+        'f16x2': L.SD_F16X2, 'split': L.SD_F16X2,
         'f32': L.SD_F32, 'fp32': L.SD_F32, 'float32': L.SD_F32}
 
 
