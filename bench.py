@@ -213,9 +213,10 @@ def main():
     ap.add_argument('--tiles', type=int, default=8, help='128^3 tiles per GPU per step')
     ap.add_argument('--tile', type=int, default=128)
     ap.add_argument('--arch', default='semseg_spine')
-    ap.add_argument('--act', default='bf16', choices=['bf16', 'f16'])
+    ap.add_argument('--act', default='bf16', choices=['bf16', 'f16', 'f16x2', 'f32'])
     ap.add_argument('--batch', type=int, default=0, help='tiles per sd_forward_batch launch set (0 = all tiles of a step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--labels-sha', action='store_true', help='report a sha256 of the result volume(s) on the JSON line (tests)')
     ap.add_argument('--workload', default='config2', choices=['config2', 'config3', 'config4', 'config5'],
                     help='BASELINE.json configs[1..4]; the default (config2 = configs[1]) is the headline metric')
     ap.add_argument('--geometry', default='tile128', choices=['tile128', 'reference'],
@@ -332,6 +333,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, sd, dm, tiles_host, ids, L)
 
+    labels_sha = None
+    if rank == 0 and args.labels_sha:
+        # checksum of the label volumes of the LAST step as they arrived in rank 0's host memory, rank by rank (tests compare
+        # an N-rank run with the same tiles predicted by one rank)
+        import hashlib
+        pipe.drain()
+        labels_sha = hashlib.sha256(pipe.out_host[(pipe.k - 1) & 1].numpy().tobytes()).hexdigest()
     if rank == 0:
         line = {'metric': 'segmented Mvoxels/s (whole node), 128^3 EM tiles', 'value': value, 'unit': 'Mvox/s',
                 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -347,7 +355,7 @@ def main():
                            'collective': 'RCCL gather of uint8 labels to rank 0, D2H there' if world > 1 else 'none',
                            'device_resident_value': value_res,
                            'device_resident_ms_per_step': elapsed_res / args.steps * 1e3,
-                           'pcie_bytes_per_step_each_way': T * S ** 3},
+                           'pcie_bytes_per_step_each_way': T * S ** 3, 'labels_sha256': labels_sha},
                 'roofline': roof, 'network': net, 'cpu_baseline': cpu}
         print(json.dumps(line))
     if world > 1:
@@ -435,6 +443,8 @@ def volume_main(args):
                                        f'{chunk} + halo {halo}, model tiles {tuple(t + 2 * h for t, h in zip(tile, halo))}, '
                                        f'{nchunks} chunks dealt round-robin over {world} rank(s)',
                            'parallelism': f'chunk-sharded x{world}', 'output_classes_nonzero': int((out[0] > 0).float().mean() > 0),
+                           'labels_sha256': (__import__('hashlib').sha256(out[0].numpy().tobytes()).hexdigest()
+                                             if args.labels_sha else None),
                            'collective': 'RCCL scatter of uint8 chunks / gather of uint8 results, rank 0 host memory' if world > 1 else 'none'}}
         print(json.dumps(line))
     if world > 1:
@@ -483,20 +493,35 @@ def cpu_baseline(args, sd, dm, tiles_host, ids, L):
     keys = ('label_agreement', 'label_mismatch_safe', 'label_mismatch_unsafe', 'label_unsafe_frac', 'argmax_agreement',
             'argmax_mismatch_safe', 'argmax_mismatch_unsafe', 'argmax_unsafe_frac', 'tol_logit_rel_stated', 'logit_err_max_rel',
             'logit_err_rms', 'median_top2_margin_over_tol')
+    def time_for(m):
+        # device-resident throughput of this storage type on the bench's own launch set (all tiles of a step in one set)
+        x = tiles_host.to(m.device)
+        out = torch.empty(tuple(x.shape), dtype=torch.uint8, device=m.device)
+        m.forward_labels_batch(x, ids, [127.5] * len(ids), out=out)
+        torch.cuda.synchronize(m.device)
+        reps, t1 = 0, time.perf_counter()
+        while reps < 3 or (time.perf_counter() - t1 < 0.5 and reps < 50):
+            m.forward_labels_batch(x, ids, [127.5] * len(ids), out=out)
+            torch.cuda.synchronize(m.device)
+            reps += 1
+        ms = (time.perf_counter() - t1) / reps / x.shape[0] * 1e3
+        return {'ms_per_tile': ms, 'mvox_per_s': S ** 3 / ms / 1e3, 'tiles_per_launch_set': int(x.shape[0])}
+
     sp = split_for(dm, args.act)
     cpu = {'value': ncpu * S ** 3 / cpu_s / 1e6, 'unit': 'Mvox/s', 'cores': torch.get_num_threads(), 'kind': 'port',
            'sample': f'{ncpu} {S}^3 tiles of the same workload through the torch-CPU fp32 oracle '
                      f'(U-Net + softmax + uint8 + label rule), {cpu_s:.1f} s'}
     cpu.update({k: sp[k] for k in keys})
-    # the same tiles in the other storage types of the library: fp16 (the library default) and the
-    # reference-precision mode 'f32' (fp32 storage + arithmetic like the reference, csrc/sd_f32.hip)
-    modes = {args.act: {k: sp[k] for k in keys}}
-    for act in ('bf16', 'f16', 'f32'):
+    # the same tiles in every storage type of the library, each with its agreement AND its device-resident throughput:
+    # 'f16x2' = the reference-precision plan on the matrix cores (what Predictor(float16=False) selects, csrc/sd_split.hip),
+    # 'f32' = fp32 storage + FMA arithmetic (csrc/sd_f32.hip), 'f16' / 'bf16' = the fast plans
+    modes = {args.act: dict({k: sp[k] for k in keys}, **time_for(dm))}
+    for act in ('bf16', 'f16', 'f16x2', 'f32'):
         if act in modes:
             continue
         m2 = DenseModel(sd, act_dtype=act, device=dm.device)
         r = split_for(m2, act)
-        modes[act] = {k: r[k] for k in keys}
+        modes[act] = dict({k: r[k] for k in keys}, **time_for(m2))
         del m2
     cpu['precision_modes'] = modes
     return cpu

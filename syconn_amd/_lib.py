@@ -107,8 +107,8 @@ def load():
 
 
 class ActivationOverflowError(RuntimeError, FloatingPointError):
-    """fp16 activation storage overflowed (> 65504) during a forward pass: its results are invalid.  Use act_dtype='bf16'
-    (fp32's exponent range) or 'f32'."""
+    """fp16 activation storage ('f16', 'f16x2') overflowed (> 65504) during a forward pass: its results are invalid.  Use
+    act_dtype='bf16' / 'f32' (fp32's exponent range)."""
 
 
 def check(rc: int, what: str = ''):

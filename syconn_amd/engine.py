@@ -155,7 +155,8 @@ class DenseModel:
 
     def overflowed(self) -> bool:
         """fp16 range guard (include/syconn_dense.h: sd_model_overflow): True if a forward pass since the last call stored
-        an activation beyond fp16's range (results invalid).  Synchronises the current stream; always False for bf16 / f32."""
+        an activation beyond fp16's range (results invalid; 'f16' and 'f16x2').  Synchronises the current stream; always False for
+        bf16 / f32."""
         flag = C.c_int(0)
         L.check(self.lib.sd_model_overflow(self._h, _stream(), C.byref(flag)), 'sd_model_overflow')
         return bool(flag.value)

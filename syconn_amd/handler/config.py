@@ -28,7 +28,10 @@ DEFAULTS = {
         'overlap_shape_tiles': [30, 31, 20],   # xyz, prediction.py:672
         'chunk_size': [482, 481, 236],         # prediction.py:674
         'tile_shape': [271, 181, 138],         # prediction.py:677
-        'act_dtype': 'f16',
+        # storage type of the activations on the device.  'f16x2' = the reference's precision (it computes in fp32,
+        # prediction.py:777-779) on the matrix cores; the fast plans 'f16' / 'bf16' (~3.4x the throughput, 0.06 % / 0.45 % of
+        # the threshold-rule labels differ from fp32) are an explicit choice; 'f32' = fp32 FMA arithmetic, ~30x slower
+        'act_dtype': 'f16x2',
     },
     # first consumer of the probability maps (object extraction): the reference's defaults,
     # /root/reference/syconn/handler/config.yml:108-136

@@ -38,6 +38,11 @@ def zyx2xyz(vol: np.ndarray) -> np.ndarray:
     return vol.swapaxes(-1, -3)
 
 
+# storage types whose range guard can fire -> the plan of the same precision class with fp32's exponent range
+_FALLBACK = {'f16': 'bf16', 'f16x2': 'f32'}
+_ACT_NAMES = {'fp16': 'f16', 'float16': 'f16', 'bfloat16': 'bf16', 'fp32': 'f32', 'float32': 'f32', 'split': 'f16x2'}
+
+
 # ------------------------------------------------------------------------------------------------------
 class Predictor:
     """MI355X implementation of ``elektronn3.inference.Predictor`` (third-party; constructed at
@@ -47,13 +52,21 @@ class Predictor:
     pickled ``.pt`` file, `state_dict_src`, `device`, `tile_shape`/`overlap_shape` (z,y,x), `out_shape`
     (C,z,y,x), `strict_shapes`, `apply_softmax`, `apply_argmax`, `float16`, `batch_size`, `verbose`.
     `transform`, `augmentations`, `offset` (valid convolutions) and `argmax_with_threshold` are unused by SyConn
-    and rejected.  Extra keyword `act_dtype` ('f16' default, 'bf16', or 'f32' = the slow reference-precision mode: fp32 storage
-    and arithmetic like the reference) names the storage type of activations on the device; accumulation is fp32.  fp16 is
-    range-guarded: an overflow (> 65504) is detected on the device; the default then repeats the prediction in bf16, an
-    explicit 'f16' raises ``ActivationOverflowError`` (a ``RuntimeError``).  The reference computes in fp32 (`float16=False`, prediction.py:777-779); fp16 storage is
-    the closest the matrix cores offer at full rate: against the fp32 oracle at the 128^3 headline configuration it
-    changes 0.06 % of the threshold-rule labels (bf16: 0.45 %, max logit error 8.7e-4 vs 7.4e-3 of the logit range;
-    tests/test_gpu_labels_headline.py).  bf16 keeps fp32's exponent range and is ~3 % faster.  `batch_size`: tiles per launch set (default: automatic,
+    and rejected.
+
+    Precision.  The reference computes in fp32 (`float16=False`, prediction.py:777-779).  `float16=False` (the default, what
+    SyConn passes) therefore selects the REFERENCE-PRECISION plan 'f16x2': every activation and weight is kept as two fp16
+    numbers hi + lo and every product is three matrix-core passes with fp32 accumulation -- logits within ~1e-6 of the fp32
+    oracle's range (stated tolerance 1e-5), argmax / threshold-rule labels equal except where the oracle itself sits on a
+    decision boundary, at ~3.4x the time of 'f16'.  `float16=True` (elektronn3: ``model.half()``) selects 'f16'.  The extra
+    keyword `act_dtype` overrides both: 'f16x2', 'f16' (0.06 % of the threshold-rule labels of the 128^3 headline tile differ
+    from the fp32 oracle, max logit error 8.7e-4 of the logit range), 'bf16' (0.45 %, 7.4e-3; fp32's exponent range, ~3 %
+    faster than 'f16'; tests/test_gpu_labels_headline.py), or 'f32' (fp32 storage and FMA arithmetic
+    off the matrix cores, ~30x slower than 'f16').  Accumulation is fp32 in every plan.  The fp16-based plans are
+    range-guarded: an overflow (> 65504) is detected on the device; with `overflow_fallback` (default: on unless `act_dtype`
+    was given explicitly) the prediction is repeated in the next plan with fp32's exponent range ('f16' -> 'bf16', 'f16x2' ->
+    'f32') and the Predictor stays there, otherwise ``ActivationOverflowError`` (a ``RuntimeError``) is raised.
+    `batch_size`: tiles per launch set (default: automatic,
     see `_batch_for`).  `n_streams` (default 1, env SYCONN_AMD_STREAMS): batches alternate over that many HIP
     streams, each with its own workspace.
 
@@ -66,7 +79,7 @@ class Predictor:
                  overlap_shape=None, offset=None, out_shape=None, out_dtype=None, float16=False,
                  apply_softmax=True, transform=None, augmentations=None, strict_shapes=False, apply_argmax=False,
                  argmax_with_threshold=None, verbose=False, report_inf_speed=False, act_dtype=None,
-                 group_norm_groups=None, n_streams=None, defer_guard=False):
+                 group_norm_groups=None, n_streams=None, defer_guard=False, overflow_fallback=None):
         from ..engine import DenseModel, StreamRing
         if transform is not None or augmentations is not None or argmax_with_threshold is not None:
             raise NotImplementedError('transform / augmentations / argmax_with_threshold are not used by SyConn\'s '
@@ -110,14 +123,18 @@ class Predictor:
         self.verbose = verbose
         self.report_inf_speed = report_inf_speed
         # fp16 range guard: fp16 storage overflows above 65504 (the reference computes in fp32 and cannot).  The library flags
-        # it (sd_model_overflow).  With the DEFAULT storage type the prediction is then repeated in bf16 (fp32's exponent
-        # range) and the Predictor stays there; an explicitly requested 'f16' raises ActivationOverflowError instead.
-        self._bf16_fallback = act_dtype is None
+        # it (sd_model_overflow).  With `overflow_fallback` the prediction is then repeated in the plan of the same precision
+        # class that has fp32's exponent range (_FALLBACK) and the Predictor stays there; without it ActivationOverflowError is
+        # raised.  Default: on for the default storage type, off for an explicitly requested one.
+        self._fallback = (act_dtype is None) if overflow_fallback is None else bool(overflow_fallback)
         # `defer_guard`: do not synchronise after every prediction (pipelined callers); the caller asks `overflowed()` once
         # its stream of predictions is done and repeats them in bf16 itself
         self.defer_guard = bool(defer_guard)
         if act_dtype is None:
-            act_dtype = 'f16'          # `float16=True` (elektronn3: model.half()) selects the same storage type
+            # the reference's precision is what `float16` says: False (SyConn's call, prediction.py:777-779) = fp32 results ->
+            # the split-fp16 reference-precision plan; True (elektronn3: model.half()) = fp16 storage
+            act_dtype = 'f16' if float16 else 'f16x2'
+        act_dtype = _ACT_NAMES.get(act_dtype, act_dtype)
         self.act_dtype = act_dtype
         self._gn_groups = group_norm_groups
         self._dm = DenseModel(model, act_dtype=act_dtype, device=self.device, group_norm_groups=group_norm_groups)
@@ -198,15 +215,16 @@ class Predictor:
         """Run one tiled prediction; if the fp16 range guard fired, repeat it in bf16 (default storage type) or raise."""
         from ..engine import DenseModel
         run()
-        if self.defer_guard or self.act_dtype not in ('f16', 'fp16', 'float16') or not self._dm.overflowed():
+        if self.defer_guard or self.act_dtype not in _FALLBACK or not self._dm.overflowed():
             return
-        if not self._bf16_fallback:
+        nxt = _FALLBACK[self.act_dtype]
+        if not self._fallback:
             raise L.ActivationOverflowError(
-                "fp16 activation overflow (a stored activation exceeded 65504): results invalid; use act_dtype='bf16' or 'f32'")
-        log_main.warning('syconn_amd.Predictor: fp16 activation overflow detected -- switching this Predictor to bf16 storage '
-                         'and repeating the prediction')
-        self.act_dtype = 'bf16'
-        self._dm = DenseModel(self.model, act_dtype='bf16', device=self.device, group_norm_groups=self._gn_groups)
+                f"fp16 activation overflow (a stored activation exceeded 65504): results invalid; use act_dtype='{nxt}'")
+        log_main.warning(f'syconn_amd.Predictor: fp16 activation overflow detected -- switching this Predictor from '
+                         f'{self.act_dtype} to {nxt} storage and repeating the prediction')
+        self.act_dtype = nxt
+        self._dm = DenseModel(self.model, act_dtype=nxt, device=self.device, group_norm_groups=self._gn_groups)
         run()
 
     def overflowed(self) -> bool:
@@ -331,13 +349,19 @@ def dense_predictor(args):
     overlap_shape = np.asarray(overlap_shape)
     overlap_shape_tiles = np.asarray(overlap_shape_tiles)
     chunk_size = np.asarray(chunk_size)
-    act_dtype = global_params.config['dense_prediction']['act_dtype'] if _wd_set() else 'f16'
+    # storage type of the activations: config['dense_prediction']['act_dtype']; default 'f16x2' = the reference's precision
+    # (the fast plans 'f16' / 'bf16' are an explicit configuration choice).  A range-guard overflow on any chunk falls back
+    # to the plan with fp32's exponent range instead of killing the worker.
+    act_dtype = global_params.config['dense_prediction']['act_dtype'] if _wd_set() else 'f16x2'
+    log_main.info(f'dense_predictor: activation storage type {act_dtype} '
+                  f'({"reference precision" if act_dtype in ("f16x2", "f32") else "reduced precision, fast plan"})')
     while True:
         try:
             out_shape = (chunk_size + 2 * np.array(overlap_shape)).astype(np.int32)[::-1]  # ZYX
             out_shape = np.insert(out_shape, 0, n_channel)  # output must equal chunk size
             predictor = Predictor(model_p, strict_shapes=True, tile_shape=tile_shape[::-1], out_shape=out_shape,
-                                  overlap_shape=overlap_shape_tiles[::-1], apply_softmax=True, act_dtype=act_dtype)
+                                  overlap_shape=overlap_shape_tiles[::-1], apply_softmax=True, act_dtype=act_dtype,
+                                  overflow_fallback=True)
             try:
                 predictor.model.ae = False
             except Exception:  # ScriptModules refuse new attributes; elektronn3's flag has no meaning here
@@ -346,6 +370,8 @@ def dense_predictor(args):
             _ = predictor.predict_proba_u8_device(
                 torch.zeros(tuple(int(s) for s in out_shape[1:]), dtype=torch.uint8, device=predictor.device))
             break
+        except L.ActivationOverflowError:      # (a RuntimeError, but not a memory problem: halving tiles would not help)
+            raise
         except RuntimeError:  # device MemoryError
             if np.all(tile_shape % 2):
                 raise ValueError('Cannot reduce tile shape anymore. Please adapt the tile/overlap/chunk shape in '
@@ -562,7 +588,8 @@ def predict_dense_to_kd(kd_path: str, target_path: str, model_path: str, n_chann
     shared = (kd_path, target_path, model_path, overlap_shape, overlap_shape_tiles, tile_shape, chunk_size, n_channel,
               channels, target_kds, thresholds, mag, coi)
     jobs = [(share, *shared) for share in chunkify(chunk_ids, conf.ngpu_total)]
-    log.info('Started dense prediction of {} in {:d} chunk(s).'.format(", ".join(names), len(chunk_ids)))
+    log.info('Started dense prediction of {} in {:d} chunk(s), activation storage type {}.'.format(
+        ", ".join(names), len(chunk_ids), conf['dense_prediction']['act_dtype']))
     cores = conf['ncores_per_node']
     if qu.batchjob_enabled():
         cores //= conf['ngpus_per_node']

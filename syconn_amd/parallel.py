@@ -60,6 +60,27 @@ def shard_units(units: Sequence, rank: Optional[int] = None, world: Optional[int
     return list(parts[rank]) if rank < len(parts) else []
 
 
+def _staged(t: torch.Tensor) -> bool:
+    """True when a payload collective on `t` has to be staged through host memory: device tensors on the gloo backend (gloo
+    moves host memory only).  That is the functional stand-in for RCCL where RCCL cannot run -- the CPU unit tests, and
+    ``SD_BENCH_ONE_GPU_DEBUG`` runs in which all ranks share ONE GPU (RCCL refuses two ranks on one device)."""
+    return t.is_cuda and dist.get_backend() == 'gloo'
+
+
+class _StagedWork:
+    """Work handle of a host-staged collective: the transfer is complete in host order when the call returns; what is left is
+    the device copy of the received payload on the issuing stream, and ``wait()`` orders the CURRENT stream behind it -- the
+    stream semantics of an RCCL work handle."""
+
+    def __init__(self, event):
+        self._ev = event
+
+    def wait(self):
+        if self._ev is not None:
+            torch.cuda.current_stream().wait_event(self._ev)
+        return True
+
+
 def _state(model) -> dict:
     return model if isinstance(model, dict) else model.state_dict()
 
@@ -117,6 +138,15 @@ def gather_to_root(local: torch.Tensor, dst: int = 0, async_op: bool = False, ou
         if out is None:
             out = torch.empty((world, *local.shape), dtype=local.dtype, device=local.device)
         bufs = list(out.unbind(0))
+    if _staged(local):
+        host = local.contiguous().cpu()                          # (ordered behind the current stream's work)
+        hbufs = [torch.empty_like(host) for _ in range(world)] if rank == dst else None
+        dist.gather(host, gather_list=hbufs, dst=dst)
+        if rank == dst:
+            for b, h in zip(bufs, hbufs):
+                b.copy_(h)
+        ev = torch.cuda.current_stream().record_event()
+        return bufs, (_StagedWork(ev) if async_op else None)
     work = dist.gather(local.contiguous(), gather_list=bufs, dst=dst, async_op=async_op)
     return bufs, (work if async_op else None)
 
@@ -130,6 +160,12 @@ def scatter_from_root(payloads: Optional[Sequence[torch.Tensor]], like: torch.Te
         return (payloads[0], None) if async_op else payloads[0]
     if out is None:
         out = torch.empty_like(like)
+    if _staged(out):
+        hout = torch.empty(out.shape, dtype=out.dtype)
+        dist.scatter(hout, scatter_list=[p.contiguous().cpu() for p in payloads] if rank == src else None, src=src)
+        out.copy_(hout)
+        ev = torch.cuda.current_stream().record_event()
+        return (out, _StagedWork(ev)) if async_op else out
     work = dist.scatter(out, scatter_list=[p.contiguous() for p in payloads] if rank == src else None, src=src,
                         async_op=async_op)
     return (out, work) if async_op else out

@@ -160,15 +160,16 @@ def test_fp16_range_guard(gpu, arch, shape):
 
 
 def test_predictor_falls_back_to_bf16_on_fp16_overflow(gpu):
-    """Predictor with the DEFAULT storage type repeats an overflowed prediction in bf16 (== a bf16 Predictor, bit for bit) and
-    stays there; an explicit act_dtype='f16' raises ActivationOverflowError (a RuntimeError)."""
+    """Predictor(float16=True) (default storage type 'f16') repeats an overflowed prediction in bf16 (== a bf16 Predictor, bit
+    for bit) and stays there; an explicit act_dtype='f16' raises ActivationOverflowError (a RuntimeError).  (float16=False and its
+    'f16x2' -> 'f32' fallback: tests/test_gpu_split.py.)"""
     from syconn_amd import _lib as L
     from syconn_amd.handler.prediction import Predictor
     model = _blow_up(build_unet('myelin', seed=3, final_scale=4.0))
     raw = _input((8, 32, 64), 2)
     kw = dict(tile_shape=(4, 16, 32), overlap_shape=(2, 4, 4), out_shape=(2, 8, 32, 64), strict_shapes=True, apply_softmax=True)
     want = Predictor(model, act_dtype='bf16', **kw).predict_proba_u8_device(raw.to(gpu))
-    p = Predictor(model, **kw)
+    p = Predictor(model, float16=True, **kw)
     assert p.act_dtype == 'f16'
     got = p.predict_proba_u8_device(raw.to(gpu))
     assert p.act_dtype == 'bf16' and torch.equal(got, want)

@@ -1,0 +1,125 @@
+"""The N > 1 paths that ship, EXECUTED: bench.py under torch.distributed.run with 2 ranks (default workload and a volume
+workload) and the device-side stream / event protocol of ``predict_volume_distributed``.  The GPU boxes of this pool have one
+GPU: ``SD_BENCH_ONE_GPU_DEBUG=1`` puts both ranks on cuda:0 with gloo and host-staged payload collectives
+(syconn_amd.parallel._staged) -- RCCL refuses two ranks on one device; on a box with two GPUs the worker test uses RCCL.
+/root/reference/syconn/handler/prediction.py:708-719 is what these paths replace (one worker process per GPU, chunks dealt
+round-robin).  Every launcher is a FRESH subprocess started before anything in it touches the GPU."""
+import hashlib
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _run(cmd, env_extra=None, timeout=1500):
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env['PYTHONPATH'] = ROOT + os.pathsep + env.get('PYTHONPATH', '')
+    env.update(env_extra or {})
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    assert r.returncode == 0, f'{" ".join(cmd)}\nrc={r.returncode}\nSTDOUT:\n{r.stdout[-3000:]}\nSTDERR:\n{r.stderr[-3000:]}'
+    return r.stdout
+
+
+def _torchrun(n, args, env_extra=None):
+    return _run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+                 '--master-port', str(_free_port())] + args, env_extra)
+
+
+def _json_line(out):
+    lines = [ln for ln in out.splitlines() if ln.startswith('{') and '"metric"' in ln]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_default_workload(gpu):
+    """`bench.py --gpus 2` as the driver launches it (HostToHostPipeline with the gather branch): rc 0, one JSON line with
+    n_gpus 2, and the label volumes that arrived in rank 0's host memory equal what ONE rank computes for the same tiles."""
+    line = _json_line(_torchrun(2, ['bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--tiles', '2', '--no-cpu-baseline',
+                                    '--labels-sha'], {'SD_BENCH_ONE_GPU_DEBUG': '1'}))
+    assert line['n_gpus'] == 2 and line['steps'] == 2 and line['value'] > 0 and line['scaling'] == 'weak'
+    assert line['roofline']['frac'] > 0 and line['config']['labels_sha256']
+    from bench import BENCH_FINAL_SCALE, synthetic_em_tiles
+    from syconn_amd.cnn import random_state_dict
+    from syconn_amd.engine import DenseModel
+    dm = DenseModel(random_state_dict('semseg_spine', seed=0, final_scale=BENCH_FINAL_SCALE), act_dtype='bf16', device=gpu)
+    ids = list(range(1, dm.out_channels))
+    labs = [dm.forward_labels_batch(torch.from_numpy(synthetic_em_tiles(2, 128, seed=1 + r)).to(gpu), ids, [127.5] * len(ids)).cpu()
+            for r in range(2)]
+    want = hashlib.sha256(torch.stack(labs).numpy().tobytes()).hexdigest()
+    assert line['config']['labels_sha256'] == want
+
+
+@pytest.mark.parametrize('workload,geometry,volume', [('config3', 'tile128', (256, 256, 256)),
+                                                       ('config4', 'reference', (236, 962, 964)),
+                                                       ('config5', 'tile128', (224, 384, 384))])
+def test_bench_volume_workloads_two_ranks_equal_one_rank(gpu, workload, geometry, volume):
+    """BASELINE configs[2], [3] (the reference's chunk / tile geometry, 2 x 2 x 1 chunks of 482 x 481 x 236 + halo) and [4]
+    (mivcsj fp16, label rule) on reduced volumes through `bench.py --workload ...`: 2 ranks (scatter / predict / gather
+    pipeline of predict_volume_distributed) give the volume 1 rank gives, bit for bit."""
+    args = ['bench.py', '--workload', workload, '--geometry', geometry, '--volume', *[str(v) for v in volume], '--steps', '1',
+            '--warmup', '0', '--labels-sha']
+    two = _json_line(_torchrun(2, args + ['--gpus', '2'], {'SD_BENCH_ONE_GPU_DEBUG': '1'}))
+    one = _json_line(_run([sys.executable] + args + ['--gpus', '1']))
+    assert two['n_gpus'] == 2 and one['n_gpus'] == 1 and two['scaling'] == 'strong'
+    assert two['config']['labels_sha256'] and two['config']['labels_sha256'] == one['config']['labels_sha256']
+    assert two['config']['output_classes_nonzero'] == 1
+
+
+def test_volume_workload_equals_per_tile_path(gpu):
+    """The configs[3] reference-geometry workload of bench.py (chunk 482 x 481 x 236 + halo (30,31,20) zero-padded and tiled
+    in 138 x 181 x 271 tiles + overlap, prediction.py:672-677, 775-781, 812) on a 2 x 2 x 1-chunk volume, in process: the
+    stitched result equals single forwards of sampled model tiles (gathered with zero padding, cropped by the overlap)."""
+    from bench import BENCH_FINAL_SCALE, _crop, synthetic_volume
+    from syconn_amd import _lib as L
+    from syconn_amd import parallel as par
+    from syconn_amd.cnn import random_state_dict
+    from syconn_amd.engine import DenseModel, tile_gather
+    from syconn_amd.handler.prediction import Predictor
+    sd = random_state_dict('myelin', seed=0, final_scale=BENCH_FINAL_SCALE)
+    chunk, halo, tile = (236, 481, 482), (20, 31, 30), (138, 181, 271)
+    vol_shape = (236, 962, 964)
+    vol = torch.from_numpy(synthetic_volume(vol_shape, seed=3))
+    pred = Predictor(sd, device=gpu, tile_shape=tile, overlap_shape=halo, apply_softmax=True, act_dtype='bf16')
+    out = par.predict_volume_distributed(vol, vol_shape, chunk, halo, lambda ch: _crop(pred.predict_proba_u8_device(ch)[1:2], halo),
+                                         n_out=1, device=gpu)
+    assert tuple(out.shape) == (1, *vol_shape)
+    dm = DenseModel(sd, act_dtype='bf16', device=gpu)
+    vdev = vol.to(gpu)
+    t, h = np.array(tile), np.array(halo)
+    for cpos, tpos in (((0, 0, 0), (0, 0, 0)), ((0, 1, 1), (1, 2, 1)), ((0, 1, 0), (0, 1, 0)), ((0, 0, 1), (1, 0, 1))):
+        c_lo = np.array(cpos) * np.array(chunk) - h                          # chunk + halo origin in the volume
+        t_lo = np.array(tpos) * t                                            # tile origin inside the (zero-padded) chunk + halo
+        # the model tile reads chunk+halo voxels [t_lo - h, t_lo + t + h); outside the chunk + halo box that is zero padding
+        ch = tile_gather(vdev, c_lo, np.array(chunk) + 2 * h)                # (zeros outside the volume, like kd.load_raw)
+        one = dm.forward(tile_gather(ch, t_lo - h, t + 2 * h), L.SD_OUT_PROBS_U8)[1]
+        keep_lo = np.maximum(t_lo, h)                                        # part of the tile inside the chunk proper
+        keep_hi = np.minimum(np.minimum(t_lo + t, h + np.array(chunk)), h + np.array(vol_shape) - np.array(cpos) * np.array(chunk))
+        if np.any(keep_hi <= keep_lo):
+            continue
+        a = one[h[0] + keep_lo[0] - t_lo[0]:h[0] + keep_hi[0] - t_lo[0], h[1] + keep_lo[1] - t_lo[1]:h[1] + keep_hi[1] - t_lo[1],
+                h[2] + keep_lo[2] - t_lo[2]:h[2] + keep_hi[2] - t_lo[2]].cpu()
+        v_lo = c_lo + keep_lo
+        b = out[0, v_lo[0]:v_lo[0] + a.shape[0], v_lo[1]:v_lo[1] + a.shape[1], v_lo[2]:v_lo[2] + a.shape[2]]
+        assert a.numel() > 0 and torch.equal(a, b), (cpos, tpos)
+
+
+def test_predict_volume_distributed_stream_protocol_two_ranks(gpu):
+    """`s_comm`, `ev_scat` / `ev_gath`, scatter(r+1) before predict(r), `root_computes=False` and the pinned pool with
+    device tensors, 2 ranks, every combination bit for bit against the single-process result (tests/_dist_gpu_worker.py)."""
+    out = _torchrun(2, [os.path.join('tests', '_dist_gpu_worker.py')])
+    assert 'DIST_GPU_WORKER_OK' in out, out[-2000:]
