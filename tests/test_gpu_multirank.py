@@ -77,7 +77,6 @@ def test_bench_volume_workloads_two_ranks_equal_one_rank(gpu, workload, geometry
     one = _json_line(_run([sys.executable] + args + ['--gpus', '1']))
     assert two['n_gpus'] == 2 and one['n_gpus'] == 1 and two['scaling'] == 'strong'
     assert two['config']['labels_sha256'] and two['config']['labels_sha256'] == one['config']['labels_sha256']
-    assert two['config']['output_classes_nonzero'] == 1
 
 
 def test_volume_workload_equals_per_tile_path(gpu):
