@@ -1249,7 +1249,8 @@ WsLayout ws_layout(int X, int Y, int Z, int P) {
     WsLayout w{};
     const Dom d = make_dom(X, Y, Z, P);
     const size_t pwords = (size_t)d.PX * d.PY * d.PZW, nvox = (size_t)X * Y * Z;
-    const size_t nblk = (nvox + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    // (run_cc scans blocks of mask WORDS, X * Y * PZW of them: more than voxels for thin volumes with a large pad)
+    const size_t nblk = (std::max(nvox, (size_t)X * Y * d.PZW) + SCAN_BLOCK - 1) / SCAN_BLOCK;
     size_t cur = 0;
     w.a = cur; cur += rup256(pwords * 4);
     w.b = cur; cur += rup256(pwords * 4);

@@ -32,7 +32,9 @@ _ready = threading.local()      # per thread (sd_init also selects the HIP devic
 def require_gpu(device_index: int = 0):
     """Fail loudly when the HIP path cannot run (no CPU fallback exists)."""
     lib = L.load()
-    if getattr(_ready, 'device', None) == int(device_index):
+    # (the cache is only valid while the thread's current device still is the one sd_init selected: a torch.cuda.device(...)
+    # block or a set_device elsewhere changes it behind our back)
+    if getattr(_ready, 'device', None) == int(device_index) and torch.cuda.current_device() == int(device_index):
         return lib
     if not torch.cuda.is_available():
         raise RuntimeError('syconn_amd: no MI355X visible to PyTorch-ROCm; this package has no CPU fallback')

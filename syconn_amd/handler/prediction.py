@@ -342,7 +342,7 @@ def dense_predictor(args):
         # chunks are not aligned to the target cubes: assemble the cubes this worker touches in memory and write each once
         # (KnossosDataset.enable_write_combining; flushed at the end of this worker)
         for tkd in target_kd_dict.values():
-            tkd.enable_write_combining()
+            tkd.enable_write_combining(chunk_shape=chunk_size)
 
     ix = 0
     tile_shape = np.array(tile_shape)

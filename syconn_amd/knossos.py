@@ -318,42 +318,72 @@ class KnossosDataset:
     # touched stay in memory; a cube whose voxels (inside the dataset) have all arrived is written ONCE without being read,
     # the rest is merged into the file (read-modify-write under the cube lock, only the boxes this process wrote) when the
     # cache overflows or at `flush()`.  Regions of different chunks never overlap, so the final dataset is the same.
-    def enable_write_combining(self, max_cubes: int = 64):
+    def enable_write_combining(self, max_cubes: Optional[int] = None, chunk_shape=None):
+        """`max_cubes`: partially assembled cubes kept in memory (all mags together).  Default: what two chunks of `chunk_shape`
+        (x,y,z at mag 1; default 482 x 481 x 236, prediction.py:674) can touch at the three mags of a save_* call -- a smaller
+        cache evicts inside every chunk and most cubes take the read-modify-write path instead of the single write."""
         import collections
         import threading
+        if max_cubes is None:
+            cs = np.asarray(self._cube_shape, dtype=np.int64)
+            ch = np.asarray((482, 481, 236) if chunk_shape is None else chunk_shape, dtype=np.int64)
+            max_cubes = 2 * sum(int(np.prod(-(-(-(-ch // m)) // cs) + 1)) for m in (1, 2, 4))
         self._wc = collections.OrderedDict()
-        self._wc_max = int(max_cubes)
+        self._wc_max = max(4, int(max_cubes))
         self._wc_mutex = threading.Lock()
 
     def _wc_add(self, key, fn, dtype, shape, dst, block, need):
-        evict = None
-        with self._wc_mutex:
-            ent = self._wc.get(key)
-            if ent is None:
-                ent = self._wc[key] = dict(fn=fn, ext=key[1], dtype=dtype, cube=np.zeros(shape, dtype=dtype), boxes=[], have=0,
-                                           need=need)
-            self._wc.move_to_end(key)
-            ent['cube'][dst] = block
-            ent['boxes'].append(dst)
-            ent['have'] += int(block.size)
-            if ent['have'] >= ent['need']:
-                del self._wc[key]
-                # "complete" only if the boxes really tile the cube: a region written twice would be counted twice
-                bx = ent['boxes']
-                disjoint = all(any(a[i].stop <= b[i].start or b[i].stop <= a[i].start for i in range(3))
-                               for n_, a in enumerate(bx) for b in bx[n_ + 1:])
-                done, evict = (ent, None) if disjoint else (None, ent)
+        import threading
+        while True:
+            evict = None
+            with self._wc_mutex:                  # the table only: the block copy below runs under the ENTRY's lock
+                ent = self._wc.get(key)
+                if ent is None:
+                    ent = self._wc[key] = dict(fn=fn, ext=key[1], dtype=dtype, cube=None, boxes=[], have=0, need=need,
+                                               lock=threading.Lock(), dead=False)
+                    if len(self._wc) > self._wc_max:
+                        old = next(iter(self._wc))
+                        if old != key:
+                            evict = self._wc.pop(old)
+                self._wc.move_to_end(key)
+            if evict is not None:
+                self._wc_merge(evict)
+            done = None
+            with ent['lock']:
+                if ent['dead']:                   # evicted / completed by another thread between the lookup and here: start over
+                    continue
+                if ent['cube'] is None:
+                    ent['cube'] = np.zeros(shape, dtype=dtype)
+                ent['cube'][dst] = block
+                ent['boxes'].append(dst)
+                ent['have'] += int(block.size)
+                if ent['have'] >= ent['need']:
+                    ent['dead'] = True
+                    done = ent
+            if done is None:
+                return
+            with self._wc_mutex:
+                if self._wc.get(key) is done:
+                    del self._wc[key]
+            # "complete" only if the boxes really tile the cube: a region written twice would be counted twice
+            bx = done['boxes']
+            disjoint = all(any(a[i].stop <= b[i].start or b[i].stop <= a[i].start for i in range(3))
+                           for n_, a in enumerate(bx) for b in bx[n_ + 1:])
+            if disjoint:                          # nobody else writes into this cube: one write, no read
+                with _cube_lock(done['fn']):
+                    self._write_cube(done['fn'], done['ext'], done['cube'])
             else:
-                done = None
-                if len(self._wc) > self._wc_max:
-                    evict = self._wc.popitem(last=False)[1]
-        if done is not None:                      # complete: nobody else writes into this cube
-            with _cube_lock(done['fn']):
-                self._write_cube(done['fn'], done['ext'], done['cube'])
-        if evict is not None:
-            self._wc_merge(evict)
+                self._wc_merge(done, locked=True)
+            return
 
-    def _wc_merge(self, ent):
+    def _wc_merge(self, ent, locked: bool = False):
+        if not locked:
+            with ent['lock']:
+                if ent['dead']:
+                    return
+                ent['dead'] = True
+        if ent['cube'] is None:
+            return
         with _cube_lock(ent['fn']):
             cube = self._read_cube(ent['fn'], ent['ext'], ent['dtype'], ent['cube'].shape)
             if cube is None:
