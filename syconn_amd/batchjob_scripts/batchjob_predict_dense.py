@@ -1,23 +1,36 @@
-"""Worker entry of the dense prediction (process boundary of /root/reference/syconn/batchjob_scripts/
-batchjob_predict_dense.py:1-20): ``python batchjob_predict_dense.py <in.pkl> <out.pkl>`` -- `in.pkl` is a stream of
-pickles, one per element of the argument tuple; `out.pkl` (``pickle.dump(None)``) is the done-marker."""
-import pickle as pkl
+"""Worker entry of the dense prediction: ``python batchjob_predict_dense.py <in.pkl> <out.pkl>``.
+
+Process-boundary contract of the reference's script of the same name (/root/reference/syconn/batchjob_scripts/
+batchjob_predict_dense.py:1-20, written by /root/reference/syconn/mp/batchjob_utils.py:227-232): ``<in.pkl>`` holds the
+elements of ``dense_predictor``'s argument tuple as CONCATENATED pickles (one ``pickle.dump`` per element, no enclosing
+container); the worker writes ``<out.pkl>`` = ``pickle.dump(None)`` when it is done -- its existence is what the dispatcher
+checks (a missing file raises ``ValueError`` there)."""
+import pickle
 import sys
 
-from syconn_amd.handler.prediction import dense_predictor
 
-path_storage_file = sys.argv[1]
-path_out_file = sys.argv[2]
+def read_pickle_stream(path):
+    """All objects of a file of back-to-back pickles, in order."""
+    items = []
+    with open(path, 'rb') as stream:
+        unpickler_eof = False
+        while not unpickler_eof:
+            try:
+                items.append(pickle.load(stream))
+            except EOFError:
+                unpickler_eof = True
+    return items
 
-with open(path_storage_file, 'rb') as f:
-    args = []
-    while True:
-        try:
-            args.append(pkl.load(f))
-        except EOFError:
-            break
 
-dense_predictor(args)
+def main(argv):
+    if len(argv) != 3:
+        raise SystemExit('usage: batchjob_predict_dense.py <in.pkl> <out.pkl>')
+    job_file, done_file = argv[1], argv[2]
+    from syconn_amd.handler.prediction import dense_predictor
+    dense_predictor(read_pickle_stream(job_file))
+    with open(done_file, 'wb') as marker:
+        pickle.dump(None, marker)
 
-with open(path_out_file, "wb") as f:
-    pkl.dump(None, f)
+
+if __name__ == '__main__':
+    main(sys.argv)

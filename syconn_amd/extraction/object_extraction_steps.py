@@ -168,7 +168,8 @@ def auto_overlap(morph_ops: dict, scaling, sigmas=None) -> np.ndarray:
 
 def object_segmentation(cset, hdf5names: Sequence[str], prob_kd_path_dict: dict, thresholds: Sequence[float],
                         overlap="auto", chunk_list: Optional[Sequence[int]] = None, morph_ops: Optional[dict] = None,
-                        min_seed_vx: Optional[dict] = None, scaling=None, with_properties: bool = True, device=None):
+                        min_seed_vx: Optional[dict] = None, scaling=None, with_properties: bool = True, device=None,
+                        sigmas=None):
     """``object_segmentation`` + ``_object_segmentation_thread`` (object_extraction_steps.py:42-201, 204-366) for the branch
     SyConn's pipeline takes after the dense prediction (object_extraction_wrapper.py:58-150: probability maps in
     KnossosDatasets ``prob_kd_path_dict``, ``load_raw``): per chunk of `cset` load size + 2 * overlap around the chunk from every
@@ -179,7 +180,11 @@ def object_segmentation(cset, hdf5names: Sequence[str], prob_kd_path_dict: dict,
     max_label]`` rows; `props[(chunk.number, hdf5_name)]`` = ``find_object_properties`` of that label volume (rep_coords,
     bounding_box, sizes in chunk-local (x,y,z) incl. the overlap margin) computed from the label volume while it is STILL ON THE
     DEVICE -- the int32 labels (4 bytes per voxel) never cross PCIe; the reference writes them to an h5 file per chunk and reads
-    them back for the statistics.  Not reproduced: Gaussian pre-smoothing, the membrane hooks, `swapdata`, overlay-cube input."""
+    them back for the statistics.  `sigmas` (object_extraction_steps.py:77-81, 135-138, 296-298: a vigra ``gaussianSmoothing`` of the
+    probability map before the threshold; SyConn's pipeline passes none) is accepted for signature parity only: ``None`` / all
+    zeros run, anything else raises ``ValueError`` naming the missing filter (vigra is absent from the reference tree and this
+    image, so its border / truncation semantics cannot be pinned).  Not reproduced either: the membrane hooks, `swapdata`,
+    overlay-cube input."""
     from .. import global_params
     from ..knossos import KnossosDataset
     from .find_object_properties import find_object_properties
@@ -187,8 +192,15 @@ def object_segmentation(cset, hdf5names: Sequence[str], prob_kd_path_dict: dict,
     morph_ops = conf['cell_objects']['extract_morph_op'] if morph_ops is None else morph_ops
     min_seed_vx = conf['cell_objects']['min_seed_vx'] if min_seed_vx is None else min_seed_vx
     scaling = np.array(conf['scaling'] if scaling is None else scaling)
+    if sigmas is not None:
+        if len(sigmas) != len(hdf5names):
+            raise Exception("Number of thresholds, sigmas and HDF5 names does not match!")      # (the reference's check, :137-139)
+        if any(float(np.sum(s)) != 0.0 for s in sigmas):
+            raise ValueError('object_segmentation: Gaussian pre-smoothing of the probability maps (`sigmas` != 0, vigra '
+                             'gaussianSmoothing, object_extraction_steps.py:296-298) is not implemented on the MI355X path; '
+                             'pass sigmas=None (what SyConn\'s pipeline does)')
     if isinstance(overlap, str) and overlap == "auto":
-        overlap = auto_overlap(morph_ops, scaling)
+        overlap = auto_overlap(morph_ops, scaling, sigmas)
     overlap = np.asarray(overlap, dtype=np.int64)
     stitch_overlap = np.max([overlap.copy(), [1, 1, 1]], axis=0)
     thresholds = np.array(thresholds, dtype=np.float64)
