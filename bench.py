@@ -216,6 +216,8 @@ def main():
     ap.add_argument('--act', default='bf16', choices=['bf16', 'f16', 'f16x2', 'f32'])
     ap.add_argument('--batch', type=int, default=0, help='tiles per sd_forward_batch launch set (0 = all tiles of a step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--predict-outside', action='store_true',
+                    help='volume workloads: also predict model tiles that lie entirely beyond the volume, as the reference does')
     ap.add_argument('--labels-sha', action='store_true', help='report a sha256 of the result volume(s) on the JSON line (tests)')
     ap.add_argument('--workload', default='config2', choices=['config2', 'config3', 'config4', 'config5'],
                     help='BASELINE.json configs[1..4]; the default (config2 = configs[1]) is the headline metric')
@@ -412,15 +414,23 @@ def volume_main(args):
     ids, thr = list(range(1, ncls)), [127.5] * (ncls - 1)      # channel_thresholds None -> 255/2 (prediction.py:824-825)
     in_halo = args.geometry != 'reference'
 
-    def predict_fn(ch):
+    skip_outside = not args.predict_outside
+
+    def predict_fn(ch, valid_box=None):
         """chunk + halo (uint8, device) -> (1, *chunk) uint8: a multi-id target gives the label volume (mivcsj: ids 1,2,3),
         a two-class model the probability map of channel 1 (myelin), as exec_dense_prediction binds them.
         tile128: the halo is real neighbouring data and the tile grid continues across chunks; reference: the chunk + halo
         is zero-padded and tiled like /root/reference/syconn/handler/prediction.py:775-781, then the halo is cropped (:812)."""
+        # model tiles whose result lies entirely beyond the volume are not predicted (Predictor._tiled, `valid_box` in the
+        # coordinates of the Predictor's output: chunk + halo for the reference geometry, chunk proper for tile128)
+        vb = None
+        if valid_box is not None and skip_outside:
+            vb = valid_box if not in_halo else (tuple(a - h for a, h in zip(valid_box[0], halo)),
+                                                tuple(b - h for b, h in zip(valid_box[1], halo)))
         if ncls > 2:
-            r = pred.predict_labels_u8_device(ch, ids, thr, halo_included=in_halo)[None]
+            r = pred.predict_labels_u8_device(ch, ids, thr, halo_included=in_halo, valid_box=vb)[None]
         else:
-            r = pred.predict_proba_u8_device(ch, halo_included=in_halo)[1:2]
+            r = pred.predict_proba_u8_device(ch, halo_included=in_halo, valid_box=vb)[1:2]
         return r if in_halo else _crop(r, halo)
     vol = torch.from_numpy(synthetic_volume(vol_shape, seed=3)).pin_memory() if rank == 0 else None
     steps, warm = (args.steps if args.steps != 20 else 2), min(args.warmup, 1)

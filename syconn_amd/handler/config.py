@@ -32,6 +32,9 @@ DEFAULTS = {
         # prediction.py:777-779) on the matrix cores; the fast plans 'f16' / 'bf16' (~3.4x the throughput, 0.06 % / 0.45 % of
         # the threshold-rule labels differ from fp32) are an explicit choice; 'f32' = fp32 FMA arithmetic, ~30x slower
         'act_dtype': 'f16x2',
+        # model tiles whose whole result lies beyond the dataset boundary are not predicted (the reference's chunk grid covers
+        # up to 1.9x the dataset and it predicts all of it); False reproduces the reference's values in that overhang too
+        'skip_tiles_outside_dataset': True,
     },
     # first consumer of the probability maps (object extraction): the reference's defaults,
     # /root/reference/syconn/handler/config.yml:108-136

@@ -164,12 +164,18 @@ class Predictor:
         ntiles = np.ceil(spatial / tile).astype(np.int64)
         return tile, ol, ntiles
 
-    def _tiled(self, vol: torch.Tensor, out: torch.Tensor, out_kind: int, label_args=None, halo_included: bool = False):
+    def _tiled(self, vol: torch.Tensor, out: torch.Tensor, out_kind: int, label_args=None, halo_included: bool = False,
+               valid_box=None):
         """tiled_apply (elektronn3) on the device: zero-padded tile extraction, forward,
         crop of the overlap, write into `out` (C,D,H,W).  vol: (D,H,W) uint8 / float32 on the device.
         `halo_included`: `vol` already carries `overlap_shape` voxels of REAL neighbouring data per side (zeros where the
         dataset ends) instead of being zero-padded here; `out` then covers the inner region only.  This is how a chunk of a
-        larger volume is predicted so that the result equals the same tile grid run over the whole volume."""
+        larger volume is predicted so that the result equals the same tile grid run over the whole volume.
+        `valid_box` = ((z0, y0, x0), (z1, y1, x1)) in `out` coordinates: the part of `out` that lies INSIDE the dataset.  The
+        reference's chunk grid (``fit_box_size=True``, prediction.py:679-683) covers up to 1.9x the dataset and it predicts
+        every tile of every chunk, also those whose whole (cropped) result lies beyond the dataset boundary -- values of a
+        zero input that nothing downstream reads.  With a `valid_box` such tiles are not predicted (their region of `out` is
+        zero); every voxel inside the dataset is unchanged, because a tile's result depends on nothing but that tile."""
         from ..engine import tile_gather, tile_scatter
         ol_in = np.zeros(3, dtype=np.int64) if self.overlap_shape is None else self.overlap_shape
         spatial = np.asarray(vol.shape, dtype=np.int64) - (2 * ol_in if halo_included else 0)
@@ -191,6 +197,15 @@ class Predictor:
         # independent tiles go through the network `nb` at a time (sd_forward_batch: one set of launches, every
         # kernel sees nb times as many blocks); batches alternate over `n_streams` HIP streams
         pos_list = list(itertools.product(*[range(int(n)) for n in ntiles]))   # z-major, like upstream
+        if valid_box is not None:
+            v_lo, v_hi = (np.asarray(v, dtype=np.int64) for v in valid_box)
+            inside = [pos for pos in pos_list
+                      if np.all(tile * np.asarray(pos) < v_hi) and np.all(np.minimum(tile * (np.asarray(pos) + 1), spatial) > v_lo)]
+            if len(inside) < len(pos_list):
+                out.zero_()
+                pos_list = inside
+            if not pos_list:
+                return
         nb = self._batch_for(tin, len(pos_list))
         ring = self._ring
         tbuf = [torch.empty((nb, *[int(t) for t in tin]), dtype=vol.dtype, device=self.device) for _ in range(ring.n)]
@@ -265,7 +280,7 @@ class Predictor:
         return out
 
     @torch.no_grad()
-    def predict_proba_u8_device(self, raw_u8: torch.Tensor, halo_included: bool = False) -> torch.Tensor:
+    def predict_proba_u8_device(self, raw_u8: torch.Tensor, halo_included: bool = False, valid_box=None) -> torch.Tensor:
         """Fast path of ``dense_predicton_helper(raw.astype(float32)/255., self)``: `raw_u8` is the (D,H,W) uint8
         chunk ON THE DEVICE; returns uint8 ``floor(255*softmax)`` (C,D,H,W) on the device.  Bit-identical to the
         slow path by construction: the kernel normalises with the table float32(v)/255 (prediction.py:808) and
@@ -278,12 +293,13 @@ class Predictor:
         inner = tuple(int(s) - (2 * int(o) if halo_included else 0) for s, o in
                       zip(raw_u8.shape, (self.overlap_shape if self.overlap_shape is not None else (0, 0, 0))))
         out = torch.empty((self.out_channels, *inner), dtype=torch.uint8, device=self.device)
-        self._guarded(lambda: self._tiled(raw_u8, out, L.SD_OUT_PROBS_U8, halo_included=halo_included))
+        self._guarded(lambda: self._tiled(raw_u8, out, L.SD_OUT_PROBS_U8, halo_included=halo_included, valid_box=valid_box))
         return out
 
 
     @torch.no_grad()
-    def predict_labels_u8_device(self, raw_u8: torch.Tensor, ids, thresholds, halo_included: bool = False) -> torch.Tensor:
+    def predict_labels_u8_device(self, raw_u8: torch.Tensor, ids, thresholds, halo_included: bool = False,
+                                 valid_box=None) -> torch.Tensor:
         """`predict_proba_u8_device` followed by the label rule of dense_predictor (prediction.py:813-833) for ONE
         multi-id target, evaluated in the network's final epilogue: (D,H,W) uint8 labels on the device.  `thresholds`
         are the resolved uint8-scale values, one per id."""
@@ -297,7 +313,7 @@ class Predictor:
         out = torch.empty((1, *inner), dtype=torch.uint8, device=self.device)
         self._guarded(lambda: self._tiled(raw_u8, out, L.SD_OUT_PROBS_U8,
                                           label_args=([int(i) for i in ids], [float(t) for t in thresholds]),
-                                          halo_included=halo_included))
+                                          halo_included=halo_included, valid_box=valid_box))
         return out[0]
 
 
@@ -353,6 +369,7 @@ def dense_predictor(args):
     # (the fast plans 'f16' / 'bf16' are an explicit configuration choice).  A range-guard overflow on any chunk falls back
     # to the plan with fp32's exponent range instead of killing the worker.
     act_dtype = global_params.config['dense_prediction']['act_dtype'] if _wd_set() else 'f16x2'
+    skip_outside = bool(global_params.config['dense_prediction'].get('skip_tiles_outside_dataset', True)) if _wd_set() else True
     log_main.info(f'dense_predictor: activation storage type {act_dtype} '
                   f'({"reference precision" if act_dtype in ("f16x2", "f32") else "reduced precision, fast plan"})')
     while True:
@@ -450,12 +467,21 @@ def dense_predictor(args):
             raw_dev.record_stream(cur)
             # one multi-id target (mivcsj, syntype): only its label volume is needed -> label rule in the final epilogue
             only_labels = len(target_channels) == 1 and len(target_channels[0]) > 1
+            # the chunk grid (fit_box_size=True) overhangs the dataset: model tiles whose whole cropped result lies beyond the
+            # boundary (or in the halo ring that is cropped below) are not predicted -- zeros instead of the network's answer to
+            # a zero input, in a region nothing reads (config['dense_prediction']['skip_tiles_outside_dataset'])
+            vbox = None
+            if skip_outside:
+                c0 = np.asarray(ch.coordinates) - np.asarray(ol)                      # origin of chunk + halo, xyz
+                v_lo = np.maximum(np.asarray(ol), -c0)
+                v_hi = np.minimum(np.asarray(ol) + np.asarray(ch.size), np.asarray(kd.boundary) // mag - c0)
+                vbox = (tuple(int(v) for v in v_lo[::-1]), tuple(int(v) for v in v_hi[::-1]))
             if only_labels:
                 ids0 = target_channels[0]
                 thr0 = [_resolve_threshold(channel_thresholds[label]) for label in ids0]
-                pred_dev = predictor.predict_labels_u8_device(raw_dev, ids0, thr0)[None]   # (1, Z, Y, X) uint8 labels
+                pred_dev = predictor.predict_labels_u8_device(raw_dev, ids0, thr0, valid_box=vbox)[None]   # (1, Z, Y, X) uint8 labels
             else:
-                pred_dev = predictor.predict_proba_u8_device(raw_dev)                 # (C, Z, Y, X) uint8
+                pred_dev = predictor.predict_proba_u8_device(raw_dev, valid_box=vbox)   # (C, Z, Y, X) uint8
             # slice out the original input volume along ZYX (prediction.py:812)
             zyx = tuple(int(s) for s in np.asarray(ch.size)[::-1])
             crop = torch.empty((pred_dev.shape[0], *zyx), dtype=torch.uint8, device=dev)

@@ -219,6 +219,9 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
     finished.  While the GPUs predict round r, xGMI carries round r+1 in and round r-1 out, and rank 0's host packs
     round r+2 and stitches round r-1 (the host part needs an asynchronous `predict_fn`).  Without `pipelined` every
     round runs scatter -> predict -> gather -> stitch strictly in sequence (A/B and debugging).
+    A `predict_fn` that takes a keyword `valid_box` receives ((z0, y0, x0), (z1, y1, x1)), the part of the chunk PROPER that
+    lies inside the volume in chunk + halo coordinates (the chunk grid overhangs the volume; ``Predictor`` skips model tiles
+    whose result lies entirely beyond it).
     `trace`: optional list that receives ('scatter' | 'predict' | 'gather' | 'stitch', round) in ISSUE order (tests)."""
     import itertools
     import numpy as np
@@ -231,6 +234,18 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
     slot_of = {w: k for k, w in enumerate(workers)}              # rank -> position of its chunk in a round
     rounds = [ids[r0:r0 + nw] for r0 in range(0, len(ids), nw)]
     nr = len(rounds)
+    import inspect
+    try:
+        wants_box = 'valid_box' in inspect.signature(predict_fn).parameters
+    except (TypeError, ValueError):
+        wants_box = False
+
+    def valid_box_of(cid):
+        lo = np.asarray(cid, dtype=np.int64) * cs - ol            # origin of the chunk + halo box in the volume
+        a = np.maximum(ol, -lo)
+        b = np.minimum(ol + cs, vs - lo)
+        return tuple(int(v) for v in a), tuple(int(v) for v in b)
+
     in_shape = tuple(int(v) for v in cs + 2 * ol)
     out_shape = (n_out, *[int(c) for c in cs])
     cuda = device is not None and torch.device(device).type == 'cuda'
@@ -377,7 +392,10 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
             if cuda and r >= 2:          # res_buf[s] is free again: round r-2's gather (download for world size 1) has read it
                 cur.wait_event(ev_gath[s] if world > 1 else ev_d2h[s])
             if my_slot >= 0 and my_slot < len(rounds[r]):
-                res_buf[s].copy_(predict_fn(in_buf[s]))
+                if wants_box:
+                    res_buf[s].copy_(predict_fn(in_buf[s], valid_box=valid_box_of(rounds[r][my_slot])))
+                else:
+                    res_buf[s].copy_(predict_fn(in_buf[s]))
             else:
                 res_buf[s].zero_()
             if cuda:

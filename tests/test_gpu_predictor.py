@@ -498,3 +498,30 @@ def test_two_concurrent_workers_write_the_same_dataset_as_one(gpu, tmp_path, mon
         assert a.shape == b.shape and np.array_equal(a, b)
     assert outs[1][0].std() > 1.0
     global_params.wd = None
+
+
+def test_tiles_beyond_the_dataset_are_skipped_without_changing_the_inside(gpu):
+    """`valid_box` (prediction.py:679-683: the fit_box_size chunk grid overhangs the dataset, the reference predicts all of it):
+    tiles whose cropped result lies entirely outside the box are not predicted -- fewer launches, zeros there -- and every voxel
+    inside the box is bit-identical to the full prediction; a box that touches every tile changes nothing."""
+    from syconn_amd.handler.prediction import Predictor
+    model = build_unet('myelin', seed=2, n_blocks=3, start_filts=16, final_scale=4.0)
+    g = torch.Generator().manual_seed(11)
+    raw = torch.randint(0, 256, (24, 60, 64), dtype=torch.uint8, generator=g)
+    raw[:, 40:, :] = 0
+    raw[:, :, 45:] = 0                                   # (what kd.load_raw returns beyond the boundary)
+    kw = dict(strict_shapes=True, tile_shape=(12, 20, 16), out_shape=(2, 24, 60, 64), overlap_shape=(4, 6, 6), apply_softmax=True,
+              act_dtype='bf16', batch_size=5)
+    p = Predictor(model, **kw)
+    full = p.predict_proba_u8_device(raw.to(gpu)).cpu()
+    box = ((4, 6, 6), (24, 40, 45))                      # chunk proper inside the dataset, chunk + halo coordinates
+    part = p.predict_proba_u8_device(raw.to(gpu), valid_box=box).cpu()
+    (z0, y0, x0), (z1, y1, x1) = box
+    assert torch.equal(part[:, z0:z1, y0:y1, x0:x1], full[:, z0:z1, y0:y1, x0:x1])
+    assert int(part[:, :, 40:, :].max()) == 0 and int(part[:, :, :, 48:].max()) == 0      # tile rows y >= 40, columns x >= 48: skipped
+    assert int(full[:, :, 40:, :].max()) > 0
+    lab_full = p.predict_labels_u8_device(raw.to(gpu), [1], [100.0]).cpu()
+    lab_part = p.predict_labels_u8_device(raw.to(gpu), [1], [100.0], valid_box=box).cpu()
+    assert torch.equal(lab_part[z0:z1, y0:y1, x0:x1], lab_full[z0:z1, y0:y1, x0:x1])
+    same = p.predict_proba_u8_device(raw.to(gpu), valid_box=((0, 0, 0), (24, 60, 64))).cpu()
+    assert torch.equal(same, full)
