@@ -426,15 +426,24 @@ def dense_predictor(args):
         spent['read'] += _time.perf_counter() - t0
         return out_dev, ev
 
+    pin_pool = {}                        # page-locked download buffers by shape (a pageable D2H copy runs at a fraction of the link rate)
+
     def write_chunk(jobs, ev):
         t0 = _time.perf_counter()
         # download on the copy-out stream, from the writer thread: only waits for THIS chunk's kernels (event), not for the
         # next chunk's work that the main thread has queued on the compute stream meanwhile
+        host = []
         with torch.cuda.stream(s_out):
             s_out.wait_event(ev)
-            host = [(save, kwargs, lvl.cpu().numpy()) for save, kwargs, lvl in jobs]
-        for save, kwargs, data in host:
-            save(data=data.astype(np.uint64) if save.__name__ == 'save_seg' else data, **kwargs)
+            for save, kwargs, lvl in jobs:
+                free = pin_pool.setdefault(tuple(lvl.shape), [])
+                h = free.pop() if free else torch.empty(tuple(lvl.shape), dtype=lvl.dtype).pin_memory()
+                h.copy_(lvl, non_blocking=True)
+                host.append((save, kwargs, h))
+            s_out.synchronize()
+        for save, kwargs, h in host:
+            save(data=h.numpy(), **kwargs)       # (uint8 labels of an overlay dataset are widened cube by cube inside save_seg)
+            pin_pool[tuple(h.shape)].append(h)
         spent['write'] += _time.perf_counter() - t0
 
     class _Inline:                       # SYCONN_AMD_SEQ_IO=1: no overlap, everything in the caller's thread (debugging / A-B)

@@ -283,7 +283,9 @@ class KnossosDataset:
                 raise NotImplementedError('upsampling is not used by the dense path')
             r = mag // data_mag
             d = data if r == 1 else data[::r, ::r, ::r]      # order-0 ("fast") resampling
-            d = np.ascontiguousarray(d, dtype=dtype)
+            # (integer data keeps its own width here -- uint8 labels for a uint64 overlay dataset are widened cube by cube in the
+            # assignments below, not as one 8x larger temporary of the whole chunk)
+            d = np.asarray(d) if np.asarray(d).dtype.kind in 'ui' else np.ascontiguousarray(d, dtype=dtype)
             off = off1 // mag
             size = np.asarray(d.shape[::-1], dtype=np.int64)
             bnd = self._boundary // mag
