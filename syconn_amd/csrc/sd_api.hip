@@ -67,6 +67,7 @@ struct Op {
     bool gn_defer = false;       // groupnorm: statistics -> scale / shift only; every consumer of the buffer applies them itself
     size_t fwfrag_off = 0;             // fused final 1x1x1: hi/lo MFMA weight fragments
     float oscale = 1.f;                // split-fp16 plan: 2^-k, undoes the power of two the packed weights / bias of this layer carry
+    float final_oscale = 1.f;          //   ... and the one of the fused final layer's fragments
     bool skipped = false;  // op is executed inside its producer
     // up-convolution heading a fused level-0 decoder (sd_dec0.hip): indices of the merge conv and the second conv (whose
     // fuse_final names the final layer); those ops are `skipped` and their output buffers are never materialised
@@ -528,6 +529,43 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
     m->ws_base = WS_SCRATCH;
     // epilogue fusions (SD_NO_FUSE=1 keeps every layer a separate launch, for layer-wise debugging; the split-fp16 plan runs
     // every op as its own launch)
+    if (!getenv("SD_NO_FUSE") && split) {
+        // split-fp16 plan: the pooling behind a convolution runs in that convolution's epilogue (on the fp32 values, any sign)
+        for (size_t i = 0; i + 1 < m->ops.size(); ++i) {
+            Op& c = m->ops[i];
+            Op& nx = m->ops[i + 1];
+            if (c.d.kind == SD_OP_CONV && !c.first && nx.d.kind == SD_OP_POOL && nx.d.src0 == c.d.dst &&
+                (c.d.kz == 3) == (nx.d.kz == 2)) {
+                c.fuse_pool = (int)(i + 1);
+                nx.skipped = true;
+            } else if (c.d.kind == SD_OP_CONV && !c.first && c.d.kz == 1 && nx.d.kind == SD_OP_FINAL && nx.d.src0 == c.d.dst &&
+                       c.NB == 1 && i + 2 == m->ops.size() && !getenv("SD_SPLIT_NO_FINAL_FUSE")) {
+                // ... and the final 1x1x1 behind the last convolution: fp32 weights as scaled fp16 hi + lo fragments in MFMA
+                // A-fragment order (row = class (lane & 31), k-step s / element jj <-> channel j*32 + 8*(2s + (jj>>2)) + 4*(lane>>5) + (jj&3))
+                c.fuse_final = (int)(i + 1);
+                nx.skipped = true;
+                const sd_op_desc& fd = nx.d;
+                float mx = 0.f;
+                for (size_t k = 0; k < (size_t)fd.cout * fd.cin0; ++k) mx = std::max(mx, std::fabs(W[fd.w_off + k]));
+                float fscale = 1.f;
+                if (mx > 0.f && std::isfinite(mx)) fscale = std::ldexp(1.f, std::max(-60, std::min(60, 14 - std::ilogb(mx))));
+                c.final_oscale = 1.f / fscale;
+                c.fwfrag_off = blob_alloc((size_t)c.NT * 2 * 2 * 64 * 8 * 2);
+                uint16_t* fp = reinterpret_cast<uint16_t*>(blob.data() + c.fwfrag_off);
+                for (int j = 0; j < c.NT; ++j)
+                    for (int s2 = 0; s2 < 2; ++s2)
+                        for (int l = 0; l < 64; ++l)
+                            for (int jj = 0; jj < 8; ++jj) {
+                                const int co = l & 31, ch = j * 32 + 8 * (2 * s2 + (jj >> 2)) + 4 * (l >> 5) + (jj & 3);
+                                const float wv = (co < fd.cout && ch < fd.cin0) ? W[fd.w_off + (size_t)co * fd.cin0 + ch] * fscale : 0.f;
+                                const uint16_t hi = f2f16(wv);
+                                _Float16 h; std::memcpy(&h, &hi, 2);
+                                fp[((size_t)((j * 2 + s2) * 2 + 0) * 64 + l) * 8 + jj] = hi;
+                                fp[((size_t)((j * 2 + s2) * 2 + 1) * 64 + l) * 8 + jj] = f2f16(wv - (float)h);
+                            }
+            }
+        }
+    }
     if (!getenv("SD_NO_FUSE") && !split) {
         // first conv (1 -> 32, 1x3x3) -> conv (1x3x3) of one input: the second conv computes its halo of the first conv's
         // output on the fly (decided per launch: only the resident-weight form of the kernel can do it)
@@ -910,6 +948,7 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
                     p.final_wfrag = m->dev_blob + op.fwfrag_off;
                     p.final_b = reinterpret_cast<const float*>(m->dev_blob + fo.bias_off);
                     p.final_cout = fo.d.cout; p.final_kind = out_kind; p.final_out = out_dev;
+                    p.final_oscale = op.final_oscale;
                     p.ovf = m->dev_ovf;
                     if (lab) p.lab = *lab;
                     p.store_main = m->keep_all ? 1 : 0;

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     // Wlo.Xhi + Whi.Xhi + Whi.Xlo with fp32 accumulation: the chunk list of an n-chunk input is the 3n VIRTUAL chunks
     // [hi | hi | lo] of the same tensor (p.nchunk0 / p.nchunk1 count virtual chunks, the host packs the weight groups in that
     // order), so the stage loop is the one of the plain form run over three times the chunks.  The epilogue splits the fp32
-    // results into hi / lo planes again.  No fused pooling / final layer / GroupNorm statistics in this form.
+    // results into hi / lo planes again (and can pool them: fused MaxPool3d; or feed a fused final 1x1x1 layer).  No GroupNorm statistics here.
     constexpr bool SP = MODE == 3;
     static_assert(!SP || std::is_same<T, f16_t>::value, "split plan: fp16 planes");
     // register diet for the forms with >= 96 accumulator registers: nothing that can be recomputed per chunk stays live
@@ -841,31 +841,125 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     SD_T(4);   // all stages done
     if constexpr (SP) {
         // ---- epilogue of the split-fp16 form: undo the weight scale, ReLU in fp32, hi = fp16(v), lo = fp16(v - hi); the hi tile
-        // goes to chunk plane (channel / 16), the lo tile Cd / 16 planes further
+        // goes to chunk plane (channel / 16), the lo tile Cd / 16 planes further.  Fused MaxPool3d(ceil_mode): the window maximum
+        // of the fp32 values ((kz,2,2) window = {z pair of tiles (3D)} x {lane^16 (y)} x {lane^1 (x)}; voxels beyond the volume
+        // count as -inf), split like every other value -- exactly what the separate pooling pass computes from the stored pairs.
         T* const dsts = reinterpret_cast<T*>(reinterpret_cast<char*>(p.dst) + (size_t)tn * p.tstride);
         T* const dstl = dsts + (size_t)(p.Cd >> 4) * p.Pd * SD_CHUNK;
+        T* const pdsts = reinterpret_cast<T*>(reinterpret_cast<char*>(p.pool_dst) + (size_t)tn * p.tstride);
+        T* const pdstl = pdsts + (size_t)(p.Cd >> 4) * p.Pp * SD_CHUNK;
         const float osc = p.oscale;
+        constexpr int NP = KZ == 3 ? 2 : 1;      // tiles per pooling window
+        static_assert(MT % NP == 0, "z pairs of tiles");
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int vz = z0 + tzs[i], vy = y0 + tys[i] + dy, vx = x0 + dxl;
-                const bool val = vz < p.D && vy < p.H && vx < p.W;
-                const size_t vo = (size_t)(vz * p.H + vy) * p.W + vx;
-                unsigned ph[8], pl[8];
+            for (int ip = 0; ip < MT; ip += NP) {
+                bool vals[NP];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    float a = acc[i][j][2 * k] * osc, b = acc[i][j][2 * k + 1] * osc;
-                    if (p.relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
-                    split_pk(a, b, ph[k], pl[k]);
-                    sguard.see_signed(ph[k]);
+                for (int e2 = 0; e2 < NP; ++e2) {
+                    const int i = ip + e2;
+                    const int vz = z0 + tzs[i], vy = y0 + tys[i] + dy, vx = x0 + dxl;
+                    const bool val = vz < p.D && vy < p.H && vx < p.W;
+                    const size_t vo = (size_t)(vz * p.H + vy) * p.W + vx;
+                    vals[e2] = val;
+                    if (p.store_main) {
+                        unsigned ph[8], pl[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            float a = acc[i][j][2 * k] * osc, b = acc[i][j][2 * k + 1] * osc;
+                            if (p.relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+                            split_pk(a, b, ph[k], pl[k]);
+                            sguard.see_signed(ph[k]);
+                        }
+                        store_tile_rows_pk<T>(ph, dsts, p.Pd, vo, val, (nb * NT + j) * 32, half, p.Cd);
+                        store_tile_rows_pk<T>(pl, dstl, p.Pd, vo, val, (nb * NT + j) * 32, half, p.Cd);
+                    }
                 }
-                store_tile_rows_pk<T>(ph, dsts, p.Pd, vo, val, (nb * NT + j) * 32, half, p.Cd);
-                store_tile_rows_pk<T>(pl, dstl, p.Pd, vo, val, (nb * NT + j) * 32, half, p.Cd);
+                if (p.pool_dst) {      // (values recomputed from the accumulators pair by pair: nothing extra stays live)
+                    unsigned ph[8], pl[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        float a = -INFINITY, b = -INFINITY;
+#pragma unroll
+                        for (int e2 = 0; e2 < NP; ++e2) {
+                            float ae = acc[ip + e2][j][2 * k] * osc, be = acc[ip + e2][j][2 * k + 1] * osc;
+                            if (p.relu) { ae = fmaxf(ae, 0.f); be = fmaxf(be, 0.f); }
+                            a = fmaxf(a, vals[e2] ? ae : -INFINITY);
+                            b = fmaxf(b, vals[e2] ? be : -INFINITY);
+                        }
+                        a = max_xor16(max_xor1(a));
+                        b = max_xor16(max_xor1(b));
+                        split_pk(a, b, ph[k], pl[k]);      // (range guard: these are values the main store has already seen)
+                    }
+                    const int pz = (KZ == 3) ? (z0 + tzs[ip]) >> 1 : z0 + tzs[ip], py = (y0 + tys[ip]) >> 1, px = (x0 + dxl) >> 1;
+                    const size_t po = (size_t)(pz * p.pH + py) * p.pW + px;
+                    const bool writer = (dy == 0) && ((dxl & 1) == 0) && vals[0];
+                    store_tile_rows_pk<T>(ph, pdsts, p.Pp, po, writer, (nb * NT + j) * 32, half, p.Cd);
+                    store_tile_rows_pk<T>(pl, pdstl, p.Pp, po, writer, (nb * NT + j) * 32, half, p.Cd);
+                }
             }
             if constexpr (SPREAD) {      // (asymmetric epilogue, see the stage loop)
                 if (j == 0 && wave >= WAVES / 2 && !p.gn_sums) asm volatile("s_barrier" ::: "memory");
             }
+        }
+        // ---- fused conv_final (1x1x1) + softmax / uint8 / labels of the split plan: logits = W . (hi + lo) on the matrix core as
+        // Wlo.Xhi + Whi.Xlo + Whi.Xhi with the fp32 final weights as scaled fp16 hi / lo fragments (the layout of the fp16 plan's
+        // fused final layer: the B fragment of k-step s is the pair of packed quads (2s, 2s + 1) a lane holds); the output tensor
+        // of this convolution is then neither written nor read back
+        // (planar forms only -- every U-Net of the path ends in planar blocks -- so that the 3x3x3 forms do not carry its scalars)
+        if constexpr (MT == 2 && KZ == 1) {
+        if (p.final_wfrag) {
+            const FinalOut fo{p.final_out, p.out_tstride, p.final_cout, p.final_kind, (long)p.D * p.H * p.W, p.ovf};
+            typedef __attribute__((ext_vector_type(4))) unsigned u4;
+#pragma unroll
+            for (int tp = 0; tp < MT; tp += 2) {
+                f32x16 lgt[2];
+                bool vv[2];
+                size_t vo2[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int vz = z0 + tzs[tp + i], vy = y0 + tys[tp + i] + dy, vx = x0 + dxl;
+                    vv[i] = vz < p.D && vy < p.H && vx < p.W;
+                    vo2[i] = (size_t)(vz * p.H + vy) * p.W + vx;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) lgt[i][r] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        unsigned ph[8], pl[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            float a = acc[tp + i][j][2 * k] * osc, b = acc[tp + i][j][2 * k + 1] * osc;
+                            if (p.relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+                            split_pk(a, b, ph[k], pl[k]);
+                            sguard.see_signed(ph[k]);
+                        }
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            const v8 bh = __builtin_bit_cast(v8, u4{ph[4 * s2], ph[4 * s2 + 1], ph[4 * s2 + 2], ph[4 * s2 + 3]});
+                            const v8 bl = __builtin_bit_cast(v8, u4{pl[4 * s2], pl[4 * s2 + 1], pl[4 * s2 + 2], pl[4 * s2 + 3]});
+                            const v8 fw0 = *reinterpret_cast<const v8*>(fwl + (((j * 2 + s2) * 2 + 0) * 64 + lane) * 16);
+                            const v8 fw1 = *reinterpret_cast<const v8*>(fwl + (((j * 2 + s2) * 2 + 1) * 64 + lane) * 16);
+                            lgt[i] = Act<T>::mfma(fw1, bh, lgt[i]);
+                            lgt[i] = Act<T>::mfma(fw0, bl, lgt[i]);
+                            lgt[i] = Act<T>::mfma(fw0, bh, lgt[i]);
+                        }
+                    }
+                }
+                float l[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // (undo the weight scale and add the class bias by a compiler-visible VALU op in front of the asm swap)
+                    const float bmine = wl[NT * 32 + 4 * half + e];
+                    unsigned a = __builtin_bit_cast(unsigned, fmaf(lgt[0][e], p.final_oscale, bmine));
+                    unsigned b2 = __builtin_bit_cast(unsigned, fmaf(lgt[1][e], p.final_oscale, bmine));
+                    swap32(a, b2);      // lower lanes: all 8 logits of tile tp's voxel; upper lanes: tile tp + 1's
+                    l[e] = __builtin_bit_cast(float, a);
+                    l[4 + e] = __builtin_bit_cast(float, b2);
+                }
+                if (half ? vv[1] : vv[0]) final_finish_exact<T>(l, fo, p.lab, tn, half ? vo2[1] : vo2[0]);
+            }
+        }
         }
     } else if constexpr (MT == 4) {
         // ---- epilogue of the 4-tile form, one z-PAIR of tiles and one 32-channel group at a time (the packed values of

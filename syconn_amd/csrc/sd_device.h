@@ -205,6 +205,54 @@ __device__ __forceinline__ void range_guard(float v, int* flag) {
         if (!(fabsf(v) < 3.0e38f)) *flag = 1;
     }
 }
+// One voxel's class logits -> what the output kind asks for (softmax with full-precision expf and a true division, floor(255 p),
+// label rule) -> planar output.  The finishing step of the split-fp16 plan's final layer, fused (k_conv_mfma MODE 3) or not.
+struct FinalOut { void* out; size_t out_tstride; int cout, kind; long nvox; int* ovf; };
+template <typename T, typename LAB>
+__device__ __forceinline__ void final_finish_exact(float (&l)[8], const FinalOut& f, const LAB& lab, int tile, size_t v) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int co = 0; co < 8; ++co)
+        if (co < f.cout) mx = fmaxf(mx, l[co]);
+    if (f.kind != 0 /* SD_OUT_LOGITS_F32 */) {
+        float sum = 0.f;
+#pragma unroll
+        for (int co = 0; co < 8; ++co) {
+            l[co] = co < f.cout ? expf(l[co] - mx) : 0.f;
+            sum += l[co];
+        }
+        if (!(fabsf(sum) < 3.0e38f)) *f.ovf = 1;
+#pragma unroll
+        for (int co = 0; co < 8; ++co) l[co] = l[co] / sum;
+    } else {
+        float c = 0.f;
+#pragma unroll
+        for (int co = 0; co < 8; ++co)
+            if (co < f.cout) c = fmaf(l[co], 0.f, c);
+        if (!(fabsf(c) < 3.0e38f)) *f.ovf = 1;
+    }
+    if (f.kind == 3 /* SD_OUT_LABELS_U8 */) {
+        uint8_t lb = 0;
+        for (int k = 0; k < lab.n; ++k) {
+            const int id = lab.ids[k];
+            float pv = 0.f;
+#pragma unroll
+            for (int co = 0; co < 8; ++co) pv = (co == id) ? l[co] : pv;
+            if ((int)(uint8_t)(pv * 255.f) >= lab.cuts[k]) lb = (uint8_t)id;
+        }
+        (reinterpret_cast<uint8_t*>(f.out) + (size_t)tile * f.out_tstride)[v] = lb;
+    } else if (f.kind == 2 /* SD_OUT_PROBS_U8 */) {
+        uint8_t* out = reinterpret_cast<uint8_t*>(f.out) + (size_t)tile * f.out_tstride;
+#pragma unroll
+        for (int co = 0; co < 8; ++co)
+            if (co < f.cout) out[(size_t)co * f.nvox + v] = (uint8_t)(l[co] * 255.f);
+    } else {
+        float* out = reinterpret_cast<float*>(reinterpret_cast<char*>(f.out) + (size_t)tile * f.out_tstride);
+#pragma unroll
+        for (int co = 0; co < 8; ++co)
+            if (co < f.cout) out[(size_t)co * f.nvox + v] = l[co];
+    }
+}
 template <typename T>
 __device__ __forceinline__ float logit_probe(const float (&l)[8], int ncls) {     // 0 iff all existing logits are finite
     float c = 0.f;

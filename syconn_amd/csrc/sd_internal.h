@@ -69,6 +69,7 @@ struct ConvParams {
     const float* gn0; const float* gn1; int gn_relu0, gn_relu1;
     int* ovf;          // fp16 range guard flag (sd_device.h: StoreGuard on every store, range_guard in the fused final layer)
     float oscale;      // split-fp16 plan (k_conv_mfma<..., MODE 3>): 2^-k, undoes the power-of-two scale of the packed weights / bias
+    float final_oscale;   // ... and the same for the fused final layer's hi / lo weight fragments
 };
 
 struct FirstParams {

@@ -249,8 +249,13 @@ __global__ __launch_bounds__(256) void k_upconv_mfma(const UpconvParams p) {
 // WL: the weight fragments of the workgroup's taps live in LDS (loaded once) and the workgroup is persistent over
 // voxel groups; blockIdx.y selects the (z-tap, y-tap) pair, so a workgroup needs NTAB*NCH KiB of weights.  Without
 // WL every wave re-reads all its weights from L2 for each 32 voxels, which bounds the 128 -> 64 channel up-convolution.
-template <typename T, int NCH, int NTAB, bool WL, bool GN>
+// SPLIT (split-fp16 plan): NCH counts the REAL input chunks n; the 2n planes [hi | lo] of the input stay in registers and meet the
+// 3n weight groups [lo | hi | hi] (virtual chunks [hi | hi | lo]); every output row is written twice, hi planes then lo planes.
+template <typename T, int NCH, int NTAB, bool WL, bool GN, bool SPLIT = false>
 __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
+    constexpr int NX = SPLIT ? 2 * NCH : NCH;      // activation planes held in registers
+    constexpr int NV = SPLIT ? 3 * NCH : NCH;      // weight groups per column tile
+    static_assert(!(SPLIT && GN), "split plan: no deferred GroupNorm");
     using v8 = typename Act<T>::v8;
     using v4 = typename Act<T>::v4;
     typedef __attribute__((ext_vector_type(4))) unsigned u4;
@@ -282,8 +287,8 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
     const int a_wg = WL ? (int)blockIdx.y : 0;
     if constexpr (WL) {
         const int first_blk = (a_wg * NTAB) >> 1, last_blk = (a_wg * NTAB + NTAB - 1) >> 1;
-        const int nbytes = (last_blk - first_blk + 1) * NCH * 2048;
-        const char* const wsrc = reinterpret_cast<const char*>(wp) + (size_t)first_blk * NCH * 2048;
+        const int nbytes = (last_blk - first_blk + 1) * NV * 2048;
+        const char* const wsrc = reinterpret_cast<const char*>(wp) + (size_t)first_blk * NV * 2048;
         for (int o = tid * 16; o < nbytes; o += 256 * 16)
             *reinterpret_cast<u4*>(smem + 4 * 32 * ROW + o) = *reinterpret_cast<const u4*>(wsrc + o);
         __syncthreads();
@@ -291,9 +296,9 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
     for (long m0 = ((long)blockIdx.x * 4 + wave) * 32; m0 < M; m0 += WL ? (long)gridDim.x * 128 : M) {
     const long m = m0 + vl;
     const bool mv = m < M;
-    v8 xf[NCH];
+    v8 xf[NX];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
+    for (int c = 0; c < NX; ++c) {
         v8 val = {};
         if (mv) val = *reinterpret_cast<const v8*>(src + ((size_t)c * M + m) * SD_CHUNK + half * 8);
         xf[c] = val;
@@ -322,20 +327,22 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
                 for (int e = 0; e < 4; ++e) acc[j][4 * q + e] = b[e];
             }
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
+        for (int c = 0; c < NV; ++c) {
 #pragma unroll
             for (int j = 0; j < NTAB; ++j) {
                 const int tl = ab * NTAB + j;             // global 32-column tile (n = tap*CD + co ordering)
                 v8 wf;
                 if constexpr (WL) {
                     const int tloc = ab * NTAB + j - 2 * ((ab0 * NTAB) >> 1);
-                    wf = *reinterpret_cast<const v8*>(wlds + ((((tloc >> 1) * NCH + c) * 2 + (tloc & 1)) * 64 + lane) * 16);
+                    wf = *reinterpret_cast<const v8*>(wlds + ((((tloc >> 1) * NV + c) * 2 + (tloc & 1)) * 64 + lane) * 16);
                 } else {
-                    wf = *reinterpret_cast<const v8*>(wp + ((((size_t)(tl >> 1) * NCH + c) * 2 + (tl & 1)) * 64 + lane) * 8);
+                    wf = *reinterpret_cast<const v8*>(wp + ((((size_t)(tl >> 1) * NV + c) * 2 + (tl & 1)) * 64 + lane) * 8);
                 }
-                acc[j] = Act<T>::mfma(wf, xf[c], acc[j]);
+                acc[j] = Act<T>::mfma(wf, xf[(SPLIT && c >= NCH) ? c - NCH : c], acc[j]);
             }
         }
+#pragma unroll
+        for (int pass = 0; pass < (SPLIT ? 2 : 1); ++pass) {      // (split plan: hi planes, then lo planes, through the same LDS tile)
         // accumulators -> rounded rows in the wave's LDS tile: voxel vl, columns 32j + 8q + 4*half + e
 #pragma unroll
         for (int j = 0; j < NTAB; ++j) {
@@ -345,10 +352,16 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v = acc[j][4 * q + e];
+                    if constexpr (SPLIT) v *= p.oscale;
                     if (p.relu) v = fmaxf(v, 0.f);
-                    o[e] = (T)v;
+                    if constexpr (SPLIT) {
+                        const T h = (T)v;
+                        o[e] = pass == 0 ? h : (T)(v - (float)h);
+                    } else {
+                        o[e] = (T)v;
+                    }
                 }
-                {
+                if (pass == 0) {
                     typedef __attribute__((ext_vector_type(2))) unsigned u2g;
                     const u2g ob = __builtin_bit_cast(u2g, o);
                     sguard.see_signed(ob.x); sguard.see_signed(ob.y);
@@ -382,8 +395,9 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
             if (okv[it & 1]) {
                 const size_t ov = ovv[it & 1] + tap;
                 const u4 val = *reinterpret_cast<const u4*>(tile + v * ROW + ((piece ^ (v & SWM)) * 16));
-                *reinterpret_cast<u4*>(dst + (((size_t)chunk * p.Pd + ov) * SD_CHUNK + hf * 8) * sizeof(T)) = val;
+                *reinterpret_cast<u4*>(dst + (((size_t)(chunk + pass * (CD / 16)) * p.Pd + ov) * SD_CHUNK + hf * 8) * sizeof(T)) = val;
             }
+        }
         }
     }
     }
@@ -1052,9 +1066,37 @@ static int launch_upconv_t(const UpconvParams& p, int NB, hipStream_t s) {
     return SD_LAUNCH_CHECK();
 }
 int launch_upconv(const UpconvParams& p, int act_dtype, int NB, hipStream_t s) {
-    if (act_dtype == SD_F16X2) {      // split-fp16 plan: the generic kernel over the 3n virtual chunks
+    if (act_dtype == SD_F16X2) {      // split-fp16 plan: row kernel for the full-resolution shapes, else the generic kernel (3n virtual chunks)
         const long M = (long)p.D * p.H * p.W;
         if (M >= (1l << 31) || p.gn) return SD_ERR_INVALID;
+        static const bool no_rows = getenv("SD_SPLIT_NO_ROWS") != nullptr;      // A/B switch
+        if (!no_rows && p.nchunk == 12 && p.Cd == 32) {       // 64 -> 32 channels (level 0)
+            dim3 grid((unsigned)((M + 127) / 128), 1, p.batch), block(256);
+            hipLaunchKernelGGL((k_upconv_rows<f16_t, 4, 2, false, false, true>), grid, block, 4 * 32 * 64 * 2, s, p);
+            return SD_LAUNCH_CHECK();
+        }
+        if (!no_rows && p.nchunk == 24 && p.Cd == 64) {       // 128 -> 64 channels: weights of one (z-tap, y-tap) pair in LDS, persistent
+            constexpr int NTAB = 4, NV = 24;
+            const size_t lds = 4 * 32 * 64 * NTAB + (size_t)(NTAB / 2) * NV * 2048;
+            auto kern = k_upconv_rows<f16_t, 8, NTAB, true, false, true>;
+            {
+                static std::mutex mu;
+                static LaunchCache cache[SD_MAX_DEVICES];
+                int dev = 0;
+                if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SD_MAX_DEVICES) return SD_ERR_HIP;
+                std::lock_guard<std::mutex> lock(mu);
+                if (lds > cache[dev].attr_set) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+                        hipSuccess) return SD_ERR_HIP;
+                    cache[dev].attr_set = lds;
+                }
+            }
+            const int per_cu = std::max(1, (int)(SD_LDS_BYTES / lds));
+            const long want = std::max(1L, (long)SD_NUM_CU * per_cu * 2 / (2 * p.kz * p.batch));     // ~2 rounds of workgroups
+            dim3 grid((unsigned)std::min((M + 127) / 128, want), 2 * p.kz, p.batch), block(256);
+            hipLaunchKernelGGL(kern, grid, block, lds, s, p);
+            return SD_LAUNCH_CHECK();
+        }
         dim3 grid((unsigned)((M + 255) / 256), NB, p.batch), block(256);
         hipLaunchKernelGGL((k_upconv_mfma<f16_t, false, true>), grid, block, 0, s, p);
         return SD_LAUNCH_CHECK();

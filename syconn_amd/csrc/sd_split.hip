@@ -23,14 +23,15 @@ int launch_conv_split_knt(const ConvParams& p, int NB, hipStream_t s) {
     const long vox = (long)p.D * p.H * p.W * p.batch;
     const int nstages = (p.nchunk0 + p.nchunk1) * KZ;
     const bool big = (vox / 512) * NB >= 512;      // the rules of launch_conv_knt (sd_kernels.hip) without the fused forms
+    const bool ff = p.final_wfrag != nullptr;
     if (big) {
-        if (conv_lds_bytes<KZ, NT, 8, 2, 2>(nstages) <= 96 * 1024) return launch_conv_k<T, KZ, NT, 8, 2, 2, 3>(p, NB, s);
+        if (conv_lds_bytes<KZ, NT, 8, 2, 2>(nstages, ff) <= 96 * 1024) return launch_conv_k<T, KZ, NT, 8, 2, 2, 3>(p, NB, s);
         if constexpr (KZ == 3 && NT == 2) {
-            if ((vox / 1024) * NB >= 256 && (p.D % 8 == 0 || p.D >= 96)) return launch_conv_k<T, KZ, NT, 8, 0, 4, 3>(p, NB, s);
+            if (!ff && (vox / 1024) * NB >= 256 && (p.D % 8 == 0 || p.D >= 96)) return launch_conv_k<T, KZ, NT, 8, 0, 4, 3>(p, NB, s);
         }
         return launch_conv_k<T, KZ, NT, 8, 0, 2, 3>(p, NB, s);
     }
-    if (conv_lds_bytes<KZ, NT, 4, 2, 2>(nstages) <= 80 * 1024) return launch_conv_k<T, KZ, NT, 4, 2, 2, 3>(p, NB, s);
+    if (conv_lds_bytes<KZ, NT, 4, 2, 2>(nstages, ff) <= 80 * 1024) return launch_conv_k<T, KZ, NT, 4, 2, 2, 3>(p, NB, s);
     return launch_conv_k<T, KZ, NT, 4, 0, 2, 3>(p, NB, s);
 }
 
@@ -263,7 +264,8 @@ __global__ __launch_bounds__(256) void k_read_buffer_split(const T* buf, int C, 
 }  // namespace
 
 int launch_conv_split(const ConvParams& p, int KZ, int NT, int NB, hipStream_t s) {
-    if (p.pool_dst || p.final_wfrag || p.gn_sums || p.first_in || p.gn0 || p.gn1) return SD_ERR_INVALID;     // no fused forms
+    if (p.pool_dir || p.gn_sums || p.first_in || p.gn0 || p.gn1) return SD_ERR_INVALID;     // fused: pooling and the final layer only
+    if (p.final_wfrag && KZ != 1) return SD_ERR_INVALID;                                   // ... the latter behind planar layers
     if (KZ == 3 && NT == 3) return launch_conv_split_knt<3, 3>(p, NB, s);
     if (KZ == 1 && NT == 3) return launch_conv_split_knt<1, 3>(p, NB, s);
     if (KZ == 3 && NT == 2) return launch_conv_split_knt<3, 2>(p, NB, s);

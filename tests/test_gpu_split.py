@@ -211,3 +211,30 @@ def test_config1_cnn3_through_the_default_predictor(gpu):
     d = np.abs(out.astype(np.int16) - g['out_u8'].astype(np.int16))
     assert d.max() <= 1 and (d > 0).mean() < 1e-4, (int(d.max()), float((d > 0).mean()))
     assert np.array_equal(out.argmax(0)[d.max(0) == 0], g['out_u8'].argmax(0)[d.max(0) == 0])
+
+
+def test_split_fusions_agree_with_the_layer_wise_split_plan(gpu, monkeypatch):
+    """The split plan's epilogue fusions -- MaxPool3d in the producing convolution (exact: the maximum of the same fp32 values)
+    and the final 1x1x1 as three fp16 MFMA products of scaled hi / lo weight fragments instead of an fp32 FMA chain -- against
+    the same plan with every op as its own launch (SD_NO_FUSE): pooled buffers bit-identical, logits within 2e-6 of the logit
+    range, uint8 probabilities within one level on a vanishing fraction of voxels."""
+    from syconn_amd import _lib as L
+    from syconn_amd.engine import DenseModel
+    for arch, shape in (('myelin', (6, 44, 70)), ('semseg_axon', (4, 33, 47)), ('mivcsj', (5, 36, 40))):
+        model = build_unet(arch, seed=4, final_scale=5.0)
+        raw = _input(shape, 6).to(gpu)
+        fused = DenseModel(model, act_dtype='f16x2', device=gpu)
+        a = fused.forward(raw, L.SD_OUT_LOGITS_F32).cpu()
+        au8 = fused.forward(raw, L.SD_OUT_PROBS_U8).cpu()
+        n_fused = fused.last_launch_count()
+        monkeypatch.setenv('SD_NO_FUSE', '1')
+        plain = DenseModel(model, act_dtype='f16x2', device=gpu)
+        monkeypatch.delenv('SD_NO_FUSE')
+        b = plain.forward(raw, L.SD_OUT_LOGITS_F32).cpu()
+        bu8 = plain.forward(raw, L.SD_OUT_PROBS_U8).cpu()
+        # (GroupNorm nets: a GroupNorm sits between every convolution and its pooling / the final layer -- nothing to fuse there)
+        assert n_fused < plain.last_launch_count() or arch == 'mivcsj', (arch, n_fused, plain.last_launch_count())
+        err = float((a - b).abs().max()) / float(b.abs().max())
+        d = (au8.int() - bu8.int()).abs()
+        assert err <= 2e-6, (arch, err)
+        assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 1e-3, (arch, int(d.max()))
