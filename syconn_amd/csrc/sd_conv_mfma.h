@@ -519,6 +519,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     }
 
     StoreGuard<T> sguard;      // fp16 range guard over everything this lane rounds to the storage type (sd_device.h)
+    // Static issue priority for the waves that run their tap loop FIRST in every stage (0 ... WAVES/2-1, also the older half of the
+    // workgroup): -0.8 % on the six 3x3x3 launches of the headline net, A/B on one box; the other half at priority 1 instead:
+    // +7 % (tools/experiments/round4_rejected.md).  Arithmetic untouched.
+#ifndef SD_PRIO
+#define SD_PRIO 2
+#endif
+    if constexpr (SPREAD && SD_PRIO != 0) {
+        if ((SD_PRIO == 1) == (wave >= WAVES / 2)) asm volatile("s_setprio 1");
+    }
     int gc = 0, gs = 0;   // chunk / stage counters across blocks (slot parity)
     int ph0 = 0;          // SPREAD: halo coordinates of this lane's first piece, packed z << 16 | y << 8 | x
     if constexpr (SPREAD) {
