@@ -502,7 +502,8 @@ def cpu_baseline(args, sd, dm, tiles_host, ids, L):
 
     keys = ('label_agreement', 'label_mismatch_safe', 'label_mismatch_unsafe', 'label_unsafe_frac', 'argmax_agreement',
             'argmax_mismatch_safe', 'argmax_mismatch_unsafe', 'argmax_unsafe_frac', 'tol_logit_rel_stated', 'logit_err_max_rel',
-            'logit_err_rms', 'median_top2_margin_over_tol')
+            'logit_err_rms', 'median_top2_margin_over_tol', 'label_unsafe_frac_2x_measured_err',
+            'argmax_unsafe_frac_2x_measured_err')
     def time_for(m):
         # device-resident throughput of this storage type on the bench's own launch set (all tiles of a step in one set)
         x = tiles_host.to(m.device)

@@ -32,12 +32,13 @@ from .predictor_ref import label_rule_ref
 # (fp32 accumulation everywhere; 'f32' = the fp32 FMA plan, which differs from torch-CPU by summation order only; 'f16x2' = the
 # split-fp16 reference-precision plan: values and weights carry 22+ mantissa bits, products lose a 2^-22 cross term)
 TOL_LOGIT_REL = {'bf16': 1e-2, 'f16': 1.3e-3, 'f16x2': 1e-5, 'f32': 2e-5}
-# the 5-level GroupNorm network (mivcsj: 26 stored layers, statistics over rounded tensors) is stated twice as wide
-TOL_LOGIT_REL_ARCH = {('mivcsj', 'bf16'): 2e-2, ('mivcsj', 'f16'): 2.5e-3}
+# (One constant per storage type, no per-architecture exceptions: the 5-level GroupNorm network mivcsj -- 26 stored layers, statistics
+# over rounded tensors -- measures 1.9e-3 in plain fp16, ABOVE the fp16 constant; its exactness claim is made where it holds, in the
+# reference-precision plan 'f16x2' (tests/test_gpu_split.py), and the fast plans only report and bound their agreement for it.)
 
 
 def stated_tolerance(arch: str, act: str) -> float:
-    return TOL_LOGIT_REL_ARCH.get((arch, act), TOL_LOGIT_REL[act])
+    return TOL_LOGIT_REL[act]
 
 
 def _cut(t: Optional[float]) -> float:
@@ -86,7 +87,18 @@ def label_split(ref_logits: torch.Tensor, gpu_logits: torch.Tensor, gpu_probs: t
         lo, hi = _shift_prob(ref_p[i], -tol_l) * 255.0 - ulp, _shift_prob(ref_p[i], tol_l) * 255.0 + ulp
         safe_t &= (lo >= cut) | (hi < cut)
     mis_t = gpu_labels.cpu().to(torch.uint8) != ref_lab
+    # the same margins measured A POSTERIORI with twice the error this comparison observed (reporting only: how much of the a-priori
+    # unsafe set is really at risk -- by construction no mismatch can lie outside it)
+    tol_m = 2.0 * err_l
+    safe_a_m = margin > 2.0 * tol_m
+    safe_t_m = torch.ones_like(margin, dtype=torch.bool)
+    for i in ids:
+        cut = _cut(channel_thresholds[i])
+        lo, hi = _shift_prob(ref_p[i], -tol_m) * 255.0 - ulp, _shift_prob(ref_p[i], tol_m) * 255.0 + ulp
+        safe_t_m &= (lo >= cut) | (hi < cut)
     return {
+        'label_unsafe_frac_2x_measured_err': float((~safe_t_m).float().mean()),
+        'argmax_unsafe_frac_2x_measured_err': float((~safe_a_m).float().mean()),
         'voxels': n,
         'tol_logit_rel_stated': float(tol_logit_rel),
         'logit_err_max': err_l, 'logit_err_rms': rms_l, 'logit_err_max_rel': err_l / max(scale, 1e-30),
@@ -113,6 +125,7 @@ def merge_splits(parts: Sequence[Dict[str, float]]) -> Dict[str, float]:
         out[k] = float(np.median([p[k] for p in parts]))
     for k in ('argmax_mismatch_safe', 'argmax_mismatch_unsafe', 'label_mismatch_safe', 'label_mismatch_unsafe'):
         out[k] = int(sum(p[k] for p in parts))
-    for k in ('argmax_unsafe_frac', 'label_unsafe_frac', 'label_agreement', 'argmax_agreement'):
+    for k in ('argmax_unsafe_frac', 'label_unsafe_frac', 'label_agreement', 'argmax_agreement', 'label_unsafe_frac_2x_measured_err',
+              'argmax_unsafe_frac_2x_measured_err'):
         out[k] = float(sum(p[k] * p['voxels'] for p in parts) / n)
     return out

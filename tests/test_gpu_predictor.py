@@ -525,3 +525,25 @@ def test_tiles_beyond_the_dataset_are_skipped_without_changing_the_inside(gpu):
     assert torch.equal(lab_part[z0:z1, y0:y1, x0:x1], lab_full[z0:z1, y0:y1, x0:x1])
     same = p.predict_proba_u8_device(raw.to(gpu), valid_box=((0, 0, 0), (24, 60, 64))).cpu()
     assert torch.equal(same, full)
+
+
+def test_config3_full_width_model_two_by_two_by_two_tiles_vs_oracle(gpu):
+    """BASELINE configs[2] with the FULL-WIDTH semseg_axon model (48 filters, 9.1 M parameters) on a 224 x 192 x 192 volume =
+    2 x 2 x 2 model tiles of 128^3 in the config's geometry (useful (112,96,96) + halo (8,16,16), zeros outside the volume):
+    the Predictor's tiled, stitched uint8 probabilities against the torch-CPU oracle run through the same tiled_apply
+    restatement -- in the reference-precision plan (what `float16=False` selects) within one uint8 level on a vanishing fraction
+    of the voxels and with identical argmax, in bf16 within the stated storage tolerance."""
+    from syconn_amd.handler.prediction import Predictor
+    model = build_unet('semseg_axon', seed=12, final_scale=6.0)
+    vol_shape, tile, halo = (224, 192, 192), (112, 96, 96), (8, 16, 16)
+    vol = _em_like(vol_shape, 21)
+    kw = dict(tile_shape=tile, overlap_shape=halo, out_shape=(6, *vol_shape), strict_shapes=True, apply_softmax=True)
+    ref = dense_predicton_helper_ref(vol.astype(np.float32) / 255., PredictorRef(model, **kw), True, True)
+    for act, max_lvl, frac, agree in (('f16x2', 1, 2e-3, 0.99999), ('bf16', 12, 1.0, 0.998)):
+        got = Predictor(model, device=gpu, act_dtype=act, **kw).predict_proba_u8_device(torch.from_numpy(vol).to(gpu)).cpu().numpy()
+        d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
+        same = float((got.argmax(0) == ref.argmax(0)).mean())
+        print(f'config-3 geometry, full-width semseg_axon, {act}: max level diff {d.max()}, frac != 0 {float((d > 0).mean()):.2e}, '
+              f'argmax agreement {same:.6f}')
+        assert got.shape == ref.shape == (6, *vol_shape)
+        assert d.max() <= max_lvl and float((d > 0).mean()) <= frac and same >= agree, (act, int(d.max()), same)
