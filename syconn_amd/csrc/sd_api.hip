@@ -530,7 +530,21 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
     // epilogue fusions (SD_NO_FUSE=1 keeps every layer a separate launch, for layer-wise debugging; the split-fp16 plan runs
     // every op as its own launch)
     if (!getenv("SD_NO_FUSE") && split) {
-        // split-fp16 plan: the pooling behind a convolution runs in that convolution's epilogue (on the fp32 values, any sign)
+        // split-fp16 plan: first conv (1 -> 32, 1x3x3) -> conv (1x3x3) of one input: the second conv computes the hi / lo halo
+        // planes of the first conv's output itself (k_conv_mfma MODE 4; decided per launch)
+        for (size_t i = 0; i + 1 < m->ops.size(); ++i) {
+            Op& f = m->ops[i];
+            Op& c = m->ops[i + 1];
+            if (f.d.kind == SD_OP_CONV && f.first && f.d.kz == 1 && m->bufCp[f.d.dst] == 32 && f.d.cout == 32 &&
+                c.d.kind == SD_OP_CONV && !c.first && c.d.kz == 1 && c.d.src0 == f.d.dst && c.d.src1 < 0 &&
+                !getenv("SD_NO_FIRST_FUSE")) {
+                bool other_reader = false;
+                for (size_t k = i + 2; k < m->ops.size(); ++k)
+                    if (m->ops[k].d.src0 == f.d.dst || m->ops[k].d.src1 == f.d.dst) other_reader = true;
+                if (!other_reader) c.fuse_first = (int)i;
+            }
+        }
+        // ... the pooling behind a convolution runs in that convolution's epilogue (on the fp32 values, any sign)
         for (size_t i = 0; i + 1 < m->ops.size(); ++i) {
             Op& c = m->ops[i];
             Op& nx = m->ops[i + 1];
@@ -899,9 +913,10 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
             bool first_fused_into_next = false;
             if (op.first && i + 1 < m->ops.size() && m->ops[i + 1].fuse_first == (int)i && !m->keep_all) {
                 const Op& c = m->ops[i + 1];
-                const int nst = (m->bufCp[c.d.src0] / SD_CHUNK) * c.d.kz;
-                first_fused_into_next = conv_can_fuse_first(c.d.kz, c.NT, c.NB, (long)o.d * o.h * o.w * N, nst,
-                                                            c.fuse_final >= 0);
+                const int nst = (m->bufCp[c.d.src0] / SD_CHUNK) * c.d.kz * (m->split ? 3 : 1);
+                first_fused_into_next = m->split
+                    ? conv_can_fuse_first_split(c.d.kz, c.NT, c.NB, (long)o.d * o.h * o.w * N, nst, c.fuse_final >= 0)
+                    : conv_can_fuse_first(c.d.kz, c.NT, c.NB, (long)o.d * o.h * o.w * N, nst, c.fuse_final >= 0);
             }
             if (first_fused_into_next) {
                 // computed inside the next convolution
@@ -954,8 +969,10 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
                     p.store_main = m->keep_all ? 1 : 0;
                 }
                 if (op.fuse_first >= 0 && !m->keep_all &&
-                    conv_can_fuse_first(d.kz, op.NT, op.NB, (long)o.d * o.h * o.w * N, (p.nchunk0 + p.nchunk1) * d.kz,
-                                        op.fuse_final >= 0)) {
+                    (m->split ? conv_can_fuse_first_split(d.kz, op.NT, op.NB, (long)o.d * o.h * o.w * N, (p.nchunk0 + p.nchunk1) * d.kz,
+                                                          op.fuse_final >= 0)
+                              : conv_can_fuse_first(d.kz, op.NT, op.NB, (long)o.d * o.h * o.w * N, (p.nchunk0 + p.nchunk1) * d.kz,
+                                                    op.fuse_final >= 0))) {
                     const Op& fo = m->ops[op.fuse_first];
                     p.first_in = in_dev; p.first_in_tstride = in_tstride; p.first_in_f32 = in_dtype == SD_F32 ? 1 : 0;
                     p.first_w = reinterpret_cast<const float*>(m->dev_blob + fo.wpack_off);

@@ -150,7 +150,7 @@ constexpr int dma_count(int w, int waves, int a_instr, int j0, int j1) {
 }
 template <typename T, int KZ, int NT, int WAVES, int NSLOT, int MT, int MODE>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(const ConvParams p) {
-    constexpr bool FF = MODE == 1, GN = MODE == 2;
+    constexpr bool FF = MODE == 1 || MODE == 4, GN = MODE == 2;
     // MODE 3 (SP, split-fp16 plan = act_dtype SD_F16X2): every tensor is stored as TWO fp16 planes per channel, x = hi + lo (hi =
     // fp16(x), lo = fp16(x - hi): 22 mantissa bits), as 2n chunks [n hi chunks | n lo chunks]; the weights are split the same
     // way (times a power of two per layer that keeps the lo parts normal; undone by p.oscale).  A product is computed as
@@ -158,7 +158,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     // [hi | hi | lo] of the same tensor (p.nchunk0 / p.nchunk1 count virtual chunks, the host packs the weight groups in that
     // order), so the stage loop is the one of the plain form run over three times the chunks.  The epilogue splits the fp32
     // results into hi / lo planes again (and can pool them: fused MaxPool3d; or feed a fused final 1x1x1 layer).  No GroupNorm statistics here.
-    constexpr bool SP = MODE == 3;
+    // MODE 4 = SP + FF: the split plan's first convolution (1 -> 32 channels) computed inside its consumer: its four halo planes
+    // [hi0, hi1, lo0, lo1] are produced straight into FOUR resident LDS slots and the six virtual chunks [hi0, hi1, hi0, hi1, lo0,
+    // lo1] of the block run on them -- the level-0 tensor behind the first convolution (268 MB per 128^3 tile as hi / lo planes)
+    // is neither written nor read, and this convolution issues no halo DMA at all.
+    constexpr bool SP = MODE == 3 || MODE == 4;
     static_assert(!SP || std::is_same<T, f16_t>::value, "split plan: fp16 planes");
     // register diet for the forms with >= 96 accumulator registers: nothing that can be recomputed per chunk stays live
     // across the block loop (DMA source addresses, halo-piece decode table)
@@ -545,7 +549,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
             // block are COMPUTED from the uint8 / float input tile instead of DMA'd from a materialised tensor (which
             // is never written).  Same arithmetic as k_conv_first: float32(v)/255 by IEEE division, the 9 taps as the
             // k dimension of exact-f32 32x32x2 MFMAs, bias after the chain, ReLU, rounding -- bit-identical values.
-            static_assert(!FF || (KZ == 1 && WRES && NA == 2), "fused first conv: planar, resident weights");
+            static_assert(!FF || (KZ == 1 && WRES && NA == (SP ? 4 : 2)), "fused first conv: planar, resident weights");
             constexpr int PXW = HX + 2, NSTEP1 = 5;
             const float* const fp = fpatch + (round & 1) * FNP;      // parked by the prologue / during the previous block
             float w1[NSTEP1];
@@ -573,6 +577,24 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                     a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[st], fp[base + toff1[st]], a1, 0, 0, 0);
                 const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
                 const bool invol = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;     // z0 < D always
+                if constexpr (SP) {
+                    if (hv < NH) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {      // channels 8q + 4*half + 0..3: chunk q >> 1, 16-byte half q & 1 of the record
+                            float v0 = a1[4 * q] + b1[q][0], v1 = a1[4 * q + 1] + b1[q][1], v2 = a1[4 * q + 2] + b1[q][2], v3 = a1[4 * q + 3] + b1[q][3];
+                            if (p.first_relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                            unsigned h01, l01, h23, l23;
+                            split_pk(v0, v1, h01, l01);
+                            split_pk(v2, v3, h23, l23);
+                            sguard.see_signed(h01); sguard.see_signed(h23);
+                            if (!invol) { h01 = 0u; l01 = 0u; h23 = 0u; l23 = 0u; }      // the second conv's zero padding
+                            typedef __attribute__((ext_vector_type(2))) unsigned u2;
+                            const int ro = hv * 32 + ((((q & 1) ^ (hy & 1))) << 4) + half * 8;
+                            *reinterpret_cast<u2*>(ldsA + (q >> 1) * A_BYTES + ro) = u2{h01, h23};           // slots 0, 1: hi planes
+                            *reinterpret_cast<u2*>(ldsA + (2 + (q >> 1)) * A_BYTES + ro) = u2{l01, l23};     // slots 2, 3: lo planes
+                        }
+                    }
+                } else
                 if (hv < NH) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -606,7 +628,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
 #endif
         int s = 0;
         for (int c = 0; c < nchunks; ++c, ++gc) {
-            const char* const abuf = ldsA + (gc % NA) * A_BYTES;
+            // (split plan with the first convolution inside: the planes live in fixed slots [hi0, hi1, lo0, lo1])
+            const char* const abuf = ldsA + ((SP && FF) ? (c < 4 ? (c & 1) : c - 2) : (gc % NA)) * A_BYTES;
             // SPREAD: the chunk fetched during this chunk's stages (the next chunk of this block, or the first chunk of the
             // workgroup's next block); everything a piece needs is pinned in scalar registers here -- a kernel-argument
             // s_load inside the tap loop would count on lgkmcnt and break the counted LDS waits
@@ -1355,7 +1378,7 @@ static size_t conv_lds_bytes(int nstages, bool fuse_final = false) {
 template <typename T, int KZ, int NT, int WAVES, int NSLOT, int MT = 2, int MODE = 0>
 static int launch_conv_k(ConvParams p, int NB, hipStream_t s) {
     using G = ConvGeo<KZ, WAVES, MT>;
-    constexpr bool FF = MODE == 1;
+    constexpr bool FF = MODE == 1 || MODE == 4;
     const size_t lds = conv_lds_bytes<KZ, NT, WAVES, MT, NSLOT>((p.nchunk0 + p.nchunk1) * KZ, p.final_wfrag != nullptr) +
                        (FF ? (size_t)2 * (G::BY + 4) * (G::BX + 4) * 4 + (5 * 64 + 32) * 4 : 0) +
                        (MODE == 2 ? (size_t)p.batch * conv_gn_lds_per_tile(p.nchunk0 + p.nchunk1) : 0);

@@ -201,6 +201,7 @@ int launch_labels(const uint8_t* probs, size_t nvox, const LabelArgs& a, void* o
 int launch_read_buffer(const void* buf, int act_dtype, int C, int Cs, int D, int H, int W, float* out, hipStream_t s);
 // split-fp16 plan (sd_split.hip; act_dtype SD_F16X2): a tensor of C (padded) channels = 2 * C / 16 fp16 chunk planes [hi | lo]
 int launch_conv_split(const ConvParams& p, int KZ, int NT, int NB, hipStream_t s);
+bool conv_can_fuse_first_split(int KZ, int NT, int NB, long vox_all_tiles, int nstages, bool fused_final);
 int launch_pool_split(const PoolParams& p, hipStream_t s);
 int launch_final_split(const FinalParams& p, hipStream_t s);
 int launch_groupnorm_split(const GnParams& p, hipStream_t s);

@@ -263,8 +263,21 @@ __global__ __launch_bounds__(256) void k_read_buffer_split(const T* buf, int C, 
 
 }  // namespace
 
+// the split plan's first convolution (1 -> 32 channels, planar) can run inside its consumer (k_conv_mfma MODE 4): one 16-channel-
+// pair input (six virtual chunks), NT = 1, enough blocks for persistent 512-voxel workgroups, LDS for 4 plane slots + resident weights
+bool conv_can_fuse_first_split(int KZ, int NT, int NB, long vox, int nstages, bool fused_final) {
+    if (KZ != 1 || NT != 1 || NB != 1 || nstages != 6) return false;
+    if ((vox / 512) * NB < 512) return false;
+    return conv_lds_bytes<1, 1, 8, 2, 4>(nstages, fused_final) + 2 * 36 * 20 * 4 + 352 * 4 <= (size_t)SD_LDS_BYTES;
+}
+
 int launch_conv_split(const ConvParams& p, int KZ, int NT, int NB, hipStream_t s) {
-    if (p.pool_dir || p.gn_sums || p.first_in || p.gn0 || p.gn1) return SD_ERR_INVALID;     // fused: pooling and the final layer only
+    if (p.pool_dir || p.gn_sums || p.gn0 || p.gn1) return SD_ERR_INVALID;     // fused: pooling, the final layer, the first convolution
+    if (p.first_in) {
+        if (!conv_can_fuse_first_split(KZ, NT, NB, (long)p.D * p.H * p.W * p.batch, (p.nchunk0 + p.nchunk1) * KZ, p.final_wfrag != nullptr))
+            return SD_ERR_INVALID;
+        return launch_conv_k<T, 1, 1, 8, 4, 2, 4>(p, NB, s);
+    }
     if (p.final_wfrag && KZ != 1) return SD_ERR_INVALID;                                   // ... the latter behind planar layers
     if (KZ == 3 && NT == 3) return launch_conv_split_knt<3, 3>(p, NB, s);
     if (KZ == 1 && NT == 3) return launch_conv_split_knt<1, 3>(p, NB, s);
