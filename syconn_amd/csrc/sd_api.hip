@@ -544,6 +544,28 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
                 if (!other_reader) c.fuse_first = (int)i;
             }
         }
+        // a GroupNorm whose only reader is the final layer: statistics -> scale / shift table only, k_final_split applies them (+ReLU)
+        // in fp32 on the exact values it reads anyway -- the normalised tensor is neither written nor re-read
+        if (!getenv("SD_NO_GN_DEFER") && !m->keep_all) {
+            for (size_t i = 0; i < m->ops.size(); ++i) {
+                Op& g = m->ops[i];
+                if (g.d.kind != SD_OP_GROUPNORM) continue;
+                const int b = g.d.src0;
+                bool ok = true, any = false;
+                for (size_t k = i + 1; k < m->ops.size(); ++k) {
+                    const Op& r = m->ops[k];
+                    if (r.d.src0 != b && r.d.src1 != b) continue;
+                    any = true;
+                    if (r.d.kind != SD_OP_FINAL) ok = false;
+                }
+                if (ok && any) { g.gn_defer = true; m->buf_gn[b] = (int)i; }
+            }
+            for (int b = 1; b < m->nbuf; ++b)
+                if (m->buf_gn[b] >= 0) {
+                    m->gn_tab_off[b] = m->ws_base;
+                    m->ws_base += rup_sz((size_t)2 * m->bufCp[b] * 4, 256);
+                }
+        }
         // ... the pooling behind a convolution runs in that convolution's epilogue (on the fp32 values, any sign)
         for (size_t i = 0; i + 1 < m->ops.size(); ++i) {
             Op& c = m->ops[i];

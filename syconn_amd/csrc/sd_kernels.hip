@@ -1075,25 +1075,28 @@ int launch_upconv(const UpconvParams& p, int act_dtype, int NB, hipStream_t s) {
             hipLaunchKernelGGL((k_upconv_rows<f16_t, 4, 2, false, false, true>), grid, block, 4 * 32 * 64 * 2, s, p);
             return SD_LAUNCH_CHECK();
         }
-        if (!no_rows && p.nchunk == 24 && p.Cd == 64) {       // 128 -> 64 channels: weights of one (z-tap, y-tap) pair in LDS, persistent
-            constexpr int NTAB = 4, NV = 24;
-            const size_t lds = 4 * 32 * 64 * NTAB + (size_t)(NTAB / 2) * NV * 2048;
-            auto kern = k_upconv_rows<f16_t, 8, NTAB, true, false, true>;
-            {
-                static std::mutex mu;
-                static LaunchCache cache[SD_MAX_DEVICES];
-                int dev = 0;
-                if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SD_MAX_DEVICES) return SD_ERR_HIP;
-                std::lock_guard<std::mutex> lock(mu);
-                if (lds > cache[dev].attr_set) {
-                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-                        hipSuccess) return SD_ERR_HIP;
-                    cache[dev].attr_set = lds;
-                }
-            }
+        // the other row-kernel shapes: weights of one (z-tap, y-tap) pair in LDS, persistent (the forms of launch_upconv_rows_wl)
+        auto rows_wl = [&](auto kern, int NTAB, int NV) -> int {
+            const size_t lds = (size_t)4 * 32 * 64 * NTAB + (size_t)(NTAB / 2 + 2 * (NTAB & 1)) * NV * 2048;
+            if (lds > (size_t)SD_LDS_BYTES) return SD_ERR_INVALID;
+            // (one attribute call per launch: the shapes are few and the call is cheap next to a launch of this size)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return SD_ERR_HIP;
             const int per_cu = std::max(1, (int)(SD_LDS_BYTES / lds));
             const long want = std::max(1L, (long)SD_NUM_CU * per_cu * 2 / (2 * p.kz * p.batch));     // ~2 rounds of workgroups
             dim3 grid((unsigned)std::min((M + 127) / 128, want), 2 * p.kz, p.batch), block(256);
+            hipLaunchKernelGGL(kern, grid, block, lds, s, p);
+            return SD_LAUNCH_CHECK();
+        };
+        if (!no_rows && p.nchunk == 24 && p.Cd == 64) return rows_wl(k_upconv_rows<f16_t, 8, 4, true, false, true>, 4, 24);     // 128 -> 64
+        if (!no_rows && p.nchunk == 18 && p.Cd == 48) return rows_wl(k_upconv_rows<f16_t, 6, 3, true, false, true>, 3, 18);     // 96 -> 48
+        // (192 -> 96 channels: 36 weight groups per column tile do not fit the LDS beside the transpose tiles: weights from L2)
+        if (!no_rows && p.nchunk == 36 && p.Cd == 96 && !getenv("SD_SPLIT_NO_ROWS96")) {
+            auto kern = k_upconv_rows<f16_t, 12, 6, false, false, true>;
+            const size_t lds = (size_t)4 * 32 * 64 * 6;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return SD_ERR_HIP;
+            dim3 grid((unsigned)((M + 127) / 128), 1, p.batch), block(256);
             hipLaunchKernelGGL(kern, grid, block, lds, s, p);
             return SD_LAUNCH_CHECK();
         }

@@ -303,11 +303,12 @@ int launch_final_split(const FinalParams& p, hipStream_t s) {
 int launch_groupnorm_split(const GnParams& p, hipStream_t s) {
     const int ng = p.C / 8;
     const long nvox = (long)p.D * p.H * p.W;
-    if (nvox * ng >= (1l << 32) || p.pool_dst || p.skip_stats || p.skip_apply) return SD_ERR_INVALID;
+    if (nvox * ng >= (1l << 32) || p.pool_dst || p.skip_stats) return SD_ERR_INVALID;
     hipLaunchKernelGGL(k_gn_stats_split, dim3(grid_for(nvox, 256 * 16, 1024), p.C / SD_CHUNK, p.batch), dim3(256), 0, s, p);
     const int rc = launch_gn_finalize(p, s);
     if (rc != SD_OK) return rc;
-    hipLaunchKernelGGL(k_gn_apply_split, dim3(grid_for(nvox * ng), 1, p.batch), dim3(256), 0, s, p);
+    if (!p.skip_apply)      // (deferred: the only reader, the final layer, applies scale / shift itself)
+        hipLaunchKernelGGL(k_gn_apply_split, dim3(grid_for(nvox * ng), 1, p.batch), dim3(256), 0, s, p);
     return SD_LAUNCH_CHECK();
 }
 
