@@ -91,6 +91,11 @@ def layer_accounting(ops, L, D, H, W, act_bytes=2, out_bytes_per_class=1, batch=
                         and lds + 36 * 20 * 4 <= 96 * 1024):
                     name = name[:-1] + ',FF>'
                     fused_first.add(io - 1)
+                elif (prev is not None and prev.kind == L.SD_OP_CONV and prev.src0 == 0 and prev.kz == 1 and prev.cout == 48
+                        and o.kz == 1 and o.src0 == prev.dst and o.src1 < 0 and nt == 2 and nstages == 3 and waves == 8
+                        and not os.environ.get('SD_NO_FIRST_FUSE48')):      # 48 filters: three resident halo slots
+                    name = 'k_conv_mfma<1x3x3,NT=2,8 waves,NSLOT=3,FF>'
+                    fused_first.add(io - 1)
             rows.append((name, flops, inb + vox * o.cout * act_bytes))
             dims[o.dst], chans[o.dst] = d, o.cout
         elif o.kind == L.SD_OP_POOL:

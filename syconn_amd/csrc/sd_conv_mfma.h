@@ -497,11 +497,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     };
     // first-conv weight fragments and bias live in LDS as well: an ordinary global load inside the block loop would make
     // the wave wait (vmcnt, in order) for the previous block's output stores
-    float* const ffw = fpatch + 2 * FNP;                      // [5 k-steps][64 lanes] + [32] bias
+    // NF1 = 32-channel tiles of the first convolution: 1 (32 filters; also the split plan), 2 (48 filters: three halo chunks, NA = 3)
+    constexpr int NF1 = (FF && !SP && NA == 3) ? 2 : 1;
+    float* const ffw = fpatch + 2 * FNP;                      // [NF1][5 k-steps][64 lanes] + [NF1 * 32] bias
     if constexpr (FF) {
         patch_fetch(z0, y0, x0, tn);
         patch_park(0);
-        for (int i = tid; i < 5 * 64 + 32; i += WAVES * 64) ffw[i] = i < 320 ? p.first_w[i] : p.first_bias[i - 320];
+        for (int i = tid; i < NF1 * (5 * 64 + 32); i += WAVES * 64) ffw[i] = i < NF1 * 320 ? p.first_w[i] : p.first_bias[i - NF1 * 320];
     }
     if (WRES) {
         for (int s = 0; s < nstages; ++s) dma_weights(s, s);
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
             // block are COMPUTED from the uint8 / float input tile instead of DMA'd from a materialised tensor (which
             // is never written).  Same arithmetic as k_conv_first: float32(v)/255 by IEEE division, the 9 taps as the
             // k dimension of exact-f32 32x32x2 MFMAs, bias after the chain, ReLU, rounding -- bit-identical values.
-            static_assert(!FF || (KZ == 1 && WRES && NA == (SP ? 4 : 2)), "fused first conv: planar, resident weights");
+            static_assert(!FF || (KZ == 1 && WRES && (SP ? NA == 4 : (NA == 2 || NA == 3))), "fused first conv: planar, resident weights");
             constexpr int PXW = HX + 2, NSTEP1 = 5;
             const float* const fp = fpatch + (round & 1) * FNP;      // parked by the prologue / during the previous block
             float w1[NSTEP1];
@@ -563,12 +565,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
             }
             f32x4 b1[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) b1[q] = *reinterpret_cast<const f32x4*>(ffw + 320 + 8 * q + 4 * half);
+            for (int q = 0; q < 4; ++q) b1[q] = *reinterpret_cast<const f32x4*>(ffw + NF1 * 320 + 8 * q + 4 * half);
             for (int t = wave; t * 32 < NH; t += WAVES) {
                 const int hv = t * 32 + (lane & 31);
                 const int hvc = hv < NH ? hv : NH - 1;
                 const int hy = hvc / HX, hx = hvc % HX;
                 const int base = hy * PXW + hx;
+#pragma unroll
+                for (int ft = 0; ft < NF1; ++ft) {      // (48 filters: channels 0-31, then 32-47 + padding; fragments re-read per tile)
+                if constexpr (NF1 > 1) {
+#pragma unroll
+                    for (int st = 0; st < NSTEP1; ++st) w1[st] = ffw[(ft * NSTEP1 + st) * 64 + lane];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) b1[q] = *reinterpret_cast<const f32x4*>(ffw + NF1 * 320 + ft * 32 + 8 * q + 4 * half);
+                }
                 f32x16 a1;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a1[r] = 0.f;
@@ -604,9 +614,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                         sguard.see_signed(lo); sguard.see_signed(hi);
                         if (!invol) { lo = 0u; hi = 0u; }      // the second conv's zero padding
                         typedef __attribute__((ext_vector_type(2))) unsigned u2;
-                        char* const slot = ldsA + ((gc + (q >> 1)) % NA) * A_BYTES;
+                        if (NF1 > 1 && 2 * ft + (q >> 1) >= NA) continue;      // (the padding chunk of a 48-filter first conv)
+                        char* const slot = ldsA + ((gc + 2 * ft + (q >> 1)) % NA) * A_BYTES;
                         *reinterpret_cast<u2*>(slot + hv * 32 + ((((q & 1) ^ (hy & 1))) << 4) + half * 8) = u2{lo, hi};
                     }
+                }
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1380,7 +1392,7 @@ static int launch_conv_k(ConvParams p, int NB, hipStream_t s) {
     using G = ConvGeo<KZ, WAVES, MT>;
     constexpr bool FF = MODE == 1 || MODE == 4;
     const size_t lds = conv_lds_bytes<KZ, NT, WAVES, MT, NSLOT>((p.nchunk0 + p.nchunk1) * KZ, p.final_wfrag != nullptr) +
-                       (FF ? (size_t)2 * (G::BY + 4) * (G::BX + 4) * 4 + (5 * 64 + 32) * 4 : 0) +
+                       (FF ? (size_t)2 * (G::BY + 4) * (G::BX + 4) * 4 + (size_t)(MODE == 1 && NSLOT == 3 ? 2 : 1) * (5 * 64 + 32) * 4 : 0) +
                        (MODE == 2 ? (size_t)p.batch * conv_gn_lds_per_tile(p.nchunk0 + p.nchunk1) : 0);
     if (lds > (size_t)SD_LDS_BYTES) return SD_ERR_INVALID;
     p.nbx = (p.W + G::BX - 1) / G::BX; p.nby = (p.H + G::BY - 1) / G::BY; p.nbz = (p.D + G::BZ - 1) / G::BZ;

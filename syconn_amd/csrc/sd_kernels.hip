@@ -899,8 +899,11 @@ __global__ __launch_bounds__(256) void k_read_buffer(const T* buf, int C, int Cs
 // launchers
 
 bool conv_can_fuse_first(int KZ, int NT, int NB, long vox, int nstages, bool fused_final) {
-    if (KZ != 1 || NT > 2 || nstages != 2) return false;
+    if (KZ != 1 || NT > 2 || (nstages != 2 && !(nstages == 3 && NT == 2))) return false;
     if ((vox / 512) * NB < 512) return false;                                   // the `big` rule of launch_conv_knt
+    if (nstages == 3)      // 48 filters: three resident halo slots; the resident-weight form of this layer holds one workgroup per CU already
+        return getenv("SD_NO_FIRST_FUSE48") == nullptr &&
+               conv_lds_bytes<1, 2, 8, 2, 3>(nstages, fused_final) + 2 * 36 * 20 * 4 + 2 * 352 * 4 <= (size_t)SD_LDS_BYTES;
     const size_t lds = NT == 1 ? conv_lds_bytes<1, 1, 8, 2, 2>(nstages, fused_final) : conv_lds_bytes<1, 2, 8, 2, 2>(nstages, fused_final);
     return lds + 2 * 36 * 20 * 4 + 352 * 4 <= 96 * 1024;
 }
@@ -920,6 +923,9 @@ static int launch_conv_knt(const ConvParams& p, int NB, hipStream_t s) {
     if constexpr (KZ == 1 && NT <= 2) {
         if (p.first_in) {
             if (!conv_can_fuse_first(KZ, NT, NB, vox, nstages, p.final_wfrag != nullptr)) return SD_ERR_INVALID;
+            if constexpr (NT == 2) {
+                if (nstages == 3) return launch_conv_k<T, KZ, NT, 8, 3, 2, 1>(p, NB, s);
+            }
             return launch_conv_k<T, KZ, NT, 8, 2, 2, 1>(p, NB, s);
         }
     } else if (p.first_in) {

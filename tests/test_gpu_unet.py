@@ -345,7 +345,9 @@ def test_fused_first_conv_is_bit_identical(gpu, monkeypatch):
     exercise the zero padding of both convolutions, two tiles the batched path."""
     from syconn_amd import _lib as L
     from syconn_amd.engine import DenseModel
-    for arch, shape in (('semseg_spine', (12, 150, 170)), ('myelin', (9, 131, 77)), ('syntype', (16, 128, 144))):
+    # (semseg_axon / er: the 48-filter family -- a two-tile first convolution into three resident halo slots, round 4)
+    for arch, shape in (('semseg_spine', (12, 150, 170)), ('myelin', (9, 131, 77)), ('syntype', (16, 128, 144)),
+                        ('semseg_axon', (10, 140, 150)), ('er', (12, 150, 170))):
         model = build_unet(arch, seed=31, final_scale=4.0)
         raw = _input((2, *shape), 8).to(gpu)
         monkeypatch.setenv('SD_NO_FIRST_FUSE', '1')
