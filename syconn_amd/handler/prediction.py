@@ -411,18 +411,32 @@ def dense_predictor(args):
     import time as _time
     spent = {'read': 0.0, 'gpu': 0.0, 'write': 0.0}       # seconds per pipeline stage (SYCONN_AMD_IO_TIMING=1 logs them)
 
+    read_bufs = {}
+
     def read_chunk(ch_id):
         t0 = _time.perf_counter()
         ch = cd.chunk_dict[ch_id]
         ol = ch.overlap
         size = np.array(np.array(ch.size) + 2 * np.array(ol), dtype=np.int32)
         coords = np.array(np.array(ch.coordinates) - np.array(ol), dtype=np.int32)
-        out = np.ascontiguousarray(kd.load_raw(size=size * mag, offset=coords * mag, mag=mag))     # uint8, ZYX
-        # upload from the reader thread on the copy-in stream: the (pageable) host-to-device copy of chunk k+1 runs beside the
-        # kernels of chunk k instead of in front of them
+        # page-locked read buffers, reused round robin (3: one being filled, one uploading, one spare): a fresh 80 MB array per
+        # chunk costs its page faults, and a pageable upload runs at a fraction of the link rate
+        shape_zyx = tuple(int(s) for s in size[::-1])
+        if read_bufs.get('shape') != shape_zyx:
+            read_bufs.update(shape=shape_zyx, bufs=[torch.empty(shape_zyx, dtype=torch.uint8).pin_memory() for _ in range(3)], evs=[None] * 3, k=0)
+        k = read_bufs['k'] % 3
+        read_bufs['k'] += 1
+        if read_bufs['evs'][k] is not None:
+            read_bufs['evs'][k].synchronize()            # its previous upload has left the buffer
+        hbuf = read_bufs['bufs'][k]
+        if isinstance(kd, KnossosDataset):
+            kd.load_raw(size=size * mag, offset=coords * mag, mag=mag, out=hbuf.numpy())          # uint8, ZYX
+        else:                                            # (a foreign dataset object: its own allocation, then one copy)
+            hbuf.numpy()[...] = kd.load_raw(size=size * mag, offset=coords * mag, mag=mag)
         with torch.cuda.stream(s_in):
-            out_dev = torch.from_numpy(out).to(dev)
+            out_dev = hbuf.to(dev, non_blocking=True)
             ev = s_in.record_event()
+        read_bufs['evs'][k] = ev
         spent['read'] += _time.perf_counter() - t0
         return out_dev, ev
 

@@ -240,10 +240,14 @@ class KnossosDataset:
         cube.tofile(tmp)
         os.replace(tmp, fn)
 
-    def _load(self, size, offset, mag: int, ext: str, dtype) -> np.ndarray:
+    def _load(self, size, offset, mag: int, ext: str, dtype, out: Optional[np.ndarray] = None) -> np.ndarray:
         size = np.asarray(size, dtype=np.int64) // mag
         off = np.asarray(offset, dtype=np.int64) // mag
-        out = np.zeros(tuple(size[::-1]), dtype=dtype)   # z,y,x
+        if out is None:
+            out = np.zeros(tuple(size[::-1]), dtype=dtype)   # z,y,x
+        else:                                             # caller-owned (e.g. page-locked) buffer, reused chunk after chunk
+            assert tuple(out.shape) == tuple(size[::-1]) and out.dtype == np.dtype(dtype) and out.flags.c_contiguous
+            out.fill(0)
         cs = np.asarray(self._cube_shape, dtype=np.int64)
         bnd = self._boundary // mag
         lo = np.maximum(off, 0)
@@ -266,8 +270,9 @@ class KnossosDataset:
                                           range(c_lo[2], c_hi[2] + 1)))
         return out
 
-    def load_raw(self, size, offset, mag: int = 1, **_) -> np.ndarray:
-        return self._load(size, offset, mag, 'raw', np.uint8)
+    def load_raw(self, size, offset, mag: int = 1, out: Optional[np.ndarray] = None, **_) -> np.ndarray:
+        """`out` (extension): a C-contiguous uint8 (z,y,x) array of the result's shape to fill instead of a fresh allocation."""
+        return self._load(size, offset, mag, 'raw', np.uint8, out=out)
 
     def load_seg(self, size, offset, mag: int = 1, **_) -> np.ndarray:
         return self._load(size, offset, mag, 'seg.sz', np.uint64)
@@ -333,6 +338,26 @@ class KnossosDataset:
         self._wc = collections.OrderedDict()
         self._wc_max = max(4, int(max_cubes))
         self._wc_mutex = threading.Lock()
+        # written-out cube buffers are kept and re-zeroed for the next cube: a fresh 16 - 134 MB array per cube is a fresh mmap
+        # whose first touch costs more (page faults) than the copy into it
+        self._wc_free = {}
+
+    def _wc_buffer(self, shape, dtype):
+        key = (tuple(shape), np.dtype(dtype).str)
+        with self._wc_mutex:
+            free = self._wc_free.get(key)
+            buf = free.pop() if free else None
+        if buf is None:
+            return np.zeros(shape, dtype=dtype)
+        buf.fill(0)
+        return buf
+
+    def _wc_recycle(self, buf):
+        key = (tuple(buf.shape), buf.dtype.str)
+        with self._wc_mutex:
+            free = self._wc_free.setdefault(key, [])
+            if len(free) < 8:
+                free.append(buf)
 
     def _wc_add(self, key, fn, dtype, shape, dst, block, need):
         import threading
@@ -355,7 +380,7 @@ class KnossosDataset:
                 if ent['dead']:                   # evicted / completed by another thread between the lookup and here: start over
                     continue
                 if ent['cube'] is None:
-                    ent['cube'] = np.zeros(shape, dtype=dtype)
+                    ent['cube'] = self._wc_buffer(shape, dtype)
                 ent['cube'][dst] = block
                 ent['boxes'].append(dst)
                 ent['have'] += int(block.size)
@@ -374,6 +399,8 @@ class KnossosDataset:
             if disjoint:                          # nobody else writes into this cube: one write, no read
                 with _cube_lock(done['fn']):
                     self._write_cube(done['fn'], done['ext'], done['cube'])
+                self._wc_recycle(done['cube'])
+                done['cube'] = None
             else:
                 self._wc_merge(done, locked=True)
             return
@@ -394,6 +421,8 @@ class KnossosDataset:
                 for box in ent['boxes']:
                     cube[box] = ent['cube'][box]
             self._write_cube(ent['fn'], ent['ext'], cube)
+        self._wc_recycle(ent['cube'])
+        ent['cube'] = None
 
     def flush(self):
         """Write out every partially assembled cube (no-op without write combining)."""
