@@ -544,6 +544,16 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
                 if (!other_reader) c.fuse_first = (int)i;
             }
         }
+        // GroupNorm (whole buffer) directly followed by the pooling of its output: one pass
+        for (size_t i = 0; i + 1 < m->ops.size(); ++i) {
+            Op& g = m->ops[i];
+            Op& nx = m->ops[i + 1];
+            if (g.d.kind == SD_OP_GROUPNORM && g.d.src1 < 0 && nx.d.kind == SD_OP_POOL && nx.d.src0 == g.d.src0 &&
+                !getenv("SD_NO_GN_FUSE")) {
+                g.gn_pool = (int)(i + 1);
+                nx.skipped = true;
+            }
+        }
         // a GroupNorm whose only reader is the final layer: statistics -> scale / shift table only, k_final_split applies them (+ReLU)
         // in fp32 on the exact values it reads anyway -- the normalised tensor is neither written nor re-read
         if (!getenv("SD_NO_GN_DEFER") && !m->keep_all) {
@@ -570,6 +580,13 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
         for (size_t i = 0; i + 1 < m->ops.size(); ++i) {
             Op& c = m->ops[i];
             Op& nx = m->ops[i + 1];
+            // GroupNorm right behind a conv over the conv's whole output: statistics in the conv epilogue
+            if (c.d.kind == SD_OP_CONV && !c.first && nx.d.kind == SD_OP_GROUPNORM && nx.d.src0 == c.d.dst && nx.d.src1 < 0 &&
+                !getenv("SD_NO_GN_FUSE")) {
+                c.fuse_gn = (int)(i + 1);
+                nx.stats_done = true;
+                continue;
+            }
             if (c.d.kind == SD_OP_CONV && !c.first && nx.d.kind == SD_OP_POOL && nx.d.src0 == c.d.dst &&
                 (c.d.kz == 3) == (nx.d.kz == 2)) {
                 c.fuse_pool = (int)(i + 1);

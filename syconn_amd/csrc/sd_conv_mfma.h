@@ -895,8 +895,25 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         const float osc = p.oscale;
         constexpr int NP = KZ == 3 ? 2 : 1;      // tiles per pooling window
         static_assert(MT % NP == 0, "z pairs of tiles");
+        // fused GroupNorm statistics (the scheme of the other forms: the matrix core transposes a tile -- packed tile as A operand x
+        // 0/1 selector -- so that a lane holds 16 voxels of ONE channel; here hi and lo tiles go through the same accumulator, which
+        // then holds the exact fp32 values hi + lo)
+        // (not in the 4-wave streamed NT = 3 form: 254 VGPRs without it; the launcher picks the 8-wave form for such a layer)
+        constexpr bool GNS = !(KZ == 3 && NT == 3 && WAVES == 4 && !WRES);
+        const bool gns = GNS && p.gn_sums != nullptr;
+        float* const part = reinterpret_cast<float*>(ldsA + ((gc - 1) % NA) * A_BYTES);   // free: last chunk's halo slot
+        v8 s1, s2;
+        if (gns) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = 8 * (e >> 2) + 4 * half + (e & 3);
+                s1[e] = (T)((c == (lane & 31)) ? 1.0f : 0.0f);
+                s2[e] = (T)((c + 16 == (lane & 31)) ? 1.0f : 0.0f);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
+            float sj = 0.f, ssj = 0.f;
 #pragma unroll
             for (int ip = 0; ip < MT; ip += NP) {
                 bool vals[NP];
@@ -918,6 +935,23 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                         }
                         store_tile_rows_pk<T>(ph, dsts, p.Pd, vo, val, (nb * NT + j) * 32, half, p.Cd);
                         store_tile_rows_pk<T>(pl, dstl, p.Pd, vo, val, (nb * NT + j) * 32, half, p.Cd);
+                        if (gns) {
+                            typedef __attribute__((ext_vector_type(4))) unsigned u4;
+                            unsigned zr = 0u;
+                            asm volatile("" : "+v"(zr));
+                            u4 h0 = {ph[0], ph[1], ph[2], ph[3]}, h1 = {ph[4], ph[5], ph[6], ph[7]};
+                            u4 l0 = {pl[0], pl[1], pl[2], pl[3]}, l1 = {pl[4], pl[5], pl[6], pl[7]};
+                            if (!val) { h0 = u4{zr, zr, zr, zr}; h1 = h0; l0 = h0; l1 = h0; }
+                            f32x16 d;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) d[r] = 0.f;
+                            d = Act<T>::mfma(__builtin_bit_cast(v8, l0), s1, d);
+                            d = Act<T>::mfma(__builtin_bit_cast(v8, l1), s2, d);
+                            d = Act<T>::mfma(__builtin_bit_cast(v8, h0), s1, d);
+                            d = Act<T>::mfma(__builtin_bit_cast(v8, h1), s2, d);
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) { sj += d[r]; ssj = fmaf(d[r], d[r], ssj); }
+                        }
                     }
                 }
                 if (p.pool_dst) {      // (values recomputed from the accumulators pair by pair: nothing extra stays live)
@@ -943,9 +977,26 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                     store_tile_rows_pk<T>(pl, pdstl, p.Pp, po, writer, (nb * NT + j) * 32, half, p.Cd);
                 }
             }
+            if (gns) {
+                float* const q = part + ((size_t)(wave * 2 + half) * (NT * 32) + j * 32 + (lane & 31)) * 2;
+                q[0] = sj; q[1] = ssj;
+            }
             if constexpr (SPREAD) {      // (asymmetric epilogue, see the stage loop)
                 if (j == 0 && wave >= WAVES / 2 && !p.gn_sums) asm volatile("s_barrier" ::: "memory");
             }
+        }
+        if (gns) {      // waves and half-waves combined in a fixed order, one double atomic per channel and statistic per block
+            __syncthreads();
+            if (tid < NT * 64) {
+                const int stat = tid / (NT * 32), cw = tid % (NT * 32);
+                double t = 0.0;
+                for (int w = 0; w < WAVES * 2; ++w) t += (double)part[((size_t)w * (NT * 32) + cw) * 2 + stat];
+                const int ch = nb * NT * 32 + cw;
+                if (ch < p.Cd)
+                    atomicAdd(reinterpret_cast<double*>(reinterpret_cast<char*>(p.gn_sums) + (size_t)tn * p.tstride) +
+                                  (size_t)stat * p.gn_C + ch, t);
+            }
+            __syncthreads();         // the slot is a DMA target again in the next block
         }
         // ---- fused conv_final (1x1x1) + softmax / uint8 / labels of the split plan: logits = W . (hi + lo) on the matrix core as
         // Wlo.Xhi + Whi.Xlo + Whi.Xhi with the fp32 final weights as scaled fp16 hi / lo fragments (the layout of the fp16 plan's

@@ -32,6 +32,9 @@ int launch_conv_split_knt(const ConvParams& p, int NB, hipStream_t s) {
         return launch_conv_k<T, KZ, NT, 8, 0, 2, 3>(p, NB, s);
     }
     if (conv_lds_bytes<KZ, NT, 4, 2, 2>(nstages, ff) <= 80 * 1024) return launch_conv_k<T, KZ, NT, 4, 2, 2, 3>(p, NB, s);
+    if constexpr (KZ == 3 && NT == 3) {      // (the 4-wave streamed form of this shape has no room for the fused GroupNorm statistics)
+        if (p.gn_sums) return launch_conv_k<T, KZ, NT, 8, 0, 2, 3>(p, NB, s);
+    }
     return launch_conv_k<T, KZ, NT, 4, 0, 2, 3>(p, NB, s);
 }
 
@@ -250,6 +253,62 @@ __global__ __launch_bounds__(256) void k_gn_apply_split(const GnParams p) {
     }
 }
 
+// GroupNorm apply + ReLU with the following MaxPool3d(ceil_mode) fused: one thread per POOLED voxel and 8-channel group normalises
+// the (pkz,2,2) window in place (exact values, fp32, re-split) and writes the window maximum -- the separate pooling pass would
+// read the whole normalised tensor again
+__global__ __launch_bounds__(256) void k_gn_apply_pool_split(const GnParams p) {
+    const int ng = p.C / 8;
+    const long total = (long)p.pD * p.pH * p.pW * ng;
+    T* const buf = reinterpret_cast<T*>(reinterpret_cast<char*>(p.buf) + blockIdx.z * p.tstride);
+    T* const pdst = reinterpret_cast<T*>(reinterpret_cast<char*>(p.pool_dst) + blockIdx.z * p.tstride);
+    const size_t blo = (size_t)(p.C >> 4) * p.P * SD_CHUNK;
+    const long npv = (long)p.pD * p.pH * p.pW;
+    const size_t plo = (size_t)(p.C >> 4) * npv * SD_CHUNK;
+    const float* const scale_shift = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.scale_shift) + blockIdx.z * p.tstride);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const unsigned pv = (unsigned)(idx >> 1), ch = pv / (unsigned)npv;  // (chunk, pooled voxel, half)
+        const long v = pv - ch * (unsigned)npv;
+        const int cg = (int)ch * 2 + (int)(idx & 1);
+        int xo, yo, zo;
+        decode_zyx((unsigned)v, (unsigned)p.pW, (unsigned)p.pH, xo, yo, zo);
+        float sc[8], sh[8], mx[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = scale_shift[cg * 8 + e]; sh[e] = scale_shift[p.C + cg * 8 + e]; mx[e] = -INFINITY; }
+        for (int dz = 0; dz < p.pkz; ++dz) {
+            const int z = zo * p.pkz + dz;
+            if (z >= p.D) continue;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                const int y = yo * 2 + dy;
+                if (y >= p.H) continue;
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int x = xo * 2 + dx;
+                    if (x >= p.W) continue;
+                    T* const q = buf + ((size_t)(cg >> 1) * p.P + ((size_t)z * p.Hs + y) * p.Ws + x) * SD_CHUNK + (cg & 1) * 8;
+                    float f[8];
+                    join8(*reinterpret_cast<const v8*>(q), *reinterpret_cast<const v8*>(q + blo), f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        f[e] = fmaf(f[e], sc[e], sh[e]);
+                        if (p.relu) f[e] = fmaxf(f[e], 0.f);
+                        mx[e] = fmaxf(mx[e], f[e]);
+                    }
+                    v8 h, l;
+                    split8(f, h, l);
+                    *reinterpret_cast<v8*>(q) = h;
+                    *reinterpret_cast<v8*>(q + blo) = l;
+                }
+            }
+        }
+        v8 h, l;
+        split8(mx, h, l);
+        T* const o = pdst + ((size_t)(cg >> 1) * npv + v) * SD_CHUNK + (cg & 1) * 8;
+        *reinterpret_cast<v8*>(o) = h;
+        *reinterpret_cast<v8*>(o + plo) = l;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_read_buffer_split(const T* buf, int C, int Cs, long nvox, float* out) {
     const long total = nvox * C;
     const size_t blo = (size_t)(Cs >> 4) * nvox * SD_CHUNK;
@@ -272,7 +331,7 @@ bool conv_can_fuse_first_split(int KZ, int NT, int NB, long vox, int nstages, bo
 }
 
 int launch_conv_split(const ConvParams& p, int KZ, int NT, int NB, hipStream_t s) {
-    if (p.pool_dir || p.gn_sums || p.gn0 || p.gn1) return SD_ERR_INVALID;     // fused: pooling, the final layer, the first convolution
+    if (p.pool_dir || p.gn0 || p.gn1) return SD_ERR_INVALID;     // fused: pooling, final layer, first convolution, GroupNorm statistics
     if (p.first_in) {
         if (!conv_can_fuse_first_split(KZ, NT, NB, (long)p.D * p.H * p.W * p.batch, (p.nchunk0 + p.nchunk1) * KZ, p.final_wfrag != nullptr))
             return SD_ERR_INVALID;
@@ -303,11 +362,14 @@ int launch_final_split(const FinalParams& p, hipStream_t s) {
 int launch_groupnorm_split(const GnParams& p, hipStream_t s) {
     const int ng = p.C / 8;
     const long nvox = (long)p.D * p.H * p.W;
-    if (nvox * ng >= (1l << 32) || p.pool_dst || p.skip_stats) return SD_ERR_INVALID;
-    hipLaunchKernelGGL(k_gn_stats_split, dim3(grid_for(nvox, 256 * 16, 1024), p.C / SD_CHUNK, p.batch), dim3(256), 0, s, p);
+    if (nvox * ng >= (1l << 32) || (p.pool_dst && (p.skip_apply || p.no_inplace))) return SD_ERR_INVALID;
+    if (!p.skip_stats)      // (else: accumulated by the producing convolution's epilogue)
+        hipLaunchKernelGGL(k_gn_stats_split, dim3(grid_for(nvox, 256 * 16, 1024), p.C / SD_CHUNK, p.batch), dim3(256), 0, s, p);
     const int rc = launch_gn_finalize(p, s);
     if (rc != SD_OK) return rc;
-    if (!p.skip_apply)      // (deferred: the only reader, the final layer, applies scale / shift itself)
+    if (p.pool_dst)         // apply + the pooling behind it in one pass
+        hipLaunchKernelGGL(k_gn_apply_pool_split, dim3(grid_for((long)p.pD * p.pH * p.pW * ng), 1, p.batch), dim3(256), 0, s, p);
+    else if (!p.skip_apply)      // (deferred: the only reader, the final layer, applies scale / shift itself)
         hipLaunchKernelGGL(k_gn_apply_split, dim3(grid_for(nvox * ng), 1, p.batch), dim3(256), 0, s, p);
     return SD_LAUNCH_CHECK();
 }

