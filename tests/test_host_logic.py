@@ -229,3 +229,106 @@ def test_random_state_dict_loads_into_oracle_and_plans_identically():
         ops_b, blob_b, info_b = plan_from_model(m)
         assert len(ops_a) == len(ops_b) and info_a == info_b and np.array_equal(blob_a, blob_b)
         assert all(bytes(a) == bytes(b) for a, b in zip(ops_a, ops_b))
+
+
+# ---- round 4 -----------------------------------------------------------------------------------------------------------
+def test_config_defaults_select_reference_precision_and_tile_skipping():
+    """`dense_prediction.act_dtype` defaults to the reference-precision plan ('f16x2' = what the reference's float16=False
+    means, prediction.py:777-779); the fast plans are an explicit choice; tiles beyond the dataset are skipped by default."""
+    from syconn_amd.handler.config import DEFAULTS
+    from syconn_amd.handler.prediction import _ACT_NAMES, _FALLBACK
+    assert DEFAULTS['dense_prediction']['act_dtype'] == 'f16x2'
+    assert DEFAULTS['dense_prediction']['skip_tiles_outside_dataset'] is True
+    assert _FALLBACK == {'f16': 'bf16', 'f16x2': 'f32'} and _ACT_NAMES['split'] == 'f16x2'
+
+
+def test_worker_script_reads_a_stream_of_pickles(tmp_path):
+    """batchjob_predict_dense.py's input contract (batchjob_utils.py:227-232): back-to-back pickles, one per tuple element."""
+    import pickle
+    from syconn_amd.batchjob_scripts.batchjob_predict_dense import read_pickle_stream
+    items = [[1, 2, 3], 'kd_path', None, np.arange(4), (1.5, 'x')]
+    f = tmp_path / 'job.pkl'
+    with open(f, 'wb') as fh:
+        for it in items:
+            pickle.dump(it, fh)
+    got = read_pickle_stream(str(f))
+    assert len(got) == len(items) and got[0] == [1, 2, 3] and got[2] is None and np.array_equal(got[3], np.arange(4))
+    (tmp_path / 'empty.pkl').write_bytes(b'')
+    assert read_pickle_stream(str(tmp_path / 'empty.pkl')) == []
+
+
+def test_object_segmentation_names_the_missing_gaussian_filter():
+    """`sigmas` (object_extraction_steps.py:77-81, 296-298): zeros run like None; anything else raises a ValueError that names
+    the filter; a wrong count raises like the reference (:137-139)."""
+    from syconn_amd.extraction.object_extraction_steps import object_segmentation
+
+    class _CS:
+        chunk_dict = {}
+    kw = dict(morph_ops={}, min_seed_vx={}, scaling=(10, 10, 20), overlap=(1, 1, 1))
+    with pytest.raises(ValueError, match='Gaussian'):
+        object_segmentation(_CS(), ['mi'], {}, [0.5], sigmas=[[1.0, 1.0, 0.5]], **kw)
+    with pytest.raises(Exception, match='does not match'):
+        object_segmentation(_CS(), ['mi', 'vc'], {}, [0.5, 0.5], sigmas=[[0, 0, 0]], **kw)
+    rows, _, props = object_segmentation(_CS(), [], {}, [], sigmas=[], **kw)          # nothing to do: no chunk, no dataset
+    assert rows == [] and props == {}
+
+
+def test_load_raw_into_a_caller_buffer_and_recycled_write_combining(tmp_path):
+    """`load_raw(out=)` fills a caller-owned (page-locked in dense_predictor) buffer: zeros beyond the boundary and in missing
+    cubes even when the buffer held data; the write-combining cache recycles its cube buffers without leaking voxels of one cube
+    into the next."""
+    from syconn_amd.knossos import KnossosDataset
+    kd = KnossosDataset()
+    kd._cube_shape = (32, 32, 32)
+    kd.initialize_without_conf(str(tmp_path / 'kd'), boundary=(70, 50, 40), scale=(1, 1, 1), experiment_name='t', mags=[1])
+    rng = np.random.default_rng(3)
+    vol = rng.integers(1, 256, (40, 50, 70), dtype=np.uint8)                      # z, y, x; no zeros inside
+    kd.enable_write_combining(max_cubes=4)
+    for z0 in (0, 20):                                                             # two z-slabs: cubes complete only at flush
+        for x0 in (0, 35):
+            kd.save_raw(offset=(x0, 0, z0), mags=[1], data=vol[z0:z0 + 20, :, x0:x0 + 35], data_mag=1)
+    kd.flush()
+    want = kd.load_raw(size=(90, 60, 48), offset=(-10, -5, -4), mag=1)
+    buf = np.full((48, 60, 90), 7, dtype=np.uint8)
+    got = kd.load_raw(size=(90, 60, 48), offset=(-10, -5, -4), mag=1, out=buf)
+    assert got is buf and np.array_equal(buf, want)
+    assert np.array_equal(buf[4:44, 5:55, 10:80], vol) and buf[:4].max() == 0 and buf[:, :, 80:].max() == 0
+    with pytest.raises(AssertionError):
+        kd.load_raw(size=(90, 60, 48), offset=(0, 0, 0), mag=1, out=np.zeros((48, 60, 91), np.uint8))
+
+
+def test_predict_volume_distributed_hands_the_valid_box_to_predict_fn():
+    """A `predict_fn` with a `valid_box` keyword receives, per chunk, the part of the chunk proper that lies inside the volume in
+    chunk + halo coordinates (what Predictor uses to skip tiles beyond the dataset); one without the keyword is called as before."""
+    from syconn_amd import parallel as par
+    vol_shape, chunk, halo = (10, 20, 30), (8, 16, 16), (1, 2, 3)
+    vol = torch.arange(int(np.prod(vol_shape)), dtype=torch.int64).remainder(251).to(torch.uint8).reshape(vol_shape)
+    seen = []
+
+    def fn(ch, valid_box=None):
+        seen.append(valid_box)
+        return ch[None, halo[0]:-halo[0], halo[1]:-halo[1], halo[2]:-halo[2]].contiguous()
+
+    out = par.predict_volume_distributed(vol, vol_shape, chunk, halo, fn, n_out=1)
+    assert torch.equal(out[0], vol)
+    assert seen == [((1, 2, 3), (9, 18, 19)), ((1, 2, 3), (9, 18, 17)), ((1, 2, 3), (9, 6, 19)), ((1, 2, 3), (9, 6, 17)),
+                    ((1, 2, 3), (3, 18, 19)), ((1, 2, 3), (3, 18, 17)), ((1, 2, 3), (3, 6, 19)), ((1, 2, 3), (3, 6, 17))]
+    out2 = par.predict_volume_distributed(vol, vol_shape, chunk, halo, lambda ch: fn(ch), n_out=1)
+    assert torch.equal(out2[0], vol)
+
+
+def test_label_split_reports_a_posteriori_margins():
+    """oracle/label_margin.py: one tolerance per storage type (no per-architecture exception) and the unsafe fractions at twice
+    the MEASURED error next to the a-priori ones."""
+    from oracle.label_margin import TOL_LOGIT_REL, label_split, merge_splits, stated_tolerance
+    assert stated_tolerance('mivcsj', 'f16') == TOL_LOGIT_REL['f16'] and TOL_LOGIT_REL['f16x2'] == 1e-5
+    g = torch.Generator().manual_seed(0)
+    ref = torch.randn((3, 8, 9, 10), generator=g) * 3
+    got = ref + torch.randn(ref.shape, generator=g) * 1e-3
+    from oracle.predictor_ref import label_rule_ref
+    lab = torch.from_numpy(label_rule_ref((got.softmax(0).numpy() * 255).astype(np.uint8), [1, 2], [None] * 3)[0].astype(np.uint8))
+    r = label_split(ref, got, got.softmax(0), lab, [1, 2], [None] * 3, 1e-2)
+    assert 0.0 <= r['label_unsafe_frac_2x_measured_err'] <= r['label_unsafe_frac'] <= 1.0
+    assert r['argmax_mismatch_safe'] == 0 and r['label_mismatch_safe'] == 0
+    m = merge_splits([r, r])
+    assert m['voxels'] == 2 * r['voxels'] and abs(m['label_unsafe_frac_2x_measured_err'] - r['label_unsafe_frac_2x_measured_err']) < 1e-12
