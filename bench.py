@@ -166,15 +166,14 @@ class HostToHostPipeline:
         self.k += 1
         if not first_use:
             self.ev_out[s].synchronize()              # host: the pinned output of step k-2 is complete (and reusable)
+        # (the host has just waited for the copy-out of step k-2, which is ordered behind that step's kernels: in_dev[s] and
+        # lab_dev[s] are free -- no device-side waits for step k-2 are needed, and every cross-stream wait queued between two
+        # kernels costs the compute stream a bubble)
         with torch.cuda.stream(self.s_in):
-            if not first_use:
-                self.s_in.wait_event(self.ev_comp[s])  # the kernels of step k-2 have consumed in_dev[s]
             self.in_dev[s].copy_(self.in_host, non_blocking=True)
             self.ev_in[s].record(self.s_in)
         with torch.cuda.stream(self.s_comp):
             self.s_comp.wait_event(self.ev_in[s])
-            if not first_use:
-                self.s_comp.wait_event(self.ev_out[s])  # lab_dev[s] of step k-2 has left the device
             for t0 in range(0, self.T, self.B):
                 n = min(self.B, self.T - t0)
                 self.dm.forward_labels_batch(self.in_dev[s][t0:t0 + n], self.ids, self.thr, out=self.lab_dev[s][t0:t0 + n])
