@@ -581,8 +581,8 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
             Op& c = m->ops[i];
             Op& nx = m->ops[i + 1];
             // GroupNorm right behind a conv over the conv's whole output: statistics in the conv epilogue
-            if (c.d.kind == SD_OP_CONV && !c.first && nx.d.kind == SD_OP_GROUPNORM && nx.d.src0 == c.d.dst && nx.d.src1 < 0 &&
-                !getenv("SD_NO_GN_FUSE")) {
+            if (c.d.kind == SD_OP_CONV && !c.first && c.NT >= 2 && nx.d.kind == SD_OP_GROUPNORM && nx.d.src0 == c.d.dst &&
+                nx.d.src1 < 0 && !getenv("SD_NO_GN_FUSE")) {
                 c.fuse_gn = (int)(i + 1);
                 nx.stats_done = true;
                 continue;

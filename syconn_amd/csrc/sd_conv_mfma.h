@@ -764,13 +764,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                     // MFMAs that last read tap t's; only the weight fragments are double-buffered.  LDS returns in
                     // order: whenever a tile row starts, exactly 3 + NT younger reads are in flight (3 - i of this tap's x
                     // fragments, NT weight fragments and i x fragments of the next tap) -> one constant lgkmcnt.
-                    static_assert(MT != 4 || KZ == 3, "MT = 4: z-stacked tiles");
+                    // (planar layers, round 4: the four tiles are y-neighbours, two halo rows apart -- the same immediate-offset scheme)
+                    constexpr int TSTEP = KZ == 3 ? SLICE : 2 * HX * 32;
                     v8 xq[4], wq[2][NT];
                     const uint32_t bA = lds_addr(bcur);
                     const uint32_t xE = lds_addr(acur) + xoffE[0], xO = lds_addr(acur) + xoffO[0];
                     auto load_x = [&](auto tc, auto ic) {
                         constexpr int t9 = decltype(tc)::value, i = decltype(ic)::value, ky = t9 / 3, kx = t9 % 3;
-                        ds_read16<(ky * HX + kx) * 32 + i * SLICE>(xq[i], (ky & 1) ? xO : xE);
+                        ds_read16<(ky * HX + kx) * 32 + i * TSTEP>(xq[i], (ky & 1) ? xO : xE);
                     };
                     auto load_w = [&](auto tc) {
                         constexpr int t9 = decltype(tc)::value;
@@ -898,8 +899,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         // fused GroupNorm statistics (the scheme of the other forms: the matrix core transposes a tile -- packed tile as A operand x
         // 0/1 selector -- so that a lane holds 16 voxels of ONE channel; here hi and lo tiles go through the same accumulator, which
         // then holds the exact fp32 values hi + lo)
-        // (not in the 4-wave streamed NT = 3 form: 254 VGPRs without it; the launcher picks the 8-wave form for such a layer)
-        constexpr bool GNS = !(KZ == 3 && NT == 3 && WAVES == 4 && !WRES);
+        // (not in the 4-wave streamed NT = 3 form: 254 VGPRs without it, the launcher picks the 8-wave form for such a layer; not
+        // in the NT = 1 forms either: their 32-channel level-0 layers live on two workgroups per CU = at most 128 VGPRs, which the
+        // statistics code would break -- the plan does not fuse the statistics of a layer with one channel tile)
+        constexpr bool GNS = NT >= 2 && !(KZ == 3 && NT == 3 && WAVES == 4 && !WRES);
         const bool gns = GNS && p.gn_sums != nullptr;
         float* const part = reinterpret_cast<float*>(ldsA + ((gc - 1) % NA) * A_BYTES);   // free: last chunk's halo slot
         v8 s1, s2;
@@ -1064,7 +1067,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         T* const dst4 = reinterpret_cast<T*>(reinterpret_cast<char*>(p.dst) + (size_t)tn * p.tstride);
         const int vy = y0 + tys[0] + dy, vx = x0 + dxl, vz0 = z0 + tzs[0];
         const bool vyx = vy < p.H && vx < p.W;
-        const size_t vo0 = (size_t)(vz0 * p.H + vy) * p.W + vx, vzs = (size_t)p.H * p.W;
+        // voxels between the wave's tiles: a z-plane (3x3x3: z-stacked tiles) or two rows (planar: y-stacked tiles)
+        const size_t vo0 = (size_t)(vz0 * p.H + vy) * p.W + vx, vzs = KZ == 3 ? (size_t)p.H * p.W : (size_t)2 * p.W;
         float* const part = reinterpret_cast<float*>(ldsA + ((gc - 1) % NA) * A_BYTES);   // free: last chunk's halo slot
         const unsigned relu_floor = p.relu ? 0u : 0x80008000u;
         const unsigned guard_mask = 0x7fff7fffu;      // (range guard: magnitudes)
@@ -1091,7 +1095,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                 bool val2[2];
 #pragma unroll
                 for (int e2 = 0; e2 < 2; ++e2) {
-                    val2[e2] = vyx && (vz0 + ip + e2) < p.D;
+                    val2[e2] = KZ == 3 ? (vyx && (vz0 + ip + e2) < p.D) : (vx < p.W && vz0 < p.D && vy + 2 * (ip + e2) < p.H);
 #pragma unroll
                     for (int k = 0; k < 8; ++k)      // ReLU = packed max against 0; without it against the most negative pair (identity)
                     {
@@ -1117,14 +1121,27 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                 }
                 if (p.pool_dst) {
                     T* const pdst = reinterpret_cast<T*>(reinterpret_cast<char*>(p.pool_dst) + (size_t)tn * p.tstride);
-                    unsigned m[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) m[k] = pk_max16(val2[0] ? pk2[0][k] : 0u, val2[1] ? pk2[1][k] : 0u);
-                    pool_xy_pk8(m);
-                    const int pz = (vz0 + ip) >> 1, py = (y0 + tys[0]) >> 1, px = (x0 + dxl) >> 1;
                     const bool writer = (dy == 0) && ((dxl & 1) == 0);
-                    store_tile_rows_pk<T>(m, pdst, p.Pp, (size_t)(pz * p.pH + py) * p.pW + px, writer && val2[0],
-                                          (nb * NT + j) * 32, half, p.Cd);
+                    if constexpr (KZ == 3) {
+                        unsigned m[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) m[k] = pk_max16(val2[0] ? pk2[0][k] : 0u, val2[1] ? pk2[1][k] : 0u);
+                        pool_xy_pk8(m);
+                        const int pz = (vz0 + ip) >> 1, py = (y0 + tys[0]) >> 1, px = (x0 + dxl) >> 1;
+                        store_tile_rows_pk<T>(m, pdst, p.Pp, (size_t)(pz * p.pH + py) * p.pW + px, writer && val2[0],
+                                              (nb * NT + j) * 32, half, p.Cd);
+                    } else {
+#pragma unroll
+                        for (int e2 = 0; e2 < 2; ++e2) {      // planar: (1,2,2) windows, every tile pools alone
+                            unsigned m[8];
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) m[k] = val2[e2] ? pk2[e2][k] : 0u;
+                            pool_xy_pk8(m);
+                            const int py = (y0 + tys[ip + e2]) >> 1, px = (x0 + dxl) >> 1;
+                            store_tile_rows_pk<T>(m, pdst, p.Pp, (size_t)(vz0 * p.pH + py) * p.pW + px, writer && val2[e2],
+                                                  (nb * NT + j) * 32, half, p.Cd);
+                        }
+                    }
                 }
             }
             if (p.gn_sums) {

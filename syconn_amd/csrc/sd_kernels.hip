@@ -954,6 +954,14 @@ static int launch_conv_knt(const ConvParams& p, int NB, hipStream_t s) {
             if (!mt2 && !p.final_wfrag && (vox / 1024) * NB >= 256 && (p.D % 8 == 0 || p.D >= 96))
                 return launch_conv_k<T, KZ, NT, 8, 0, 4>(p, NB, s);
         }
+        if constexpr (KZ == 1 && NT == 2) {
+            // planar 64 / 128-filter layers with streamed weights (levels 2+ of the 32-filter family): 4 y-stacked voxel tiles per
+            // wave, 4-wave workgroups of 1 x 32 x 16 voxels, two per CU -- 0.75 instead of 1.0 LDS fragment reads per MFMA (at 1.0
+            // the four SIMDs of a CU ask for 128 B per cycle: all the LDS has) and a barrier per 72 instead of 36 MFMAs
+            const bool no_p4 = getenv("SD_NO_PLANAR4") != nullptr;      // A/B switch (read per launch)
+            if (!no_p4 && !p.final_wfrag && (p.H % 32 == 0 || p.H >= 128) && (vox / 512) * NB >= 1024)
+                return launch_conv_k<T, KZ, NT, 4, 0, 4>(p, NB, s);
+        }
         if constexpr (KZ == 1 && NT == 3) {
             // (measured: 48-filter family -6 % on these layers; the NT = 2 layers are LDS-bandwidth bound -- 1.0 fragment reads per
             // MFMA -- and do not move)

@@ -29,6 +29,10 @@ int launch_conv_split_knt(const ConvParams& p, int NB, hipStream_t s) {
         if constexpr (KZ == 3 && NT == 2) {
             if (!ff && (vox / 1024) * NB >= 256 && (p.D % 8 == 0 || p.D >= 96)) return launch_conv_k<T, KZ, NT, 8, 0, 4, 3>(p, NB, s);
         }
+        if constexpr (KZ == 1 && NT == 2) {      // (the planar 4-tile form of launch_conv_knt)
+            if (!getenv("SD_NO_PLANAR4") && !ff && !p.gn_sums && (p.H % 32 == 0 || p.H >= 128) && (vox / 512) * NB >= 1024)
+                return launch_conv_k<T, KZ, NT, 4, 0, 4, 3>(p, NB, s);
+        }
         return launch_conv_k<T, KZ, NT, 8, 0, 2, 3>(p, NB, s);
     }
     if (conv_lds_bytes<KZ, NT, 4, 2, 2>(nstages, ff) <= 80 * 1024) return launch_conv_k<T, KZ, NT, 4, 2, 2, 3>(p, NB, s);
@@ -332,6 +336,7 @@ bool conv_can_fuse_first_split(int KZ, int NT, int NB, long vox, int nstages, bo
 
 int launch_conv_split(const ConvParams& p, int KZ, int NT, int NB, hipStream_t s) {
     if (p.pool_dir || p.gn0 || p.gn1) return SD_ERR_INVALID;     // fused: pooling, final layer, first convolution, GroupNorm statistics
+    if (p.gn_sums && NT < 2) return SD_ERR_INVALID;              // (the one-tile forms carry no statistics code)
     if (p.first_in) {
         if (!conv_can_fuse_first_split(KZ, NT, NB, (long)p.D * p.H * p.W * p.batch, (p.nchunk0 + p.nchunk1) * KZ, p.final_wfrag != nullptr))
             return SD_ERR_INVALID;

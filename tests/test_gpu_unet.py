@@ -425,6 +425,27 @@ def test_four_tile_form_is_bit_identical(gpu, monkeypatch):
             assert torch.equal(ref, b), (arch, sh)
 
 
+def test_planar_four_tile_form_is_bit_identical(gpu, monkeypatch):
+    """Planar 64 / 128-filter layers (level 2 of the 32-filter nets) run with 4 y-stacked voxel tiles per wave in 4-wave workgroups
+    of 1 x 32 x 16 voxels where the row count allows (round 4); same per-output summation order as the 2-tile form
+    (SD_NO_PLANAR4) -> bit-identical logits, incl. the fused planar pooling of the encoder's second convolution, in the bf16
+    plan and in the split plan."""
+    from syconn_amd import _lib as L
+    from syconn_amd.cnn import random_state_dict
+    from syconn_amd.engine import DenseModel
+    for act in ('bf16', 'f16x2'):
+        for arch, shapes in (('semseg_spine', ((8, 64, 128, 128), (2, 32, 128, 144), (1, 16, 512, 200))), ('syntype', ((4, 48, 128, 128),))):
+            sd = random_state_dict(arch, seed=13, final_scale=6.0)
+            monkeypatch.setenv('SD_NO_PLANAR4', '1')
+            two = DenseModel(sd, act_dtype=act, device=gpu)
+            a = [two.forward_batch(_input(sh, 4).to(gpu), L.SD_OUT_LOGITS_F32).clone() for sh in shapes]
+            monkeypatch.delenv('SD_NO_PLANAR4')                    # (the switch is read at every launch)
+            four = DenseModel(sd, act_dtype=act, device=gpu)
+            for sh, ref in zip(shapes, a):
+                b = four.forward_batch(_input(sh, 4).to(gpu), L.SD_OUT_LOGITS_F32, slot=1)
+                assert torch.equal(ref, b), (act, arch, sh)
+
+
 @pytest.mark.parametrize('arch,act', [('semseg_spine', 'bf16'), ('semseg_spine', 'f16'), ('myelin', 'bf16'), ('syntype', 'f16')])
 def test_fused_level0_decoder_matches_separate_layers(gpu, monkeypatch, arch, act):
     """sd_dec0.hip (up-convolution + merge conv + conv + final layer of the planar top level in ONE streaming launch) against the
