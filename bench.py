@@ -84,6 +84,10 @@ def layer_accounting(ops, L, D, H, W, act_bytes=2, out_bytes_per_class=1, batch=
                 lds = 2 * a_bytes + nstages * 9 * nt * 1024 + 512 + (nt * 4096 if fused_final else 0) + 1024
                 resident = lds <= (96 if waves == 8 else 80) * 1024
                 name = 'k_conv_mfma<%dx3x3,NT=%d,%d waves,%s>' % (o.kz, nt, waves, 'NSLOT=2' if resident else 'NSLOT=0')
+                # planar 4-tile form (round 4): 4-wave workgroups of 1 x 32 x 16 voxels for the streamed-weight planar NT = 2 layers
+                if (o.kz == 1 and nt == 2 and waves == 8 and not resident and not fused_final and (d[1] % 32 == 0 or d[1] >= 128)
+                        and ((vox * batch) // 512) * nbk >= 1024 and not os.environ.get('SD_NO_PLANAR4')):
+                    name = 'k_conv_mfma<1x3x3,NT=2,4 waves,NSLOT=0,MT=4>'
                 # first conv computed inside this conv (conv_can_fuse_first in sd_kernels.hip)
                 prev = ops[io - 1] if io > 0 else None
                 if (prev is not None and prev.kind == L.SD_OP_CONV and prev.src0 == 0 and prev.kz == 1 and prev.cout == 32

@@ -97,6 +97,8 @@ struct sd_model {
     long n_forward = 0;
     int last_launches = 0;             // ops of the last forward that ran as their own launch
     std::vector<hipEvent_t> events;    // [slot][n_ops + 1]
+    std::vector<char> ev_recorded;     // [slot][n_ops + 1]: event was recorded by the forward that used the slot (ops that run inside
+                                       // another op's launch record none: every record is a packet between two kernels)
     int final_cout = 0;
     bool keep_all = false;   // SD_KEEP_ALL=1: also store activations that only feed a fused consumer (tests)
     bool ws_reuse = true;    // activation buffers with disjoint lifetimes share workspace memory
@@ -827,6 +829,7 @@ int sd_profile_enable(sd_model* m, int n_slots) {
     m->events.clear();
     m->profile_slots = n_slots;
     m->n_forward = 0;
+    m->ev_recorded.assign((size_t)std::max(n_slots, 0) * (m->ops.size() + 1), 0);
     if (n_slots > 0) {
         m->events.resize((size_t)n_slots * (m->ops.size() + 1));
         for (auto& e : m->events) HIP_TRY(hipEventCreate(&e));
@@ -837,9 +840,17 @@ int sd_profile_enable(sd_model* m, int n_slots) {
 int sd_profile_read(sd_model* m, int slot, float* ms, int n_ops) {
     if (!m || !ms || m->profile_slots <= 0 || slot < 0 || slot >= m->profile_slots)
         return fail(SD_ERR_INVALID, "sd_profile_read: profiling not enabled or bad slot");
-    const int n = std::min<int>(n_ops, (int)m->ops.size());
+    const int n = std::min<int>(n_ops, (int)m->ops.size()), nall = (int)m->ops.size();
     const hipEvent_t* ev = m->events.data() + (size_t)slot * (m->ops.size() + 1);
-    for (int i = 0; i < n; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
+    const char* rec = m->ev_recorded.data() + (size_t)slot * (m->ops.size() + 1);
+    for (int i = 0; i < n; ++i) {
+        ms[i] = 0.f;
+        if (!rec[i]) continue;                       // ran inside another op's launch
+        int j = i + 1;
+        while (j < nall && !rec[j]) ++j;             // next op that launched (or the end-of-forward event)
+        if (!rec[j]) return fail(SD_ERR_INVALID, "sd_profile_read: slot holds no complete forward");
+        HIP_TRY(hipEventElapsedTime(&ms[i], ev[i], ev[j]));
+    }
     return SD_OK;
 }
 
@@ -902,7 +913,11 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
     if ((long)D * H * W >= (1l << 31)) return fail(SD_ERR_INVALID, "tile has 2^31 or more voxels");
     if (m->f32) {
         hipEvent_t* ev32 = nullptr;
-        if (m->profile_slots > 0) ev32 = m->events.data() + (size_t)(m->n_forward % m->profile_slots) * (m->ops.size() + 1);
+        if (m->profile_slots > 0) {
+            ev32 = m->events.data() + (size_t)(m->n_forward % m->profile_slots) * (m->ops.size() + 1);
+            char* rec = m->ev_recorded.data() + (size_t)(m->n_forward % m->profile_slots) * (m->ops.size() + 1);
+            std::fill(rec, rec + m->ops.size() + 1, 1);      // (the fp32 plan launches every op)
+        }
         ++m->n_forward;
         m->last_launches = (int)m->ops.size();
         return f32_forward(m->f32, in_dev, in_dtype, N, D, H, W, out_dev, out_kind, lab, ws, ws_bytes,
@@ -922,8 +937,12 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
     const bool dec0 = dec0_shape_ok(m->dims[0]);
     auto bufp = [&](int b) -> void* { return wsb + m->buf_off[b]; };
     hipEvent_t* ev = nullptr;
-    if (m->profile_slots > 0)
+    char* ev_rec = nullptr;
+    if (m->profile_slots > 0) {
         ev = m->events.data() + (size_t)(m->n_forward % m->profile_slots) * (m->ops.size() + 1);
+        ev_rec = m->ev_recorded.data() + (size_t)(m->n_forward % m->profile_slots) * (m->ops.size() + 1);
+        std::fill(ev_rec, ev_rec + m->ops.size() + 1, 0);
+    }
     ++m->n_forward;
     m->last_launches = 0;
     {
@@ -943,8 +962,18 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
     for (size_t i = 0; i < m->ops.size(); ++i) {
         const Op& op = m->ops[i];
         const sd_op_desc& d = op.d;
-        if (ev) HIP_TRY(hipEventRecord(ev[i], s));
         if (op.skipped || (op.in_dec0 && dec0)) continue;
+        if (op.first && d.kind == SD_OP_CONV && i + 1 < m->ops.size() && m->ops[i + 1].fuse_first == (int)i && !m->keep_all) {
+            // (a first convolution that will run inside its consumer launches nothing: no event either; decided below per launch)
+            const Op& c = m->ops[i + 1];
+            const Dims o1 = m->dims[d.dst];
+            const int nst1 = (m->bufCp[c.d.src0] / SD_CHUNK) * c.d.kz * (m->split ? 3 : 1);
+            const bool fused1 = m->split
+                ? conv_can_fuse_first_split(c.d.kz, c.NT, c.NB, (long)o1.d * o1.h * o1.w * N, nst1, c.fuse_final >= 0)
+                : conv_can_fuse_first(c.d.kz, c.NT, c.NB, (long)o1.d * o1.h * o1.w * N, nst1, c.fuse_final >= 0);
+            if (fused1) { ++m->last_launches; continue; }
+        }
+        if (ev) { HIP_TRY(hipEventRecord(ev[i], s)); ev_rec[i] = 1; }
         ++m->last_launches;
         switch (d.kind) {
         case SD_OP_CONV: {
@@ -1163,7 +1192,7 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
             return fail(rc, msg);
         }
     }
-    if (ev) HIP_TRY(hipEventRecord(ev[m->ops.size()], s));
+    if (ev) { HIP_TRY(hipEventRecord(ev[m->ops.size()], s)); ev_rec[m->ops.size()] = 1; }
     return SD_OK;
 }
 
