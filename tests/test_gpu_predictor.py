@@ -547,3 +547,37 @@ def test_config3_full_width_model_two_by_two_by_two_tiles_vs_oracle(gpu):
               f'argmax agreement {same:.6f}')
         assert got.shape == ref.shape == (6, *vol_shape)
         assert d.max() <= max_lvl and float((d > 0).mean()) <= frac and same >= agree, (act, int(d.max()), same)
+
+
+def test_default_configuration_end_to_end_is_reference_precision(gpu, tmp_path):
+    """The drop-in with NOTHING configured (no `act_dtype`, tile skipping at its default): predict_myelin and
+    predict_cellorganelles on a volume whose chunk grid overhangs the dataset run in the reference-precision plan 'f16x2' --
+    the myelin probability map within one uint8 level of the oracle on a vanishing fraction of the voxels, the mivcsj labels
+    equal to the oracle's wherever every probability is at least two levels from its threshold (and on > 99.9 % overall)."""
+    from syconn_amd import global_params
+    from syconn_amd.exec.exec_dense_prediction import predict_cellorganelles, predict_myelin
+    from syconn_amd.handler.basics import kd_factory
+    geo = {'overlap_shape_tiles': [6, 6, 4], 'chunk_size': [40, 40, 24], 'tile_shape': [26, 26, 16]}      # geometry only
+    model = build_unet('myelin', seed=11, n_blocks=3, start_filts=8, final_scale=4.0)
+    shape_xyz = (260, 200, 112)                          # at mag 4: 65 x 50 x 28 -> 2 x 2 x 2 chunks, the last ones mostly outside
+    wd, kd_path, vol = _make_wd(tmp_path, model, 'myelin', shape_xyz, 23, geo)
+    assert global_params.config['dense_prediction']['act_dtype'] == 'f16x2'
+    predict_myelin()
+    got = kd_factory(f'{wd}/knossosdatasets/myelin/').load_raw(size=shape_xyz, offset=(0, 0, 0), mag=4)
+    ref = _oracle_volume(model, vol[::4, ::4, ::4], geo, (65, 50, 28), 2)[1]
+    d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
+    print('default configuration, myelin vs oracle: max diff', d.max(), 'frac != 0', float((d > 0).mean()))
+    assert got.shape == ref.shape and d.max() <= 1 and float((d > 0).mean()) < 2e-3
+    global_params.wd = None
+    model2 = build_unet('mivcsj', seed=12, n_blocks=3, start_filts=8, final_scale=6.0)
+    shape2 = (70, 60, 40)
+    wd2, _, vol2 = _make_wd(tmp_path / 'b', model2, 'mivcsj', shape2, 22, geo)
+    predict_cellorganelles()
+    lab = kd_factory(f'{wd2}/knossosdatasets/mivcsj/').load_seg(size=shape2, offset=(0, 0, 0), mag=1)
+    probs = _oracle_volume(model2, vol2, geo, shape2, 4)
+    want, _ = label_rule_ref(probs, (1, 2, 3), [None] * 4)
+    safe = np.all(np.abs(probs[1:].astype(np.int16) - 127.5) > 2, axis=0)
+    mism = lab != want
+    print(f'default configuration, mivcsj labels: agreement {1 - mism.mean():.6f}, margin-safe mismatches {int((mism & safe).sum())}')
+    assert not (mism & safe).any() and mism.mean() < 1e-3
+    global_params.wd = None
