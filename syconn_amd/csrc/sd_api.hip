@@ -364,8 +364,11 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
                 for (int nt = 0; nt < ntile; ++nt)
                     for (int s = 0; s < nstep; ++s)
                         for (int l = 0; l < 64; ++l) {
+                            // (taps is odd: the last k slot of the MFMA chain is free and carries the folded BIAS -- the kernels feed it
+                            // a 1.0, which makes the bias the last fma of the chain = the separate add it replaces, bit for bit)
                             const int n = nt * 32 + (l & 31), tap = 2 * s + (l >> 5);
-                            wp[(nt * nstep + s) * 64 + l] = (n < d.cout && tap < taps) ? wat(n, 0, tap / 9, tap % 9) : 0.f;
+                            wp[(nt * nstep + s) * 64 + l] = (n < d.cout && tap < taps) ? wat(n, 0, tap / 9, tap % 9)
+                                                            : (n < d.cout && tap == taps) ? W[d.b_off + n] * sc[n] + sh[n] : 0.f;
                         }
                 for (int n = 0; n < d.cout; ++n) bp[n] = W[d.b_off + n] * sc[n] + sh[n];
             } else {

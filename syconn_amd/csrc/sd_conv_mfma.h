@@ -563,9 +563,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                 if (tap >= 9) tap = 0;                       // (its weight is zero)
                 toff1[st] = (tap / 3) * PXW + (tap % 3);
             }
-            f32x4 b1[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) b1[q] = *reinterpret_cast<const f32x4*>(ffw + NF1 * 320 + 8 * q + 4 * half);
+            // (the folded bias is the weight of the chain's last, otherwise empty k slot and meets a 1.0 there: see k_conv_first)
             for (int t = wave; t * 32 < NH; t += WAVES) {
                 const int hv = t * 32 + (lane & 31);
                 const int hvc = hv < NH ? hv : NH - 1;
@@ -576,22 +574,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                 if constexpr (NF1 > 1) {
 #pragma unroll
                     for (int st = 0; st < NSTEP1; ++st) w1[st] = ffw[(ft * NSTEP1 + st) * 64 + lane];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) b1[q] = *reinterpret_cast<const f32x4*>(ffw + NF1 * 320 + ft * 32 + 8 * q + 4 * half);
                 }
                 f32x16 a1;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a1[r] = 0.f;
 #pragma unroll
                 for (int st = 0; st < NSTEP1; ++st)
-                    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[st], fp[base + toff1[st]], a1, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[st], (st == NSTEP1 - 1 && half) ? 1.0f : fp[base + toff1[st]], a1, 0, 0, 0);
                 const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
                 const bool invol = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;     // z0 < D always
                 if constexpr (SP) {
                     if (hv < NH) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {      // channels 8q + 4*half + 0..3: chunk q >> 1, 16-byte half q & 1 of the record
-                            float v0 = a1[4 * q] + b1[q][0], v1 = a1[4 * q + 1] + b1[q][1], v2 = a1[4 * q + 2] + b1[q][2], v3 = a1[4 * q + 3] + b1[q][3];
+                            float v0 = a1[4 * q], v1 = a1[4 * q + 1], v2 = a1[4 * q + 2], v3 = a1[4 * q + 3];
                             if (p.first_relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
                             unsigned h01, l01, h23, l23;
                             split_pk(v0, v1, h01, l01);
@@ -608,8 +604,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                 if (hv < NH) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        unsigned lo = Act<T>::pack2(a1[4 * q] + b1[q][0], a1[4 * q + 1] + b1[q][1]);
-                        unsigned hi = Act<T>::pack2(a1[4 * q + 2] + b1[q][2], a1[4 * q + 3] + b1[q][3]);
+                        unsigned lo = Act<T>::pack2(a1[4 * q], a1[4 * q + 1]);
+                        unsigned hi = Act<T>::pack2(a1[4 * q + 2], a1[4 * q + 3]);
                         if (p.first_relu) { lo = pk_max16(lo, 0u); hi = pk_max16(hi, 0u); }
                         sguard.see_signed(lo); sguard.see_signed(hi);
                         if (!invol) { lo = 0u; hi = 0u; }      // the second conv's zero padding

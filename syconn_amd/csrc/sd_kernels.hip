@@ -73,9 +73,8 @@ __global__ __launch_bounds__(256) void k_conv_first(const FirstParams p) {
         float wf[NSTEP];
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) wf[s] = p.wpack[(nt * NSTEP + s) * 64 + lane];
-        f32x4 bq[4];                  // folded bias of this lane's 16 channels (added AFTER the tap chain, like the oracle)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(p.bias + nt * 32 + 8 * q + 4 * half);
+        // (the folded bias rides in the last, otherwise empty k slot of the chain -- weight = bias, activation = 1.0: the last fma of
+        // the chain, i.e. added AFTER the taps like the oracle does, without 16 adds per tile)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int t = wave * 2 + i;
@@ -88,14 +87,14 @@ __global__ __launch_bounds__(256) void k_conv_first(const FirstParams p) {
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
             for (int s = 0; s < NSTEP; ++s)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[s], patch[base + toff[s]], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[s], (s == NSTEP - 1 && half) ? 1.0f : patch[base + toff[s]], acc, 0, 0, 0);
             const int vz = z0 + tz, vy = y0 + ly, vx = x0 + lx;
             const bool valid = vz < p.D && vy < p.H && vx < p.W;
             if constexpr (SPLIT) {
                 unsigned ph[8], pl[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    float a = acc[2 * k] + bq[k >> 1][(2 * k) & 3], b = acc[2 * k + 1] + bq[k >> 1][(2 * k + 1) & 3];
+                    float a = acc[2 * k], b = acc[2 * k + 1];
                     if (p.relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
                     split_pk(a, b, ph[k], pl[k]);
                     sguard.see_signed(ph[k]);
@@ -109,7 +108,7 @@ __global__ __launch_bounds__(256) void k_conv_first(const FirstParams p) {
             unsigned pk[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k)
-                pk[k] = Act<T>::pack2(acc[2 * k] + bq[k >> 1][(2 * k) & 3], acc[2 * k + 1] + bq[k >> 1][(2 * k + 1) & 3]);
+                pk[k] = Act<T>::pack2(acc[2 * k], acc[2 * k + 1]);
             if (p.relu) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) pk[k] = pk_max16(pk[k], 0u);
