@@ -9,8 +9,11 @@
 // layout of the other plans, so the convolution is k_conv_mfma (sd_conv_mfma.h, MODE 3) walking the 3n VIRTUAL chunks
 // [hi | hi | lo] of an n-chunk input against weight groups packed [lo | hi | hi].  Weights and bias carry a power of two per
 // layer (2^k: largest |w| near 2^14, so every lo part is a normal fp16 number); the epilogues multiply by 2^-k (exact).
-// This file: the launch rules of that form and the HBM-bound helper passes on split tensors (pooling, final 1x1x1 + softmax,
-// GroupNorm, buffer read-back).  First convolution and up-convolution are the SPLIT forms of the kernels in sd_kernels.hip.
+// Fused into that kernel's epilogue: MaxPool3d (on the fp32 values), the final 1x1x1 + softmax / labels (three MFMA products of
+// scaled hi / lo weight fragments), GroupNorm statistics; MODE 4 computes the first convolution inside its consumer.
+// This file: the launch rules of these forms and the HBM-bound helper passes on split tensors for what cannot be fused (pooling,
+// final layer, GroupNorm statistics / apply [+ pooling], buffer read-back).  First convolution and up-convolutions are the SPLIT
+// forms of the kernels in sd_kernels.hip.
 #include "sd_conv_mfma.h"
 
 namespace {
@@ -22,7 +25,7 @@ template <int KZ, int NT>
 int launch_conv_split_knt(const ConvParams& p, int NB, hipStream_t s) {
     const long vox = (long)p.D * p.H * p.W * p.batch;
     const int nstages = (p.nchunk0 + p.nchunk1) * KZ;
-    const bool big = (vox / 512) * NB >= 512;      // the rules of launch_conv_knt (sd_kernels.hip) without the fused forms
+    const bool big = (vox / 512) * NB >= 512;      // the form rules of launch_conv_knt (sd_kernels.hip)
     const bool ff = p.final_wfrag != nullptr;
     if (big) {
         if (conv_lds_bytes<KZ, NT, 8, 2, 2>(nstages, ff) <= 96 * 1024) return launch_conv_k<T, KZ, NT, 8, 2, 2, 3>(p, NB, s);
