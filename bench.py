@@ -226,6 +226,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--predict-outside', action='store_true',
                     help='volume workloads: also predict model tiles that lie entirely beyond the volume, as the reference does')
+    ap.add_argument('--full-windows', action='store_true',
+                    help='volume workloads: predict tiles that reach beyond the volume on their full window (no clipping)')
     ap.add_argument('--labels-sha', action='store_true', help='report a sha256 of the result volume(s) on the JSON line (tests)')
     ap.add_argument('--workload', default='config2', choices=['config2', 'config3', 'config4', 'config5'],
                     help='BASELINE.json configs[1..4]; the default (config2 = configs[1]) is the headline metric')
@@ -422,7 +424,7 @@ def volume_main(args):
     else:                                 # model tile 128^3 = useful (112,96,96) + halo (8,16,16); 2x2x2 tiles per chunk
         chunk, halo, tile = (224, 192, 192), (8, 16, 16), (112, 96, 96)
     pred = Predictor(sd, device=dev, tile_shape=tile, overlap_shape=halo, apply_softmax=True, act_dtype=act,
-                     defer_guard=True)      # (fp16 range guard asked once per volume: no sync per chunk inside the pipeline)
+                     defer_guard=True, clip_tiles=not args.full_windows)      # (fp16 range guard asked once per volume: no sync per chunk inside the pipeline)
     ncls = pred.out_channels
     ids, thr = list(range(1, ncls)), [127.5] * (ncls - 1)      # channel_thresholds None -> 255/2 (prediction.py:824-825)
     in_halo = args.geometry != 'reference'

@@ -12,7 +12,7 @@ import threading
 import torch
 
 from . import _lib as L
-from .plan import plan_from_model
+from .plan import clipped_extent, plan_from_model
 
 # 'f16x2': the reference-precision plan on the matrix cores (csrc/sd_split.hip: every value kept as fp16 hi + lo, three MFMA
 # passes per product, fp32-level logits at ~3x the cost of 'f16'); 'f32': fp32 storage and FMA arithmetic (csrc/sd_f32.hip, slow)
@@ -76,12 +76,22 @@ class DenseModel:
         self._h = handle
         self._ws_slots = {}            # workspace per slot: forwards on different HIP streams use different slots
         self._profile = False
+        self._clip_cache = {}
 
     def __del__(self):
         h = getattr(self, '_h', None)
         if h is not None and h.value:
             self.lib.sd_model_destroy(h)
             self._h = None
+
+    def clipped_extent(self, need: int, full: int, axis: int) -> int:
+        """Input extent along `axis` that leaves the outputs with index < `need` unchanged (`plan.clipped_extent`); multiples
+        of 8 so that two poolings of the clipped window stay whole."""
+        key = (need, full, axis)
+        e = self._clip_cache.get(key)
+        if e is None:
+            e = self._clip_cache[key] = clipped_extent(self.ops, need, full, axis, multiple=8)
+        return e
 
     # -- workspace ------------------------------------------------------------------------------------
     def workspace_bytes(self, shape: Sequence[int]) -> int:

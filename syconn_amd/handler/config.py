@@ -35,6 +35,9 @@ DEFAULTS = {
         # model tiles whose whole result lies beyond the dataset boundary are not predicted (the reference's chunk grid covers
         # up to 1.9x the dataset and it predicts all of it); False reproduces the reference's values in that overhang too
         'skip_tiles_outside_dataset': True,
+        # model tiles that reach beyond the dataset boundary are predicted on the part of their window the voxels inside the
+        # dataset depend on (identical values there; GroupNorm networks always use full windows)
+        'clip_boundary_tiles': True,
     },
     # first consumer of the probability maps (object extraction): the reference's defaults,
     # /root/reference/syconn/handler/config.yml:108-136

@@ -79,7 +79,7 @@ class Predictor:
                  overlap_shape=None, offset=None, out_shape=None, out_dtype=None, float16=False,
                  apply_softmax=True, transform=None, augmentations=None, strict_shapes=False, apply_argmax=False,
                  argmax_with_threshold=None, verbose=False, report_inf_speed=False, act_dtype=None,
-                 group_norm_groups=None, n_streams=None, defer_guard=False, overflow_fallback=None):
+                 group_norm_groups=None, n_streams=None, defer_guard=False, overflow_fallback=None, clip_tiles=True):
         from ..engine import DenseModel, StreamRing
         if transform is not None or augmentations is not None or argmax_with_threshold is not None:
             raise NotImplementedError('transform / augmentations / argmax_with_threshold are not used by SyConn\'s '
@@ -130,6 +130,8 @@ class Predictor:
         # `defer_guard`: do not synchronise after every prediction (pipelined callers); the caller asks `overflowed()` once
         # its stream of predictions is done and repeats them in bf16 itself
         self.defer_guard = bool(defer_guard)
+        # tiles that overhang the volume are predicted on the part of their window that matters (see `_tiled`); same values
+        self.clip_tiles = bool(clip_tiles)
         if act_dtype is None:
             # the reference's precision is what `float16` says: False (SyConn's call, prediction.py:777-779) = fp32 results ->
             # the split-fp16 reference-precision plan; True (elektronn3: model.half()) = fp16 storage
@@ -175,7 +177,11 @@ class Predictor:
         reference's chunk grid (``fit_box_size=True``, prediction.py:679-683) covers up to 1.9x the dataset and it predicts
         every tile of every chunk, also those whose whole (cropped) result lies beyond the dataset boundary -- values of a
         zero input that nothing downstream reads.  With a `valid_box` such tiles are not predicted (their region of `out` is
-        zero); every voxel inside the dataset is unchanged, because a tile's result depends on nothing but that tile."""
+        zero); every voxel inside the dataset is unchanged, because a tile's result depends on nothing but that tile.
+        `self.clip_tiles`: a tile that reaches beyond `vol` or the `valid_box` (the last tile of a chunk that is no multiple of
+        the tile shape: 58 of 178 planes wanted in the reference's geometry) is predicted on the part of its window the wanted
+        voxels can depend on (`plan.clipped_extent`: the far border of every layer stays outside their cones) -- same values,
+        less arithmetic; networks with GroupNorm (whole-tile statistics) keep full windows."""
         from ..engine import tile_gather, tile_scatter
         ol_in = np.zeros(3, dtype=np.int64) if self.overlap_shape is None else self.overlap_shape
         spatial = np.asarray(vol.shape, dtype=np.int64) - (2 * ol_in if halo_included else 0)
@@ -197,34 +203,48 @@ class Predictor:
         # independent tiles go through the network `nb` at a time (sd_forward_batch: one set of launches, every
         # kernel sees nb times as many blocks); batches alternate over `n_streams` HIP streams
         pos_list = list(itertools.product(*[range(int(n)) for n in ntiles]))   # z-major, like upstream
+        zero = False
         if valid_box is not None:
             v_lo, v_hi = (np.asarray(v, dtype=np.int64) for v in valid_box)
             inside = [pos for pos in pos_list
                       if np.all(tile * np.asarray(pos) < v_hi) and np.all(np.minimum(tile * (np.asarray(pos) + 1), spatial) > v_lo)]
-            if len(inside) < len(pos_list):
-                out.zero_()
-                pos_list = inside
+            zero = len(inside) < len(pos_list)
+            pos_list = inside
             if not pos_list:
+                out.zero_()
                 return
-        nb = self._batch_for(tin, len(pos_list))
+        # window of every tile: full, or clipped at the far side to what its wanted voxels depend on; equal windows batch
+        by_window = {}
+        for pos in pos_list:
+            lo = tile * np.asarray(pos, dtype=np.int64)
+            keep = np.minimum(tile, spatial - lo)
+            want = keep if valid_box is None else np.minimum(keep, v_hi - lo)
+            win = tuple(self._dm.clipped_extent(int(ol[a] + want[a]), int(tin[a]), a) for a in range(3)) \
+                if self.clip_tiles else tuple(int(t) for t in tin)
+            zero = zero or bool(np.any(want < keep))
+            by_window.setdefault(win, []).append((lo, want))
+        if zero:                                 # beyond the dataset `out` reads zero, whatever was skipped or clipped
+            out.zero_()
+        nb = self._batch_for(tin, max(len(g) for g in by_window.values()))
         ring = self._ring
-        tbuf = [torch.empty((nb, *[int(t) for t in tin]), dtype=vol.dtype, device=self.device) for _ in range(ring.n)]
-        obuf = [torch.empty((nb, nch, *[int(t) for t in tin]), dtype=out.dtype, device=self.device)
-                for _ in range(ring.n)]
+        tbuf = [torch.empty(nb * int(np.prod(tin)), dtype=vol.dtype, device=self.device) for _ in range(ring.n)]
+        obuf = [torch.empty(nb * nch * int(np.prod(tin)), dtype=out.dtype, device=self.device) for _ in range(ring.n)]
+        i = 0
         with ring:
-            for i, b0 in enumerate(range(0, len(pos_list), nb)):
-                group = pos_list[b0:b0 + nb]
-                k = ring.slot(i)
-                with ring.stream(i):
-                    for j, pos in enumerate(group):
-                        lo = tile * np.asarray(pos, dtype=np.int64)
-                        tile_gather(vol, lo - ol + shift, tin, tbuf[k][j])
-                    n = len(group)
-                    run(tbuf[k][:n], obuf[k][:n], k)
-                    for j, pos in enumerate(group):
-                        lo = tile * np.asarray(pos, dtype=np.int64)
-                        keep = np.minimum(tile, spatial - lo)
-                        tile_scatter(obuf[k][j], ol, keep, out, lo)
+            for win, tiles in by_window.items():
+                nvox = int(np.prod(win))
+                for b0 in range(0, len(tiles), nb):
+                    group = tiles[b0:b0 + nb]
+                    n, k = len(group), ring.slot(i)
+                    tb = tbuf[k][:n * nvox].view(n, *win)
+                    ob = obuf[k][:n * nch * nvox].view(n, nch, *win)
+                    with ring.stream(i):
+                        for j, (lo, _) in enumerate(group):
+                            tile_gather(vol, lo - ol + shift, win, tb[j])
+                        run(tb, ob, k)
+                        for j, (lo, want) in enumerate(group):
+                            tile_scatter(ob[j], ol, want, out, lo)
+                    i += 1
 
     def _guarded(self, run):
         """Run one tiled prediction; if the fp16 range guard fired, repeat it in bf16 (default storage type) or raise."""
@@ -370,6 +390,7 @@ def dense_predictor(args):
     # to the plan with fp32's exponent range instead of killing the worker.
     act_dtype = global_params.config['dense_prediction']['act_dtype'] if _wd_set() else 'f16x2'
     skip_outside = bool(global_params.config['dense_prediction'].get('skip_tiles_outside_dataset', True)) if _wd_set() else True
+    clip_tiles = bool(global_params.config['dense_prediction'].get('clip_boundary_tiles', True)) if _wd_set() else True
     log_main.info(f'dense_predictor: activation storage type {act_dtype} '
                   f'({"reference precision" if act_dtype in ("f16x2", "f32") else "reduced precision, fast plan"})')
     while True:
@@ -378,7 +399,7 @@ def dense_predictor(args):
             out_shape = np.insert(out_shape, 0, n_channel)  # output must equal chunk size
             predictor = Predictor(model_p, strict_shapes=True, tile_shape=tile_shape[::-1], out_shape=out_shape,
                                   overlap_shape=overlap_shape_tiles[::-1], apply_softmax=True, act_dtype=act_dtype,
-                                  overflow_fallback=True)
+                                  overflow_fallback=True, clip_tiles=clip_tiles)
             try:
                 predictor.model.ae = False
             except Exception:  # ScriptModules refuse new attributes; elektronn3's flag has no meaning here

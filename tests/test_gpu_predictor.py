@@ -527,6 +527,45 @@ def test_tiles_beyond_the_dataset_are_skipped_without_changing_the_inside(gpu):
     assert torch.equal(same, full)
 
 
+@pytest.mark.parametrize('arch,act', [('myelin', 'bf16'), ('myelin', 'f16x2'), ('semseg_axon', 'f16'), ('syntype', 'bf16'),
+                                      ('mivcsj', 'f16')])
+def test_boundary_tiles_on_clipped_windows_are_bit_identical(gpu, arch, act):
+    """`clip_tiles` (Predictor._tiled / plan.clipped_extent): tiles that reach beyond the `valid_box` run on the part of their
+    window the voxels inside the box depend on.  Full-width networks (the fused level-0 forms, the streaming decoder, the
+    split plan), 2 x 2 x 2 tiles, the box ends inside the second tile of every axis: probabilities and labels inside the box are
+    bit-identical to full windows, the clipped windows are really smaller, and a GroupNorm network keeps full windows."""
+    from syconn_amd.cnn import random_state_dict
+    from syconn_amd.handler.prediction import Predictor
+    sd = random_state_dict(arch, seed=4, final_scale=4.0)
+    tile, ol, shape = (24, 96, 128), (4, 8, 8), (48, 192, 256)
+    box = ((0, 0, 0), (30, 110, 150))
+    g = torch.Generator().manual_seed(12)
+    raw = torch.randint(0, 256, shape, dtype=torch.uint8, generator=g)
+    raw[30:], raw[:, 110:], raw[:, :, 150:] = 0, 0, 0          # (what kd.load_raw returns beyond the boundary)
+    nc = random_state_dict(arch, seed=4)['conv_final.bias'].numel()
+    kw = dict(strict_shapes=True, tile_shape=tile, out_shape=(nc, *shape), overlap_shape=ol, apply_softmax=True, act_dtype=act)
+    clip, full = Predictor(sd, **kw), Predictor(sd, clip_tiles=False, **kw)
+    wins = [clip._dm.clipped_extent(o + w, t + 2 * o, a) for a, (o, w, t) in enumerate(zip(ol, (6, 14, 22), tile))]
+    if arch == 'mivcsj':
+        assert wins == [t + 2 * o for t, o in zip(tile, ol)]
+    else:
+        assert all(w <= t + 2 * o for w, t, o in zip(wins, tile, ol)) and wins[1] < tile[1] + 2 * ol[1] \
+            and wins[2] < tile[2] + 2 * ol[2], wins           # (z: syntype's reach exceeds the 32-plane window)
+    x = raw.to(gpu)
+    (z0, y0, x0), (z1, y1, x1) = box
+    a = clip.predict_proba_u8_device(x, valid_box=box).cpu()
+    b = full.predict_proba_u8_device(x, valid_box=box).cpu()
+    assert torch.equal(a[:, z0:z1, y0:y1, x0:x1], b[:, z0:z1, y0:y1, x0:x1])
+    assert int(a[:, z1:].max()) == 0 and int(a[:, :, y1:].max()) == 0 and int(a[:, :, :, x1:].max()) == 0   # beyond the box: zeros
+    ids, thr = list(range(1, nc)), [110.0] * (nc - 1)
+    la = clip.predict_labels_u8_device(x, ids, thr, valid_box=box).cpu()
+    lb = full.predict_labels_u8_device(x, ids, thr, valid_box=box).cpu()
+    assert torch.equal(la[z0:z1, y0:y1, x0:x1], lb[z0:z1, y0:y1, x0:x1]) and len(torch.unique(lb)) >= 2
+    # without a box only the volume's own end clips, and there is none here: identical everywhere
+    assert torch.equal(clip.predict_proba_u8_device(x).cpu(), full.predict_proba_u8_device(x).cpu())
+    assert not clip.overflowed() and not full.overflowed()
+
+
 def test_config3_full_width_model_two_by_two_by_two_tiles_vs_oracle(gpu):
     """BASELINE configs[2] with the FULL-WIDTH semseg_axon model (48 filters, 9.1 M parameters) on a 224 x 192 x 192 volume =
     2 x 2 x 2 model tiles of 128^3 in the config's geometry (useful (112,96,96) + halo (8,16,16), zeros outside the volume):

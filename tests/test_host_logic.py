@@ -332,3 +332,35 @@ def test_label_split_reports_a_posteriori_margins():
     assert r['argmax_mismatch_safe'] == 0 and r['label_mismatch_safe'] == 0
     m = merge_splits([r, r])
     assert m['voxels'] == 2 * r['voxels'] and abs(m['label_unsafe_frac_2x_measured_err'] - r['label_unsafe_frac_2x_measured_err']) < 1e-12
+
+
+@pytest.mark.parametrize('arch,axis', [('myelin', 0), ('myelin', 2), ('syntype', 0), ('syntype', 1), ('mivcsj', 2)])
+def test_clipped_extent_keeps_the_wanted_outputs_of_the_oracle_unet(arch, axis):
+    """`plan.clipped_extent` (boundary tiles are predicted on a clipped window): the oracle U-Net's outputs below `need` are the
+    same at the clipped and the full extent -- odd and even extents, also when the input BEYOND the clipped extent is not
+    zero (the cone argument does not use that) -- and one block less is not enough somewhere; GroupNorm nets are never clipped."""
+    from syconn_amd.plan import clipped_extent, plan_from_model
+    net = build_unet(arch, seed=3, start_filts=8 if arch == 'mivcsj' else 4)
+    ops, _, _ = plan_from_model(net)
+    full_shape = [21, 45, 45]
+    full_shape[axis] = 91
+    gen = torch.Generator().manual_seed(7)
+    x = torch.rand((1, 1, *full_shape), generator=gen)
+    with torch.no_grad():
+        ref = net(x)
+    too_small_differs = False
+    for need in (9, 20, 33):
+        e = clipped_extent(ops, need, 91, axis, multiple=1)
+        if arch == 'mivcsj':
+            assert e == 91
+            continue
+        assert need < e <= need + 64
+        for ext in (e, e + 1, clipped_extent(ops, need, 91, axis, multiple=8)):
+            with torch.no_grad():
+                got = net(x.narrow(2 + axis, 0, ext))
+            a, b = ref.narrow(2 + axis, 0, need), got.narrow(2 + axis, 0, need)
+            assert torch.allclose(a, b, rtol=0, atol=2e-6 * float(ref.abs().max())), (need, ext, float((a - b).abs().max()))
+        with torch.no_grad():
+            got = net(x.narrow(2 + axis, 0, need + 2))
+        too_small_differs |= not torch.allclose(ref.narrow(2 + axis, 0, need), got.narrow(2 + axis, 0, need), atol=1e-4)
+    assert too_small_differs or arch == 'mivcsj'
