@@ -12,7 +12,7 @@ import threading
 import torch
 
 from . import _lib as L
-from .plan import clipped_extent, plan_from_model
+from .plan import clipped_window, plan_from_model
 
 # 'f16x2': the reference-precision plan on the matrix cores (csrc/sd_split.hip: every value kept as fp16 hi + lo, three MFMA
 # passes per product, fp32-level logits at ~3x the cost of 'f16'); 'f32': fp32 storage and FMA arithmetic (csrc/sd_f32.hip, slow)
@@ -84,14 +84,15 @@ class DenseModel:
             self.lib.sd_model_destroy(h)
             self._h = None
 
-    def clipped_extent(self, need: int, full: int, axis: int) -> int:
-        """Input extent along `axis` that leaves the outputs with index < `need` unchanged (`plan.clipped_extent`); multiples
-        of 8 so that two poolings of the clipped window stay whole."""
-        key = (need, full, axis)
-        e = self._clip_cache.get(key)
-        if e is None:
-            e = self._clip_cache[key] = clipped_extent(self.ops, need, full, axis, multiple=8)
-        return e
+    def clipped_window(self, lo: int, hi: int, full: int, axis: int):
+        """(start, extent) of the part of an input window of `full` voxels along `axis` on which the outputs lo <= index < hi
+        are what they are on the whole window (`plan.clipped_window`); extents in multiples of 8 so that two poolings of the
+        clipped window stay whole."""
+        key = (lo, hi, full, axis)
+        w = self._clip_cache.get(key)
+        if w is None:
+            w = self._clip_cache[key] = clipped_window(self.ops, lo, hi, full, axis, multiple=8)
+        return w
 
     # -- workspace ------------------------------------------------------------------------------------
     def workspace_bytes(self, shape: Sequence[int]) -> int:

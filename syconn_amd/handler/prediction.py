@@ -178,10 +178,10 @@ class Predictor:
         every tile of every chunk, also those whose whole (cropped) result lies beyond the dataset boundary -- values of a
         zero input that nothing downstream reads.  With a `valid_box` such tiles are not predicted (their region of `out` is
         zero); every voxel inside the dataset is unchanged, because a tile's result depends on nothing but that tile.
-        `self.clip_tiles`: a tile that reaches beyond `vol` or the `valid_box` (the last tile of a chunk that is no multiple of
-        the tile shape: 58 of 178 planes wanted in the reference's geometry) is predicted on the part of its window the wanted
-        voxels can depend on (`plan.clipped_extent`: the far border of every layer stays outside their cones) -- same values,
-        less arithmetic; networks with GroupNorm (whole-tile statistics) keep full windows."""
+        `self.clip_tiles`: a tile that reaches beyond `vol` or the `valid_box` (the dataset ends inside it; or its outer rim
+        is the chunk's halo ring, which dense_predictor crops at prediction.py:812) is predicted on the part of its window the
+        wanted voxels can depend on (`plan.clipped_window`: the borders of every layer stay outside their cones) -- same
+        values, less arithmetic; beyond the box `out` is zero; networks with GroupNorm (whole-tile statistics) keep full windows."""
         from ..engine import tile_gather, tile_scatter
         ol_in = np.zeros(3, dtype=np.int64) if self.overlap_shape is None else self.overlap_shape
         spatial = np.asarray(vol.shape, dtype=np.int64) - (2 * ol_in if halo_included else 0)
@@ -218,11 +218,13 @@ class Predictor:
         for pos in pos_list:
             lo = tile * np.asarray(pos, dtype=np.int64)
             keep = np.minimum(tile, spatial - lo)
-            want = keep if valid_box is None else np.minimum(keep, v_hi - lo)
-            win = tuple(self._dm.clipped_extent(int(ol[a] + want[a]), int(tin[a]), a) for a in range(3)) \
-                if self.clip_tiles else tuple(int(t) for t in tin)
-            zero = zero or bool(np.any(want < keep))
-            by_window.setdefault(win, []).append((lo, want))
+            w0 = np.zeros(3, dtype=np.int64) if valid_box is None else np.maximum(v_lo - lo, 0)      # wanted: [w0, w1) from lo
+            w1 = keep if valid_box is None else np.minimum(keep, v_hi - lo)
+            win = [self._dm.clipped_window(int(ol[a] + w0[a]), int(ol[a] + w1[a]), int(tin[a]), a) for a in range(3)] \
+                if self.clip_tiles else [(0, int(t)) for t in tin]
+            zero = zero or bool(np.any(w1 < keep) or np.any(w0 > 0))
+            start = np.asarray([w[0] for w in win], dtype=np.int64)
+            by_window.setdefault(tuple(w[1] for w in win), []).append((lo, start, w0, w1))
         if zero:                                 # beyond the dataset `out` reads zero, whatever was skipped or clipped
             out.zero_()
         nb = self._batch_for(tin, max(len(g) for g in by_window.values()))
@@ -239,11 +241,11 @@ class Predictor:
                     tb = tbuf[k][:n * nvox].view(n, *win)
                     ob = obuf[k][:n * nch * nvox].view(n, nch, *win)
                     with ring.stream(i):
-                        for j, (lo, _) in enumerate(group):
-                            tile_gather(vol, lo - ol + shift, win, tb[j])
+                        for j, (lo, start, _, _) in enumerate(group):
+                            tile_gather(vol, lo - ol + shift + start, win, tb[j])
                         run(tb, ob, k)
-                        for j, (lo, want) in enumerate(group):
-                            tile_scatter(ob[j], ol, want, out, lo)
+                        for j, (lo, start, w0, w1) in enumerate(group):
+                            tile_scatter(ob[j], ol + w0 - start, w1 - w0, out, lo + w0)
                     i += 1
 
     def _guarded(self, run):

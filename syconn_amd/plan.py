@@ -10,6 +10,7 @@ Two model families reach ``Predictor`` in SyConn's dense path (SURVEY.md rows P1
 
 The result is ``(list[OpDesc], weight blob float32, info)``; ``sd_model_create`` does folding / packing / upload.
 """
+import math
 import re
 from typing import Dict, List, Optional, Tuple
 
@@ -247,4 +248,40 @@ def clipped_extent(ops, need: int, full: int, axis: int, multiple: int = 1) -> i
     while e < full and not fits(e):
         e += multiple
     return min(e, full)
+
+
+def clipped_window(ops, lo: int, hi: int, full: int, axis: int, multiple: int = 1):
+    """(start, extent) of the part of an input window of `full` voxels along `axis` that the outputs lo <= index < hi depend
+    on: `clipped_extent` for the far side plus the same argument for the near side.  The near border may only move by a multiple
+    of the network's total pooling stride along the axis (pooling windows and up-convolution parities keep their places), and no
+    wanted output may read any buffer below its new first index (conv k: - k//2; pooling f: * f; transposed conv f: floor(/ f))."""
+    ksz = (lambda d: (d.kz, d.ky, d.kx)[axis])
+    if any(d.kind == L.SD_OP_GROUPNORM for d in ops) or lo <= 0:
+        return 0, clipped_extent(ops, hi, full, axis, multiple)
+    scale, reads = {0: 1}, {}
+    for d in ops:
+        if d.kind != L.SD_OP_FINAL:
+            k, sc = int(ksz(d)), scale[int(d.src0)]
+            scale[int(d.dst)] = sc * k if d.kind == L.SD_OP_POOL else sc // k if d.kind == L.SD_OP_UPCONV else sc
+    for d in reversed(ops):
+        k = int(ksz(d))
+        if d.kind == L.SD_OP_FINAL:
+            n = lo
+        elif int(d.dst) in reads:
+            n = reads[int(d.dst)]
+        else:
+            continue
+        if d.kind == L.SD_OP_CONV:
+            n -= k // 2
+        elif d.kind == L.SD_OP_POOL:
+            n *= k
+        elif d.kind == L.SD_OP_UPCONV:
+            n //= k
+        for s in (int(d.src0), int(d.src1)) if d.kind == L.SD_OP_CONV else (int(d.src0),):
+            if s >= 0:
+                reads[s] = min(reads.get(s, n), n)
+    stride = max(scale.values())
+    stride = stride * multiple // math.gcd(stride, multiple)
+    start = max(0, min(n * scale[b] for b, n in reads.items()) // stride * stride)
+    return start, clipped_extent(ops, hi - start, full - start, axis, multiple)
 

@@ -538,25 +538,28 @@ def test_boundary_tiles_on_clipped_windows_are_bit_identical(gpu, arch, act):
     from syconn_amd.handler.prediction import Predictor
     sd = random_state_dict(arch, seed=4, final_scale=4.0)
     tile, ol, shape = (24, 96, 128), (4, 8, 8), (48, 192, 256)
-    box = ((0, 0, 0), (30, 110, 150))
+    box = ((12, 60, 60), (30, 110, 150))          # (near side: as if a wide halo ring were cropped afterwards)
     g = torch.Generator().manual_seed(12)
     raw = torch.randint(0, 256, shape, dtype=torch.uint8, generator=g)
     raw[30:], raw[:, 110:], raw[:, :, 150:] = 0, 0, 0          # (what kd.load_raw returns beyond the boundary)
     nc = random_state_dict(arch, seed=4)['conv_final.bias'].numel()
     kw = dict(strict_shapes=True, tile_shape=tile, out_shape=(nc, *shape), overlap_shape=ol, apply_softmax=True, act_dtype=act)
     clip, full = Predictor(sd, **kw), Predictor(sd, clip_tiles=False, **kw)
-    wins = [clip._dm.clipped_extent(o + w, t + 2 * o, a) for a, (o, w, t) in enumerate(zip(ol, (6, 14, 22), tile))]
+    wins = [clip._dm.clipped_window(o, o + w, t + 2 * o, a)[1] for a, (o, w, t) in enumerate(zip(ol, (6, 14, 22), tile))]
+    starts = [clip._dm.clipped_window(o + w, t + o, t + 2 * o, a)[0] for a, (o, w, t) in enumerate(zip(ol, box[0], tile))]
     if arch == 'mivcsj':
-        assert wins == [t + 2 * o for t, o in zip(tile, ol)]
+        assert wins == [t + 2 * o for t, o in zip(tile, ol)] and starts == [0, 0, 0]
     else:
         assert all(w <= t + 2 * o for w, t, o in zip(wins, tile, ol)) and wins[1] < tile[1] + 2 * ol[1] \
             and wins[2] < tile[2] + 2 * ol[2], wins           # (z: syntype's reach exceeds the 32-plane window)
+        assert starts[1] >= 8 and starts[2] >= 8, starts
     x = raw.to(gpu)
     (z0, y0, x0), (z1, y1, x1) = box
     a = clip.predict_proba_u8_device(x, valid_box=box).cpu()
     b = full.predict_proba_u8_device(x, valid_box=box).cpu()
     assert torch.equal(a[:, z0:z1, y0:y1, x0:x1], b[:, z0:z1, y0:y1, x0:x1])
     assert int(a[:, z1:].max()) == 0 and int(a[:, :, y1:].max()) == 0 and int(a[:, :, :, x1:].max()) == 0   # beyond the box: zeros
+    assert int(a[:, :z0].max()) == 0 and int(a[:, :, :y0].max()) == 0 and int(a[:, :, :, :x0].max()) == 0
     ids, thr = list(range(1, nc)), [110.0] * (nc - 1)
     la = clip.predict_labels_u8_device(x, ids, thr, valid_box=box).cpu()
     lb = full.predict_labels_u8_device(x, ids, thr, valid_box=box).cpu()

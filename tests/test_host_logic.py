@@ -364,3 +364,15 @@ def test_clipped_extent_keeps_the_wanted_outputs_of_the_oracle_unet(arch, axis):
             got = net(x.narrow(2 + axis, 0, need + 2))
         too_small_differs |= not torch.allclose(ref.narrow(2 + axis, 0, need), got.narrow(2 + axis, 0, need), atol=1e-4)
     assert too_small_differs or arch == 'mivcsj'
+    # near side: outputs lo <= index < hi on the window [start, start + extent)
+    from syconn_amd.plan import clipped_window
+    for lo, hi in ((60, 80), (48, 91), (70, 75), (3, 30)):
+        start, ext = clipped_window(ops, lo, hi, 91, axis, multiple=8)
+        if arch == 'mivcsj':
+            assert (start, ext) == (0, 91)
+            continue
+        assert start + ext <= 91 and start <= lo and start % 8 == 0 and (start > 0 or lo < 60)
+        with torch.no_grad():
+            got = net(x.narrow(2 + axis, start, ext))
+        a, b = ref.narrow(2 + axis, lo, hi - lo), got.narrow(2 + axis, lo - start, hi - lo)
+        assert torch.allclose(a, b, rtol=0, atol=2e-6 * float(ref.abs().max())), (lo, hi, start, ext, float((a - b).abs().max()))
