@@ -221,7 +221,8 @@ def main():
     ap.add_argument('--tiles', type=int, default=8, help='128^3 tiles per GPU per step')
     ap.add_argument('--tile', type=int, default=128)
     ap.add_argument('--arch', default='semseg_spine')
-    ap.add_argument('--act', default='bf16', choices=['bf16', 'f16', 'f16x2', 'f32'])
+    ap.add_argument('--act', default=None, choices=['bf16', 'f16', 'f16x2', 'f32'],
+                    help="activation storage type (default: bf16 = what BASELINE configs[1] names; volume workloads: their config's)")
     ap.add_argument('--batch', type=int, default=0, help='tiles per sd_forward_batch launch set (0 = all tiles of a step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--predict-outside', action='store_true',
@@ -237,6 +238,7 @@ def main():
     args = ap.parse_args()
     if args.workload != 'config2':
         return volume_main(args)
+    args.act = args.act or 'bf16'
 
     from syconn_amd import _lib as L
     from syconn_amd import parallel as par
@@ -408,6 +410,7 @@ def volume_main(args):
     from syconn_amd.cnn import random_state_dict
     from syconn_amd.handler.prediction import Predictor
     arch, act, vol_default, what = VOLUME_WORKLOADS[args.workload]
+    act = args.act or act
     vol_shape = tuple(args.volume) if args.volume else vol_default
     one_gpu_debug = bool(os.environ.get('SD_BENCH_ONE_GPU_DEBUG'))
     rank, world, local_rank = par.init_distributed('gloo' if one_gpu_debug else None)
