@@ -282,6 +282,19 @@ int sd_host_box_copy(const uint8_t* src, int64_t src_stride_z, int64_t src_strid
                      int64_t dst_stride_y, int64_t nz, int64_t ny, int64_t nx, int n_threads);
 int sd_host_zero(uint8_t* dst, int64_t nbytes, int n_threads);
 
+/* Window clipping for model tiles of which only a part is wanted (host arithmetic on the plan, no GPU).  The reference's
+ * chunk grid overhangs the dataset (fit_box_size=True, /root/reference/syconn/handler/prediction.py:679-683), every chunk is
+ * predicted with a halo ring that is cropped afterwards (:812), and tiled_apply (elektronn3, row P3) runs every tile on its
+ * full window.  Along `axis` (0 = z, 1 = y, 2 = x) the outputs lo <= index < hi of a window of `full` voxels depend on a cone of
+ * the input only; this returns the sub-window [*start, *start + *extent) on which those outputs have the SAME values as on the
+ * whole window: the far border of every layer ('same' padding, partial ceil-mode pooling windows, the up-convolution crop)
+ * stays outside every cone (backward pass: conv k reads k/2 further, pooling f reads f times as far, a transposed conv f
+ * ceil(/ f)), and the near border moves only by multiples of the network's total pooling stride along the axis, never past
+ * the lowest index a wanted output reads in any buffer.  *extent is a multiple of `multiple` (or what is left of `full`), *start a
+ * multiple of lcm(stride, multiple).  Plans with SD_OP_GROUPNORM (statistics over the whole window) return (0, full). */
+int sd_plan_clip_window(const sd_op_desc* ops, int n_ops, int axis, int lo, int hi, int full, int multiple, int* start,
+                        int* extent);
+
 #ifdef __cplusplus
 }
 #endif

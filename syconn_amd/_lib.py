@@ -22,7 +22,7 @@ EXPORTS = ['sd_init', 'sd_device_count', 'sd_model_create', 'sd_model_destroy', 
            'sd_snappy_compress', 'sd_snappy_uncompressed_length', 'sd_snappy_uncompress', 'sd_downsample2', 'sd_box_majority',
            'sd_objtable_bytes', 'sd_pairtable_bytes', 'sd_segstats_scan', 'sd_segstats_compact_objects',
            'sd_segstats_compact_pairs', 'sd_objseg_workspace_bytes', 'sd_object_segmentation', 'sd_objseg_watershed_workspace_bytes',
-           'sd_object_segmentation_watershed', 'sd_marker_flood', 'sd_host_box_copy', 'sd_host_zero']
+           'sd_object_segmentation_watershed', 'sd_marker_flood', 'sd_host_box_copy', 'sd_host_zero', 'sd_plan_clip_window']
 
 
 class OpDesc(C.Structure):
@@ -102,6 +102,8 @@ def load():
     i64 = C.c_int64
     lib.sd_host_box_copy.argtypes = [vp, i64, i64, vp, i64, i64, i64, i64, i64, i32]; lib.sd_host_box_copy.restype = i32
     lib.sd_host_zero.argtypes = [vp, i64, i32]; lib.sd_host_zero.restype = i32
+    lib.sd_plan_clip_window.argtypes = [C.POINTER(OpDesc), i32, i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
+    lib.sd_plan_clip_window.restype = i32
     _lib = lib
     return lib
 

@@ -12,7 +12,7 @@ import threading
 import torch
 
 from . import _lib as L
-from .plan import clipped_window, plan_from_model
+from .plan import plan_from_model
 
 # 'f16x2': the reference-precision plan on the matrix cores (csrc/sd_split.hip: every value kept as fp16 hi + lo, three MFMA
 # passes per product, fp32-level logits at ~3x the cost of 'f16'); 'f32': fp32 storage and FMA arithmetic (csrc/sd_f32.hip, slow)
@@ -68,7 +68,7 @@ class DenseModel:
         self.ops = ops
         self.out_channels = info['out_channels']
         self.act_dtype = act_dtype
-        arr = (L.OpDesc * len(ops))(*ops)
+        arr = self._ops_arr = (L.OpDesc * len(ops))(*ops)
         blob = np.ascontiguousarray(blob, dtype=np.float32)
         handle = C.c_void_p()
         L.check(self.lib.sd_model_create(arr, len(ops), blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size,
@@ -86,12 +86,15 @@ class DenseModel:
 
     def clipped_window(self, lo: int, hi: int, full: int, axis: int):
         """(start, extent) of the part of an input window of `full` voxels along `axis` on which the outputs lo <= index < hi
-        are what they are on the whole window (`plan.clipped_window`); extents in multiples of 8 so that two poolings of the
+        are what they are on the whole window (`sd_plan_clip_window`); extents in multiples of 8 so that the poolings of the
         clipped window stay whole."""
         key = (lo, hi, full, axis)
         w = self._clip_cache.get(key)
         if w is None:
-            w = self._clip_cache[key] = clipped_window(self.ops, lo, hi, full, axis, multiple=8)
+            start, extent = C.c_int32(), C.c_int32()
+            L.check(self.lib.sd_plan_clip_window(self._ops_arr, self.n_ops, axis, lo, hi, full, 8, C.byref(start),
+                                                 C.byref(extent)), 'sd_plan_clip_window')
+            w = self._clip_cache[key] = (int(start.value), int(extent.value))
         return w
 
     # -- workspace ------------------------------------------------------------------------------------

@@ -180,7 +180,7 @@ class Predictor:
         zero); every voxel inside the dataset is unchanged, because a tile's result depends on nothing but that tile.
         `self.clip_tiles`: a tile that reaches beyond `vol` or the `valid_box` (the dataset ends inside it; or its outer rim
         is the chunk's halo ring, which dense_predictor crops at prediction.py:812) is predicted on the part of its window the
-        wanted voxels can depend on (`plan.clipped_window`: the borders of every layer stay outside their cones) -- same
+        wanted voxels can depend on (`sd_plan_clip_window`: the borders of every layer stay outside their cones) -- same
         values, less arithmetic; beyond the box `out` is zero; networks with GroupNorm (whole-tile statistics) keep full windows."""
         from ..engine import tile_gather, tile_scatter
         ol_in = np.zeros(3, dtype=np.int64) if self.overlap_shape is None else self.overlap_shape

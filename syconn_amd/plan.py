@@ -10,7 +10,6 @@ Two model families reach ``Predictor`` in SyConn's dense path (SURVEY.md rows P1
 
 The result is ``(list[OpDesc], weight blob float32, info)``; ``sd_model_create`` does folding / packing / upload.
 """
-import math
 import re
 from typing import Dict, List, Optional, Tuple
 
@@ -195,93 +194,3 @@ def plan_from_model(model, group_norm_groups: Optional[int] = None):
                 groups = m.num_groups
                 break
     return plan_from_unet_state_dict(sd, group_norm_groups=groups)
-
-
-def clipped_extent(ops, need: int, full: int, axis: int, multiple: int = 1) -> int:
-    """Smallest input extent E <= `full` along `axis` (0 = z, 1 = y, 2 = x) for which the network's outputs with index
-    < `need` are what they are at extent `full`, given that the input is unchanged below E.  Used for model tiles that reach
-    beyond the chunk / dataset (tiled_apply pads them with zeros and the crop throws the results away): everything an output
-    voxel depends on lies inside a cone, and 'same' padding, ceil-mode pooling windows and the up-convolution crop at the far
-    border only matter to voxels whose cone touches that border.  Backward pass: how many leading indices of every buffer the
-    wanted outputs read (conv k: + k//2; pooling f: * f; transposed conv f: ceil(/ f)); forward pass: the extent every buffer
-    has at input extent E; E is valid when no buffer is read beyond its extent, which keeps the far border of every layer
-    outside every cone.  GroupNorm reads the whole tile: `full`."""
-    ksz = (lambda d: (d.kz, d.ky, d.kx)[axis])
-    if need >= full or any(d.kind == L.SD_OP_GROUPNORM for d in ops):
-        return full
-    reads = {}
-    for d in reversed(ops):
-        k = int(ksz(d))
-        if d.kind == L.SD_OP_FINAL:
-            n = need
-        else:
-            n = reads.get(int(d.dst), 0)
-            if n == 0:
-                continue
-        if d.kind == L.SD_OP_CONV:
-            n += k // 2
-        elif d.kind == L.SD_OP_POOL:
-            n *= k
-        elif d.kind == L.SD_OP_UPCONV:
-            n = -(-n // k)
-        for s in (int(d.src0), int(d.src1)) if d.kind == L.SD_OP_CONV else (int(d.src0),):
-            if s >= 0:
-                reads[s] = max(reads.get(s, 0), n)
-
-    def fits(e: int) -> bool:
-        ext = {0: e}
-        for d in ops:
-            k = int(ksz(d))
-            if d.kind == L.SD_OP_FINAL:
-                continue
-            a = ext[int(d.src0)]
-            if d.kind == L.SD_OP_CONV and d.src1 >= 0:
-                a = min(a, ext[int(d.src1)])           # autocrop (row U4): the larger operand loses its far end
-            elif d.kind == L.SD_OP_POOL:
-                a = -(-a // k)                         # ceil_mode
-            elif d.kind == L.SD_OP_UPCONV:
-                a *= k
-            ext[int(d.dst)] = a
-        return all(ext[b] >= n for b, n in reads.items())
-
-    e = -(-max(reads.get(0, need), need) // multiple) * multiple
-    while e < full and not fits(e):
-        e += multiple
-    return min(e, full)
-
-
-def clipped_window(ops, lo: int, hi: int, full: int, axis: int, multiple: int = 1):
-    """(start, extent) of the part of an input window of `full` voxels along `axis` that the outputs lo <= index < hi depend
-    on: `clipped_extent` for the far side plus the same argument for the near side.  The near border may only move by a multiple
-    of the network's total pooling stride along the axis (pooling windows and up-convolution parities keep their places), and no
-    wanted output may read any buffer below its new first index (conv k: - k//2; pooling f: * f; transposed conv f: floor(/ f))."""
-    ksz = (lambda d: (d.kz, d.ky, d.kx)[axis])
-    if any(d.kind == L.SD_OP_GROUPNORM for d in ops) or lo <= 0:
-        return 0, clipped_extent(ops, hi, full, axis, multiple)
-    scale, reads = {0: 1}, {}
-    for d in ops:
-        if d.kind != L.SD_OP_FINAL:
-            k, sc = int(ksz(d)), scale[int(d.src0)]
-            scale[int(d.dst)] = sc * k if d.kind == L.SD_OP_POOL else sc // k if d.kind == L.SD_OP_UPCONV else sc
-    for d in reversed(ops):
-        k = int(ksz(d))
-        if d.kind == L.SD_OP_FINAL:
-            n = lo
-        elif int(d.dst) in reads:
-            n = reads[int(d.dst)]
-        else:
-            continue
-        if d.kind == L.SD_OP_CONV:
-            n -= k // 2
-        elif d.kind == L.SD_OP_POOL:
-            n *= k
-        elif d.kind == L.SD_OP_UPCONV:
-            n //= k
-        for s in (int(d.src0), int(d.src1)) if d.kind == L.SD_OP_CONV else (int(d.src0),):
-            if s >= 0:
-                reads[s] = min(reads.get(s, n), n)
-    stride = max(scale.values())
-    stride = stride * multiple // math.gcd(stride, multiple)
-    start = max(0, min(n * scale[b] for b, n in reads.items()) // stride * stride)
-    return start, clipped_extent(ops, hi - start, full - start, axis, multiple)
-

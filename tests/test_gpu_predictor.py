@@ -530,7 +530,7 @@ def test_tiles_beyond_the_dataset_are_skipped_without_changing_the_inside(gpu):
 @pytest.mark.parametrize('arch,act', [('myelin', 'bf16'), ('myelin', 'f16x2'), ('semseg_axon', 'f16'), ('syntype', 'bf16'),
                                       ('mivcsj', 'f16')])
 def test_boundary_tiles_on_clipped_windows_are_bit_identical(gpu, arch, act):
-    """`clip_tiles` (Predictor._tiled / plan.clipped_extent): tiles that reach beyond the `valid_box` run on the part of their
+    """`clip_tiles` (Predictor._tiled / sd_plan_clip_window): tiles that reach beyond the `valid_box` run on the part of their
     window the voxels inside the box depend on.  Full-width networks (the fused level-0 forms, the streaming decoder, the
     split plan), 2 x 2 x 2 tiles, the box ends inside the second tile of every axis: probabilities and labels inside the box are
     bit-identical to full windows, the clipped windows are really smaller, and a GroupNorm network keeps full windows."""

@@ -334,12 +334,22 @@ def test_label_split_reports_a_posteriori_margins():
     assert m['voxels'] == 2 * r['voxels'] and abs(m['label_unsafe_frac_2x_measured_err'] - r['label_unsafe_frac_2x_measured_err']) < 1e-12
 
 
+def _c_clip_window(ops, lo, hi, full, axis, multiple):
+    import ctypes as C
+    from syconn_amd import _lib as L
+    arr = (L.OpDesc * len(ops))(*ops)
+    start, extent = C.c_int32(), C.c_int32()
+    L.check(L.load().sd_plan_clip_window(arr, len(ops), axis, lo, hi, full, multiple, C.byref(start), C.byref(extent)))
+    return int(start.value), int(extent.value)
+
+
 @pytest.mark.parametrize('arch,axis', [('myelin', 0), ('myelin', 2), ('syntype', 0), ('syntype', 1), ('mivcsj', 2)])
-def test_clipped_extent_keeps_the_wanted_outputs_of_the_oracle_unet(arch, axis):
-    """`plan.clipped_extent` (boundary tiles are predicted on a clipped window): the oracle U-Net's outputs below `need` are the
-    same at the clipped and the full extent -- odd and even extents, also when the input BEYOND the clipped extent is not
-    zero (the cone argument does not use that) -- and one block less is not enough somewhere; GroupNorm nets are never clipped."""
-    from syconn_amd.plan import clipped_extent, plan_from_model
+def test_clipped_windows_keep_the_wanted_outputs_of_the_oracle_unet(arch, axis):
+    """`sd_plan_clip_window` (model tiles of which only a part is wanted run on a clipped window): the oracle U-Net's outputs
+    lo <= index < hi are the same on the clipped and the full window -- odd and even extents, also when the input BEYOND the
+    window is not zero (the cone argument does not use that) -- and a window two voxels past the wanted ones is not enough
+    somewhere; GroupNorm nets are never clipped."""
+    from syconn_amd.plan import plan_from_model
     net = build_unet(arch, seed=3, start_filts=8 if arch == 'mivcsj' else 4)
     ops, _, _ = plan_from_model(net)
     full_shape = [21, 45, 45]
@@ -348,26 +358,27 @@ def test_clipped_extent_keeps_the_wanted_outputs_of_the_oracle_unet(arch, axis):
     x = torch.rand((1, 1, *full_shape), generator=gen)
     with torch.no_grad():
         ref = net(x)
+    tol = 2e-6 * float(ref.abs().max())
     too_small_differs = False
     for need in (9, 20, 33):
-        e = clipped_extent(ops, need, 91, axis, multiple=1)
+        s0, e = _c_clip_window(ops, 0, need, 91, axis, 1)
+        assert s0 == 0
         if arch == 'mivcsj':
             assert e == 91
             continue
         assert need < e <= need + 64
-        for ext in (e, e + 1, clipped_extent(ops, need, 91, axis, multiple=8)):
+        for ext in (e, e + 1, _c_clip_window(ops, 0, need, 91, axis, 8)[1]):
             with torch.no_grad():
                 got = net(x.narrow(2 + axis, 0, ext))
             a, b = ref.narrow(2 + axis, 0, need), got.narrow(2 + axis, 0, need)
-            assert torch.allclose(a, b, rtol=0, atol=2e-6 * float(ref.abs().max())), (need, ext, float((a - b).abs().max()))
+            assert torch.allclose(a, b, rtol=0, atol=tol), (need, ext, float((a - b).abs().max()))
         with torch.no_grad():
             got = net(x.narrow(2 + axis, 0, need + 2))
         too_small_differs |= not torch.allclose(ref.narrow(2 + axis, 0, need), got.narrow(2 + axis, 0, need), atol=1e-4)
     assert too_small_differs or arch == 'mivcsj'
     # near side: outputs lo <= index < hi on the window [start, start + extent)
-    from syconn_amd.plan import clipped_window
     for lo, hi in ((60, 80), (48, 91), (70, 75), (3, 30)):
-        start, ext = clipped_window(ops, lo, hi, 91, axis, multiple=8)
+        start, ext = _c_clip_window(ops, lo, hi, 91, axis, 8)
         if arch == 'mivcsj':
             assert (start, ext) == (0, 91)
             continue
@@ -375,4 +386,30 @@ def test_clipped_extent_keeps_the_wanted_outputs_of_the_oracle_unet(arch, axis):
         with torch.no_grad():
             got = net(x.narrow(2 + axis, start, ext))
         a, b = ref.narrow(2 + axis, lo, hi - lo), got.narrow(2 + axis, lo - start, hi - lo)
-        assert torch.allclose(a, b, rtol=0, atol=2e-6 * float(ref.abs().max())), (lo, hi, start, ext, float((a - b).abs().max()))
+        assert torch.allclose(a, b, rtol=0, atol=tol), (lo, hi, start, ext, float((a - b).abs().max()))
+
+
+def test_clip_window_in_c_equals_its_python_restatement_on_every_architecture():
+    """`sd_plan_clip_window` against oracle/clip_ref.py: all 8 architectures + the sequential config-1 net, every axis, random
+    wanted ranges, window sizes and multiples; argument errors are SD_ERR_INVALID -> ValueError."""
+    from oracle.clip_ref import clipped_window
+    from syconn_amd.plan import plan_from_model
+    rng = np.random.default_rng(5)
+    plans = [plan_from_model(build_unet(a, seed=1, start_filts=8))[0] for a in ARCHS] + [plan_from_model(build_cnn3(0))[0]]
+    smaller = 0
+    for ops in plans:
+        for axis in range(3):
+            for _ in range(40):
+                full = int(rng.integers(8, 400))
+                lo = int(rng.integers(0, full))
+                hi = int(rng.integers(lo + 1, full + 1))
+                mult = int(rng.choice([1, 2, 8, 16, 32]))
+                got = _c_clip_window(ops, lo, hi, full, axis, mult)
+                assert got == tuple(int(v) for v in clipped_window(ops, lo, hi, full, axis, mult)), (axis, lo, hi, full, mult)
+                assert 0 <= got[0] <= lo and got[0] + got[1] <= full and hi <= got[0] + got[1]
+                smaller += got[1] < full
+    assert smaller > 300
+    with pytest.raises(ValueError):
+        _c_clip_window(plans[0], 5, 3, 10, 0, 8)
+    with pytest.raises(ValueError):
+        _c_clip_window(plans[0], 0, 3, 10, 3, 8)
