@@ -27,8 +27,9 @@ int launch_conv_split_knt(const ConvParams& p, int NB, hipStream_t s) {
     const int nstages = (p.nchunk0 + p.nchunk1) * KZ;
     const bool big = (vox / 512) * NB >= 512;      // the form rules of launch_conv_knt (sd_kernels.hip)
     const bool ff = p.final_wfrag != nullptr;
+    static const size_t wres8 = (size_t)(getenv("SD_SPLIT_WRES8_KB") ? atoi(getenv("SD_SPLIT_WRES8_KB")) : 96) * 1024;
     if (big) {
-        if (conv_lds_bytes<KZ, NT, 8, 2, 2>(nstages, ff) <= 96 * 1024) return launch_conv_k<T, KZ, NT, 8, 2, 2, 3>(p, NB, s);
+        if (conv_lds_bytes<KZ, NT, 8, 2, 2>(nstages, ff) <= wres8) return launch_conv_k<T, KZ, NT, 8, 2, 2, 3>(p, NB, s);
         if constexpr (KZ == 3 && NT == 2) {
             if (!ff && (vox / 1024) * NB >= 256 && (p.D % 8 == 0 || p.D >= 96)) return launch_conv_k<T, KZ, NT, 8, 0, 4, 3>(p, NB, s);
         }
