@@ -64,6 +64,18 @@ def test_bench_two_ranks_default_workload(gpu):
     assert line['config']['labels_sha256'] == want
 
 
+def test_config4_full_size_clipped_windows_equal_full_windows(gpu):
+    """BASELINE configs[3] at FULL size (2048 x 2048 x 512, the reference's chunk / tile geometry: 75 chunks, 585 predicted
+    tiles): the result volume with tiles on clipped windows (default) is the one with full windows, by sha256 of all 2.1 G
+    values -- the size-independent property of `sd_plan_clip_window` at the size the metric is quoted on."""
+    args = ['bench.py', '--workload', 'config4', '--geometry', 'reference', '--steps', '1', '--warmup', '0', '--labels-sha',
+            '--no-cpu-baseline', '--gpus', '1']
+    clip = _json_line(_run([sys.executable] + args))
+    full = _json_line(_run([sys.executable] + args + ['--full-windows']))
+    assert clip['config']['labels_sha256'] and clip['config']['labels_sha256'] == full['config']['labels_sha256']
+    assert clip['ms_per_step'] < 0.85 * full['ms_per_step'], (clip['ms_per_step'], full['ms_per_step'])
+
+
 @pytest.mark.parametrize('workload,geometry,volume', [('config3', 'tile128', (256, 256, 256)),
                                                        ('config4', 'reference', (236, 962, 964)),
                                                        ('config5', 'tile128', (224, 384, 384))])
