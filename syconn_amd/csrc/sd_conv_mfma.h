@@ -294,12 +294,41 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     };
     // (deferred GroupNorm apply: the decode table stays in registers -- it is needed twice per chunk, for the DMA and for the in-LDS
     // rewrite, and the ~30 VALU operations of a re-decode per piece are what the rewrite is made of)
-    constexpr bool HPACK_REGS = !LEAN || GN || (NT == 3 && MT == 2);
+    // POFF (every form outside the register diet, plain or split): a lane's halo-piece offsets inside a chunk plane are the same
+    // for every chunk of a source tensor, so they are computed once per (block, source) into AJ registers (0xffffffff = beyond
+    // the volume -> the zero page); a chunk's DMA is then one 64-bit add and one select per piece instead of decode, three bounds
+    // tests, two quarter-rate multiplies and the add -- and the decode table plus what the compiler hoisted around it (12-60
+    // registers, e.g. 213 -> 166 for the streamed 3x3x3 NT = 2 form, 171 -> 120 for its NT = 1 sibling) is gone.  Same addresses,
+    // bit-identical results; time: -0.5 % on semseg_spine bf16 / semseg_axon, +-0 on the split plan (A/B of two libraries on one
+    // box) -- the stage loop of these forms has ~58 VALU per 18 MFMAs, their epilogues 1000-1600 per block: that is where their
+    // issue slots go.
+#ifdef SD_NO_POFF
+    constexpr bool POFF = false;
+#else
+    constexpr bool POFF = !LEAN && !GN;
+#endif
+    constexpr bool HPACK_REGS = !POFF && (!LEAN || GN || (NT == 3 && MT == 2));
     int hpack[HPACK_REGS ? AJ : 1];
     if constexpr (HPACK_REGS) {
 #pragma unroll
         for (int j = 0; j < AJ; ++j) hpack[j] = hpack_of(j);
     }
+    unsigned poff[POFF ? AJ : 1];
+    auto halo_offsets = [&](int bz, int by, int bx, int Hs, int Ws) {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            int idx = (wave + j * WAVES) * 64 + lane;
+            asm volatile("" : "+v"(idx));      // decoded here, once per block: nothing of it stays live across the block loop
+            const int hv = idx >> 1;
+            const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+            const int z = bz - PZ + hz, y = by - 1 + hy, x = bx - 1 + hx;
+            const bool ok = idx < NH * 2 && (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            // (< 2^32 bytes per chunk plane: sd_forward's size limit)
+            const unsigned o = ((((unsigned)z * (unsigned)Hs + (unsigned)y) * (unsigned)Ws + (unsigned)x) * SD_CHUNK +
+                                (unsigned)(((idx & 1) ^ (hy & 1)) * 8)) * (unsigned)sizeof(T);
+            poff[j] = ok ? o : 0xffffffffu;
+        }
+    };
     // logical block of (round, this workgroup); -1 when the round has no block for it
     const int nsb_all = nsb * p.batch;      // the tiles of a batched launch are simply more blocks
 #ifdef SD_XCD_ROUNDS
@@ -369,6 +398,21 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         }
         sbase += (size_t)cc * Ps * (SD_CHUNK * sizeof(T)) + (size_t)tile * p.tstride;      // chunk plane of this tile
         char* dst = ldsA + slot * A_BYTES + wave * 1024;
+        if constexpr (POFF) {
+            // chunk 0 is the first DMA of a block, chunk nchunk0 the first of the second source (other extents behind an up-convolution)
+            if (real && (c == 0 || (c == p.nchunk0 && (p.H1 != p.H0 || p.W1 != p.W0)))) halo_offsets(z0, y0, x0, Hs, Ws);
+#pragma unroll
+            for (int j = 0; j < AJ; ++j) {
+                const bool inst = real && (wave + j * WAVES < A_INSTR);       // wave-uniform
+                if (inst || NA > 2) {
+                    const unsigned o = poff[j];
+                    const char* src = reinterpret_cast<const char*>(p.zero);
+                    if (inst && o != 0xffffffffu) src = sbase + o;
+                    glds16(src, inst ? dst + j * (WAVES * 1024) : ldsDummy);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             const bool inst = real && (wave + j * WAVES < A_INSTR);       // wave-uniform
