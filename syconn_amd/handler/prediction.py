@@ -67,7 +67,7 @@ class Predictor:
     was given explicitly) the prediction is repeated in the next plan with fp32's exponent range ('f16' -> 'bf16', 'f16x2' ->
     'f32') and the Predictor stays there, otherwise ``ActivationOverflowError`` (a ``RuntimeError``) is raised.
     `batch_size`: tiles per launch set (default: automatic,
-    see `_batch_for`).  `n_streams` (default 1, env SYCONN_AMD_STREAMS): batches alternate over that many HIP
+    see `_batch_for`).  `n_streams` (default: 1, or 2 for single-tile launch sets; env SYCONN_AMD_STREAMS): batches alternate over that many HIP
     streams, each with its own workspace.
 
     ``predict(inp)`` takes an ``np.ndarray`` / ``Tensor`` of shape (N,1,D,H,W) and any float dtype and returns a
@@ -141,9 +141,14 @@ class Predictor:
         self._gn_groups = group_norm_groups
         self._dm = DenseModel(model, act_dtype=act_dtype, device=self.device, group_norm_groups=group_norm_groups)
         self.out_channels = self._dm.out_channels
-        if n_streams is None:
-            n_streams = int(os.environ.get('SYCONN_AMD_STREAMS', '1'))
-        self._ring = StreamRing(self.device, n_streams)
+        # HIP streams that tiles alternate over.  Given (argument or SYCONN_AMD_STREAMS): that many, always.  Default: one, and
+        # two for tiles that run one per launch set (the reference's 178 x 243 x 331 windows): the small deep layers and the
+        # launch tail of one tile then run under the big layers of the next (+2.5 ... 5 % on the reference geometry; batches of
+        # 128^3 tiles fill the GPU by themselves: +-0)
+        if n_streams is None and 'SYCONN_AMD_STREAMS' in os.environ:
+            n_streams = int(os.environ['SYCONN_AMD_STREAMS'])
+        self._ring = StreamRing(self.device, 1 if n_streams is None else n_streams)
+        self._ring2 = StreamRing(self.device, 2) if n_streams is None else None
 
     # -- geometry --------------------------------------------------------------------------------------
     def _geometry(self, spatial: np.ndarray):
@@ -228,7 +233,7 @@ class Predictor:
         if zero:                                 # beyond the dataset `out` reads zero, whatever was skipped or clipped
             out.zero_()
         nb = self._batch_for(tin, max(len(g) for g in by_window.values()))
-        ring = self._ring
+        ring = self._ring2 if (self._ring2 is not None and nb == 1 and len(pos_list) > 1) else self._ring
         tbuf = [torch.empty(nb * int(np.prod(tin)), dtype=vol.dtype, device=self.device) for _ in range(ring.n)]
         obuf = [torch.empty(nb * nch * int(np.prod(tin)), dtype=out.dtype, device=self.device) for _ in range(ring.n)]
         i = 0
