@@ -76,6 +76,17 @@ def test_config4_full_size_clipped_windows_equal_full_windows(gpu):
     assert clip['ms_per_step'] < 0.85 * full['ms_per_step'], (clip['ms_per_step'], full['ms_per_step'])
 
 
+def test_config5_full_size_skipping_tiles_beyond_the_dataset_changes_nothing(gpu):
+    """BASELINE configs[4] at FULL size (mivcsj fp16, GroupNorm, label rule, 2048 x 2048 x 512 in 128^3 model tiles): the label
+    volume with the tiles beyond the dataset skipped (default) is the one with every tile of every chunk predicted, as the
+    reference does -- sha256 of all 2.1 G labels; several classes occur."""
+    args = ['bench.py', '--workload', 'config5', '--steps', '1', '--warmup', '0', '--labels-sha', '--no-cpu-baseline', '--gpus', '1']
+    skip = _json_line(_run([sys.executable] + args))
+    full = _json_line(_run([sys.executable] + args + ['--predict-outside']))
+    assert skip['config']['labels_sha256'] and skip['config']['labels_sha256'] == full['config']['labels_sha256']
+    assert skip['dtype'] == 'f16' and skip['ms_per_step'] < full['ms_per_step']
+
+
 @pytest.mark.parametrize('workload,geometry,volume', [('config3', 'tile128', (256, 256, 256)),
                                                        ('config4', 'reference', (236, 962, 964)),
                                                        ('config5', 'tile128', (224, 384, 384))])
