@@ -180,9 +180,40 @@ def plan_from_sequential(model: torch.nn.Sequential):
     return ops, blob.array(), dict(family='sequential', out_channels=int(ops[-1].cout), n_buffers=nxt)
 
 
+# what a state_dict cannot show: the plan assumes ReLU activations and transposed-convolution upsampling (all of SyConn's
+# models: activation='relu', syconn/cnn/cnn_*.py).  A traced / scripted model or an nn.Module that uses anything else is
+# refused instead of being predicted with the wrong function.
+_UNSUPPORTED_ATEN = ('aten::leaky_relu', 'aten::prelu', 'aten::rrelu', 'aten::elu', 'aten::selu', 'aten::celu', 'aten::gelu',
+                     'aten::silu', 'aten::mish', 'aten::hardswish', 'aten::softplus', 'aten::tanh', 'aten::sigmoid',
+                     'aten::upsample', 'aten::interpolate', 'aten::instance_norm', 'aten::layer_norm')
+
+
+def _refuse_unsupported_layers(model):
+    import torch.nn as nn
+    if isinstance(model, torch.jit.ScriptModule):
+        try:
+            graph = str(model.inlined_graph)
+        except Exception:       # (no graph to look at: nothing to check)
+            return
+        found = sorted({op for op in _UNSUPPORTED_ATEN if op in graph})
+        if found:
+            raise ValueError(f'the model uses {", ".join(found)}: only ReLU activations, BatchNorm / GroupNorm and transposed-'
+                             f'convolution upsampling are implemented (what syconn/cnn/cnn_*.py build)')
+    elif isinstance(model, nn.Module):
+        ok = (nn.Conv3d, nn.ConvTranspose3d, nn.BatchNorm3d, nn.GroupNorm, nn.ReLU, nn.MaxPool3d, nn.Identity, nn.Dropout,
+              nn.Dropout3d, nn.Sequential, nn.ModuleList)
+        bad = sorted({type(m).__name__ for m in model.modules()
+                      if not list(m.children()) and not isinstance(m, ok) and type(m).__module__.startswith('torch.nn')})
+        if bad:
+            raise ValueError(f'the model contains {", ".join(bad)}: only Conv3d / ConvTranspose3d / BatchNorm3d / GroupNorm / ReLU '
+                             f'/ MaxPool3d networks are implemented (what syconn/cnn/cnn_*.py build)')
+
+
 def plan_from_model(model, group_norm_groups: Optional[int] = None):
     """Dispatch on the model type: ScriptModule / nn.Module with a UNet state_dict, or nn.Sequential."""
     import torch.nn as nn
+    if not isinstance(model, dict):
+        _refuse_unsupported_layers(model)
     if isinstance(model, nn.Sequential) and not isinstance(model, torch.jit.ScriptModule):
         return plan_from_sequential(model)
     sd = model if isinstance(model, dict) else model.state_dict()

@@ -413,3 +413,31 @@ def test_clip_window_in_c_equals_its_python_restatement_on_every_architecture():
         _c_clip_window(plans[0], 5, 3, 10, 0, 8)
     with pytest.raises(ValueError):
         _c_clip_window(plans[0], 0, 3, 10, 3, 8)
+
+
+def test_models_with_other_activations_are_refused():
+    """A state_dict does not show the activation function: a traced or eager model that is not ReLU / transposed-conv (everything
+    SyConn's cnn_*.py build is) raises ValueError instead of being predicted as if it were."""
+    import torch.nn as nn
+    from syconn_amd.plan import plan_from_model
+    net = build_unet('myelin', seed=0, start_filts=4)
+    plan_from_model(net)
+    traced = torch.jit.trace(net, torch.randn(1, 1, 8, 16, 16))
+    plan_from_model(traced)
+
+    def swap(m):
+        for name, ch in m.named_children():
+            if isinstance(ch, nn.ReLU):
+                setattr(m, name, nn.LeakyReLU(0.1))
+            else:
+                swap(ch)
+    leaky = build_unet('myelin', seed=0, start_filts=4)
+    swap(leaky)
+    if any(isinstance(m, nn.LeakyReLU) for m in leaky.modules()):
+        with pytest.raises(ValueError, match='LeakyReLU'):
+            plan_from_model(leaky)
+        with pytest.raises(ValueError, match='leaky_relu'):
+            plan_from_model(torch.jit.trace(leaky, torch.randn(1, 1, 8, 16, 16)))
+    seq = nn.Sequential(nn.Conv3d(1, 4, 3, padding=1), nn.Tanh(), nn.Conv3d(4, 2, 1))
+    with pytest.raises(ValueError, match='Tanh'):
+        plan_from_model(seq)
