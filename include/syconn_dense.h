@@ -274,6 +274,19 @@ int sd_object_segmentation_watershed(const uint8_t* prob_dev, int X, int Y, int 
 int sd_marker_flood(const int32_t* d2_dev, const int32_t* markers_dev, const uint8_t* mask_dev, int X, int Y, int Z,
                     int32_t* labels_dev, int32_t* max_label_dev, void* workspace_dev, size_t ws_bytes, void* stream);
 
+/* Gaussian pre-smoothing of a probability map followed by the threshold (object_extraction_steps.py:296-297
+ * `gaussianSmoothing(tmp_data, sigmas[...])`, vigra; :316-317 `tmp_data > thresholds[...]`) -- the optional first step of
+ * _object_segmentation_thread (SyConn's own pipeline passes no sigmas).  prob_dev (X,Y,Z) uint8, z fastest; sigma_xyz HOST
+ * double[3] per axis in voxels (0: axis not smoothed).  vigra's published algorithm restated (parity UNPINNED, vigra is absent
+ * here): separable, axis order x, y, z, window radius int(3 sigma + 0.5) (>= 1, <= 64) of exp(-t^2 / 2 sigma^2) normalised to
+ * sum 1, reflective border without repeating the edge, sums in double, every pass stored as float32.
+ *   mask_dev     (X,Y,Z) uint8: 1 where smoothed > threshold (uint8 scale like the input), else 0 -- pass it to
+ *                sd_object_segmentation* with threshold 0;
+ *   smoothed_dev optional (X,Y,Z) float32: the smoothed map. */
+size_t sd_gauss_workspace_bytes(int X, int Y, int Z);
+int sd_gaussian_threshold(const uint8_t* prob_dev, int X, int Y, int Z, const double* sigma_xyz, double threshold,
+                          uint8_t* mask_dev, float* smoothed_dev, void* workspace_dev, size_t ws_bytes, void* stream);
+
 /* ---- host-side helpers of the chunk pipeline (no GPU) -----------------------------------------------------------------
  * Multi-threaded strided copy of an (nz, ny, nx)-byte box between two uint8 host arrays whose x-rows are contiguous
  * (strides in bytes), and a multi-threaded memset: what numpy slicing does on one core when the reference cuts a chunk

@@ -22,7 +22,8 @@ EXPORTS = ['sd_init', 'sd_device_count', 'sd_model_create', 'sd_model_destroy', 
            'sd_snappy_compress', 'sd_snappy_uncompressed_length', 'sd_snappy_uncompress', 'sd_downsample2', 'sd_box_majority',
            'sd_objtable_bytes', 'sd_pairtable_bytes', 'sd_segstats_scan', 'sd_segstats_compact_objects',
            'sd_segstats_compact_pairs', 'sd_objseg_workspace_bytes', 'sd_object_segmentation', 'sd_objseg_watershed_workspace_bytes',
-           'sd_object_segmentation_watershed', 'sd_marker_flood', 'sd_host_box_copy', 'sd_host_zero', 'sd_plan_clip_window']
+           'sd_object_segmentation_watershed', 'sd_marker_flood', 'sd_host_box_copy', 'sd_host_zero', 'sd_plan_clip_window',
+           'sd_gauss_workspace_bytes', 'sd_gaussian_threshold']
 
 
 class OpDesc(C.Structure):
@@ -99,6 +100,9 @@ def load():
                                                      C.POINTER(C.c_int32), vp, vp, vp, vp, vp, vp, sz, vp]
     lib.sd_object_segmentation_watershed.restype = i32
     lib.sd_marker_flood.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, sz, vp]; lib.sd_marker_flood.restype = i32
+    lib.sd_gauss_workspace_bytes.argtypes = [i32, i32, i32]; lib.sd_gauss_workspace_bytes.restype = sz
+    lib.sd_gaussian_threshold.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_double), C.c_double, vp, vp, vp, sz, vp]
+    lib.sd_gaussian_threshold.restype = i32
     i64 = C.c_int64
     lib.sd_host_box_copy.argtypes = [vp, i64, i64, vp, i64, i64, i64, i64, i64, i32]; lib.sd_host_box_copy.restype = i32
     lib.sd_host_zero.argtypes = [vp, i64, i32]; lib.sd_host_zero.restype = i32

@@ -1426,6 +1426,45 @@ void flood_run(hipStream_t s, const uint32_t* M, const uint32_t* seed_bits, cons
 }
 }  // namespace
 
+// ---- Gaussian pre-smoothing (sd_gaussian_threshold) ------------------------------------------------------------------------------
+constexpr int GAUSS_MAX_R = 64;
+struct GaussTaps { int r; double w[2 * GAUSS_MAX_R + 1]; };
+// one axis of the separable filter: out[v] = float(sum_k w[k] * in[reflect(i + k - r)]), i = index of v along the axis
+template <typename TI>
+__global__ __launch_bounds__(256) void k_gauss_axis(const TI* __restrict__ in, float* __restrict__ out, size_t nvox, int n, long stride,
+                                                    const GaussTaps t) {
+    const int period = n > 1 ? 2 * (n - 1) : 1;
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < nvox; v += (size_t)gridDim.x * 256) {
+        const int i = (int)((v / (size_t)stride) % (size_t)n);
+        const TI* const line = in + (v - (size_t)i * stride);
+        double acc = 0.0;
+        for (int k = 0; k <= 2 * t.r; ++k) {
+            int j = i + k - t.r;
+            if (j < 0 || j >= n) {                     // mirror without repeating the edge sample, as often as the window needs
+                j %= period;
+                if (j < 0) j += period;
+                if (j >= n) j = period - j;
+            }
+            acc += t.w[k] * (double)line[(size_t)j * stride];
+        }
+        out[v] = (float)acc;
+    }
+}
+// mask = smoothed > threshold (threshold 0: any non-zero value); `sm` == nullptr: no axis was smoothed, the uint8 values themselves
+__global__ __launch_bounds__(256) void k_gauss_threshold(const uint8_t* __restrict__ prob, const float* __restrict__ sm, size_t nvox,
+                                                         float thr, uint8_t* __restrict__ mask, float* __restrict__ smoothed_out) {
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < nvox; v += (size_t)gridDim.x * 256) {
+        const float x = sm ? sm[v] : (float)prob[v];
+        mask[v] = x > thr ? 1 : 0;
+        if (smoothed_out) smoothed_out[v] = x;
+    }
+}
+
+extern "C" size_t sd_gauss_workspace_bytes(int X, int Y, int Z) {
+    if (X <= 0 || Y <= 0 || Z <= 0) return 0;
+    return 2 * (((size_t)X * Y * Z + 63) / 64) * 64 * sizeof(float);
+}
+
 extern "C" {
 
 int sd_object_segmentation(const uint8_t* prob_dev, int X, int Y, int Z, double threshold, const int32_t* ops,
@@ -1549,6 +1588,44 @@ int sd_marker_flood(const int32_t* d2_dev, const int32_t* markers_dev, const uin
     flood_components(s, M, nullptr, d, markers_dev, B, max_label_dev, nullptr);
     flood_run(s, M, nullptr, d, markers_dev, d2_dev, B, labels_dev);
     return hipGetLastError() == hipSuccess ? SD_OK : sd_fail_msg(SD_ERR_HIP, "sd_marker_flood: launch failed");
+}
+
+// ---- Gaussian pre-smoothing of a probability map + threshold (object_extraction_steps.py:296-297, 316-317) -------------------
+// vigra.gaussianSmoothing restated from its published algorithm (vigra is absent from the reference tree and this image: parity
+// UNPINNED): separable, axes in memory order (x, then y, then z), per axis a window of radius int(3 sigma + 0.5) (at least 1)
+// sampled from exp(-t^2 / (2 sigma^2)) and normalised to sum 1, reflective border without repeating the edge
+// (BORDER_TREATMENT_REFLECT), sums in double (the promote type of float data and double taps), every pass stored as float32.
+int sd_gaussian_threshold(const uint8_t* prob_dev, int X, int Y, int Z, const double* sigma_xyz, double threshold,
+                          uint8_t* mask_dev, float* smoothed_dev, void* ws, size_t ws_bytes, void* stream) {
+    if (!prob_dev || !sigma_xyz || !mask_dev || !ws || X <= 0 || Y <= 0 || Z <= 0)
+        return sd_fail_msg(SD_ERR_INVALID, "sd_gaussian_threshold: bad argument");
+    const size_t nvox = (size_t)X * Y * Z;
+    if (nvox >= (1ull << 31)) return sd_fail_msg(SD_ERR_INVALID, "sd_gaussian_threshold: volume must have < 2^31 voxels");
+    if (ws_bytes < sd_gauss_workspace_bytes(X, Y, Z)) return sd_fail_msg(SD_ERR_NOMEM, "sd_gaussian_threshold: workspace too small");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float* buf[2] = {reinterpret_cast<float*>(ws), reinterpret_cast<float*>(ws) + ((nvox + 63) / 64) * 64};
+    const int n[3] = {X, Y, Z};
+    const long stride[3] = {(long)Y * Z, (long)Z, 1};
+    const float* cur = nullptr;      // nullptr: still the uint8 input
+    int nb = 0;
+    for (int a = 0; a < 3; ++a) {
+        const double sg = sigma_xyz[a];
+        if (!(sg >= 0.0) || !std::isfinite(sg)) return sd_fail_msg(SD_ERR_INVALID, "sd_gaussian_threshold: sigma must be >= 0");
+        if (sg == 0.0) continue;                                   // this axis is not smoothed
+        GaussTaps t;
+        t.r = std::max(1, (int)(3.0 * sg + 0.5));
+        if (t.r > GAUSS_MAX_R) return sd_fail_msg(SD_ERR_INVALID, "sd_gaussian_threshold: sigma too large (window radius > 64)");
+        double sum = 0.0;
+        for (int k = -t.r; k <= t.r; ++k) sum += (t.w[k + t.r] = std::exp(-0.5 * (double)k * k / (sg * sg)));
+        for (int k = 0; k <= 2 * t.r; ++k) t.w[k] /= sum;
+        float* const dst = buf[nb];
+        if (cur) hipLaunchKernelGGL(k_gauss_axis<float>, dim3(grid_for(nvox)), dim3(256), 0, s, cur, dst, nvox, n[a], stride[a], t);
+        else hipLaunchKernelGGL(k_gauss_axis<uint8_t>, dim3(grid_for(nvox)), dim3(256), 0, s, prob_dev, dst, nvox, n[a], stride[a], t);
+        cur = dst;
+        nb ^= 1;
+    }
+    hipLaunchKernelGGL(k_gauss_threshold, dim3(grid_for(nvox)), dim3(256), 0, s, prob_dev, cur, nvox, (float)threshold, mask_dev, smoothed_dev);
+    return hipGetLastError() == hipSuccess ? SD_OK : sd_fail_msg(SD_ERR_HIP, "sd_gaussian_threshold: launch failed");
 }
 
 #ifdef SD_WS_TIMING

@@ -10,7 +10,8 @@ anisotropic Euclidean distance transform -> marker-based priority flood inside t
 Parity: everything up to and including the relabelled marker volume is scipy / numpy in the reference and is reproduced bit
 for bit (goldens from the reference's own code, tests/golden/g9_objseg.npz, g10_objseg_ws.npz).  The distance transform
 (vigra) and the flood (skimage) restate the published algorithms of packages that are absent from the reference tree and
-from this image: parity-UNPINNED (oracle/objseg_ref.py).  Gaussian pre-smoothing (`sigmas`, vigra; unused by default) is not offered.
+from this image: parity-UNPINNED (oracle/objseg_ref.py), like the optional Gaussian pre-smoothing (`sigmas`, vigra; SyConn's own
+pipeline passes none): `gaussian_threshold` / `sd_gaussian_threshold`.
 """
 import ctypes as C
 from typing import List, Optional, Sequence, Tuple, Union
@@ -124,6 +125,39 @@ def object_segmentation_first_stage(prob, threshold: float, morph_ops: Sequence[
     return (labels.cpu().numpy(), int(max_label.item())) + tuple(e.cpu().numpy() for e in extra)
 
 
+def gaussian_threshold(prob, sigma, threshold: float, device=None, return_device: bool = False, return_smoothed: bool = False):
+    """``gaussianSmoothing(tmp_data, sigma)`` followed by ``tmp_data > threshold`` (object_extraction_steps.py:296-297, 316-317)
+    for one uint8 (x,y,z) probability map: `sigma` a number or one per axis (x,y,z) in voxels, `threshold` in uint8 units ->
+    uint8 0/1 mask (x,y,z) [+ the float32 smoothed map].  vigra's algorithm restated (`sd_gaussian_threshold`, parity unpinned)."""
+    lib = L.load()
+    if not torch.cuda.is_available():
+        raise RuntimeError('syconn_amd: no MI355X visible to PyTorch-ROCm; this package has no CPU fallback')
+    device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    L.check(lib.sd_init(device.index or 0), 'sd_init')
+    p = torch.from_numpy(np.ascontiguousarray(prob)) if isinstance(prob, np.ndarray) else prob
+    if p.dtype != torch.uint8:
+        raise TypeError('probability maps are uint8 (KnossosDataset raw data)')
+    p = p.to(device).contiguous()
+    if p.dim() != 3:
+        raise ValueError('expected a 3D (x, y, z) volume')
+    sg = np.broadcast_to(np.asarray(sigma, dtype=np.float64), (3,)) if np.ndim(sigma) == 0 else np.asarray(sigma, dtype=np.float64)
+    if sg.shape != (3,) or np.any(sg < 0) or not np.all(np.isfinite(sg)):
+        raise ValueError('sigma: one non-negative number, or one per axis (x, y, z)')
+    X, Y, Z = (int(v) for v in p.shape)
+    mask = torch.empty((X, Y, Z), dtype=torch.uint8, device=device)
+    sm = torch.empty((X, Y, Z), dtype=torch.float32, device=device) if return_smoothed else None
+    ws_bytes = lib.sd_gauss_workspace_bytes(X, Y, Z)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+    sg_a = (C.c_double * 3)(*[float(v) for v in sg])
+    L.check(lib.sd_gaussian_threshold(p.data_ptr(), X, Y, Z, sg_a, float(threshold), mask.data_ptr(),
+                                      sm.data_ptr() if sm is not None else None, ws.data_ptr(), ws_bytes,
+                                      torch.cuda.current_stream(device).cuda_stream), 'sd_gaussian_threshold')
+    out = (mask,) + ((sm,) if sm is not None else ())
+    if not return_device:
+        out = tuple(o.cpu().numpy() for o in out)
+    return out if len(out) > 1 else out[0]
+
+
 def marker_flood(d2, markers, mask, device=None, return_device: bool = False):
     """``skimage.segmentation.watershed(-distance, markers, mask=mask)`` as `_object_segmentation_thread` calls it
     (object_extraction_steps.py:351) for ``distance ** 2 == d2`` (int32 >= 0): (x, y, z) arrays or device tensors -> int32 labels
@@ -181,10 +215,9 @@ def object_segmentation(cset, hdf5names: Sequence[str], prob_kd_path_dict: dict,
     bounding_box, sizes in chunk-local (x,y,z) incl. the overlap margin) computed from the label volume while it is STILL ON THE
     DEVICE -- the int32 labels (4 bytes per voxel) never cross PCIe; the reference writes them to an h5 file per chunk and reads
     them back for the statistics.  `sigmas` (object_extraction_steps.py:77-81, 135-138, 296-298: a vigra ``gaussianSmoothing`` of the
-    probability map before the threshold; SyConn's pipeline passes none) is accepted for signature parity only: ``None`` / all
-    zeros run, anything else raises ``ValueError`` naming the missing filter (vigra is absent from the reference tree and this
-    image, so its border / truncation semantics cannot be pinned).  Not reproduced either: the membrane hooks, `swapdata`,
-    overlay-cube input."""
+    probability map before the threshold, one sigma or (x,y,z) triple per name; SyConn's pipeline passes none): maps with a
+    non-zero sigma are smoothed and thresholded on the device (`gaussian_threshold`; vigra's algorithm restated, parity
+    unpinned).  Not reproduced: the membrane hooks, `swapdata`, overlay-cube input."""
     from .. import global_params
     from ..knossos import KnossosDataset
     from .find_object_properties import find_object_properties
@@ -195,10 +228,6 @@ def object_segmentation(cset, hdf5names: Sequence[str], prob_kd_path_dict: dict,
     if sigmas is not None:
         if len(sigmas) != len(hdf5names):
             raise Exception("Number of thresholds, sigmas and HDF5 names does not match!")      # (the reference's check, :137-139)
-        if any(float(np.sum(s)) != 0.0 for s in sigmas):
-            raise ValueError('object_segmentation: Gaussian pre-smoothing of the probability maps (`sigmas` != 0, vigra '
-                             'gaussianSmoothing, object_extraction_steps.py:296-298) is not implemented on the MI355X path; '
-                             'pass sigmas=None (what SyConn\'s pipeline does)')
     if isinstance(overlap, str) and overlap == "auto":
         overlap = auto_overlap(morph_ops, scaling, sigmas)
     overlap = np.asarray(overlap, dtype=np.int64)
@@ -220,7 +249,11 @@ def object_segmentation(cset, hdf5names: Sequence[str], prob_kd_path_dict: dict,
             tmp_data = np.ascontiguousarray(kds[name].load_raw(size=size, offset=box_offset, mag=1).swapaxes(0, 2))
             ops = list(morph_ops.get(name, [])) if name in morph_ops else []
             seed = int(min_seed_vx.get(name, 0)) if name in min_seed_vx else 0
-            labels, max_label = object_segmentation_first_stage(tmp_data, float(thresholds[i]), ops, scaling, device=device,
+            thr = float(thresholds[i])
+            if sigmas is not None and float(np.sum(sigmas[i])) != 0.0:                      # :296-297
+                tmp_data = gaussian_threshold(tmp_data, sigmas[i], thr, device=device, return_device=True)
+                thr = 0.0                                                                    # (a 0/1 mask from here on)
+            labels, max_label = object_segmentation_first_stage(tmp_data, thr, ops, scaling, device=device,
                                                                 return_device=True, min_seed_vx=seed)
             if with_properties:
                 props[(chunk.number, name)] = find_object_properties(labels)

@@ -257,20 +257,30 @@ def test_worker_script_reads_a_stream_of_pickles(tmp_path):
     assert read_pickle_stream(str(tmp_path / 'empty.pkl')) == []
 
 
-def test_object_segmentation_names_the_missing_gaussian_filter():
-    """`sigmas` (object_extraction_steps.py:77-81, 296-298): zeros run like None; anything else raises a ValueError that names
-    the filter; a wrong count raises like the reference (:137-139)."""
+def test_object_segmentation_checks_the_sigma_count_and_the_gaussian_restatement_equals_scipy():
+    """`sigmas` (object_extraction_steps.py:77-81, 296-298): a wrong count raises like the reference (:137-139); the oracle's
+    restatement of vigra's filter equals scipy's ``gaussian_filter(mode='mirror', truncate=3)`` wherever both use the same
+    window (sigma >= 1/6: scipy shrinks the window to one tap below that, vigra keeps radius 1)."""
+    from scipy.ndimage import gaussian_filter
+    from oracle.objseg_ref import gaussian_kernel_ref, gaussian_smoothing_ref
     from syconn_amd.extraction.object_extraction_steps import object_segmentation
 
     class _CS:
         chunk_dict = {}
     kw = dict(morph_ops={}, min_seed_vx={}, scaling=(10, 10, 20), overlap=(1, 1, 1))
-    with pytest.raises(ValueError, match='Gaussian'):
-        object_segmentation(_CS(), ['mi'], {}, [0.5], sigmas=[[1.0, 1.0, 0.5]], **kw)
     with pytest.raises(Exception, match='does not match'):
         object_segmentation(_CS(), ['mi', 'vc'], {}, [0.5, 0.5], sigmas=[[0, 0, 0]], **kw)
     rows, _, props = object_segmentation(_CS(), [], {}, [], sigmas=[], **kw)          # nothing to do: no chunk, no dataset
     assert rows == [] and props == {}
+    rng = np.random.default_rng(3)
+    vol = rng.integers(0, 256, (9, 14, 23), dtype=np.uint8)
+    for sigma in (1.0, (1.5, 0.7, 2.2), (0.0, 1.0, 0.0)):
+        a = gaussian_smoothing_ref(vol, sigma)
+        b = gaussian_filter(vol.astype(np.float32), sigma, mode='mirror', truncate=3.0)
+        assert a.dtype == np.float32 and np.allclose(a, b, rtol=0, atol=2e-4), float(np.abs(a - b).max())
+    k = gaussian_kernel_ref(0.1)
+    assert len(k) == 3 and abs(k.sum() - 1) < 1e-15 and k[1] > 0.999999
+    assert len(gaussian_kernel_ref(2.0)) == 13
 
 
 def test_load_raw_into_a_caller_buffer_and_recycled_write_combining(tmp_path):

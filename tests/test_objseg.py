@@ -297,6 +297,33 @@ def test_gpu_chunk_driver_kd_to_labels_to_properties(gpu, tmp_path):
             assert props[(nb, name)] == find_object_properties_np(want.astype(np.uint32))
             n_obj += want_max
     assert n_obj > 8
+    # the same driver with Gaussian pre-smoothing of one map (object_extraction_steps.py:296-297): overlap = 4 sigma (auto rule),
+    # rows of the smoothed map = the oracle's segmentation of the oracle-smoothed box; the map with sigma 0 takes the plain path
+    from oracle.objseg_ref import gaussian_smoothing_ref, object_segmentation_ref
+    ops = {'sj': ['binary_opening', 'binary_closing'], 'vc': ['binary_opening']}
+    sig, ov2 = [[2.0, 2.0, 1.0], [0, 0, 0]], np.array([8, 8, 4])
+    boxes = {nb: (np.array(ch.coordinates) - ov2, np.array(ch.size) + 2 * ov2) for nb, ch in cset.chunk_dict.items()}
+    smoothed = {nb: gaussian_smoothing_ref(_box(vols['sj'], lo, size), sig[0]) for nb, (lo, size) in boxes.items()}
+    # a threshold no smoothed value sits on (then the masks are EQUAL, whatever the last bit of a sum is)
+    allv = np.sort(np.concatenate([sm.ravel() for sm in smoothed.values()]))
+    allv = allv[(allv > 100) & (allv < 140)]
+    k = int(np.argmax(np.diff(allv)))
+    thr_sj = float(0.5 * (float(allv[k]) + float(allv[k + 1])))          # the middle of the widest gap between smoothed values
+    assert allv[k + 1] - allv[k] > 1e-3
+    res2, _, _ = object_segmentation(cset, ['sj', 'vc'], paths, [thr_sj, 127.5], overlap=tuple(ov2), morph_ops=ops, min_seed_vx={},
+                                     scaling=scaling, sigmas=sig, with_properties=False)
+    assert len(res2) == 8
+    for nb, (lo, size) in boxes.items():
+        n_sj = object_segmentation_ref((smoothed[nb] > thr_sj).astype(np.uint8), 0, ops['sj'], scaling)[1]
+        assert [nb, 'sj', n_sj] in res2 and n_sj > 0
+        assert [nb, 'vc', object_segmentation_ref(_box(vols['vc'], lo, size), 127.5, ops['vc'], scaling)[1]] in res2
+
+
+def _box(vol, lo, size):
+    box = np.zeros(size, np.uint8)
+    a, b = np.maximum(lo, 0), np.minimum(lo + size, vol.shape)
+    box[a[0] - lo[0]:b[0] - lo[0], a[1] - lo[1]:b[1] - lo[1], a[2] - lo[2]:b[2] - lo[2]] = vol[a[0]:b[0], a[1]:b[1], a[2]:b[2]]
+    return box
 
 
 # ---- the marker flood on its own (sd_marker_flood: level-synchronous form, csrc/sd_objseg.hip::k_ws_flood) -------------------------------
@@ -429,3 +456,46 @@ def test_gpu_watershed_branch_random_configurations(gpu):
         assert mx == want_max and np.array_equal(lab, want), (case, shape, ops, scaling, min_seed)
         flooded += int(((want > 0) & (markers == 0)).sum())
     assert flooded > 20000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape,sigma', [((40, 52, 31), 1.0), ((33, 20, 47), (1.5, 0.7, 2.2)), ((17, 64, 9), (0.0, 3.0, 0.0)),
+                                         ((5, 6, 70), (4.0, 0.1, 1.0)), ((1, 30, 30), 2.0)])
+def test_gpu_gaussian_threshold_equals_the_restatement(gpu, shape, sigma):
+    """`sd_gaussian_threshold` (object_extraction_steps.py:296-297 + 316-317) against oracle/objseg_ref.gaussian_smoothing_ref:
+    smoothed map equal to float32 rounding (sums in double on both sides, in different orders), masks equal except where the
+    smoothed value sits on the threshold; windows longer than the axis (repeated mirroring), skipped axes, one-voxel axes."""
+    from oracle.objseg_ref import gaussian_smoothing_ref
+    from syconn_amd.extraction.object_extraction_steps import gaussian_threshold
+    rng = np.random.default_rng(11)
+    g = ndimage.gaussian_filter(rng.random(shape), 1.2)
+    vol = ((g - g.min()) / (g.max() - g.min()) * 255).astype(np.uint8)
+    thr = float(np.median(vol))
+    mask, sm = gaussian_threshold(vol, sigma, thr, device=gpu, return_smoothed=True)
+    ref = gaussian_smoothing_ref(vol, sigma)
+    assert sm.dtype == np.float32 and sm.shape == vol.shape
+    assert float(np.abs(sm - ref).max()) <= 6.2e-5, float(np.abs(sm - ref).max())      # (two float32 ulps at 255)
+    clear = np.abs(ref - thr) > 1e-3
+    assert np.array_equal(mask[clear], (ref > thr).astype(np.uint8)[clear]) and 0.05 < mask.mean() < 0.95
+    assert set(np.unique(mask)) <= {0, 1}
+
+
+@pytest.mark.gpu
+def test_gpu_smoothed_mask_feeds_the_segmentation(gpu, tmp_path):
+    """`gaussian_threshold` -> `object_segmentation_first_stage(mask, 0)`: the labels equal the oracle's segmentation of the
+    oracle-smoothed mask."""
+    from oracle.objseg_ref import gaussian_smoothing_ref, object_segmentation_ref
+    from syconn_amd.extraction.object_extraction_steps import (gaussian_threshold, object_segmentation,
+                                                               object_segmentation_first_stage)
+    rng = np.random.default_rng(5)
+    g = ndimage.gaussian_filter(rng.random((48, 40, 24)), 1.5)
+    vol = ((g - g.min()) / (g.max() - g.min()) * 255).astype(np.uint8)
+    sigma, ops = (1.0, 1.0, 0.5), ['binary_opening', 'binary_closing']
+    ref = gaussian_smoothing_ref(vol, sigma)
+    # a threshold no smoothed value sits on (then the masks must be EQUAL, whatever the last bit of a sum is)
+    thr = next(t for t in float(np.percentile(vol, 70)) + np.arange(0.0, 1.0, 0.0137) if np.abs(ref - t).min() > 2e-3)
+    want, n_want = object_segmentation_ref((ref > thr).astype(np.uint8), 0, ops, (10, 10, 20))
+    mask = gaussian_threshold(vol, sigma, thr, device=gpu)
+    got, n_got = object_segmentation_first_stage(mask, 0.0, ops, (10, 10, 20), device=gpu)
+    assert n_got == n_want and n_want > 3 and np.array_equal(got, want)
+
