@@ -273,6 +273,32 @@ class Predictor:
         """fp16 range guard of the predictions since the last call (synchronises the current stream); for `defer_guard`."""
         return self._dm.overflowed()
 
+    @torch.no_grad()
+    def probe_memory(self, spatial_shape) -> None:
+        """What dense_predictor's warm-up prediction of a zero chunk is for (prediction.py:781-794: a CUDA out-of-memory
+        ``RuntimeError`` there makes the caller halve the tile shape): reserve everything a prediction of a (D,H,W) volume holds
+        at the same time -- result tensor, tile and output buffers and the workspaces of every stream for the largest window --
+        and run ONE launch set of zero tiles per stream (first-launch costs of the kernels), instead of predicting all tiles of
+        the chunk (12 in the reference's geometry: 0.2 s of a worker's life in the reference-precision plan)."""
+        spatial = np.asarray(spatial_shape, dtype=np.int64)
+        tile, ol, ntiles = self._geometry(spatial)
+        tin = tile + 2 * ol
+        n_all = int(np.prod(ntiles))
+        nb = self._batch_for(tin, n_all)
+        ring = self._ring2 if (self._ring2 is not None and nb == 1 and n_all > 1) else self._ring
+        torch.cuda.set_device(self.device)
+        shape = [int(t) for t in tin]
+        out = torch.empty((self.out_channels, *[int(s) for s in spatial]), dtype=torch.uint8, device=self.device)
+        tb = [torch.zeros((nb, *shape), dtype=torch.uint8, device=self.device) for _ in range(ring.n)]
+        ob = [torch.empty((nb, self.out_channels, *shape), dtype=torch.uint8, device=self.device) for _ in range(ring.n)]
+        with ring:
+            for k in range(ring.n):
+                with ring.stream(k):
+                    self._dm.forward_batch(tb[k], L.SD_OUT_PROBS_U8, ob[k], slot=ring.slot(k))
+        torch.cuda.current_stream(self.device).synchronize()
+        self._dm.overflowed()                    # (clears the range-guard flag; zeros cannot overflow)
+        del out, tb, ob
+
     def _batch_for(self, tin, ntiles: int) -> int:
         """Tiles per launch set: `batch_size` if given (elektronn3's Predictor argument), else as many as keep the
         workspaces of one batch under ~8 GiB (at most 8): 128^3 tiles run 8 at a time, the reference's
@@ -411,9 +437,12 @@ def dense_predictor(args):
                 predictor.model.ae = False
             except Exception:  # ScriptModules refuse new attributes; elektronn3's flag has no meaning here
                 pass
-            # warm-up / memory probe on a full-size chunk (prediction.py:781 uses float64 zeros)
-            _ = predictor.predict_proba_u8_device(
-                torch.zeros(tuple(int(s) for s in out_shape[1:]), dtype=torch.uint8, device=predictor.device))
+            # warm-up / memory probe for a full-size chunk (prediction.py:781 predicts float64 zeros of that size)
+            if os.environ.get('SYCONN_AMD_FULL_WARMUP'):      # (A/B switch: the reference's full-chunk warm-up)
+                _ = predictor.predict_proba_u8_device(
+                    torch.zeros(tuple(int(s) for s in out_shape[1:]), dtype=torch.uint8, device=predictor.device))
+            else:
+                predictor.probe_memory(tuple(int(s) for s in out_shape[1:]))
             break
         except L.ActivationOverflowError:      # (a RuntimeError, but not a memory problem: halving tiles would not help)
             raise

@@ -10,6 +10,10 @@ from syconn_amd.knossos import KnossosDataset
 
 shape_xyz = (1024, 1024, 256)
 geo = {'overlap_shape_tiles': [16, 16, 8], 'chunk_size': [480, 480, 240], 'tile_shape': [256, 256, 128], 'act_dtype': 'bf16'}
+if os.environ.get('E2E_DEFAULT'):      # the reference's own chunk / tile geometry and the default storage type (f16x2)
+    geo = {}
+if os.environ.get('E2E_ACT'):
+    geo = dict(geo, act_dtype=os.environ['E2E_ACT'])
 with tempfile.TemporaryDirectory(dir='/dev/shm' if os.path.isdir('/dev/shm') else None) as tmp:
     wd, kd_path = tmp + '/wd', tmp + '/kd_raw'
     generate_default_conf(wd, scaling=(10, 10, 25), kd_seg=kd_path,
