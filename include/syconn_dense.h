@@ -95,6 +95,15 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* weights, size
                     sd_model** out);
 void sd_model_destroy(sd_model* m);
 
+/* Output box of interest for the following forward passes of this model (lo inclusive, hi exclusive, z,y,x in tile coordinates;
+ * two NULLs: the whole tile again).  tiled_apply (elektronn3, row P3) keeps only the core of every tile and throws the overlap
+ * rim away (prediction.py:777-779 overlap_shape; dense_predictor also crops the chunk's halo, :812): with a box set, the decoder
+ * layers (up-convolutions, the convolutions behind them, the fused final layer) compute only the sub-boxes that box depends on
+ * -- every value INSIDE the box is the one a whole-tile pass computes, bit for bit; what the output holds outside it is
+ * unspecified.  The fused level-0 decoder kernel is replaced by its layers, so call this BEFORE sd_workspace_bytes.  Networks
+ * with GroupNorm (statistics over whole tensors) and SD_F32 ignore the box. */
+int sd_model_set_roi(sd_model* m, const int32_t* lo_zyx, const int32_t* hi_zyx);
+
 /* Workspace bytes sd_forward needs for a (D,H,W) input tile (a multiple of 256); 0 on error.  sd_forward_batch needs
  * N times this value. */
 size_t sd_workspace_bytes(const sd_model* m, int D, int H, int W);

@@ -23,7 +23,7 @@ EXPORTS = ['sd_init', 'sd_device_count', 'sd_model_create', 'sd_model_destroy', 
            'sd_objtable_bytes', 'sd_pairtable_bytes', 'sd_segstats_scan', 'sd_segstats_compact_objects',
            'sd_segstats_compact_pairs', 'sd_objseg_workspace_bytes', 'sd_object_segmentation', 'sd_objseg_watershed_workspace_bytes',
            'sd_object_segmentation_watershed', 'sd_marker_flood', 'sd_host_box_copy', 'sd_host_zero', 'sd_plan_clip_window',
-           'sd_gauss_workspace_bytes', 'sd_gaussian_threshold']
+           'sd_gauss_workspace_bytes', 'sd_gaussian_threshold', 'sd_model_set_roi']
 
 
 class OpDesc(C.Structure):
@@ -100,6 +100,7 @@ def load():
                                                      C.POINTER(C.c_int32), vp, vp, vp, vp, vp, vp, sz, vp]
     lib.sd_object_segmentation_watershed.restype = i32
     lib.sd_marker_flood.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, sz, vp]; lib.sd_marker_flood.restype = i32
+    lib.sd_model_set_roi.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]; lib.sd_model_set_roi.restype = i32
     lib.sd_gauss_workspace_bytes.argtypes = [i32, i32, i32]; lib.sd_gauss_workspace_bytes.restype = sz
     lib.sd_gaussian_threshold.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_double), C.c_double, vp, vp, vp, sz, vp]
     lib.sd_gaussian_threshold.restype = i32

@@ -101,6 +101,10 @@ struct sd_model {
                                        // another op's launch record none: every record is a packet between two kernels)
     int final_cout = 0;
     bool keep_all = false;   // SD_KEEP_ALL=1: also store activations that only feed a fused consumer (tests)
+    // sd_model_set_roi: the part of the network output the caller keeps (z,y,x; hi exclusive) -- decoder ops then compute only
+    // what that box depends on (forward_impl)
+    bool roi_set = false;
+    int roi_lo[3] = {0, 0, 0}, roi_hi[3] = {0, 0, 0};
     bool ws_reuse = true;    // activation buffers with disjoint lifetimes share workspace memory
     // deferred GroupNorm apply: buffer b holds the RAW tensor, its consumers apply scale / shift (+ReLU) on the fly from a
     // per-tile [2*Cp] float table that lives in the workspace at gn_tab_off[b] (buf_gn[b] = index of the GroupNorm op)
@@ -181,9 +185,12 @@ bool dec0_shape_ok(const Dims& o) {
            (long)o.d * o.h * o.w < (1l << 31) && o.w * 10 >= nstrip * 64 * 7;
 }
 
+// the fused level-0 decoder computes whole tiles: with an output box of interest the layers run one by one on their sub-boxes
+static bool use_dec0(const sd_model* m, const Dims& o) { return dec0_shape_ok(o) && !m->roi_set; }
+
 size_t plan_workspace(const sd_model* m, const std::vector<Dims>& dims, std::vector<size_t>& off) {
     const int nb = m->nbuf;
-    const bool dec0 = dec0_shape_ok(dims[0]);
+    const bool dec0 = use_dec0(m, dims[0]);
     off.assign(nb, 0);
     const size_t WS_BASE = m->ws_base;      // statistics scratch + the scale / shift tables of deferred GroupNorm applies
     std::vector<size_t> bytes(nb, 0);
@@ -826,6 +833,16 @@ size_t sd_workspace_bytes(const sd_model* m, int D, int H, int W) {
     return (plan_workspace(m, dims, off) + 255) & ~(size_t)255;
 }
 
+int sd_model_set_roi(sd_model* m, const int32_t* lo_zyx, const int32_t* hi_zyx) {
+    if (!m || ((lo_zyx == nullptr) != (hi_zyx == nullptr))) return fail(SD_ERR_INVALID, "sd_model_set_roi: bad argument");
+    m->roi_set = lo_zyx != nullptr;
+    for (int a = 0; a < 3; ++a) { m->roi_lo[a] = lo_zyx ? lo_zyx[a] : 0; m->roi_hi[a] = hi_zyx ? hi_zyx[a] : 0; }
+    if (m->roi_set)
+        for (int a = 0; a < 3; ++a)
+            if (m->roi_lo[a] < 0 || m->roi_hi[a] <= m->roi_lo[a]) { m->roi_set = false; return fail(SD_ERR_INVALID, "sd_model_set_roi: empty box"); }
+    return SD_OK;
+}
+
 int sd_profile_enable(sd_model* m, int n_slots) {
     if (!m || n_slots < 0) return fail(SD_ERR_INVALID, "sd_profile_enable: bad argument");
     for (hipEvent_t e : m->events) (void)hipEventDestroy(e);
@@ -937,8 +954,77 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
                                                             : (size_t)m->final_cout * D * H * W * (out_kind == SD_OUT_PROBS_U8 ? 1 : 4);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     char* const wsb = reinterpret_cast<char*>(ws);
-    const bool dec0 = dec0_shape_ok(m->dims[0]);
+    const bool dec0 = use_dec0(m, m->dims[0]);
     auto bufp = [&](int b) -> void* { return wsb + m->buf_off[b]; };
+    // ---- output box of interest (sd_model_set_roi): which sub-box every decoder op computes ------------------------------------
+    // need[b] = the part of buffer b that must hold CORRECT values; an op that can work on a sub-box computes view = need[dst]
+    // widened by its kernel radius (clipped to the tensor): the kernel zero-pads at the view's border, so the outermost shell of
+    // the view is wrong where that border is not the tensor's -- it lies outside need[dst] by construction, and everything it
+    // reads is real data (need[src] = view), so no uninitialised value is ever touched.  Ops that cannot (first conv, fused
+    // pooling / statistics, separate pooling / final / GroupNorm launches) compute everything and need everything.
+    struct Box { int lo[3], hi[3]; bool any; };
+    const size_t nops = m->ops.size();
+    std::vector<Box> view(nops, Box{{0, 0, 0}, {0, 0, 0}, false});          // any == false: the whole tensor
+    bool has_gn = false;
+    for (const Op& op : m->ops) has_gn |= op.d.kind == SD_OP_GROUPNORM;
+    if (m->roi_set)
+        for (int a = 0; a < 3; ++a) {
+            const int n = a == 0 ? D : a == 1 ? H : W;
+            if (m->roi_lo[a] < 0 || m->roi_hi[a] > n || m->roi_lo[a] >= m->roi_hi[a]) return fail(SD_ERR_INVALID, "sd_model_set_roi: box outside the tile");
+        }
+    if (m->roi_set && !has_gn && !m->keep_all) {
+        std::vector<Box> need(m->nbuf, Box{{0, 0, 0}, {0, 0, 0}, false});   // any == false: nothing needed yet
+        auto dims3 = [&](int b, int* n) { n[0] = m->dims[b].d; n[1] = m->dims[b].h; n[2] = m->dims[b].w; };
+        auto add = [&](int b, const Box& x) {
+            if (b <= 0) return;
+            Box& t = need[b];
+            for (int a = 0; a < 3; ++a) {
+                t.lo[a] = t.any ? std::min(t.lo[a], x.lo[a]) : x.lo[a];
+                t.hi[a] = t.any ? std::max(t.hi[a], x.hi[a]) : x.hi[a];
+            }
+            t.any = true;
+        };
+        auto add_full = [&](int b) { if (b > 0) { Box f; int n[3]; dims3(b, n); for (int a = 0; a < 3; ++a) { f.lo[a] = 0; f.hi[a] = n[a]; } f.any = true; add(b, f); } };
+        for (size_t k = nops; k-- > 0;) {
+            const Op& op = m->ops[k];
+            const sd_op_desc& d = op.d;
+            if (op.skipped) continue;
+            if (d.kind == SD_OP_CONV && !op.first) {
+                Box c{{0, 0, 0}, {0, 0, 0}, false};
+                if (op.fuse_final >= 0) { for (int a = 0; a < 3; ++a) { c.lo[a] = m->roi_lo[a]; c.hi[a] = m->roi_hi[a]; } c.any = true; }
+                else c = need[d.dst];
+                const bool capable = op.fuse_pool < 0 && op.fuse_pool_raw < 0 && op.fuse_gn < 0 && op.fuse_first < 0 && c.any;
+                if (capable) {
+                    int n[3];
+                    dims3(d.dst, n);
+                    const int r[3] = {d.kz / 2, 1, 1};
+                    Box v; v.any = false;
+                    for (int a = 0; a < 3; ++a) {
+                        v.lo[a] = std::max(0, c.lo[a] - r[a]);
+                        v.hi[a] = std::min(n[a], c.hi[a] + r[a]);
+                        v.any |= v.lo[a] > 0 || v.hi[a] < n[a];
+                    }
+                    if (v.any) { view[k] = v; add(d.src0, v); add(d.src1, v); continue; }
+                }
+                add_full(d.src0); add_full(d.src1);
+            } else if (d.kind == SD_OP_UPCONV && need[d.dst].any && !(op.dec0_c1 >= 0 && dec0)) {
+                const Box& c = need[d.dst];
+                int n[3];
+                dims3(d.src0, n);
+                const int f[3] = {d.kz, 2, 2};
+                Box v; v.any = false;
+                for (int a = 0; a < 3; ++a) {
+                    v.lo[a] = std::max(0, c.lo[a] / f[a]);
+                    v.hi[a] = std::min(n[a], (c.hi[a] + f[a] - 1) / f[a]);
+                    v.any |= v.lo[a] > 0 || v.hi[a] < n[a];
+                }
+                if (v.any) { view[k] = v; add(d.src0, v); } else add_full(d.src0);
+            } else {
+                add_full(d.src0); add_full(d.src1);
+                if (op.dec0_c1 >= 0 && dec0) add_full(m->ops[op.dec0_c1].d.src1);
+            }
+        }
+    }
     hipEvent_t* ev = nullptr;
     char* ev_rec = nullptr;
     if (m->profile_slots > 0) {
@@ -1016,6 +1102,7 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
                 }
                 p.dst = bufp(d.dst); p.Cd = m->bufCp[d.dst];
                 p.D = o.d; p.H = o.h; p.W = o.w; p.Pd = (size_t)o.d * o.h * o.w;
+                p.Hd = o.h; p.Wd = o.w; p.final_nvox = (long)o.d * o.h * o.w;
                 p.wpack = m->dev_blob + op.wpack_off;
                 p.bias = reinterpret_cast<const float*>(m->dev_blob + op.bias_off);
                 p.relu = d.relu; p.zero = m->dev_zero;
@@ -1061,6 +1148,17 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
                     p.pool_dir = reinterpret_cast<const unsigned*>(m->dev_blob + op.pooldir_off);
                 }
                 p.nbx = (o.w + SD_BX - 1) / SD_BX; p.nby = (o.h + BY - 1) / BY; p.nbz = (o.d + BZ - 1) / BZ;
+                if (view[i].any) {      // sub-box launch: same strides, shifted bases, the box as the extent
+                    const Box& v = view[i];
+                    const size_t esz = SD_CHUNK * 2;      // bytes per voxel of a chunk plane (bf16 / fp16 storage)
+                    auto vox = [&](int hh, int ww) { return ((size_t)v.lo[0] * hh + v.lo[1]) * ww + v.lo[2]; };
+                    p.src0 = reinterpret_cast<const char*>(p.src0) + vox(p.H0, p.W0) * esz;
+                    if (p.src1) p.src1 = reinterpret_cast<const char*>(p.src1) + vox(p.H1, p.W1) * esz;
+                    p.dst = reinterpret_cast<char*>(p.dst) + vox(o.h, o.w) * esz;
+                    if (p.final_out)
+                        p.final_out = reinterpret_cast<char*>(p.final_out) + vox(o.h, o.w) * (out_kind == SD_OUT_PROBS_U8 || out_kind == SD_OUT_LABELS_U8 ? 1 : 4);
+                    p.D = v.hi[0] - v.lo[0]; p.H = v.hi[1] - v.lo[1]; p.W = v.hi[2] - v.lo[2];
+                }
                 auto gn_of = [&](int b, const float*& tab, int& relu) {
                     if (b > 0 && m->buf_gn[b] >= 0) {
                         tab = reinterpret_cast<const float*>(wsb + m->gn_tab_off[b]);
@@ -1130,8 +1228,16 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
             p.src = bufp(d.src0); p.Cs = m->bufCp[d.src0]; p.nchunk = p.Cs / SD_CHUNK * (m->split ? 3 : 1);
             p.oscale = op.oscale;
             p.D = a.d; p.H = a.h; p.W = a.w;
+            p.Ps = (size_t)a.d * a.h * a.w; p.Hs = a.h; p.Ws = a.w; p.Hd = m->dims[d.dst].h; p.Wd = m->dims[d.dst].w;
             p.dst = bufp(d.dst); p.Cd = m->bufCp[d.dst]; p.kz = d.kz;
             p.Pd = (size_t)m->dims[d.dst].d * m->dims[d.dst].h * m->dims[d.dst].w;
+            if (view[i].any) {      // sub-box of the source voxels (and the 2x box of the output they produce)
+                const Box& v = view[i];
+                const size_t esz = SD_CHUNK * 2;
+                p.src = reinterpret_cast<const char*>(p.src) + (((size_t)v.lo[0] * a.h + v.lo[1]) * a.w + v.lo[2]) * esz;
+                p.dst = reinterpret_cast<char*>(p.dst) + (((size_t)v.lo[0] * d.kz * p.Hd + 2 * v.lo[1]) * p.Wd + 2 * v.lo[2]) * esz;
+                p.D = v.hi[0] - v.lo[0]; p.H = v.hi[1] - v.lo[1]; p.W = v.hi[2] - v.lo[2];
+            }
             p.wpack = m->dev_blob + op.wpack_off;
             p.bias = reinterpret_cast<const float*>(m->dev_blob + op.bias_off);
             p.relu = d.relu; p.ntot = d.kz * 4 * p.Cd; p.ovf = m->dev_ovf;

@@ -965,7 +965,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                     const int i = ip + e2;
                     const int vz = z0 + tzs[i], vy = y0 + tys[i] + dy, vx = x0 + dxl;
                     const bool val = vz < p.D && vy < p.H && vx < p.W;
-                    const size_t vo = (size_t)(vz * p.H + vy) * p.W + vx;
+                    const size_t vo = (size_t)(vz * p.Hd + vy) * p.Wd + vx;
                     vals[e2] = val;
                     if (p.store_main) {
                         unsigned ph[8], pl[8];
@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         // (planar forms only -- every U-Net of the path ends in planar blocks -- so that the 3x3x3 forms do not carry its scalars)
         if constexpr (MT == 2 && KZ == 1) {
         if (p.final_wfrag) {
-            const FinalOut fo{p.final_out, p.out_tstride, p.final_cout, p.final_kind, (long)p.D * p.H * p.W, p.ovf};
+            const FinalOut fo{p.final_out, p.out_tstride, p.final_cout, p.final_kind, p.final_nvox, p.ovf};
             typedef __attribute__((ext_vector_type(4))) unsigned u4;
 #pragma unroll
             for (int tp = 0; tp < MT; tp += 2) {
@@ -1059,7 +1059,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                 for (int i = 0; i < 2; ++i) {
                     const int vz = z0 + tzs[tp + i], vy = y0 + tys[tp + i] + dy, vx = x0 + dxl;
                     vv[i] = vz < p.D && vy < p.H && vx < p.W;
-                    vo2[i] = (size_t)(vz * p.H + vy) * p.W + vx;
+                    vo2[i] = (size_t)(vz * p.Hd + vy) * p.Wd + vx;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) lgt[i][r] = 0.f;
 #pragma unroll
@@ -1108,7 +1108,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         const int vy = y0 + tys[0] + dy, vx = x0 + dxl, vz0 = z0 + tzs[0];
         const bool vyx = vy < p.H && vx < p.W;
         // voxels between the wave's tiles: a z-plane (3x3x3: z-stacked tiles) or two rows (planar: y-stacked tiles)
-        const size_t vo0 = (size_t)(vz0 * p.H + vy) * p.W + vx, vzs = KZ == 3 ? (size_t)p.H * p.W : (size_t)2 * p.W;
+        const size_t vo0 = (size_t)(vz0 * p.Hd + vy) * p.Wd + vx, vzs = KZ == 3 ? (size_t)p.Hd * p.Wd : (size_t)2 * p.Wd;
         float* const part = reinterpret_cast<float*>(ldsA + ((gc - 1) % NA) * A_BYTES);   // free: last chunk's halo slot
         const unsigned relu_floor = p.relu ? 0u : 0x80008000u;
         const unsigned guard_mask = 0x7fff7fffu;      // (range guard: magnitudes)
@@ -1213,7 +1213,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     for (int i = 0; i < MT; ++i) {
         const int vz = z0 + tzs[i], vy = y0 + tys[i] + dy, vx = x0 + dxl;
         valid[i] = vz < p.D && vy < p.H && vx < p.W;
-        voxoff[i] = (size_t)(vz * p.H + vy) * p.W + vx;          // voxel index inside the tile's tensor
+        voxoff[i] = (size_t)(vz * p.Hd + vy) * p.Wd + vx;        // voxel index inside the tile's tensor (Hd, Wd: its y / x extents)
     }
     T* const dst = reinterpret_cast<T*>(reinterpret_cast<char*>(p.dst) + (size_t)tn * p.tstride);
     // rounded outputs, packed two channels per register: pk[i][j][2q + h] = channels cbase + 8q + 4*half + 2h, +1.
@@ -1365,7 +1365,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     // in registers 0-3, upper lanes classes 4-7; one half-wave swap per register then gives the lower lane all 8
     // logits of tile tp's voxel and the upper lane those of tile tp+1's voxel.
     if (p.final_wfrag) {
-        const long nvox = (long)p.D * p.H * p.W;
+        const long nvox = p.final_nvox;
 #pragma unroll
         for (int tp = 0; tp < MT; tp += 2) {
             f32x16 lgt[2];

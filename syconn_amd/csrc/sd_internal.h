@@ -34,7 +34,9 @@ struct ConvParams {
     int nchunk0, nchunk1;
     void* dst;
     int Cd;            // channel stride of dst; channels >= Cd are not stored
-    int D, H, W;       // output extent
+    int D, H, W;       // output extent = the box the launch computes (zero padding beyond it)
+    int Hd, Wd;        // y / x extents of the dst tensor (= H, W unless the launch computes a sub-box of it: sd_model_set_roi)
+    long final_nvox;   // voxels per class plane of final_out (= D*H*W unless a sub-box)
     const void* wpack; // [nb][chunk][kz][9][NT][64 lanes][8] of T
     const float* bias; // padded to NB*NT*32
     int relu;
@@ -88,7 +90,9 @@ struct FirstParams {
 struct UpconvParams {
     const void* src;   // (D,H,W,Cs)
     int Cs, nchunk;
-    int D, H, W;
+    int D, H, W;       // the box of source voxels the launch works on
+    size_t Ps; int Hs, Ws;   // voxels per chunk plane and y / x extents of the source tensor (D*H*W, H, W unless a sub-box)
+    int Hd, Wd;        // y / x extents of the dst tensor (2H, 2W unless a sub-box)
     void* dst;         // (D*kz, 2H, 2W, Cd)
     size_t Pd;         // voxels per chunk plane of dst
     int Cd;

@@ -127,6 +127,15 @@ __global__ __launch_bounds__(256) void k_conv_first(const FirstParams p) {
 // global memory (each voxel's chunk is 32 contiguous bytes; successive chunks hit the same lines in L1/L2).
 // SPLIT (split-fp16 plan): p.nchunk counts the 3n virtual chunks [hi | hi | lo] of the n-chunk input stored as planes [hi | lo],
 // the weights are packed in that order (lo parts, hi parts, hi parts; times 2^k, undone by p.oscale), outputs are split again.
+// voxel m of the (D,H,W) box an up-convolution launch works on -> its index inside a chunk plane of the source tensor (whose
+// y / x extents are Hs, Ws: the box is the whole tensor unless sd_model_set_roi asked for a part of the output)
+__device__ __forceinline__ size_t upconv_src_index(const UpconvParams& p, long m) {
+    if (p.Hs == p.H && p.Ws == p.W) return (size_t)m;
+    const unsigned mu = (unsigned)m, xy = mu % (unsigned)(p.W * p.H), z = mu / (unsigned)(p.W * p.H);
+    const unsigned y = xy / (unsigned)p.W, x = xy - y * (unsigned)p.W;
+    return ((size_t)z * p.Hs + y) * p.Ws + x;
+}
+
 template <typename T, bool GN, bool SPLIT = false>
 __global__ __launch_bounds__(256) void k_upconv_mfma(const UpconvParams p) {
     using v8 = typename Act<T>::v8;
@@ -171,7 +180,7 @@ __global__ __launch_bounds__(256) void k_upconv_mfma(const UpconvParams p) {
             v8 val = {};
             if (mv[i]) {
                 const int sc = (SPLIT && c >= p.nchunk / 3) ? c - p.nchunk / 3 : c;
-                val = *reinterpret_cast<const v8*>(src + ((size_t)sc * M + m[i]) * SD_CHUNK + (lane >> 5) * 8);
+                val = *reinterpret_cast<const v8*>(src + ((size_t)sc * p.Ps + upconv_src_index(p, m[i])) * SD_CHUNK + (lane >> 5) * 8);
                 if constexpr (GN) val = gn_apply8<T>(val, gss + c * SD_CHUNK + (lane >> 5) * 8, gss + p.Cs + c * SD_CHUNK + (lane >> 5) * 8, p.gn_relu);
             }
             xf[i] = val;
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(256) void k_upconv_mfma(const UpconvParams p) {
 
     T* const dst = reinterpret_cast<T*>(reinterpret_cast<char*>(p.dst) + blockIdx.z * p.tstride);
     StoreGuard<T> sguard;
-    const int H2 = 2 * p.H, W2 = 2 * p.W;
+    const int H2 = p.Hd, W2 = p.Wd;      // y / x extents of the dst tensor (2H, 2W unless the launch computes a sub-box)
     // The lane pair (l, l^32) holds channels 8q + 0..3 / 8q + 4..7 of the same voxel: trading quad q0 of the upper lane against
     // quad q1 of the lower one gives every lane 8 consecutive channels = ONE 16-byte store per quad pair instead of two
     // 8-byte ones (this generic form is bound by its scattered stores).  Swaps are executed by all lanes, stores are predicated.
@@ -269,7 +278,7 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
     const T* const src = reinterpret_cast<const T*>(reinterpret_cast<const char*>(p.src) + blockIdx.z * p.tstride);
     const T* const wp = reinterpret_cast<const T*>(p.wpack);
     char* const dst = reinterpret_cast<char*>(p.dst) + blockIdx.z * p.tstride;
-    const int H2 = 2 * p.H, W2 = 2 * p.W;
+    const int H2 = p.Hd, W2 = p.Wd;      // y / x extents of the dst tensor (2H, 2W unless the launch computes a sub-box)
     StoreGuard<T> sguard;
     __shared__ __attribute__((aligned(16))) float gtab[GN ? 2 * NCH * SD_CHUNK : 4];     // deferred GroupNorm scale / shift of this tile
     const float* gss = nullptr;
@@ -295,11 +304,12 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
     for (long m0 = ((long)blockIdx.x * 4 + wave) * 32; m0 < M; m0 += WL ? (long)gridDim.x * 128 : M) {
     const long m = m0 + vl;
     const bool mv = m < M;
+    const size_t sidx = mv ? upconv_src_index(p, m) : 0;
     v8 xf[NX];
 #pragma unroll
     for (int c = 0; c < NX; ++c) {
         v8 val = {};
-        if (mv) val = *reinterpret_cast<const v8*>(src + ((size_t)c * M + m) * SD_CHUNK + half * 8);
+        if (mv) val = *reinterpret_cast<const v8*>(src + ((size_t)c * p.Ps + sidx) * SD_CHUNK + half * 8);
         xf[c] = val;
     }
     if constexpr (GN) {

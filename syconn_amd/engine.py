@@ -77,6 +77,7 @@ class DenseModel:
         self._ws_slots = {}            # workspace per slot: forwards on different HIP streams use different slots
         self._profile = False
         self._clip_cache = {}
+        self._roi = None
 
     def __del__(self):
         h = getattr(self, '_h', None)
@@ -96,6 +97,18 @@ class DenseModel:
                                                  C.byref(extent)), 'sd_plan_clip_window')
             w = self._clip_cache[key] = (int(start.value), int(extent.value))
         return w
+
+    def set_roi(self, roi=None):
+        """Output box of interest ((z0, y0, x0), (z1, y1, x1)) in tile coordinates for the following forward passes, or None for
+        whole tiles (`sd_model_set_roi`): decoder layers then compute only what the box depends on; values inside the box are
+        unchanged, the rest of the output is unspecified."""
+        if roi is None:
+            L.check(self.lib.sd_model_set_roi(self._h, None, None), 'sd_model_set_roi')
+        else:
+            lo = (C.c_int32 * 3)(*[int(v) for v in roi[0]])
+            hi = (C.c_int32 * 3)(*[int(v) for v in roi[1]])
+            L.check(self.lib.sd_model_set_roi(self._h, lo, hi), 'sd_model_set_roi')
+        self._roi = roi
 
     # -- workspace ------------------------------------------------------------------------------------
     def workspace_bytes(self, shape: Sequence[int]) -> int:
@@ -127,6 +140,8 @@ class DenseModel:
         stream; forwards that may overlap (different streams) must use different workspace `slot`s."""
         assert inp.is_cuda and inp.dim() == 3 and inp.is_contiguous()
         D, H, W = inp.shape
+        if self._roi is not None:
+            self.set_roi(None)
         ws = self._workspace((D, H, W), slot)
         odt = torch.uint8 if out_kind == L.SD_OUT_PROBS_U8 else torch.float32
         if out is None:
@@ -137,11 +152,13 @@ class DenseModel:
         return out
 
     def forward_batch(self, inp: torch.Tensor, out_kind: int = L.SD_OUT_PROBS_F32, out: Optional[torch.Tensor] = None,
-                      slot: int = 0):
+                      slot: int = 0, roi=None):
         """N independent tiles in one set of launches: inp (N,D,H,W) uint8 / float32 -> (N,C,D,H,W).  Identical
         results to N `forward` calls; every kernel sees N times as many blocks (fills the GPU in the small layers)."""
         assert inp.is_cuda and inp.dim() == 4 and inp.is_contiguous()
         N, D, H, W = inp.shape
+        if roi != self._roi:
+            self.set_roi(roi)
         ws = self._workspace((D, H, W), slot, N)
         odt = torch.uint8 if out_kind == L.SD_OUT_PROBS_U8 else torch.float32
         if out is None:
@@ -152,11 +169,13 @@ class DenseModel:
         return out
 
     def forward_labels_batch(self, inp: torch.Tensor, ids: Sequence[int], thresholds: Sequence[float],
-                             out: Optional[torch.Tensor] = None, slot: int = 0) -> torch.Tensor:
+                             out: Optional[torch.Tensor] = None, slot: int = 0, roi=None) -> torch.Tensor:
         """N tiles -> (N,D,H,W) uint8 labels: the label rule of dense_predictor (prediction.py:813-833) evaluated in
         the final layer's epilogue on floor(255*softmax); identical to ``postproc_labels(forward_batch(PROBS_U8))``."""
         assert inp.is_cuda and inp.dim() == 4 and inp.is_contiguous()
         N, D, H, W = inp.shape
+        if roi != self._roi:
+            self.set_roi(roi)
         ws = self._workspace((D, H, W), slot, N)
         if out is None:
             out = torch.empty((N, D, H, W), dtype=torch.uint8, device=self.device)

@@ -196,11 +196,11 @@ class Predictor:
         single = bool(np.all(ntiles == 1) and np.all(ol == 0) and np.all(tile == spatial) and not halo_included)
         nch = 1 if label_args is not None else self.out_channels
 
-        def run(inp, outp, slot):           # inp (n,D,H,W) -> outp (n,nch,D,H,W)
+        def run(inp, outp, slot, roi=None):           # inp (n,D,H,W) -> outp (n,nch,D,H,W); roi: the part of the window that is kept
             if label_args is not None:
-                self._dm.forward_labels_batch(inp, label_args[0], label_args[1], out=outp[:, 0], slot=slot)
+                self._dm.forward_labels_batch(inp, label_args[0], label_args[1], out=outp[:, 0], slot=slot, roi=roi)
             else:
-                self._dm.forward_batch(inp, out_kind, outp, slot=slot)
+                self._dm.forward_batch(inp, out_kind, outp, slot=slot, roi=roi)
 
         if single:
             run(vol[None], out[None], 0)
@@ -229,7 +229,12 @@ class Predictor:
                 if self.clip_tiles else [(0, int(t)) for t in tin]
             zero = zero or bool(np.any(w1 < keep) or np.any(w0 > 0))
             start = np.asarray([w[0] for w in win], dtype=np.int64)
-            by_window.setdefault(tuple(w[1] for w in win), []).append((lo, start, w0, w1))
+            # the box of the window that is scattered (tiled_apply keeps the core of a tile): the decoder computes only what it
+            # depends on (`sd_model_set_roi`); tiles of one window that keep the same box share a launch set
+            roi = (tuple(int(v) for v in ol + w0 - start), tuple(int(v) for v in ol + w1 - start)) if self.clip_tiles else None
+            if roi is not None and not any(roi[0]) and roi[1] == tuple(w[1] for w in win):
+                roi = None                       # (the whole window is kept: nothing to leave out)
+            by_window.setdefault((tuple(w[1] for w in win), roi), []).append((lo, start, w0, w1))
         if zero:                                 # beyond the dataset `out` reads zero, whatever was skipped or clipped
             out.zero_()
         nb = self._batch_for(tin, max(len(g) for g in by_window.values()))
@@ -238,7 +243,7 @@ class Predictor:
         obuf = [torch.empty(nb * nch * int(np.prod(tin)), dtype=out.dtype, device=self.device) for _ in range(ring.n)]
         i = 0
         with ring:
-            for win, tiles in by_window.items():
+            for (win, roi), tiles in by_window.items():
                 nvox = int(np.prod(win))
                 for b0 in range(0, len(tiles), nb):
                     group = tiles[b0:b0 + nb]
@@ -248,7 +253,7 @@ class Predictor:
                     with ring.stream(i):
                         for j, (lo, start, _, _) in enumerate(group):
                             tile_gather(vol, lo - ol + shift + start, win, tb[j])
-                        run(tb, ob, k)
+                        run(tb, ob, k, roi)
                         for j, (lo, start, w0, w1) in enumerate(group):
                             tile_scatter(ob[j], ol + w0 - start, w1 - w0, out, lo + w0)
                     i += 1
@@ -291,10 +296,11 @@ class Predictor:
         out = torch.empty((self.out_channels, *[int(s) for s in spatial]), dtype=torch.uint8, device=self.device)
         tb = [torch.zeros((nb, *shape), dtype=torch.uint8, device=self.device) for _ in range(ring.n)]
         ob = [torch.empty((nb, self.out_channels, *shape), dtype=torch.uint8, device=self.device) for _ in range(ring.n)]
+        roi = (tuple(int(v) for v in ol), tuple(int(v) for v in ol + tile)) if (self.clip_tiles and np.any(ol > 0)) else None
         with ring:
             for k in range(ring.n):
                 with ring.stream(k):
-                    self._dm.forward_batch(tb[k], L.SD_OUT_PROBS_U8, ob[k], slot=ring.slot(k))
+                    self._dm.forward_batch(tb[k], L.SD_OUT_PROBS_U8, ob[k], slot=ring.slot(k), roi=roi)
         torch.cuda.current_stream(self.device).synchronize()
         self._dm.overflowed()                    # (clears the range-guard flag; zeros cannot overflow)
         del out, tb, ob

@@ -623,3 +623,37 @@ def test_default_configuration_end_to_end_is_reference_precision(gpu, tmp_path):
     print(f'default configuration, mivcsj labels: agreement {1 - mism.mean():.6f}, margin-safe mismatches {int((mism & safe).sum())}')
     assert not (mism & safe).any() and mism.mean() < 1e-3
     global_params.wd = None
+
+
+@pytest.mark.parametrize('arch,act', [('myelin', 'bf16'), ('myelin', 'f16'), ('myelin', 'f16x2'), ('semseg_axon', 'bf16'),
+                                      ('semseg_axon', 'f16x2'), ('syntype', 'f16'), ('mivcsj', 'f16')])
+def test_output_box_of_interest_leaves_the_kept_values_unchanged(gpu, arch, act):
+    """`sd_model_set_roi` (DenseModel.forward_batch(roi=...)): with an output box set, the decoder computes sub-boxes only (the
+    fused level-0 decoder is replaced by its layers) -- probabilities, logits and labels INSIDE the box are bit-identical to a
+    whole-tile pass for boxes in the middle, at a corner, one voxel thick and odd; batches of tiles; a GroupNorm network ignores
+    the box; fewer launches are not required, identical values are."""
+    from syconn_amd import _lib as L
+    from syconn_amd.cnn import random_state_dict
+    from syconn_amd.engine import DenseModel
+    sd = random_state_dict(arch, seed=6, final_scale=4.0)
+    dm = DenseModel(sd, act_dtype=act, device=gpu)
+    g = torch.Generator().manual_seed(3)
+    shape = (40, 112, 144)
+    x = torch.randint(0, 256, (2, *shape), dtype=torch.uint8, generator=g).to(gpu)
+    full_p = dm.forward_batch(x, L.SD_OUT_PROBS_U8).cpu()
+    full_l = dm.forward_batch(x, L.SD_OUT_LOGITS_F32).cpu()
+    ids, thr = list(range(1, dm.out_channels)), [120.0] * (dm.out_channels - 1)
+    full_lab = dm.forward_labels_batch(x, ids, thr).cpu()
+    for roi in (((8, 16, 16), (32, 96, 128)), ((0, 0, 0), (17, 33, 65)), ((39, 50, 3), (40, 51, 144)), ((5, 7, 9), (36, 101, 139))):
+        (z0, y0, x0), (z1, y1, x1) = roi
+        p = dm.forward_batch(x, L.SD_OUT_PROBS_U8, roi=roi).cpu()
+        assert torch.equal(p[:, :, z0:z1, y0:y1, x0:x1], full_p[:, :, z0:z1, y0:y1, x0:x1]), roi
+        lg = dm.forward_batch(x, L.SD_OUT_LOGITS_F32, roi=roi).cpu()
+        assert torch.equal(lg[:, :, z0:z1, y0:y1, x0:x1], full_l[:, :, z0:z1, y0:y1, x0:x1]), roi
+        lab = dm.forward_labels_batch(x, ids, thr, roi=roi).cpu()
+        assert torch.equal(lab[:, z0:z1, y0:y1, x0:x1], full_lab[:, z0:z1, y0:y1, x0:x1]), roi
+    assert torch.equal(dm.forward_batch(x, L.SD_OUT_PROBS_U8).cpu(), full_p)          # (the box is gone again)
+    assert torch.equal(dm.forward(x[0], L.SD_OUT_PROBS_U8).cpu(), full_p[0])
+    with pytest.raises(ValueError):
+        dm.forward_batch(x, L.SD_OUT_PROBS_U8, roi=((0, 0, 0), (41, 10, 10)))
+    assert not dm.overflowed()
