@@ -18,12 +18,14 @@ shape = tuple(int(v) for v in sys.argv[4].split('x')) if len(sys.argv) > 4 and '
 dm = DenseModel(random_state_dict(arch, seed=0, final_scale=8.0), act, torch.device('cuda', 0))
 x = torch.randint(0, 256, (B, *shape), dtype=torch.uint8, device='cuda')
 ids, thr = list(range(1, dm.out_channels)), [127.5] * (dm.out_channels - 1)
+# LAYER_ROI="z0,y0,x0:z1,y1,x1": output box of interest (sd_model_set_roi), e.g. the core a tile keeps
+ROI = tuple(tuple(int(v) for v in part.split(',')) for part in os.environ['LAYER_ROI'].split(':')) if os.environ.get('LAYER_ROI') else None
 for _ in range(3):
-    dm.forward_labels_batch(x, ids, thr)
+    dm.forward_labels_batch(x, ids, thr, roi=ROI)
 torch.cuda.synchronize()
 dm.profile(5)
 for _ in range(5):
-    dm.forward_labels_batch(x, ids, thr)
+    dm.forward_labels_batch(x, ids, thr, roi=ROI)
 us = sum(dm.profile_read(k) for k in range(5)) / 5 / B * 1e3
 # shapes per buffer
 dims = {0: shape}
