@@ -993,17 +993,36 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
                 Box c{{0, 0, 0}, {0, 0, 0}, false};
                 if (op.fuse_final >= 0) { for (int a = 0; a < 3; ++a) { c.lo[a] = m->roi_lo[a]; c.hi[a] = m->roi_hi[a]; } c.any = true; }
                 else c = need[d.dst];
-                const bool capable = op.fuse_pool < 0 && op.fuse_pool_raw < 0 && op.fuse_gn < 0 && op.fuse_first < 0 && c.any;
-                if (capable) {
-                    int n[3];
-                    dims3(d.dst, n);
+                int n[3];
+                dims3(d.dst, n);
+                // fused MaxPool (1,2,2) / (2,2,2) behind a planar / 3x3x3 convolution: what the pooled tensor is needed for, in
+                // this convolution's coordinates
+                const int kzp = d.kz == 3 ? 2 : 1;
+                if (op.fuse_pool >= 0 && need[m->ops[op.fuse_pool].d.dst].any) {
+                    const Box& q = need[m->ops[op.fuse_pool].d.dst];
+                    const int f[3] = {kzp, 2, 2};
+                    Box up; up.any = true;
+                    for (int a = 0; a < 3; ++a) { up.lo[a] = q.lo[a] * f[a]; up.hi[a] = std::min(n[a], q.hi[a] * f[a]); }
+                    if (c.any) for (int a = 0; a < 3; ++a) { c.lo[a] = std::min(c.lo[a], up.lo[a]); c.hi[a] = std::max(c.hi[a], up.hi[a]); }
+                    else c = up;
+                }
+                // in y / x only plain convolutions work on a sub-box; along z also those with fused pooling or the first
+                // convolution inside (a z-range is a shift of every base pointer: planes are never addressed through the extent)
+                static const bool no_zenc = getenv("SD_ROI_NO_ENCODER") != nullptr;
+                const bool yx = op.fuse_pool < 0 && op.fuse_pool_raw < 0 && op.fuse_gn < 0 && op.fuse_first < 0;
+                const bool zok = op.fuse_pool_raw < 0 && op.fuse_gn < 0 && (yx || !no_zenc);
+                if (c.any && zok) {
                     const int r[3] = {d.kz / 2, 1, 1};
                     Box v; v.any = false;
                     for (int a = 0; a < 3; ++a) {
-                        v.lo[a] = std::max(0, c.lo[a] - r[a]);
-                        v.hi[a] = std::min(n[a], c.hi[a] + r[a]);
-                        v.any |= v.lo[a] > 0 || v.hi[a] < n[a];
+                        v.lo[a] = (a == 0 || yx) ? std::max(0, c.lo[a] - r[a]) : 0;
+                        v.hi[a] = (a == 0 || yx) ? std::min(n[a], c.hi[a] + r[a]) : n[a];
                     }
+                    if (op.fuse_pool >= 0 && kzp == 2) {      // whole pooling windows: an even start, an even end (or the tensor's own)
+                        v.lo[0] &= ~1;
+                        v.hi[0] = std::min(n[0], (v.hi[0] + 1) & ~1);
+                    }
+                    for (int a = 0; a < 3; ++a) v.any |= v.lo[a] > 0 || v.hi[a] < n[a];
                     if (v.any) { view[k] = v; add(d.src0, v); add(d.src1, v); continue; }
                 }
                 add_full(d.src0); add_full(d.src1);
@@ -1048,6 +1067,12 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
         }
     }
 
+    // voxels of all tiles that op k's launch computes (its sub-box, if it has one): what the launchers choose the kernel form by
+    auto launch_vox = [&](size_t k) -> long {
+        const Dims o = m->dims[m->ops[k].d.dst];
+        const Box& v = view[k];
+        return (v.any ? (long)(v.hi[0] - v.lo[0]) * (v.hi[1] - v.lo[1]) * (v.hi[2] - v.lo[2]) : (long)o.d * o.h * o.w) * N;
+    };
     for (size_t i = 0; i < m->ops.size(); ++i) {
         const Op& op = m->ops[i];
         const sd_op_desc& d = op.d;
@@ -1055,11 +1080,10 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
         if (op.first && d.kind == SD_OP_CONV && i + 1 < m->ops.size() && m->ops[i + 1].fuse_first == (int)i && !m->keep_all) {
             // (a first convolution that will run inside its consumer launches nothing: no event either; decided below per launch)
             const Op& c = m->ops[i + 1];
-            const Dims o1 = m->dims[d.dst];
             const int nst1 = (m->bufCp[c.d.src0] / SD_CHUNK) * c.d.kz * (m->split ? 3 : 1);
             const bool fused1 = m->split
-                ? conv_can_fuse_first_split(c.d.kz, c.NT, c.NB, (long)o1.d * o1.h * o1.w * N, nst1, c.fuse_final >= 0)
-                : conv_can_fuse_first(c.d.kz, c.NT, c.NB, (long)o1.d * o1.h * o1.w * N, nst1, c.fuse_final >= 0);
+                ? conv_can_fuse_first_split(c.d.kz, c.NT, c.NB, launch_vox(i + 1), nst1, c.fuse_final >= 0)
+                : conv_can_fuse_first(c.d.kz, c.NT, c.NB, launch_vox(i + 1), nst1, c.fuse_final >= 0);
             if (fused1) { ++m->last_launches; continue; }
         }
         if (ev) { HIP_TRY(hipEventRecord(ev[i], s)); ev_rec[i] = 1; }
@@ -1073,8 +1097,8 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
                 const Op& c = m->ops[i + 1];
                 const int nst = (m->bufCp[c.d.src0] / SD_CHUNK) * c.d.kz * (m->split ? 3 : 1);
                 first_fused_into_next = m->split
-                    ? conv_can_fuse_first_split(c.d.kz, c.NT, c.NB, (long)o.d * o.h * o.w * N, nst, c.fuse_final >= 0)
-                    : conv_can_fuse_first(c.d.kz, c.NT, c.NB, (long)o.d * o.h * o.w * N, nst, c.fuse_final >= 0);
+                    ? conv_can_fuse_first_split(c.d.kz, c.NT, c.NB, launch_vox(i + 1), nst, c.fuse_final >= 0)
+                    : conv_can_fuse_first(c.d.kz, c.NT, c.NB, launch_vox(i + 1), nst, c.fuse_final >= 0);
             }
             if (first_fused_into_next) {
                 // computed inside the next convolution
@@ -1128,9 +1152,9 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
                     p.store_main = m->keep_all ? 1 : 0;
                 }
                 if (op.fuse_first >= 0 && !m->keep_all &&
-                    (m->split ? conv_can_fuse_first_split(d.kz, op.NT, op.NB, (long)o.d * o.h * o.w * N, (p.nchunk0 + p.nchunk1) * d.kz,
+                    (m->split ? conv_can_fuse_first_split(d.kz, op.NT, op.NB, launch_vox(i), (p.nchunk0 + p.nchunk1) * d.kz,
                                                           op.fuse_final >= 0)
-                              : conv_can_fuse_first(d.kz, op.NT, op.NB, (long)o.d * o.h * o.w * N, (p.nchunk0 + p.nchunk1) * d.kz,
+                              : conv_can_fuse_first(d.kz, op.NT, op.NB, launch_vox(i), (p.nchunk0 + p.nchunk1) * d.kz,
                                                     op.fuse_final >= 0))) {
                     const Op& fo = m->ops[op.fuse_first];
                     p.first_in = in_dev; p.first_in_tstride = in_tstride; p.first_in_f32 = in_dtype == SD_F32 ? 1 : 0;
@@ -1157,6 +1181,10 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
                     p.dst = reinterpret_cast<char*>(p.dst) + vox(o.h, o.w) * esz;
                     if (p.final_out)
                         p.final_out = reinterpret_cast<char*>(p.final_out) + vox(o.h, o.w) * (out_kind == SD_OUT_PROBS_U8 || out_kind == SD_OUT_LABELS_U8 ? 1 : 4);
+                    if (p.pool_dst)      // (only z-ranges reach a convolution with fused pooling: lo[1] = lo[2] = 0)
+                        p.pool_dst = reinterpret_cast<char*>(p.pool_dst) + (size_t)(v.lo[0] / (d.kz == 3 ? 2 : 1)) * p.pH * p.pW * esz;
+                    if (p.first_in)
+                        p.first_in = reinterpret_cast<const char*>(p.first_in) + (size_t)v.lo[0] * o.h * o.w * (in_dtype == SD_U8 ? 1 : 4);
                     p.D = v.hi[0] - v.lo[0]; p.H = v.hi[1] - v.lo[1]; p.W = v.hi[2] - v.lo[2];
                 }
                 auto gn_of = [&](int b, const float*& tab, int& relu) {
