@@ -117,10 +117,10 @@ struct sd_model {
 
 namespace {
 
-// f(0) .. f(n - 1) on up to 16 host threads (independent items writing disjoint memory)
+// f(0) .. f(n - 1) on up to 48 host threads (independent items writing disjoint memory)
 template <class F>
 static void parallel_for(int n, F f) {
-    const int nt = std::max(1, std::min({n, 16, (int)std::thread::hardware_concurrency()}));
+    const int nt = std::max(1, std::min({n, 48, (int)std::thread::hardware_concurrency()}));
     if (nt == 1) { for (int i = 0; i < n; ++i) f(i); return; }
     std::atomic<int> next{0};
     std::vector<std::thread> th;

@@ -232,8 +232,8 @@ class Predictor:
             # the box of the window that is scattered (tiled_apply keeps the core of a tile): the decoder computes only what it
             # depends on (`sd_model_set_roi`); tiles of one window that keep the same box share a launch set
             roi = (tuple(int(v) for v in ol + w0 - start), tuple(int(v) for v in ol + w1 - start)) if self.clip_tiles else None
-            if roi is not None and not any(roi[0]) and roi[1] == tuple(w[1] for w in win):
-                roi = None                       # (the whole window is kept: nothing to leave out)
+            if roi is not None and np.prod(np.subtract(roi[1], roi[0])) > 0.8 * np.prod([w[1] for w in win]):
+                roi = None                       # (nearly the whole window is kept: whole-tile kernels -- the fused level-0 decoder -- win)
             by_window.setdefault((tuple(w[1] for w in win), roi), []).append((lo, start, w0, w1))
         if zero:                                 # beyond the dataset `out` reads zero, whatever was skipped or clipped
             out.zero_()
