@@ -657,3 +657,20 @@ def test_output_box_of_interest_leaves_the_kept_values_unchanged(gpu, arch, act)
     with pytest.raises(ValueError):
         dm.forward_batch(x, L.SD_OUT_PROBS_U8, roi=((0, 0, 0), (41, 10, 10)))
     assert not dm.overflowed()
+
+
+def test_output_box_of_interest_on_the_sequential_config1_net(gpu):
+    """BASELINE configs[0]'s 3-layer CNN (plan_from_sequential: first conv, conv, final) with an output box: values inside the box
+    are those of the whole-tile pass in every storage type (the second convolution runs on a sub-box, the first one in full)."""
+    from syconn_amd import _lib as L
+    from syconn_amd.engine import DenseModel
+    net = build_cnn3(0)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randint(0, 256, (3, 24, 40, 56), dtype=torch.uint8, generator=g).to(gpu)
+    for act in ('bf16', 'f16x2', 'f32'):
+        dm = DenseModel(net, act_dtype=act, device=gpu)
+        full = dm.forward_batch(x, L.SD_OUT_PROBS_U8).cpu()
+        for roi in (((4, 8, 8), (20, 32, 48)), ((0, 0, 0), (3, 40, 5))):
+            (z0, y0, x0), (z1, y1, x1) = roi
+            got = dm.forward_batch(x, L.SD_OUT_PROBS_U8, roi=roi).cpu()
+            assert torch.equal(got[:, :, z0:z1, y0:y1, x0:x1], full[:, :, z0:z1, y0:y1, x0:x1]), (act, roi)
