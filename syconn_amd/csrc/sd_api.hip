@@ -185,8 +185,34 @@ bool dec0_shape_ok(const Dims& o) {
            (long)o.d * o.h * o.w < (1l << 31) && o.w * 10 >= nstrip * 64 * 7;
 }
 
-// the fused level-0 decoder computes whole tiles: with an output box of interest the layers run one by one on their sub-boxes
-static bool use_dec0(const sd_model* m, const Dims& o) { return dec0_shape_ok(o) && !m->roi_set; }
+struct Box { int lo[3], hi[3]; bool any; };      // z,y,x; hi exclusive; any == false: "the whole tensor" / "nothing yet" by context
+// the sub-box the fused level-0 decoder computes for the model's output box of interest: two voxel shells wider in y / x (its two
+// 3x3 convolutions zero-pad at the box border), starting on even y / x (the level-1 tensor is addressed at half resolution)
+static Box dec0_view(const sd_model* m, const Dims& o) {
+    Box v;
+    const int n[3] = {o.d, o.h, o.w};
+    v.any = false;
+    for (int a = 0; a < 3; ++a) {
+        const int r = a == 0 ? 0 : 2;
+        v.lo[a] = std::max(0, m->roi_lo[a] - r);
+        if (a > 0) v.lo[a] &= ~1;
+        v.hi[a] = std::min(n[a], m->roi_hi[a] + r);
+        v.any |= v.lo[a] > 0 || v.hi[a] < n[a];
+    }
+    return v;
+}
+// with an output box of interest the fused level-0 decoder runs on its sub-box if that is a shape it serves; else its layers
+// run one by one on theirs
+static bool use_dec0(const sd_model* m, const Dims& o) {
+    if (!dec0_shape_ok(o)) return false;
+    if (!m->roi_set) return true;
+    static const bool no_view = getenv("SD_ROI_NO_DEC0") != nullptr;
+    if (no_view) return false;
+    for (int a = 0; a < 3; ++a)
+        if (m->roi_lo[a] < 0 || m->roi_hi[a] > (a == 0 ? o.d : a == 1 ? o.h : o.w) || m->roi_lo[a] >= m->roi_hi[a]) return false;
+    const Box v = dec0_view(m, o);
+    return dec0_shape_ok(Dims{v.hi[0] - v.lo[0], v.hi[1] - v.lo[1], v.hi[2] - v.lo[2]});
+}
 
 size_t plan_workspace(const sd_model* m, const std::vector<Dims>& dims, std::vector<size_t>& off) {
     const int nb = m->nbuf;
@@ -962,7 +988,6 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
     // the view is wrong where that border is not the tensor's -- it lies outside need[dst] by construction, and everything it
     // reads is real data (need[src] = view), so no uninitialised value is ever touched.  Ops that cannot (first conv, fused
     // pooling / statistics, separate pooling / final / GroupNorm launches) compute everything and need everything.
-    struct Box { int lo[3], hi[3]; bool any; };
     const size_t nops = m->ops.size();
     std::vector<Box> view(nops, Box{{0, 0, 0}, {0, 0, 0}, false});          // any == false: the whole tensor
     bool has_gn = false;
@@ -988,7 +1013,18 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
         for (size_t k = nops; k-- > 0;) {
             const Op& op = m->ops[k];
             const sd_op_desc& d = op.d;
-            if (op.skipped) continue;
+            if (op.skipped || (op.in_dec0 && dec0)) continue;
+            if (d.kind == SD_OP_UPCONV && op.dec0_c1 >= 0 && dec0) {      // the fused level-0 decoder on its sub-box
+                const Box v = dec0_view(m, m->dims[m->ops[op.dec0_c1].d.src1]);
+                if (v.any) {
+                    view[k] = v;
+                    add(m->ops[op.dec0_c1].d.src1, v);
+                    Box l; l.any = true;
+                    for (int a = 0; a < 3; ++a) { l.lo[a] = a == 0 ? v.lo[a] : v.lo[a] / 2; l.hi[a] = a == 0 ? v.hi[a] : (v.hi[a] + 1) / 2; }
+                    add(d.src0, l);
+                } else { add_full(d.src0); add_full(m->ops[op.dec0_c1].d.src1); }
+                continue;
+            }
             if (d.kind == SD_OP_CONV && !op.first) {
                 Box c{{0, 0, 0}, {0, 0, 0}, false};
                 if (op.fuse_final >= 0) { for (int a = 0; a < 3; ++a) { c.lo[a] = m->roi_lo[a]; c.hi[a] = m->roi_hi[a]; } c.any = true; }
@@ -1026,7 +1062,7 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
                     if (v.any) { view[k] = v; add(d.src0, v); add(d.src1, v); continue; }
                 }
                 add_full(d.src0); add_full(d.src1);
-            } else if (d.kind == SD_OP_UPCONV && need[d.dst].any && !(op.dec0_c1 >= 0 && dec0)) {
+            } else if (d.kind == SD_OP_UPCONV && need[d.dst].any) {
                 const Box& c = need[d.dst];
                 int n[3];
                 dims3(d.src0, n);
@@ -1040,7 +1076,6 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
                 if (v.any) { view[k] = v; add(d.src0, v); } else add_full(d.src0);
             } else {
                 add_full(d.src0); add_full(d.src1);
-                if (op.dec0_c1 >= 0 && dec0) add_full(m->ops[op.dec0_c1].d.src1);
             }
         }
     }
@@ -1247,6 +1282,18 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
                 if (lab) p.lab = *lab;
                 p.zero = m->dev_zero; p.ovf = m->dev_ovf;
                 p.batch = N; p.tstride = tstride; p.out_tstride = out_tstride;
+                if (view[i].any) {      // sub-box launch: the tensors' extents as strides, shifted bases, the box as the extent
+                    const Box& v = view[i];
+                    const size_t esz = SD_CHUNK * 2;
+                    p.sH = o.h; p.sW = o.w; p.sH1 = a.h; p.sW1 = a.w;
+                    p.Pl1 = (size_t)a.d * a.h * a.w; p.out_nvox = (long)o.d * o.h * o.w;
+                    const size_t vo = ((size_t)v.lo[0] * o.h + v.lo[1]) * o.w + v.lo[2];
+                    p.skip = reinterpret_cast<const char*>(p.skip) + vo * esz;
+                    p.l1 = reinterpret_cast<const char*>(p.l1) + (((size_t)v.lo[0] * a.h + v.lo[1] / 2) * a.w + v.lo[2] / 2) * esz;
+                    p.final_out = reinterpret_cast<char*>(p.final_out) + vo * (out_kind == SD_OUT_PROBS_U8 || out_kind == SD_OUT_LABELS_U8 ? 1 : 4);
+                    p.D = v.hi[0] - v.lo[0]; p.H = v.hi[1] - v.lo[1]; p.W = v.hi[2] - v.lo[2];
+                    p.H1 = (v.hi[1] + 1) / 2 - v.lo[1] / 2; p.W1 = (v.hi[2] + 1) / 2 - v.lo[2] / 2;
+                }
                 p.dbg = getenv("SD_DEC0_DBG") ? reinterpret_cast<long long*>(wsb) : nullptr;      // (timing builds) GroupNorm scratch
                 rc = launch_dec0(p, m->act_dtype, s);
                 break;

@@ -70,7 +70,10 @@ __device__ __forceinline__ uint32_t wrap(uint32_t v, uint32_t ring) { return min
 // advance by additions and compares (no division in the loop), fragment addresses advance by a constant and a wrap, and the
 // final layer / softmax / store runs once per TWO steps on both half-waves (lower lanes: even step's tile, upper: odd).
 // KIND: an sd_out_kind (SD_OUT_LABELS_U8: label rule from the per-class table) or 4 = labels with the generic id list
-template <typename T, int KIND>
+// VIEW: the launch computes a sub-box of the tile (sd_model_set_roi): D, H, W, H1, W1 are the box, sH, sW, sH1, sW1 the y / x extents of
+// the tensors it lies in (the bases are shifted by the host); zero padding at a box border that is not the tensor's only reaches the
+// two outermost voxel shells, which the host keeps outside what it needs.
+template <typename T, int KIND, bool VIEW = false>
 __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
     using v8 = typename Act<T>::v8;
     typedef __attribute__((ext_vector_type(4))) unsigned u4;
@@ -93,6 +96,8 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
     // their uses (s_load + s_waitcnt lgkmcnt(0), ~200 cycles each) once it runs out of scalar registers.
     int gH = p.H, gW = p.W, gH1 = p.H1, gW1 = p.W1, gcout = p.final_cout;
     asm volatile("" : "+s"(gH), "+s"(gW), "+s"(gH1), "+s"(gW1), "+s"(gcout));
+    int sH = VIEW ? p.sH : gH, sW = VIEW ? p.sW : gW, sH1 = VIEW ? p.sH1 : gH1, sW1 = VIEW ? p.sW1 : gW1;      // tensor extents (strides)
+    if constexpr (VIEW) asm volatile("" : "+s"(sH), "+s"(sW), "+s"(sH1), "+s"(sW1));
 
     for (int i = tid; i < LDS_L / 16; i += 512) reinterpret_cast<u4*>(smem)[i] = u4{0u, 0u, 0u, 0u};     // rings (and constants)
     __syncthreads();
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
         Cur cm = cur_at(32 * cw + l31, PW, HP);                                 // merge-conv output position (k = 0)
         uint32_t cC = LDS_C + half * (RC * 32) + (((uint32_t)(32 * cw + l31 + QOFF) & (RC - 1)) << 5);   // ... its C1 record
         const uint32_t cCsw = ((((uint32_t)(32 * cw + l31 + QOFF)) >> 3) & 1u) << 4;
-        const size_t chunk_l1 = (size_t)cw * p.D * gH1 * gW1 * 32;
+        const size_t chunk_l1 = (size_t)cw * p.Pl1 * 32;
         const f32x16 bias_c1 = bias_init(32);
         for (int k = -5; k < nsteps; ++k) {
             D0_T(0);
@@ -192,8 +197,8 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
                 const char* s0 = reinterpret_cast<const char*>(p.zero);
                 const char* s1 = s0;
                 if ((unsigned)cs.plane < (unsigned)nz && cs.y < gH && (unsigned)x < (unsigned)gW) {
-                    const unsigned row = __umul24(z0 + cs.plane, gH) + cs.y;
-                    s0 = skip + (((size_t)__umul24(row, gW) + x) * 32 + dh * 16);
+                    const unsigned row = __umul24(z0 + cs.plane, sH) + cs.y;
+                    s0 = skip + (((size_t)__umul24(row, sW) + x) * 32 + dh * 16);
                     s1 = s0 + p.Ps * 32;
                 }
                 glds16(s0, smem + LDS_S + dS * 32);
@@ -206,8 +211,8 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
                 const int x1 = (c0 >> 1) - 1 + cl.xx;
                 const char* s0 = reinterpret_cast<const char*>(p.zero);
                 if ((unsigned)cl.plane < (unsigned)nz && cl.y < gH1 && (unsigned)x1 < (unsigned)gW1) {
-                    const unsigned row = __umul24(z0 + cl.plane, gH1) + cl.y;
-                    s0 = lvl1 + chunk_l1 + (((size_t)__umul24(row, gW1) + x1) * 32 + dh * 16);
+                    const unsigned row = __umul24(z0 + cl.plane, sH1) + cl.y;
+                    s0 = lvl1 + chunk_l1 + (((size_t)__umul24(row, sW1) + x1) * 32 + dh * 16);
                 }
                 glds16(s0, smem + LDS_L + ((u & 3) * 4 + cw) * 1024);
                 cur_adv(cl, 32, 0, PW / 2, HP1);
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) { pkA[i] = 0u; pkB[i] = 0u; }
         int pending = 0;      // 1: the final layer of a finished pair of tiles is due
-        const long nvox = (long)p.D * gH * gW;
+        const long nvox = p.out_nvox;
         char* const outb = reinterpret_cast<char*>(p.final_out) + (size_t)tile * p.out_tstride;
         auto final_pair = [&]() {
             // ---- final 1x1x1 on the matrix core for the tiles of this step (pk) and the previous one (pkA): the B fragment
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
 #endif
             const int x = c0 - 2 + co.xx;
             if ((unsigned)co.plane < (unsigned)nz && co.y < gH && co.xx >= 2 && co.xx < PW - 2 && x < gW) {
-                const size_t v = (size_t)(__umul24(__umul24(z0 + co.plane, gH) + co.y, gW) + x);      // < 2^31 (launch_dec0)
+                const size_t v = (size_t)(__umul24(__umul24(z0 + co.plane, sH) + co.y, sW) + x);      // < 2^31 (launch_dec0)
                 range_guard<T>(guard, p.ovf);
                 if constexpr (KIND >= SD_OUT_LABELS_U8) {
                     uint8_t lab = 0;
@@ -506,18 +511,26 @@ int launch_dec0(Dec0Params p, int act_dtype, hipStream_t s) {
     if ((long)p.D * p.H * p.W >= (1l << 31)) return SD_ERR_INVALID;
     if (p.final_kind < 0 || p.final_kind > SD_OUT_LABELS_U8) return SD_ERR_INVALID;
     const int kind = p.final_kind == SD_OUT_LABELS_U8 && !p.lab_fast ? 4 : p.final_kind;
+    // whole tile unless the host filled in the extents of the tensors a sub-box lies in
+    if (p.sH == 0) { p.sH = p.H; p.sW = p.W; p.sH1 = p.H1; p.sW1 = p.W1; }
+    if (p.Pl1 == 0) p.Pl1 = (size_t)p.D * p.H1 * p.W1;
+    if (p.out_nvox == 0) p.out_nvox = (long)p.D * p.H * p.W;
+    const bool vw = p.sH != p.H || p.sW != p.W || p.sH1 != p.H1 || p.sW1 != p.W1;
     void (*kern)(const Dec0Params) = nullptr;
-    if (act_dtype == SD_BF16)
-        kern = kind == 0 ? k_dec0<bf16_t, 0> : kind == 1 ? k_dec0<bf16_t, 1> : kind == 2 ? k_dec0<bf16_t, 2> : kind == 3 ? k_dec0<bf16_t, 3> : k_dec0<bf16_t, 4>;
-    else
-        kern = kind == 0 ? k_dec0<f16_t, 0> : kind == 1 ? k_dec0<f16_t, 1> : kind == 2 ? k_dec0<f16_t, 2> : kind == 3 ? k_dec0<f16_t, 3> : k_dec0<f16_t, 4>;
+    if (act_dtype == SD_BF16) {
+        if (vw) kern = kind == 0 ? k_dec0<bf16_t, 0, true> : kind == 1 ? k_dec0<bf16_t, 1, true> : kind == 2 ? k_dec0<bf16_t, 2, true> : kind == 3 ? k_dec0<bf16_t, 3, true> : k_dec0<bf16_t, 4, true>;
+        else kern = kind == 0 ? k_dec0<bf16_t, 0> : kind == 1 ? k_dec0<bf16_t, 1> : kind == 2 ? k_dec0<bf16_t, 2> : kind == 3 ? k_dec0<bf16_t, 3> : k_dec0<bf16_t, 4>;
+    } else {
+        if (vw) kern = kind == 0 ? k_dec0<f16_t, 0, true> : kind == 1 ? k_dec0<f16_t, 1, true> : kind == 2 ? k_dec0<f16_t, 2, true> : kind == 3 ? k_dec0<f16_t, 3, true> : k_dec0<f16_t, 4, true>;
+        else kern = kind == 0 ? k_dec0<f16_t, 0> : kind == 1 ? k_dec0<f16_t, 1> : kind == 2 ? k_dec0<f16_t, 2> : kind == 3 ? k_dec0<f16_t, 3> : k_dec0<f16_t, 4>;
+    }
     static std::mutex mu;
-    static bool attr_done[10][64] = {};      // the attribute is per kernel and device
+    static bool attr_done[20][64] = {};      // the attribute is per kernel and device
     {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SD_ERR_HIP;
         std::lock_guard<std::mutex> g(mu);
-        bool& done = attr_done[(act_dtype == SD_BF16 ? 0 : 5) + kind][dev];
+        bool& done = attr_done[(act_dtype == SD_BF16 ? 0 : 5) + kind + (vw ? 10 : 0)][dev];
         if (!done) {
             const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
             if (ea != hipSuccess) {

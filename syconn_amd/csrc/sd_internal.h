@@ -158,8 +158,11 @@ struct GnParams {
 struct Dec0Params {
     const void* l1;    // level-1 tensor, 4 chunks, extents (D, H1, W1)
     const void* skip;  // encoder skip tensor, 2 chunks, extents (D, H, W)
-    size_t Ps;         // D*H*W
-    int D, H, W, H1, W1;
+    size_t Ps;         // voxels per chunk plane of the skip tensor
+    int D, H, W, H1, W1;   // the box the launch computes and its level-1 counterpart
+    int sH, sW, sH1, sW1;  // y / x extents of the tensors the box lies in (0: the box is the whole tile; launch_dec0 fills them in)
+    size_t Pl1;        // voxels per chunk plane of the level-1 tensor (0: D*H1*W1)
+    long out_nvox;     // voxels per class plane of final_out (0: D*H*W)
     const void* wup; const float* bup;   // up-conv fragments [tap pair][chunk][tap & 1][64][8], folded bias (32 floats)
     const void* w1; const float* b1;     // merge conv fragments [chunk 0..3][tap][64][8], folded bias
     const void* w2; const float* b2;     // second conv fragments [chunk 0..1][tap][64][8], folded bias

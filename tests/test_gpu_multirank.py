@@ -73,6 +73,7 @@ def test_config4_full_size_clipped_windows_equal_full_windows(gpu):
     clip = _json_line(_run([sys.executable] + args))
     full = _json_line(_run([sys.executable] + args + ['--full-windows']))
     assert clip['config']['labels_sha256'] and clip['config']['labels_sha256'] == full['config']['labels_sha256']
+    assert clip['config']['output_distinct_values'] >= 16          # (the volume is not a constant)
     assert clip['ms_per_step'] < 0.85 * full['ms_per_step'], (clip['ms_per_step'], full['ms_per_step'])
 
 
@@ -84,6 +85,7 @@ def test_config5_full_size_skipping_tiles_beyond_the_dataset_changes_nothing(gpu
     skip = _json_line(_run([sys.executable] + args))
     full = _json_line(_run([sys.executable] + args + ['--predict-outside']))
     assert skip['config']['labels_sha256'] and skip['config']['labels_sha256'] == full['config']['labels_sha256']
+    assert skip['config']['output_distinct_values'] >= 3
     assert skip['dtype'] == 'f16' and skip['ms_per_step'] < full['ms_per_step']
 
 
@@ -100,6 +102,7 @@ def test_bench_volume_workloads_two_ranks_equal_one_rank(gpu, workload, geometry
     one = _json_line(_run([sys.executable] + args + ['--gpus', '1']))
     assert two['n_gpus'] == 2 and one['n_gpus'] == 1 and two['scaling'] == 'strong'
     assert two['config']['labels_sha256'] and two['config']['labels_sha256'] == one['config']['labels_sha256']
+    assert one['config']['output_distinct_values'] >= 2            # (not a constant volume)
 
 
 def test_volume_workload_equals_per_tile_path(gpu):
