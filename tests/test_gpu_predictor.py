@@ -253,6 +253,7 @@ def test_predict_myelin_end_to_end(gpu, tmp_path):
     vol4 = vol[::4, ::4, ::4]
     ref = _oracle_volume(model, vol4, geo, (70, 60, 40), 2)[1]
     assert got.shape == ref.shape
+    assert int(ref.max()) - int(ref.min()) >= 16         # (a probability map with a spread, not a constant)
     d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
     print('myelin prob map vs oracle: max diff', d.max(), 'mean', d.mean())
     assert d.max() <= TOL_U8
@@ -557,7 +558,7 @@ def test_boundary_tiles_on_clipped_windows_are_bit_identical(gpu, arch, act):
     (z0, y0, x0), (z1, y1, x1) = box
     a = clip.predict_proba_u8_device(x, valid_box=box).cpu()
     b = full.predict_proba_u8_device(x, valid_box=box).cpu()
-    assert torch.equal(a[:, z0:z1, y0:y1, x0:x1], b[:, z0:z1, y0:y1, x0:x1])
+    assert torch.equal(a[:, z0:z1, y0:y1, x0:x1], b[:, z0:z1, y0:y1, x0:x1]) and len(torch.unique(b[:, z0:z1, y0:y1, x0:x1])) >= 16
     assert int(a[:, z1:].max()) == 0 and int(a[:, :, y1:].max()) == 0 and int(a[:, :, :, x1:].max()) == 0   # beyond the box: zeros
     assert int(a[:, :z0].max()) == 0 and int(a[:, :, :y0].max()) == 0 and int(a[:, :, :, :x0].max()) == 0
     ids, thr = list(range(1, nc)), [110.0] * (nc - 1)
@@ -607,6 +608,7 @@ def test_default_configuration_end_to_end_is_reference_precision(gpu, tmp_path):
     predict_myelin()
     got = kd_factory(f'{wd}/knossosdatasets/myelin/').load_raw(size=shape_xyz, offset=(0, 0, 0), mag=4)
     ref = _oracle_volume(model, vol[::4, ::4, ::4], geo, (65, 50, 28), 2)[1]
+    assert int(ref.max()) - int(ref.min()) >= 16
     d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
     print('default configuration, myelin vs oracle: max diff', d.max(), 'frac != 0', float((d > 0).mean()))
     assert got.shape == ref.shape and d.max() <= 1 and float((d > 0).mean()) < 2e-3
@@ -644,6 +646,7 @@ def test_output_box_of_interest_leaves_the_kept_values_unchanged(gpu, arch, act)
     full_l = dm.forward_batch(x, L.SD_OUT_LOGITS_F32).cpu()
     ids, thr = list(range(1, dm.out_channels)), [120.0] * (dm.out_channels - 1)
     full_lab = dm.forward_labels_batch(x, ids, thr).cpu()
+    assert len(torch.unique(full_p)) >= 16 and len(torch.unique(full_lab)) >= 2      # (not a constant answer)
     for roi in (((8, 16, 16), (32, 96, 128)), ((0, 0, 0), (17, 33, 65)), ((39, 50, 3), (40, 51, 144)), ((5, 7, 9), (36, 101, 139))):
         (z0, y0, x0), (z1, y1, x1) = roi
         p = dm.forward_batch(x, L.SD_OUT_PROBS_U8, roi=roi).cpu()
