@@ -12,7 +12,7 @@ sds = {a: random_state_dict(a, seed=5, final_scale=4.0) for a in ('myelin', 'sem
 t0 = time.time(); n = 0
 while time.time() - t0 < budget:
     arch = str(rng.choice(list(sds)))
-    act = str(rng.choice(['bf16', 'f16x2']))
+    act = str(rng.choice(['bf16', 'f16', 'f16x2']))
     tile = np.array([int(rng.integers(6, 24)), int(rng.integers(24, 72)), int(rng.integers(24, 80))])
     ol = np.array([int(rng.integers(0, 10)), int(rng.integers(0, 40)), int(rng.integers(0, 40))])
     nt = np.array([int(rng.integers(1, 3)), int(rng.integers(1, 4)), int(rng.integers(1, 3))])
@@ -28,5 +28,9 @@ while time.time() - t0 < budget:
     sl = (slice(None),) + (tuple(slice(l, h) for l, h in zip(vlo, vhi)) if box is not None else (slice(None),) * 3)
     if not torch.equal(pa[sl], pb[sl]):
         print('MISMATCH', arch, act, tile, ol, nt, box); sys.exit(1)
+    ids, thr = list(range(1, nc)), [float(rng.integers(60, 200))] * (nc - 1)
+    la, lb = a.predict_labels_u8_device(x, ids, thr, valid_box=box), b.predict_labels_u8_device(x, ids, thr, valid_box=box)
+    if not torch.equal(la[sl[1:]], lb[sl[1:]]):
+        print('LABEL MISMATCH', arch, act, tile, ol, nt, box); sys.exit(1)
     n += 1
 print(f'fuzz_tiles: {n} cases ok in {time.time() - t0:.0f} s')
