@@ -677,3 +677,32 @@ def test_output_box_of_interest_on_the_sequential_config1_net(gpu):
             (z0, y0, x0), (z1, y1, x1) = roi
             got = dm.forward_batch(x, L.SD_OUT_PROBS_U8, roi=roi).cpu()
             assert torch.equal(got[:, :, z0:z1, y0:y1, x0:x1], full[:, :, z0:z1, y0:y1, x0:x1]), (act, roi)
+
+
+def test_file_system_mode_datasets_are_byte_identical_with_and_without_clipping(gpu, tmp_path):
+    """predict_dense_to_kd on one synthetic KnossosDataset with `clip_boundary_tiles` on (default: clipped windows, output
+    boxes, sub-box decoder) and off (whole windows, as the reference computes): every cube file of the target dataset -- all
+    three mags -- has the same bytes, and the probability map has a spread.  Full-width myelin net, chunks that overhang
+    the dataset in x and y, the reference-precision plan."""
+    import hashlib
+    from syconn_amd import global_params
+    from syconn_amd.exec.exec_dense_prediction import predict_myelin
+    from syconn_amd.handler.basics import kd_factory
+    model = build_unet('myelin', seed=3, final_scale=8.0)
+    shape_xyz = (400, 360, 96)                                     # at mag 4: 100 x 90 x 24
+    digests = {}
+    for clip in (True, False):
+        sub = tmp_path / f'clip{int(clip)}'
+        sub.mkdir()
+        geo = {'overlap_shape_tiles': [12, 12, 4], 'chunk_size': [64, 56, 24], 'tile_shape': [44, 40, 16], 'act_dtype': 'f16x2',
+               'clip_boundary_tiles': clip}
+        wd, kd_path, vol = _make_wd(sub, model, 'myelin', shape_xyz, 33, geo)
+        predict_myelin()
+        files = sorted(p for p in (sub / 'wd' / 'knossosdatasets' / 'myelin').rglob('*') if p.is_file() and p.suffix in ('.raw', '.zip', '.sz'))
+        assert len(files) >= 3
+        digests[clip] = {str(p.relative_to(sub)): hashlib.sha256(p.read_bytes()).hexdigest() for p in files}
+        if clip:
+            got = kd_factory(f'{wd}/knossosdatasets/myelin/').load_raw(size=shape_xyz, offset=(0, 0, 0), mag=4)
+            assert int(got.max()) - int(got.min()) >= 16
+        global_params.wd = None
+    assert digests[True] == digests[False]
