@@ -53,6 +53,7 @@ struct Op {
     sd_op_desc d{};
     // device pointers (into the model's weight blob)
     size_t wpack_off = 0, bias_off = 0, aux_off = 0;   // byte offsets
+    size_t w3_off = 0;     // first conv, planar, bf16 / fp16 plans: three-way bf16 split of the weights / 255 for uint8 input (0: none)
     int NT = 1, NB = 1;
     bool first = false;    // conv reading the network input (cin = 1)
     int fuse_pool = -1;    // index of the MaxPool op computed in this conv's epilogue
@@ -404,6 +405,47 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
                                                             : (n < d.cout && tap == taps) ? W[d.b_off + n] * sc[n] + sh[n] : 0.f;
                         }
                 for (int n = 0; n < d.cout; ++n) bp[n] = W[d.b_off + n] * sc[n] + sh[n];
+                if (d.kz == 1 && !split && act_dtype != SD_F32) {
+                    // uint8 input on the bf16 matrix pipe (k_conv_first / k_conv_mfma MODE 5): a uint8 voxel v is EXACT in bf16, so
+                    // conv(v / 255) = sum_t v_t * W'_t with W' = fp32(w / 255) carried as THREE bf16 parts (hi + mid + lo = all 24
+                    // mantissa bits; every product v * part is exact in fp32) -- 9 taps x 3 parts + 3 parts of the folded bias
+                    // (meeting a 1.0) are 30 of the 32 k slots of TWO v_mfma_f32_32x32x16_bf16 instead of five 64-cycle
+                    // v_mfma_f32_32x32x2_f32.  Slot order (what the kernels' B operand looks like): lanes 0-31 hold taps 0-4,
+                    // lanes 32-63 taps 5-8 and the constant; B dwords = [(t0,t0) (t1,t1) (t2,t2) (t3,t3)] [(t4,t4) (t0,t1) (t2,t3)
+                    // (t4,1)] with a dword (a,b) = k slots (2i, 2i+1): a pair (t,t) meets (hi, mid), the mixed pairs meet lo parts.
+                    op.w3_off = blob_alloc((size_t)ntile * 2 * 64 * 8 * 2);
+                    uint16_t* w3 = reinterpret_cast<uint16_t*>(blob.data() + op.w3_off);
+                    auto part3 = [&](float v, uint16_t (&o)[3]) {
+                        float r = v;
+                        for (int k = 0; k < 3; ++k) {
+                            o[k] = f2bf16(r);
+                            uint32_t u = (uint32_t)o[k] << 16; float h; std::memcpy(&h, &u, 4);
+                            r -= h;      // exact
+                        }
+                    };
+                    for (int nt = 0; nt < ntile; ++nt)
+                        for (int l = 0; l < 64; ++l) {
+                            const int n = nt * 32 + (l & 31), hf = l >> 5;
+                            uint16_t tp[5][3] = {}, bpart[3] = {};
+                            if (n < d.cout) {
+                                for (int a = 0; a < 5; ++a) {
+                                    const int tap = hf * 5 + a;
+                                    if (tap < 9) part3((float)((double)wat(n, 0, 0, tap) / 255.0), tp[a]);
+                                }
+                                part3(W[d.b_off + n] * sc[n] + sh[n], bpart);
+                            }
+                            uint16_t* m0 = w3 + ((size_t)(nt * 2 + 0) * 64 + l) * 8;
+                            uint16_t* m1 = w3 + ((size_t)(nt * 2 + 1) * 64 + l) * 8;
+                            for (int a = 0; a < 4; ++a) { m0[2 * a] = tp[a][0]; m0[2 * a + 1] = tp[a][1]; }
+                            if (hf == 0) {
+                                m1[0] = tp[4][0]; m1[1] = tp[4][1];
+                                m1[2] = tp[0][2]; m1[3] = tp[1][2]; m1[4] = tp[2][2]; m1[5] = tp[3][2]; m1[6] = tp[4][2]; m1[7] = 0;
+                            } else {      // the fifth read of the upper lanes is the constant (1.0, 1.0), and so is their last dword
+                                m1[0] = bpart[0]; m1[1] = bpart[1];
+                                m1[2] = tp[0][2]; m1[3] = tp[1][2]; m1[4] = tp[2][2]; m1[5] = tp[3][2]; m1[6] = bpart[2]; m1[7] = 0;
+                            }
+                        }
+                }
             } else {
                 if (m->bufC[d.src0] != d.cin0) MODEL_FAIL("conv: cin0 does not match producer of src0");
                 if (d.src1 >= 0 && m->bufC[d.src1] != d.cin1) MODEL_FAIL("conv: cin1 does not match producer of src1");
@@ -1088,6 +1130,7 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
     }
     ++m->n_forward;
     m->last_launches = 0;
+    const bool no_first_u8 = getenv("SD_NO_FIRST_U8") != nullptr;      // A/B switch (read per forward): uint8 input through the exact-f32 MFMA chain
     {
         // GroupNorm statistics scratch (sum and sum of squares per channel, doubles, at the start of every tile's workspace): zeroed
         // ONCE per forward pass; every k_gn_finalize leaves it zeroed for the next GroupNorm op
@@ -1142,6 +1185,7 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
                 p.in = in_dev; p.D = o.d; p.H = o.h; p.W = o.w;
                 p.dst = bufp(d.dst); p.Cd = m->bufCp[d.dst];
                 p.wpack = reinterpret_cast<const float*>(m->dev_blob + op.wpack_off);
+                p.wpack3 = (op.w3_off && !no_first_u8) ? m->dev_blob + op.w3_off : nullptr;
                 p.bias = reinterpret_cast<const float*>(m->dev_blob + op.bias_off);
                 p.relu = d.relu;
                 p.batch = N; p.tstride = tstride; p.in_tstride = in_tstride; p.ovf = m->dev_ovf;
@@ -1195,6 +1239,7 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
                     p.first_in = in_dev; p.first_in_tstride = in_tstride; p.first_in_f32 = in_dtype == SD_F32 ? 1 : 0;
                     p.first_w = reinterpret_cast<const float*>(m->dev_blob + fo.wpack_off);
                     p.first_bias = reinterpret_cast<const float*>(m->dev_blob + fo.bias_off);
+                    p.first_w3 = (fo.w3_off && in_dtype == SD_U8 && !no_first_u8) ? m->dev_blob + fo.w3_off : nullptr;
                     p.first_relu = fo.d.relu;
                 }
                 if (op.fuse_gn >= 0) {      // (scratch is zero: see the start of the forward pass and k_gn_finalize)

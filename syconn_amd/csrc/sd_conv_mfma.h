@@ -150,7 +150,10 @@ constexpr int dma_count(int w, int waves, int a_instr, int j0, int j1) {
 }
 template <typename T, int KZ, int NT, int WAVES, int NSLOT, int MT, int MODE>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(const ConvParams p) {
-    constexpr bool FF = MODE == 1 || MODE == 4, GN = MODE == 2;
+    // MODE 5 (FU8) = MODE 1 for UINT8 network input: the first convolution runs as two bf16 MFMAs per 32 halo voxels on the exact uint8
+    // values (weights / 255 and bias split three ways into bf16 parts: sd_device.h first_u8_mfma) instead of five 64-cycle
+    // v_mfma_f32_32x32x2_f32 -- a fifth of the matrix-pipe time; fp32-level result, not the bit pattern of the float32(v) / 255 chain.
+    constexpr bool FF = MODE == 1 || MODE == 4 || MODE == 5, GN = MODE == 2, FU8 = MODE == 5;
     // MODE 3 (SP, split-fp16 plan = act_dtype SD_F16X2): every tensor is stored as TWO fp16 planes per channel, x = hi + lo (hi =
     // fp16(x), lo = fp16(x - hi): 22 mantissa bits), as 2n chunks [n hi chunks | n lo chunks]; the weights are split the same
     // way (times a power of two per layer that keeps the lo parts normal; undone by p.oscale).  A product is computed as
@@ -526,7 +529,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
             if (i < FNP && (unsigned)bz0 < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
                 const size_t idx = ((size_t)bz0 * p.H + y) * p.W + x;
                 const char* const in = reinterpret_cast<const char*>(p.first_in) + (size_t)btile * p.first_in_tstride;
-                if (p.first_in_f32) v = reinterpret_cast<const float*>(in)[idx];
+                if constexpr (FU8) v = __builtin_bit_cast(float, u8_bf16_pair(reinterpret_cast<const uint8_t*>(in)[idx]));
+                else if (p.first_in_f32) v = reinterpret_cast<const float*>(in)[idx];
                 else v = (float)reinterpret_cast<const uint8_t*>(in)[idx] / 255.0f;
             }
             fpv[k] = v;
@@ -547,6 +551,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     if constexpr (FF) {
         patch_fetch(z0, y0, x0, tn);
         patch_park(0);
+        if constexpr (FU8) {      // [0] = the constant (1.0, 1.0) the bias parts meet; from +16 bytes: [NF1][2 MFMAs][64 lanes][8] bf16
+            if (tid == 0) reinterpret_cast<unsigned*>(ffw)[0] = SD_BF16_ONE_PAIR;
+            typedef __attribute__((ext_vector_type(4))) unsigned u4;
+            for (int i = tid; i < NF1 * 2 * 64; i += WAVES * 64) reinterpret_cast<u4*>(ffw + 4)[i] = reinterpret_cast<const u4*>(p.first_w3)[i];
+        } else
         for (int i = tid; i < NF1 * (5 * 64 + 32); i += WAVES * 64) ffw[i] = i < NF1 * 320 ? p.first_w[i] : p.first_bias[i - NF1 * 320];
     }
     if (WRES) {
@@ -585,6 +594,22 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         ph0 = ((hv0 / (HX * HY)) << 16) | (((hv0 / HX) % HY) << 8) | (hv0 % HX);
         static_assert(!SPREAD || (HX < 256 && HY < 256), "packed piece coordinates");
     }
+    // MODE 5: lane constants of the FIT tiles of 32 halo voxels a wave converts per block -- patch byte offset of the voxel, its halo
+    // coordinates hy << 16 | hx (-1: beyond the halo block), and this lane's byte offset inside a tile's 1 KiB of halo records
+    constexpr int FIT = FU8 ? (NH + 32 * WAVES - 1) / (32 * WAVES) : 1;
+    int fc_off[FIT], fc_yx[FIT], fc_wr = (lane & 31) * 32 + half * 8;
+    if constexpr (FU8) {
+#pragma unroll
+        for (int it = 0; it < FIT; ++it) {
+            const int hv = (wave + it * WAVES) * 32 + (lane & 31);
+            const int hvc = hv < NH ? hv : NH - 1;
+            const int hy = hvc / HX, hx = hvc % HX;
+            fc_off[it] = (hy * (HX + 2) + hx) * 4;
+            fc_yx[it] = hv < NH ? ((hy << 16) | hx) : -1;
+            asm volatile("" : "+v"(fc_off[it]), "+v"(fc_yx[it]));      // (kept in registers, not re-derived per block)
+        }
+        asm volatile("" : "+v"(fc_wr));
+    }
     for (int round = 0; lb >= 0; ++round) {
         const int nlb = block_of(round + 1);
         int nz0 = 0, ny0 = 0, nx0 = 0, ntn = 0;
@@ -598,6 +623,66 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
             static_assert(!FF || (KZ == 1 && WRES && (SP ? NA == 4 : (NA == 2 || NA == 3))), "fused first conv: planar, resident weights");
             constexpr int PXW = HX + 2, NSTEP1 = 5;
             const float* const fp = fpatch + (round & 1) * FNP;      // parked by the prologue / during the previous block
+            if constexpr (FU8) {
+                const unsigned* const up = reinterpret_cast<const unsigned*>(fp);
+                const unsigned* const cpair = reinterpret_cast<const unsigned*>(ffw);
+                const bf16x8* const w3l = reinterpret_cast<const bf16x8*>(ffw + 4);
+                bf16x8 w30 = w3l[lane], w31 = w3l[64 + lane];
+                int toff5[5];
+#pragma unroll
+                for (int a = 0; a < 5; ++a) {
+                    const int tap = half * 5 + a;      // lanes 0-31: taps 0-4; lanes 32-63: taps 5-8, then the constant
+                    toff5[a] = tap < 9 ? ((tap / 3) * PXW + (tap % 3)) * 4 : 0;      // (bytes)
+                }
+                const unsigned relu_floor = p.first_relu ? 0u : 0x80008000u;      // packed signed max against the most negative pair = identity
+                const char* const upb = reinterpret_cast<const char*>(up);
+#pragma unroll
+                for (int it = 0; it < FIT; ++it) {
+                    const int t = wave + it * WAVES;
+                    if (t * 32 >= NH) break;                 // (wave-uniform)
+                    const int yx = fc_yx[it];                // lane constants of this wave's it-th tile of halo voxels (below, before the block loop)
+                    const bool inb = yx >= 0;
+                    const int hy = yx >> 16, hx = yx & 0xffff;
+                    const char* const ub = upb + fc_off[it];
+                    unsigned r[5];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) r[a] = *reinterpret_cast<const unsigned*>(ub + toff5[a]);
+                    r[4] = *reinterpret_cast<const unsigned*>(half ? reinterpret_cast<const char*>(cpair) : ub + toff5[4]);
+                    const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+                    const bool invol = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;     // z0 < D always
+                    const bool border = __any(!invol);      // (wave-uniform: interior tiles skip the zero-padding selects)
+                    const int hyb = (hy & 1) << 4;      // odd halo rows: the 16-byte halves of a record trade places
+                    char* const wr0 = ldsA + t * 1024 + fc_wr + hyb;
+                    char* const wr1 = ldsA + t * 1024 + fc_wr + (hyb ^ 16);
+#pragma unroll
+                    for (int ft = 0; ft < NF1; ++ft) {      // (48 filters: channels 0-31, then 32-47 + padding; fragments re-read per tile)
+                        if constexpr (NF1 > 1) { w30 = w3l[(ft * 2 + 0) * 64 + lane]; w31 = w3l[(ft * 2 + 1) * 64 + lane]; }
+                        const f32x16 a1 = first_u8_mfma(w30, w31, r);
+                        unsigned o[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            o[k] = pk_max16(Act<T>::pack2(a1[2 * k], a1[2 * k + 1]), relu_floor);
+                            sguard.see_signed(o[k]);
+                        }
+                        if (border) {      // the second conv's zero padding (a real branch: the volatile statement keeps it from becoming eight selects)
+                            asm volatile("; halo tile at the volume border");
+                            if (!invol) {
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) o[k] = 0u;
+                            }
+                        }
+                        if (inb) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                typedef __attribute__((ext_vector_type(2))) unsigned u2;
+                                if (NF1 > 1 && 2 * ft + (q >> 1) >= NA) continue;      // (the padding chunk of a 48-filter first conv)
+                                const int so = ((gc + 2 * ft + (q >> 1)) % NA) * A_BYTES;
+                                *reinterpret_cast<u2*>(((q & 1) ? wr1 : wr0) + so) = u2{o[2 * q], o[2 * q + 1]};
+                            }
+                        }
+                    }
+                }
+            } else {
             float w1[NSTEP1];
             int toff1[NSTEP1];
 #pragma unroll
@@ -660,6 +745,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                     }
                 }
                 }
+            }
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (nlb >= 0) patch_fetch(nz0, ny0, nx0, ntn);       // lands during stage 0 (its end waits vmcnt(0))
@@ -1267,7 +1353,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
             for (int i = 0; i < MT; ++i) {
                 u4 lo = {pk[i][j][0], pk[i][j][1], pk[i][j][2], pk[i][j][3]};
                 u4 hi = {pk[i][j][4], pk[i][j][5], pk[i][j][6], pk[i][j][7]};
-                if (!valid[i]) { lo = u4{0u, 0u, 0u, 0u}; hi = lo; }
+                unsigned zr = 0u;
+                asm volatile("" : "+v"(zr));      // (keeps the eight selects inside this branch: BatchNorm nets never take it)
+                if (!valid[i]) { lo = u4{zr, zr, zr, zr}; hi = lo; }
                 f32x16 d;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) d[r] = 0.f;
@@ -1294,23 +1382,17 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
 #ifdef SD_T5_EARLY
     SD_T(5);
 #endif
-    if (p.store_main) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-                store_tile_rows_pk<T>(pk[i][j], dst, p.Pd, voxoff[i], valid[i], (nb * NT + j) * 32, half, p.Cd);
-    }
-
-#ifndef SD_T5_EARLY
-    SD_T(5);   // main store done
-#endif
+    // (the pooled tensor first: its window maxima read the packed values, the row stores below may then trade them in place)
     // ---- fused MaxPool(ceil_mode): (kz,2,2) window = {the wave's two tiles (3D)} x {lane^16 (y)} x {lane^1 (x)} ----
     // Only planned behind a ReLU (sd_api.hip): all values are >= 0, so the packed integer max is the float max and
     // voxels beyond the volume contribute 0.
     if (p.pool_dst) {
         T* const pdst = reinterpret_cast<T*>(reinterpret_cast<char*>(p.pool_dst) + (size_t)tn * p.tstride);
         const bool writer = (dy == 0) && ((dxl & 1) == 0);
+        bool allv = true;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) allv = allv && valid[i];
+        const bool ragged = __any(!allv);      // wave-uniform
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             if (KZ == 3 && (i & 1)) continue;   // 3D: tiles (i, i+1) form ONE pooled tile (z pair)
@@ -1344,12 +1426,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
 #pragma unroll
                     for (int k = 0; k < 8; ++k) m[k] = pk_order_unkey(m[k], dk[k]);
                     }
-                } else {
+                } else if (ragged) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         m[k] = valid[i] ? pk[i][j][k] : 0u;
                         if (KZ == 3) m[k] = pk_max16(m[k], valid[i | 1] ? pk[i | 1][j][k] : 0u);
                     }
+                    pool_xy_pk8(m);
+                } else {      // every voxel of the wave's tiles lies inside the volume (all but the last blocks of a ragged extent)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) m[k] = KZ == 3 ? pk_max16(pk[i][j][k], pk[i | 1][j][k]) : pk[i][j][k];
                     pool_xy_pk8(m);
                 }
                 store_tile_rows_pk<T>(m, pdst, p.Pp, po, writer && valid[i], (nb * NT + j) * 32, half, p.Cd);
@@ -1357,6 +1443,17 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
         }
     }
 
+    if (p.store_main) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                store_tile_rows_pk<T>(pk[i][j], dst, p.Pd, voxoff[i], valid[i], (nb * NT + j) * 32, half, p.Cd);
+    }
+
+#ifndef SD_T5_EARLY
+    SD_T(5);   // main store done
+#endif
     // ---- fused conv_final (1x1x1) + softmax + uint8, on the matrix core --------------------------------------------
     // logits[class][voxel] = W[class][channel] . act[channel][voxel]: the B fragment of k-step s is exactly the pair
     // of packed output quads (2s, 2s+1) this lane already holds (the k order of an MFMA is free, the weight fragment
@@ -1498,9 +1595,10 @@ static size_t conv_lds_bytes(int nstages, bool fuse_final = false) {
 template <typename T, int KZ, int NT, int WAVES, int NSLOT, int MT = 2, int MODE = 0>
 static int launch_conv_k(ConvParams p, int NB, hipStream_t s) {
     using G = ConvGeo<KZ, WAVES, MT>;
-    constexpr bool FF = MODE == 1 || MODE == 4;
+    constexpr bool FF = MODE == 1 || MODE == 4 || MODE == 5;
     const size_t lds = conv_lds_bytes<KZ, NT, WAVES, MT, NSLOT>((p.nchunk0 + p.nchunk1) * KZ, p.final_wfrag != nullptr) +
-                       (FF ? (size_t)2 * (G::BY + 4) * (G::BX + 4) * 4 + (size_t)(MODE == 1 && NSLOT == 3 ? 2 : 1) * (5 * 64 + 32) * 4 : 0) +
+                       (FF ? (size_t)2 * (G::BY + 4) * (G::BX + 4) * 4 + (MODE == 5 ? (size_t)16 + (NSLOT == 3 ? 2 : 1) * 2048
+                                                                                      : (size_t)(MODE == 1 && NSLOT == 3 ? 2 : 1) * (5 * 64 + 32) * 4) : 0) +
                        (MODE == 2 ? (size_t)p.batch * conv_gn_lds_per_tile(p.nchunk0 + p.nchunk1) : 0);
     if (lds > (size_t)SD_LDS_BYTES) return SD_ERR_INVALID;
     p.nbx = (p.W + G::BX - 1) / G::BX; p.nby = (p.H + G::BY - 1) / G::BY; p.nbz = (p.D + G::BZ - 1) / G::BZ;

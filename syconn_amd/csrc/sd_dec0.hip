@@ -34,6 +34,7 @@
 #include "sd_device.h"
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 
 namespace {
@@ -165,6 +166,10 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
 #define D0_T(i) do {} while (0)
 #define D0_DUMP() do {} while (0)
 #endif
+    // static issue priority of one role (A/B: SD_DEC0_PRIO = 1 tail waves, 2 merge waves, 3 tail waves at level 3)
+    if (p.prio == 1 && wave >= 4) asm volatile("s_setprio 1");
+    if (p.prio == 2 && wave < 4) asm volatile("s_setprio 1");
+    if (p.prio == 3 && wave >= 4) asm volatile("s_setprio 3");
     if (wave < 4) {
         // ------------------------------------------------------------------------------------------- merge waves
         const int cw = wave;
@@ -506,6 +511,7 @@ int launch_dec0(Dec0Params p, int act_dtype, hipStream_t s) {
         if (span < best * 0.999 || (span < best * 1.001 && zs > p.zsplit)) { best = std::min(best, span); p.zsplit = zs; }
     }
     p.nzg = (p.D + p.zsplit - 1) / p.zsplit;
+    p.prio = getenv("SD_DEC0_PRIO") ? atoi(getenv("SD_DEC0_PRIO")) : 0;
     if ((long)p.zsplit * p.HP * PW > (1l << 30) || p.H < 8 || (long)p.D * p.H >= (1l << 24) || p.W >= (1 << 24))
         return SD_ERR_INVALID;      // 32-bit positions, 24-bit row arithmetic, cursor wraps once per advance (== dec0_shape_ok, sd_api.hip)
     if ((long)p.D * p.H * p.W >= (1l << 31)) return SD_ERR_INVALID;

@@ -63,6 +63,27 @@ __device__ __forceinline__ unsigned pk_max16(unsigned a, unsigned b) {
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s2, a), __builtin_bit_cast(s2, b)));
 }
 
+// Planar first convolution (1 -> 32 channels) on UINT8 input as two bf16 MFMAs (weight layout: sd_api.hip, `w3_off`).  The input
+// patch holds every voxel as the dword (bf16(v), bf16(v)) -- a uint8 is exact in bf16 --, r[0..4] = this lane's five patch reads
+// (lanes 0-31: taps 0-4; lanes 32-63: taps 5-8 and the constant dword (1.0, 1.0), which meets the bias parts).  Products
+// v * weight part are exact in fp32, the accumulation is the matrix core's fp32: conv(float32(v) / 255) to fp32 rounding.
+constexpr unsigned SD_BF16_ONE_PAIR = 0x3f803f80u;
+__device__ __forceinline__ unsigned u8_bf16_pair(unsigned v) {      // v in 0..255 -> (bf16(v), bf16(v))
+    const unsigned b = __builtin_bit_cast(unsigned, (float)v);     // (low 16 bits of the float are zero: 8 significant bits)
+    return b | (b >> 16);
+}
+__device__ __forceinline__ f32x16 first_u8_mfma(bf16x8 w0, bf16x8 w1, const unsigned (&r)[5]) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u4;
+    const unsigned m = 0xffffu;
+    const u4 b0 = {r[0], r[1], r[2], r[3]};
+    const u4 b1 = {r[4], (r[0] & m) | (r[1] & ~m), (r[2] & m) | (r[3] & ~m), (r[4] & m) | (SD_BF16_ONE_PAIR & ~m)};
+    f32x16 a;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = 0.f;
+    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, __builtin_bit_cast(bf16x8, b0), a, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, __builtin_bit_cast(bf16x8, b1), a, 0, 0, 0);
+}
+
 // Hardware places workgroup b on XCD b % 8 (observed; used for L2 locality only).  Map it to a logical block id
 // such that each XCD owns a contiguous run of logical ids (neighbouring blocks share halo voxels in that L2).
 // Bijective for any grid size.

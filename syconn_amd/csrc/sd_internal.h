@@ -65,6 +65,7 @@ struct ConvParams {
     const void* first_in; size_t first_in_tstride; int first_in_f32;
     const float* first_w;      // [5 k-steps][64 lanes] exact-f32 MFMA A fragments of the 32 output channels
     const float* first_bias;   // folded bias, 32 floats
+    const void* first_w3;      // uint8 input on the bf16 pipe (MODE 5): [tile][2 MFMAs][64 lanes][8] bf16 parts of weights / 255 and bias, or nullptr
     int first_relu;
     // deferred GroupNorm apply (k_conv_mfma<..., MODE 2>): src0 / src1 hold RAW convolution outputs; gn0 / gn1 = their
     // per-tile [2*C] float tables (scale then shift; tile t at + t*tstride bytes) or nullptr when that input is final
@@ -80,6 +81,7 @@ struct FirstParams {
     void* dst;
     int Cd;
     const float* wpack;  // [ntile][nstep][64 lanes] float
+    const void* wpack3;  // planar first conv on uint8 input, bf16 / fp16 plans: [ntile][2 MFMAs][64 lanes][8] bf16 (sd_api.hip), or nullptr
     const float* bias;   // padded to ntile*32
     int relu;
     int nbx, nby, nbz;
@@ -174,7 +176,7 @@ struct Dec0Params {
     const void* zero;  // >= 16 zero bytes
     int batch; size_t tstride, out_tstride;
     // filled in by launch_dec0
-    int HP, HP1, nstrip, zsplit, nzg;
+    int HP, HP1, nstrip, zsplit, nzg, prio;
     unsigned magic_hp, magic_hp1;
     long long* dbg;    // SD_DEC0_TIMING builds: per-wave cycle stamps of one step (else unused)
     int* ovf;          // fp16 range guard (sd_device.h: range_guard)

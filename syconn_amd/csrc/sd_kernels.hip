@@ -53,6 +53,56 @@ __global__ __launch_bounds__(256) void k_conv_first(const FirstParams p) {
         }
         patch[i] = v;
     }
+    T* const dst = reinterpret_cast<T*>(reinterpret_cast<char*>(p.dst) + blockIdx.z * p.tstride);
+    StoreGuard<T> sguard;
+    const int ntiles = (p.Cd + 31) / 32;
+    const int half = lane >> 5;
+    const size_t P = (size_t)p.D * p.H * p.W;
+    // uint8 input of a planar first convolution in the bf16 / fp16 plans: two bf16 MFMAs on the exact uint8 values with the weights / 255
+    // split three ways (sd_device.h first_u8_mfma; the same arithmetic as the form fused into the next convolution, k_conv_mfma MODE 5)
+    if constexpr (KZ == 1 && sizeof(IN) == 1 && !SPLIT) {
+        if (p.wpack3) {
+            __shared__ unsigned upatch[NH + 1];
+            for (int i = tid; i < NH + 1; i += 256) {
+                const int hx = i % HX, hy = i / HX;
+                const int y = y0 + hy - 1, x = x0 + hx - 1;
+                unsigned v = 0u;
+                if (i < NH && (unsigned)z0 < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W)
+                    v = u8_bf16_pair(in[((size_t)z0 * p.H + y) * p.W + x]);
+                upatch[i] = i < NH ? v : SD_BF16_ONE_PAIR;
+            }
+            __syncthreads();
+            for (int nt = 0; nt < ntiles; ++nt) {
+                const bf16x8 w0 = reinterpret_cast<const bf16x8*>(p.wpack3)[(nt * 2 + 0) * 64 + lane];
+                const bf16x8 w1 = reinterpret_cast<const bf16x8*>(p.wpack3)[(nt * 2 + 1) * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int t = wave * 2 + i;
+                    const int ly = t * 2 + ((lane & 31) >> 4), lx = lane & 15;
+                    const int base = ly * HX + lx;
+                    unsigned r[5];
+#pragma unroll
+                    for (int a = 0; a < 5; ++a) {
+                        const int tap = half * 5 + a;
+                        r[a] = upatch[tap < 9 ? base + (tap / 3) * HX + (tap % 3) : NH];
+                    }
+                    const f32x16 acc = first_u8_mfma(w0, w1, r);
+                    const int vy = y0 + ly, vx = x0 + lx;
+                    const bool valid = z0 < p.D && vy < p.H && vx < p.W;
+                    unsigned pk[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        pk[k] = Act<T>::pack2(acc[2 * k], acc[2 * k + 1]);
+                        if (p.relu) pk[k] = pk_max16(pk[k], 0u);
+                        sguard.see_signed(pk[k]);
+                    }
+                    store_tile_rows_pk<T>(pk, dst, P, (size_t)(z0 * p.H + vy) * p.W + vx, valid, nt * 32, half, p.Cd);
+                }
+            }
+            sguard.flush(p.ovf);
+            return;
+        }
+    }
     __syncthreads();
 
     // tap offsets of this lane's k index (k = 2*step + (lane>>5)); taps beyond NTAP have zero weights
@@ -64,11 +114,6 @@ __global__ __launch_bounds__(256) void k_conv_first(const FirstParams p) {
         const int kz = tap / 9, ky = (tap % 9) / 3, kx = tap % 3;
         toff[s] = (kz * HY + ky) * HX + kx;
     }
-    T* const dst = reinterpret_cast<T*>(reinterpret_cast<char*>(p.dst) + blockIdx.z * p.tstride);
-    StoreGuard<T> sguard;
-    const int ntiles = (p.Cd + 31) / 32;
-    const int half = lane >> 5;
-    const size_t P = (size_t)p.D * p.H * p.W;
     for (int nt = 0; nt < ntiles; ++nt) {
         float wf[NSTEP];
 #pragma unroll
@@ -912,9 +957,9 @@ bool conv_can_fuse_first(int KZ, int NT, int NB, long vox, int nstages, bool fus
     if ((vox / 512) * NB < 512) return false;                                   // the `big` rule of launch_conv_knt
     if (nstages == 3)      // 48 filters: three resident halo slots; the resident-weight form of this layer holds one workgroup per CU already
         return getenv("SD_NO_FIRST_FUSE48") == nullptr &&
-               conv_lds_bytes<1, 2, 8, 2, 3>(nstages, fused_final) + 2 * 36 * 20 * 4 + 2 * 352 * 4 <= (size_t)SD_LDS_BYTES;
+               conv_lds_bytes<1, 2, 8, 2, 3>(nstages, fused_final) + 2 * 36 * 20 * 4 + 16 + 2 * 2048 <= (size_t)SD_LDS_BYTES;
     const size_t lds = NT == 1 ? conv_lds_bytes<1, 1, 8, 2, 2>(nstages, fused_final) : conv_lds_bytes<1, 2, 8, 2, 2>(nstages, fused_final);
-    return lds + 2 * 36 * 20 * 4 + 352 * 4 <= 96 * 1024;
+    return lds + 2 * 36 * 20 * 4 + 16 + 2048 <= 96 * 1024;      // (the larger of the two first-conv weight images: MODE 5)
 }
 
 template <typename T, int KZ, int NT>
@@ -932,6 +977,12 @@ static int launch_conv_knt(const ConvParams& p, int NB, hipStream_t s) {
     if constexpr (KZ == 1 && NT <= 2) {
         if (p.first_in) {
             if (!conv_can_fuse_first(KZ, NT, NB, vox, nstages, p.final_wfrag != nullptr)) return SD_ERR_INVALID;
+            if (p.first_w3 && !p.first_in_f32) {      // uint8 input: the first convolution on the bf16 pipe (MODE 5)
+                if constexpr (NT == 2) {
+                    if (nstages == 3) return launch_conv_k<T, KZ, NT, 8, 3, 2, 5>(p, NB, s);
+                }
+                return launch_conv_k<T, KZ, NT, 8, 2, 2, 5>(p, NB, s);
+            }
             if constexpr (NT == 2) {
                 if (nstages == 3) return launch_conv_k<T, KZ, NT, 8, 3, 2, 1>(p, NB, s);
             }

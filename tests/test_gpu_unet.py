@@ -6,6 +6,8 @@ Two references per case:
   rounded to the activation dtype, fp32 accumulate) -- differs from the HIP path only by summation order, so the
   tolerance is tight and catches indexing bugs a loose bf16 tolerance would hide.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -58,9 +60,19 @@ def _run_case(gpu, model, shape, act, seed=0, check_layers=True):
     print(msg)
     assert e_emu <= TOL_EMU[act] and r_emu <= TOL_EMU_RMS[act], msg
     assert e_ref <= TOL_FP32[act] and r_ref <= TOL_FP32_RMS[act], msg
-    # same input as float32 (Predictor.predict's path) must give the same result as the uint8 fast path
-    out_f = dm.forward((raw.to(torch.float32) / 255.).to(gpu), out_kind=L.SD_OUT_LOGITS_F32).cpu()
-    assert torch.equal(out_f, out), 'uint8 (LUT) and float32 input paths differ'
+    # same input as float32 (Predictor.predict's path) against the uint8 fast path.  A planar first convolution takes uint8 input
+    # through two bf16 MFMAs on the exact uint8 values (weights / 255 split three ways: fp32-level arithmetic, but not the bit pattern
+    # of the float32(v) / 255 chain): a rounding of a stored activation flips here and there, so the two paths agree like two summation
+    # orders do (the emulation tolerance).  With the chain forced for uint8 too (SD_NO_FIRST_U8) they are equal bit for bit.
+    xf = (raw.to(torch.float32) / 255.).to(gpu)
+    out_f = dm.forward(xf, out_kind=L.SD_OUT_LOGITS_F32).cpu()
+    assert float((out_f - out).abs().max()) / scale <= TOL_EMU[act], 'uint8 and float32 input paths differ'
+    os.environ['SD_NO_FIRST_U8'] = '1'
+    try:
+        out_c = dm.forward(raw.to(gpu), out_kind=L.SD_OUT_LOGITS_F32).cpu()
+    finally:
+        del os.environ['SD_NO_FIRST_U8']
+    assert torch.equal(out_f, out_c), 'uint8 (exact-f32 chain) and float32 input paths differ'
     return out, ref, emu
 
 
@@ -221,7 +233,10 @@ def test_uint8_normalisation_is_exact_for_all_values(gpu, monkeypatch):
     model = build_unet('myelin', seed=3, n_blocks=2, start_filts=16)
     raw = torch.arange(256, dtype=torch.uint8).reshape(1, 16, 16).repeat(2, 1, 1).contiguous()
     dm = DenseModel(model, act_dtype='bf16', device=gpu)
+    fast = dm.forward(raw.to(gpu), L.SD_OUT_LOGITS_F32).cpu()      # (the default uint8 form: bf16 MFMAs on the exact uint8 values)
+    monkeypatch.setenv('SD_NO_FIRST_U8', '1')                       # the exact-f32 chain on float32(v) / 255 for uint8 input too
     a = dm.forward(raw.to(gpu), L.SD_OUT_LOGITS_F32).cpu()
+    assert float((fast - a).abs().max()) <= TOL_EMU['bf16'] * float(a.abs().max())
     b = dm.forward(torch.from_numpy(raw.numpy().astype(np.float32) / 255.).to(gpu), L.SD_OUT_LOGITS_F32).cpu()
     assert torch.equal(a, b)
     # ... and on the first layer's own output (SD_KEEP_ALL: every buffer materialised in its own range, no fusion skips it)
@@ -231,6 +246,11 @@ def test_uint8_normalisation_is_exact_for_all_values(gpu, monkeypatch):
     first_u8 = dk.read_buffer(1).cpu().clone()
     dk.forward(torch.from_numpy(raw.numpy().astype(np.float32) / 255.).to(gpu), L.SD_OUT_LOGITS_F32)
     assert torch.equal(first_u8, dk.read_buffer(1).cpu()) and float(first_u8.abs().max()) > 0
+    # ... and the default uint8 form gives the same first-layer tensor up to one rounding step of a stored value here and there
+    monkeypatch.delenv('SD_NO_FIRST_U8')
+    dk.forward(raw.to(gpu), L.SD_OUT_LOGITS_F32)
+    d = (dk.read_buffer(1).cpu() - first_u8).abs()
+    assert float(d.max()) <= 2.0 ** -7 * float(first_u8.abs().max()) and float((d > 0).float().mean()) < 1e-2
 
 
 @pytest.mark.parametrize('arch,shape', [('er', (20, 150, 170)), ('syntype', (18, 140, 150)), ('mivcsj', (16, 100, 120))])
