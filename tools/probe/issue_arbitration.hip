@@ -55,11 +55,13 @@ __global__ void __launch_bounds__(512) k(long long* out, float* sink, int iters)
             }
             n = iters;
         } else {
-            while (!done) {
+            // (a fixed count that takes about as long alone as the partner's MFMA loop: 128 cycles per MFMA iteration, ~6 per VALU)
+            const int nb = iters * 128 / (6 * VB);
+            for (int it = 0; it < nb; ++it) {
 #pragma unroll
                 for (int j = 0; j < VB; ++j) asm volatile("v_add_u32 %0, %0, %1" : "+v"(v[j & 15]) : "v"(v[(j + 5) & 15]));
-                ++n;
             }
+            n = nb;
         }
     }
     long long t1 = __builtin_readcyclecounter();
@@ -82,7 +84,7 @@ static void run(const char* what, int nwg) {
     const double ca = (double)h[0] / (h[1] ? h[1] : 1), cb = (double)h[8] / (h[9] ? h[9] : 1);
     printf("%-58s WGs %3d | MFMA wave: %7.1f cyc / iteration (4 MFMA) | VALU wave: %7.1f cyc / iteration (%2d VALU) = %5.2f cyc / VALU", what, nwg,
            MA ? ca : 0.0, VB ? cb : 0.0, VB, VB ? cb / VB : 0.0);
-    if (MA && VB) printf(" | %5.1f VALU issued per MFMA of the partner", (double)h[9] * VB / ((double)h[1] * 4));
+    if (MA && VB) printf(" | wave durations %lld / %lld", h[0], h[8]);
     printf("\n");
     (void)hipFree(d); (void)hipFree(sink);
 }
