@@ -52,93 +52,42 @@ def synthetic_em_tiles(n, size, seed):
     return out
 
 
-def layer_accounting(ops, L, D, H, W, act_bytes=2, out_bytes_per_class=1, batch=1):
-    """Algorithmic FLOPs and bytes of every plan op for a (D,H,W) tile.  Bytes follow SURVEY.md section 8(d):
-    activation read + write per fused conv(+norm+act) layer, a pooled tensor counts its write only (it belongs in
-    the producing conv's epilogue), concat = two read pointers, weights ignored (L2/MALL resident)."""
+def layer_accounting(ops, L, D, H, W, act_bytes=2, out_bytes_per_class=1):
+    """Algorithmic FLOPs and bytes of every plan op for a (D,H,W) tile, [(flops, bytes)] in op order.  Bytes follow SURVEY.md section
+    8(d): activation read + write per fused conv(+norm+act) layer, a pooled tensor counts its write only (it belongs in the producing
+    conv's epilogue), concat = two read pointers, weights ignored (L2/MALL resident).  Which KERNEL computed an op is not decided here:
+    the library reports it (sd_debug_op_kernel -> DenseModel.op_kernels())."""
     dims = {0: (D, H, W)}
     chans = {0: 1}
     rows = []
-    fused_first = set()
-    for io, o in enumerate(ops):
+    for o in ops:
         if o.kind == L.SD_OP_CONV:
             d = dims[o.src1] if o.src1 >= 0 else dims[o.src0]
             vox = d[0] * d[1] * d[2]
             cin = o.cin0 + max(o.cin1, 0)
-            taps = o.kz * 9
-            flops = 2.0 * vox * cin * o.cout * taps
             inb = vox * (1 if o.src0 == 0 else cin * act_bytes)
-            # kernel instantiation the library dispatches (mirrors launch_conv_knt in sd_kernels.hip)
-            if o.src0 == 0:
-                name = 'k_conv_first<%dx3x3>' % o.kz
-            else:
-                ntile = (o.cout + 31) // 32
-                nt = 3 if ntile % 3 == 0 else (2 if ntile >= 2 else 1)
-                nbk = (ntile + nt - 1) // nt
-                waves = 8 if ((vox * batch) // 512) * nbk >= 512 else 4
-                # LDS-resident weights (NSLOT=2) when the layer's weight groups fit beside a 2-slot halo ring
-                bz, by = ((waves // 4) * 2, 8) if o.kz == 3 else (1, waves * 4)
-                a_bytes = -(-((bz + o.kz - 1) * (by + 2) * 18 * 2) // 64) * 1024
-                nstages = (-(-o.cin0 // 16) + (-(-o.cin1 // 16) if o.cin1 > 0 else 0)) * o.kz
-                fused_final = io + 1 < len(ops) and ops[io + 1].kind == L.SD_OP_FINAL and nbk == 1
-                lds = 2 * a_bytes + nstages * 9 * nt * 1024 + 512 + (nt * 4096 if fused_final else 0) + 1024
-                resident = lds <= (96 if waves == 8 else 80) * 1024
-                name = 'k_conv_mfma<%dx3x3,NT=%d,%d waves,%s>' % (o.kz, nt, waves, 'NSLOT=2' if resident else 'NSLOT=0')
-                # planar 4-tile form (round 4): 4-wave workgroups of 1 x 32 x 16 voxels for the streamed-weight planar NT = 2 layers
-                if (o.kz == 1 and nt == 2 and waves == 8 and not resident and not fused_final and (d[1] % 32 == 0 or d[1] >= 128)
-                        and ((vox * batch) // 512) * nbk >= 1024 and not os.environ.get('SD_NO_PLANAR4')):
-                    name = 'k_conv_mfma<1x3x3,NT=2,4 waves,NSLOT=0,MT=4>'
-                # first conv computed inside this conv (conv_can_fuse_first in sd_kernels.hip)
-                prev = ops[io - 1] if io > 0 else None
-                if (prev is not None and prev.kind == L.SD_OP_CONV and prev.src0 == 0 and prev.kz == 1 and prev.cout == 32
-                        and o.kz == 1 and o.src0 == prev.dst and o.src1 < 0 and nt <= 2 and nstages == 2 and waves == 8
-                        and lds + 36 * 20 * 4 <= 96 * 1024):
-                    name = name[:-1] + ',FF>'
-                    fused_first.add(io - 1)
-                elif (prev is not None and prev.kind == L.SD_OP_CONV and prev.src0 == 0 and prev.kz == 1 and prev.cout == 48
-                        and o.kz == 1 and o.src0 == prev.dst and o.src1 < 0 and nt == 2 and nstages == 3 and waves == 8
-                        and not os.environ.get('SD_NO_FIRST_FUSE48')):      # 48 filters: three resident halo slots
-                    name = 'k_conv_mfma<1x3x3,NT=2,8 waves,NSLOT=3,FF>'
-                    fused_first.add(io - 1)
-            rows.append((name, flops, inb + vox * o.cout * act_bytes))
+            rows.append((2.0 * vox * cin * o.cout * o.kz * 9, inb + vox * o.cout * act_bytes))
             dims[o.dst], chans[o.dst] = d, o.cout
         elif o.kind == L.SD_OP_POOL:
             d = dims[o.src0]
             do = ((d[0] + 1) // 2 if o.kz == 2 else d[0], (d[1] + 1) // 2, (d[2] + 1) // 2)
-            rows.append(('pool', 0.0, do[0] * do[1] * do[2] * chans[o.src0] * act_bytes))
+            rows.append((0.0, do[0] * do[1] * do[2] * chans[o.src0] * act_bytes))
             dims[o.dst], chans[o.dst] = do, chans[o.src0]
         elif o.kind == L.SD_OP_UPCONV:
             d = dims[o.src0]
             vox = d[0] * d[1] * d[2]
             taps = o.kz * 4
-            do = (d[0] * o.kz, d[1] * 2, d[2] * 2)
-            rows.append(('upconv', 2.0 * vox * o.cin0 * o.cout * taps,
-                         (vox * o.cin0 + vox * taps * o.cout) * act_bytes))
-            dims[o.dst], chans[o.dst] = do, o.cout
+            rows.append((2.0 * vox * o.cin0 * o.cout * taps, (vox * o.cin0 + vox * taps * o.cout) * act_bytes))
+            dims[o.dst], chans[o.dst] = (d[0] * o.kz, d[1] * 2, d[2] * 2), o.cout
         elif o.kind == L.SD_OP_GROUPNORM:
             d = dims[o.src1] if o.src1 >= 0 else dims[o.src0]
-            vox = d[0] * d[1] * d[2]
-            rows.append(('groupnorm', 0.0, 2.0 * vox * chans[o.src0] * act_bytes))
+            rows.append((0.0, 2.0 * d[0] * d[1] * d[2] * chans[o.src0] * act_bytes))
         elif o.kind == L.SD_OP_FINAL:
             d = dims[o.src0]
             vox = d[0] * d[1] * d[2]
-            rows.append(('final', 2.0 * vox * o.cin0 * o.cout, vox * (o.cin0 * act_bytes + o.cout * out_bytes_per_class)))
-    for i in fused_first:             # the first conv's work is done inside its consumer: no launch of its own
-        rows[i] = ('k_conv_first(fused into next)',) + tuple(rows[i][1:])
-    # level-0 decoder as one streaming launch (sd_dec0.hip; mirrors the plan pass in sd_api.hip): the planar up-convolution
-    # 64 -> 32, the merge conv, the second conv and the final layer run inside the up-convolution's launch
-    r16 = lambda c: -(-c // 16) * 16
-    if (not os.environ.get('SD_NO_DEC0') and not os.environ.get('SD_NO_FUSE') and not os.environ.get('SD_KEEP_ALL') and H >= 8
-            and W * 10 >= -(-W // 64) * 64 * 7):
-        for i in range(len(ops) - 3):
-            u, c1, c2, f = ops[i:i + 4]
-            if (u.kind == L.SD_OP_UPCONV and u.kz == 1 and u.relu and r16(u.cin0) == 64 and r16(u.cout) == 32
-                    and c1.kind == L.SD_OP_CONV and c1.kz == 1 and c1.relu and c1.src0 == u.dst and c1.src1 >= 0
-                    and r16(c1.cin1) == 32 and r16(c1.cout) == 32
-                    and c2.kind == L.SD_OP_CONV and c2.kz == 1 and c2.relu and c2.src0 == c1.dst and c2.src1 < 0
-                    and r16(c2.cout) == 32 and f.kind == L.SD_OP_FINAL and i + 4 == len(ops)):
-                for j in (i, i + 1, i + 2, i + 3):
-                    rows[j] = ('k_dec0<up-conv + merge conv + conv + final>',) + tuple(rows[j][1:])
+            rows.append((2.0 * vox * o.cin0 * o.cout, vox * (o.cin0 * act_bytes + o.cout * out_bytes_per_class)))
+        else:
+            rows.append((0.0, 0.0))
     return rows
 
 
@@ -305,17 +254,39 @@ def main():
     if world == 1:
         assert torch.equal(lab_res.cpu(), pipe.out_host[(pipe.k - 1) & 1][0]), 'host-to-host labels differ from resident run'
 
+    # ---- what BASELINE configs[1] literally names -- ONE 128^3 tile per launch set -- and the reference-precision plan, device-resident
+    def resident_rate(model, n_tiles, min_reps=5, budget_s=0.4):
+        x, o = tiles_dev[:n_tiles], torch.empty((n_tiles, S, S, S), dtype=torch.uint8, device=dev)
+        model.forward_labels_batch(x, ids, thr, out=o)
+        torch.cuda.synchronize(dev)
+        reps, t1 = 0, time.perf_counter()
+        while reps < min_reps or (time.perf_counter() - t1 < budget_s and reps < 200):
+            model.forward_labels_batch(x, ids, thr, out=o)
+            reps += 1
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t1) / reps / n_tiles * 1e3      # ms per tile
+    single_tile_ms = resident_rate(dm, 1)
+    ref_prec = None
+    if world == 1 and args.act != 'f16x2':
+        m2 = DenseModel(sd, act_dtype='f16x2', device=dev)
+        ref_prec = resident_rate(m2, T)
+        del m2
+    dm.forward_labels_batch(tiles_dev[:B], ids, thr, out=lab_res[:B])      # (the launch set op_kernels() below reports on)
+
     tiles_per_launch = T / nbatch                 # average tiles one launch processes
-    rows = [(n, f * tiles_per_launch, b * tiles_per_launch)
-            for n, f, b in layer_accounting(dm.ops, L, S, S, S, batch=B)]
+    rows = [(f * tiles_per_launch, b * tiles_per_launch) for f, b in layer_accounting(dm.ops, L, S, S, S)]
+    # kernel of every op as the library ran it in the last forward (fused ops: the launch they ran inside); the algorithmic work of an op
+    # is booked on that launch, its HIP-event time is the launch's
+    executed = dm.op_kernels()
     groups = {}
-    for (name, fl, by), ms in zip(rows, per_op):
-        g = groups.setdefault(name, [0.0, 0.0, 0.0, 0])
-        g[0] += fl; g[1] += by; g[2] += ms; g[3] += 1
+    for i, ((fl, by), ms) in enumerate(zip(rows, per_op)):
+        e, name = executed[i]
+        g = groups.setdefault(name or 'not run', [0.0, 0.0, 0.0, 0])
+        g[0] += fl; g[1] += by; g[2] += ms; g[3] += 1 if e == i else 0
     dom = max(groups, key=lambda k: groups[k][2])
     fl, by, ms, nlaunch = groups[dom]
     kern_ms = float(per_op.sum())
-    b_alg = sum(r[2] for r in rows)
+    b_alg = sum(r[1] for r in rows)
     if fl / max(by, 1) > PEAK_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
         roof = {'kernel': dom, 'bound': 'mfma', 'achieved': fl / (ms * 1e-3) / 1e12, 'peak': PEAK_MFMA_TFLOPS,
                 'unit': 'TFLOP/s'}
@@ -336,16 +307,18 @@ def main():
     if os.path.isfile(tr_file):
         tr = json.load(open(tr_file))
         if tr.get('arch') == args.arch and tr.get('tile') == S and tr.get('act') == args.act:
-            t1 = tr.get('hbm_bytes_per_launch', {}).get(dom)      # measured with tr['tiles_per_launch'] tiles per launch
+            per = tr.get('hbm_bytes_per_launch', {})                # measured with tr['tiles_per_launch'] tiles per launch
+            # (rocprofv3 prints the planar 16-bit forms without their storage type: those entries carry a '*' there)
+            t1 = per.get(dom, per.get(dom.replace('<bf16,', '<*,').replace('<f16,', '<*,')))
             roof['traffic'] = None if t1 is None else t1 * tiles_per_launch / float(tr.get('tiles_per_launch', 1))
             roof['traffic_note'] = tr.get('note')
     # whole-network view the north star asks for: algorithmic bytes of one tile / device time of one tile / 8 TB/s
     b_alg /= tiles_per_launch
     kern_ms /= tiles_per_launch
-    rows = [(n, f / tiles_per_launch, b / tiles_per_launch) for n, f, b in rows]
-    net = {'b_alg_bytes_per_tile': b_alg, 'gflop_per_tile': sum(r[1] for r in rows) / 1e9,
+    rows = [(f / tiles_per_launch, b / tiles_per_launch) for f, b in rows]
+    net = {'b_alg_bytes_per_tile': b_alg, 'gflop_per_tile': sum(r[0] for r in rows) / 1e9,
            'kernel_ms_per_tile': kern_ms, 'hbm_roofline_frac': b_alg / (kern_ms * 1e-3) / (PEAK_HBM_GBS * 1e9),
-           'effective_tflops': sum(r[1] for r in rows) / (kern_ms * 1e-3) / 1e12,
+           'effective_tflops': sum(r[0] for r in rows) / (kern_ms * 1e-3) / 1e12,
            'per_kernel_ms_per_tile': {k: round(v[2] / tiles_per_launch, 4) for k, v in groups.items()}}
 
     cpu = None
@@ -372,6 +345,9 @@ def main():
                            'tiles_per_gpu_per_step': T, 'tile': [S, S, S], 'parallelism': f'tile-sharded x{world}',
                            'hip_streams_per_gpu': 3,
                            'collective': 'RCCL gather of uint8 labels to rank 0, D2H there' if world > 1 else 'none',
+                           'single_tile_ms': single_tile_ms, 'single_tile_mvox_per_s': S ** 3 / single_tile_ms / 1e3,
+                           'reference_precision_f16x2_mvox_per_s': None if ref_prec is None else S ** 3 / ref_prec / 1e3,
+                           'reference_precision_f16x2_ms_per_tile': ref_prec,
                            'device_resident_value': value_res,
                            'device_resident_ms_per_step': elapsed_res / args.steps * 1e3,
                            'pcie_bytes_per_step_each_way': T * S ** 3, 'labels_sha256': labels_sha},

@@ -172,6 +172,11 @@ int sd_model_num_ops(const sd_model* m);
  * pooling / final layer in a convolution's epilogue, first convolution inside the second, the level-0 decoder inside its
  * up-convolution's launch).  For tests that must know which plan a shape was served by. */
 int sd_debug_last_launch_count(const sd_model* m);
+/* Which kernel computed plan op `op` in the last sd_forward* call: returns the index of the op whose LAUNCH did it (`op` itself, or the
+ * op it is fused into: a pooling / final layer in a convolution's epilogue, a first convolution inside the second, the members of the
+ * level-0 decoder), -1 when it did not run; the kernel symbol of that launch ("k_conv_mfma<bf16,3x3x3,NT=2,WAVES=8,NSLOT=0,MT=4,MODE=0>")
+ * is copied into buf (n bytes, NUL-terminated).  What bench.py names its roofline kernel by -- the launchers note what they picked. */
+int sd_debug_op_kernel(const sd_model* m, int op, char* buf, int n);
 
 const char* sd_last_error(void);
 const char* sd_version(void);

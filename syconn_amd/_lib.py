@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.g
 # every symbol include/syconn_dense.h declares (checked by tests/test_abi.py)
 EXPORTS = ['sd_init', 'sd_device_count', 'sd_model_create', 'sd_model_destroy', 'sd_workspace_bytes', 'sd_model_overflow', 'sd_forward', 'sd_forward_batch', 'sd_forward_labels_batch',
            'sd_tile_gather', 'sd_tile_scatter', 'sd_postproc_labels', 'sd_profile_enable', 'sd_profile_read',
-           'sd_debug_read_buffer', 'sd_model_num_ops', 'sd_debug_last_launch_count', 'sd_last_error', 'sd_version', 'sd_snappy_max_compressed_length',
+           'sd_debug_read_buffer', 'sd_model_num_ops', 'sd_debug_last_launch_count', 'sd_debug_op_kernel', 'sd_last_error', 'sd_version', 'sd_snappy_max_compressed_length',
            'sd_snappy_compress', 'sd_snappy_uncompressed_length', 'sd_snappy_uncompress', 'sd_downsample2', 'sd_box_majority',
            'sd_objtable_bytes', 'sd_pairtable_bytes', 'sd_segstats_scan', 'sd_segstats_compact_objects',
            'sd_segstats_compact_pairs', 'sd_objseg_workspace_bytes', 'sd_object_segmentation', 'sd_objseg_watershed_workspace_bytes',
@@ -72,6 +72,7 @@ def load():
     lib.sd_debug_read_buffer.restype = i32
     lib.sd_model_num_ops.argtypes = [vp]; lib.sd_model_num_ops.restype = i32
     lib.sd_debug_last_launch_count.argtypes = [vp]; lib.sd_debug_last_launch_count.restype = i32
+    lib.sd_debug_op_kernel.argtypes = [vp, i32, C.c_char_p, i32]; lib.sd_debug_op_kernel.restype = i32
     lib.sd_last_error.argtypes = []; lib.sd_last_error.restype = C.c_char_p
     lib.sd_version.argtypes = []; lib.sd_version.restype = C.c_char_p
     lib.sd_snappy_max_compressed_length.argtypes = [sz]; lib.sd_snappy_max_compressed_length.restype = sz

@@ -78,6 +78,7 @@ struct Op {
 
 }  // namespace
 
+thread_local const char* sd_tls_kernel = nullptr;      // (sd_internal.h)
 int sd_fail_msg(int code, const char* msg) { return fail(code, msg); }   // for the other translation units
 
 struct sd_model {
@@ -87,6 +88,8 @@ struct sd_model {
     int nbuf = 0;
     std::vector<int> bufC;    // real channels per buffer id
     std::vector<int> bufCp;   // padded channel stride
+    std::vector<const char*> op_kernel;   // last forward: kernel symbol each op's launch used (static strings; nullptr: no launch of its own)
+    std::vector<int> op_exec;             // last forward: index of the op whose launch computed this op (itself, or the op it is fused into); -1: not run
     char* dev_blob = nullptr; // packed weights
     size_t blob_bytes = 0;
     void* dev_zero = nullptr;
@@ -297,6 +300,20 @@ int sd_init(int device_ordinal) {
 
 int sd_model_num_ops(const sd_model* m) { return m ? (int)m->ops.size() : 0; }
 int sd_debug_last_launch_count(const sd_model* m) { return m ? m->last_launches : 0; }
+int sd_debug_op_kernel(const sd_model* m, int op, char* buf, int n) {
+    if (!m) return -1;
+    if (m->f32) {      // (the fp32 FMA plan keeps its own op list: one k32_* launch per op)
+        if (buf && n > 0) snprintf(buf, (size_t)n, "k32_* (fp32 FMA plan)");
+        return op;
+    }
+    if (op < 0 || op >= (int)m->ops.size()) return -1;
+    const int e = op < (int)m->op_exec.size() ? m->op_exec[op] : -1;
+    if (buf && n > 0) {
+        const char* name = (e >= 0 && e < (int)m->op_kernel.size() && m->op_kernel[e]) ? m->op_kernel[e] : "";
+        snprintf(buf, (size_t)n, "%s", name);
+    }
+    return e;
+}
 
 int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_floats, int act_dtype,
                     sd_model** out) {
@@ -1130,6 +1147,8 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
     }
     ++m->n_forward;
     m->last_launches = 0;
+    m->op_kernel.assign(m->ops.size(), nullptr);
+    m->op_exec.assign(m->ops.size(), -1);
     const bool no_first_u8 = getenv("SD_NO_FIRST_U8") != nullptr;      // A/B switch (read per forward): uint8 input through the exact-f32 MFMA chain
     {
         // GroupNorm statistics scratch (sum and sum of squares per channel, doubles, at the start of every tile's workspace): zeroed
@@ -1162,10 +1181,11 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
             const bool fused1 = m->split
                 ? conv_can_fuse_first_split(c.d.kz, c.NT, c.NB, launch_vox(i + 1), nst1, c.fuse_final >= 0)
                 : conv_can_fuse_first(c.d.kz, c.NT, c.NB, launch_vox(i + 1), nst1, c.fuse_final >= 0);
-            if (fused1) { ++m->last_launches; continue; }
+            if (fused1) { ++m->last_launches; m->op_exec[i] = (int)i + 1; continue; }
         }
         if (ev) { HIP_TRY(hipEventRecord(ev[i], s)); ev_rec[i] = 1; }
         ++m->last_launches;
+        sd_tls_kernel = nullptr;
         switch (d.kind) {
         case SD_OP_CONV: {
             const Dims o = m->dims[d.dst];
@@ -1419,6 +1439,14 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
             snprintf(msg, sizeof msg, "launch of op %zu (kind %d) failed: %s", i, d.kind,
                      hipGetErrorString(hipGetLastError()));
             return fail(rc, msg);
+        }
+        // what ran: this op by the kernel its launcher noted, and inside that launch the ops fused into it
+        m->op_kernel[i] = sd_tls_kernel;
+        if (m->op_exec[i] < 0) m->op_exec[i] = (int)i;
+        auto own = [&](int j) { if (j >= 0 && j < (int)m->ops.size()) m->op_exec[j] = (int)i; };
+        own(op.fuse_pool); own(op.fuse_final); own(op.fuse_pool_raw); own(op.gn_pool);
+        if (d.kind == SD_OP_UPCONV && op.dec0_c1 >= 0 && dec0) {
+            own(op.dec0_c1); own(op.dec0_c2); own(m->ops[op.dec0_c2].fuse_final);
         }
     }
     if (ev) { HIP_TRY(hipEventRecord(ev[m->ops.size()], s)); ev_rec[m->ops.size()] = 1; }

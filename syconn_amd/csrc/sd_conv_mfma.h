@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <mutex>
+#include <string>
 #include <type_traits>
 #include <utility>
 
@@ -1635,6 +1636,12 @@ static int launch_conv_k(ConvParams p, int NB, hipStream_t s) {
     const int cap = std::max(8, SD_NUM_CU * wg_per_cu / NB / 8 * 8);
     static const bool no_persist = getenv("SD_NO_PERSIST") != nullptr;   // debugging aid
     dim3 grid(!no_persist ? std::min(nsb, cap) : nsb, NB), block(WAVES * 64);
+    {
+        static const std::string name = std::string("k_conv_mfma<") + (std::is_same<T, bf16_t>::value ? "bf16" : "f16") + "," +
+            std::to_string(KZ) + "x3x3,NT=" + std::to_string(NT) + ",WAVES=" + std::to_string(WAVES) + ",NSLOT=" + std::to_string(NSLOT) +
+            ",MT=" + std::to_string(MT) + ",MODE=" + std::to_string(MODE) + ">";
+        SD_NOTE_KERNEL(name.c_str());
+    }
     hipLaunchKernelGGL(kern, grid, block, lds, s, p);
     return SD_LAUNCH_CHECK();
 }

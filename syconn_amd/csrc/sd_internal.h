@@ -23,6 +23,11 @@ constexpr int SD_BX = 16;
 __host__ __device__ constexpr int sd_bz(int KZ) { return KZ == 3 ? 2 : 1; }
 __host__ __device__ constexpr int sd_by(int KZ) { return KZ == 3 ? 8 : 16; }
 
+// Every launcher notes the kernel symbol it picked (a string with static storage); sd_forward* keeps it per plan operation for
+// sd_debug_op_kernel, so that a benchmark names the kernels that RAN instead of restating the selection rules.
+extern thread_local const char* sd_tls_kernel;
+#define SD_NOTE_KERNEL(str) (sd_tls_kernel = (str))
+
 struct LabelArgs { int n; int ids[16]; int cuts[16]; };   // label rule: later entries override; p >= cut <=> p > t
 
 struct ConvParams {

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <mutex>
+#include <string>
 #include <type_traits>
 #include <utility>
 
@@ -1053,6 +1054,8 @@ int launch_conv(const ConvParams& p, int act_dtype, int KZ, int NT, int NB, hipS
 
 template <typename T, typename IN>
 static int launch_first_t(const FirstParams& p, int KZ, hipStream_t s) {
+    SD_NOTE_KERNEL(sizeof(IN) == 1 ? (p.wpack3 && KZ == 1 ? "k_conv_first<uint8 input, bf16 MFMA on the exact values>" : "k_conv_first<uint8 input, f32 MFMA chain>")
+                                   : "k_conv_first<float32 input, f32 MFMA chain>");
     dim3 grid(p.nbx * p.nby * p.nbz, 1, p.batch), block(256);
     if (KZ == 3) hipLaunchKernelGGL((k_conv_first<T, 3, IN>), grid, block, 0, s, p);
     else if (KZ == 1) hipLaunchKernelGGL((k_conv_first<T, 1, IN>), grid, block, 0, s, p);
@@ -1061,6 +1064,7 @@ static int launch_first_t(const FirstParams& p, int KZ, hipStream_t s) {
 }
 int launch_first(const FirstParams& p, int act_dtype, int in_dtype, int KZ, hipStream_t s) {
     if (act_dtype == SD_F16X2) {
+        SD_NOTE_KERNEL("k_conv_first<split-fp16, f32 MFMA chain>");
         dim3 grid(p.nbx * p.nby * p.nbz, 1, p.batch), block(256);
         if (KZ == 3 && in_dtype == SD_U8) hipLaunchKernelGGL((k_conv_first<f16_t, 3, uint8_t, true>), grid, block, 0, s, p);
         else if (KZ == 3) hipLaunchKernelGGL((k_conv_first<f16_t, 3, float, true>), grid, block, 0, s, p);
@@ -1076,6 +1080,7 @@ int launch_first(const FirstParams& p, int act_dtype, int in_dtype, int KZ, hipS
 
 template <typename T, int NCH, int NTAB>
 static int launch_upconv_rows(const UpconvParams& p, hipStream_t s) {
+    { static const std::string name = "k_upconv_rows<NCH=" + std::to_string(NCH) + ",NTAB=" + std::to_string(NTAB) + ">"; SD_NOTE_KERNEL(name.c_str()); }
     const long M = (long)p.D * p.H * p.W;
     if (M >= (1l << 31)) return SD_ERR_INVALID;        // the kernel decodes input voxel indices with 32-bit arithmetic
     dim3 grid((unsigned)((M + 127) / 128), 1, p.batch), block(256);
@@ -1085,6 +1090,7 @@ static int launch_upconv_rows(const UpconvParams& p, hipStream_t s) {
 }
 template <typename T, int NCH, int NTAB>
 static int launch_upconv_rows_wl(const UpconvParams& p, hipStream_t s) {      // LDS-resident weights, persistent
+    { static const std::string name = "k_upconv_rows<NCH=" + std::to_string(NCH) + ",NTAB=" + std::to_string(NTAB) + ",LDS weights>"; SD_NOTE_KERNEL(name.c_str()); }
     const long M = (long)p.D * p.H * p.W;
     if (M >= (1l << 31)) return SD_ERR_INVALID;
     const size_t lds = 4 * 32 * 64 * NTAB + (size_t)(NTAB / 2 + 2 * (NTAB & 1)) * NCH * 2048;
@@ -1119,6 +1125,7 @@ bool upconv_rows_kernel(int nchunk, int Cd) {
 
 template <typename T>
 static int launch_upconv_t(const UpconvParams& p, int NB, hipStream_t s) {
+    SD_NOTE_KERNEL("k_upconv_mfma");      // (the row-kernel launchers below overwrite it)
     // the store-bound full-resolution shapes get the row-coalescing kernel (64 -> 32 channels: 77 -> 52 us at 128^3);
     // at 128 -> 64 channels it needs its weights in LDS (plain rows kernel 85 us, k_upconv_mfma 63 us, LDS weights with
     // one tap pair per workgroup and two workgroups per CU 51 us; 48 -> 33 us per tile at 8 tiles per launch)
@@ -1141,6 +1148,7 @@ static int launch_upconv_t(const UpconvParams& p, int NB, hipStream_t s) {
 }
 int launch_upconv(const UpconvParams& p, int act_dtype, int NB, hipStream_t s) {
     if (act_dtype == SD_F16X2) {      // split-fp16 plan: row kernel for the full-resolution shapes, else the generic kernel (3n virtual chunks)
+        SD_NOTE_KERNEL(p.nchunk == 12 || p.nchunk == 24 || p.nchunk == 18 || p.nchunk == 36 ? "k_upconv_rows<split-fp16> / k_upconv_mfma<split-fp16>" : "k_upconv_mfma<split-fp16>");
         const long M = (long)p.D * p.H * p.W;
         if (M >= (1l << 31) || p.gn) return SD_ERR_INVALID;
         static const bool no_rows = getenv("SD_SPLIT_NO_ROWS") != nullptr;      // A/B switch
@@ -1188,6 +1196,7 @@ int launch_upconv(const UpconvParams& p, int act_dtype, int NB, hipStream_t s) {
 }
 
 int launch_pool(const PoolParams& p, int act_dtype, hipStream_t s) {
+    SD_NOTE_KERNEL(act_dtype == SD_F16X2 ? "k_maxpool_split" : "k_maxpool");
     if (act_dtype == SD_F16X2) return launch_pool_split(p, s);
     const long total = (long)p.Do * p.Ho * p.Wo * (p.C / 8);
     if (total >= (1l << 32)) return SD_ERR_INVALID;       // (32-bit element decode in the kernel)
@@ -1198,6 +1207,7 @@ int launch_pool(const PoolParams& p, int act_dtype, hipStream_t s) {
 }
 
 int launch_final(const FinalParams& p, int act_dtype, hipStream_t s) {
+    SD_NOTE_KERNEL(act_dtype == SD_F16X2 ? "k_final_split" : "k_final_mfma / k_final");
     if (act_dtype == SD_F16X2) return launch_final_split(p, s);
     static const bool scalar_final = getenv("SD_FINAL_SCALAR") != nullptr;     // debugging aid: the FMA-chain version
     const size_t lds = (size_t)(p.Cs / SD_CHUNK) * 2048 + (size_t)(2 * p.Cs + 8) * 4;
@@ -1219,6 +1229,7 @@ int launch_gn_finalize(const GnParams& p, hipStream_t s) {
 }
 
 int launch_groupnorm(const GnParams& p, int act_dtype, hipStream_t s) {
+    SD_NOTE_KERNEL(p.skip_stats ? (p.skip_apply ? "k_gn_finalize" : "k_gn_finalize + k_gn_apply") : (p.skip_apply ? "k_gn_stats + k_gn_finalize" : "k_gn_stats + k_gn_finalize + k_gn_apply"));
     if (act_dtype == SD_F16X2) return launch_groupnorm_split(p, s);
     const int ng = p.C / 8;
     // (the statistics scratch is zero here: zeroed at the start of the forward pass and again by every k_gn_finalize)

@@ -65,6 +65,7 @@ class DenseModel:
         self.info = info
         self.n_ops = len(ops)
         self.op_kinds = [int(o.kind) for o in ops]
+        self.has_groupnorm = L.SD_OP_GROUPNORM in self.op_kinds      # (statistics over whole tiles: no output box, no clipped windows)
         self.ops = ops
         self.out_channels = info['out_channels']
         self.act_dtype = act_dtype
@@ -98,10 +99,12 @@ class DenseModel:
             w = self._clip_cache[key] = (int(start.value), int(extent.value))
         return w
 
-    def set_roi(self, roi=None):
-        """Output box of interest ((z0, y0, x0), (z1, y1, x1)) in tile coordinates for the following forward passes, or None for
-        whole tiles (`sd_model_set_roi`): decoder layers then compute only what the box depends on; values inside the box are
-        unchanged, the rest of the output is unspecified."""
+    def _set_roi(self, roi=None):
+        """Output box of interest ((z0, y0, x0), (z1, y1, x1)) in tile coordinates, or None for whole tiles (`sd_model_set_roi`): decoder
+        layers then compute only what the box depends on; values inside the box are unchanged, the rest of the output is unspecified.
+        The box is state of the sd_model handle; the forward methods own it: every call states its box through its `roi` argument
+        (default: whole tiles) and switches the handle when that differs from the last call's.  A DenseModel -- like the handle,
+        include/syconn_dense.h -- serves ONE host thread at a time (dims, buffer offsets and the box are recomputed per forward)."""
         if roi is None:
             L.check(self.lib.sd_model_set_roi(self._h, None, None), 'sd_model_set_roi')
         else:
@@ -141,7 +144,7 @@ class DenseModel:
         assert inp.is_cuda and inp.dim() == 3 and inp.is_contiguous()
         D, H, W = inp.shape
         if self._roi is not None:
-            self.set_roi(None)
+            self._set_roi(None)
         ws = self._workspace((D, H, W), slot)
         odt = torch.uint8 if out_kind == L.SD_OUT_PROBS_U8 else torch.float32
         if out is None:
@@ -158,7 +161,7 @@ class DenseModel:
         assert inp.is_cuda and inp.dim() == 4 and inp.is_contiguous()
         N, D, H, W = inp.shape
         if roi != self._roi:
-            self.set_roi(roi)
+            self._set_roi(roi)
         ws = self._workspace((D, H, W), slot, N)
         odt = torch.uint8 if out_kind == L.SD_OUT_PROBS_U8 else torch.float32
         if out is None:
@@ -175,7 +178,7 @@ class DenseModel:
         assert inp.is_cuda and inp.dim() == 4 and inp.is_contiguous()
         N, D, H, W = inp.shape
         if roi != self._roi:
-            self.set_roi(roi)
+            self._set_roi(roi)
         ws = self._workspace((D, H, W), slot, N)
         if out is None:
             out = torch.empty((N, D, H, W), dtype=torch.uint8, device=self.device)
@@ -213,6 +216,15 @@ class DenseModel:
     def last_launch_count(self) -> int:
         """Plan ops the last forward executed as launches of their own (fused ops run inside another op's launch)."""
         return int(self.lib.sd_debug_last_launch_count(self._h))
+
+    def op_kernels(self):
+        """[(index of the op whose launch computed op i, kernel symbol of that launch)] for the last forward (sd_debug_op_kernel)."""
+        out = []
+        buf = C.create_string_buffer(160)
+        for i in range(self.n_ops):
+            e = int(self.lib.sd_debug_op_kernel(self._h, i, buf, 160))
+            out.append((e, buf.value.decode()))
+        return out
 
     def profile(self, n_slots: int = 1):
         """Bracket every layer launch with HIP events; forward k records into slot k % n_slots (0 = off)."""

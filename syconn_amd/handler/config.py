@@ -38,6 +38,9 @@ DEFAULTS = {
         # model tiles that reach beyond the dataset boundary are predicted on the part of their window the voxels inside the
         # dataset depend on (identical values there; GroupNorm networks always use full windows)
         'clip_boundary_tiles': True,
+        # fp16 range guard: a chunk whose activations overflow fp16 storage is predicted again in the plan with fp32's exponent range
+        # ('f16x2' -> 'f32', 'f16' -> 'bf16'); False = only that chunk, True = the worker stays in the fallback plan for its remaining chunks
+        'sticky_overflow_fallback': False,
     },
     # first consumer of the probability maps (object extraction): the reference's defaults,
     # /root/reference/syconn/handler/config.yml:108-136

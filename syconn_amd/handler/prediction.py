@@ -79,7 +79,8 @@ class Predictor:
                  overlap_shape=None, offset=None, out_shape=None, out_dtype=None, float16=False,
                  apply_softmax=True, transform=None, augmentations=None, strict_shapes=False, apply_argmax=False,
                  argmax_with_threshold=None, verbose=False, report_inf_speed=False, act_dtype=None,
-                 group_norm_groups=None, n_streams=None, defer_guard=False, overflow_fallback=None, clip_tiles=True):
+                 group_norm_groups=None, n_streams=None, defer_guard=False, overflow_fallback=None, clip_tiles=True,
+                 sticky_fallback=True):
         from ..engine import DenseModel, StreamRing
         if transform is not None or augmentations is not None or argmax_with_threshold is not None:
             raise NotImplementedError('transform / augmentations / argmax_with_threshold are not used by SyConn\'s '
@@ -127,6 +128,12 @@ class Predictor:
         # class that has fp32's exponent range (_FALLBACK) and the Predictor stays there; without it ActivationOverflowError is
         # raised.  Default: on for the default storage type, off for an explicitly requested one.
         self._fallback = (act_dtype is None) if overflow_fallback is None else bool(overflow_fallback)
+        # `sticky_fallback`: after an overflow the Predictor STAYS in the fallback plan (default; 'f16x2' -> 'f32' is ~9x slower).  False:
+        # only the prediction that overflowed is repeated there and the next one runs in the configured plan again (what dense_predictor
+        # asks for: one hot chunk must not slow the worker's remaining chunks); `n_fallbacks` counts the repeats either way.
+        self.sticky_fallback = bool(sticky_fallback)
+        self.n_fallbacks = 0
+        self._dm_fallback = None
         # `defer_guard`: do not synchronise after every prediction (pipelined callers); the caller asks `overflowed()` once
         # its stream of predictions is done and repeats them in bf16 itself
         self.defer_guard = bool(defer_guard)
@@ -232,8 +239,9 @@ class Predictor:
             # the box of the window that is scattered (tiled_apply keeps the core of a tile): the decoder computes only what it
             # depends on (`sd_model_set_roi`); tiles of one window that keep the same box share a launch set
             roi = (tuple(int(v) for v in ol + w0 - start), tuple(int(v) for v in ol + w1 - start)) if self.clip_tiles else None
-            if roi is not None and np.prod(np.subtract(roi[1], roi[0])) > 0.8 * np.prod([w[1] for w in win]):
-                roi = None                       # (nearly the whole window is kept: whole-tile kernels -- the fused level-0 decoder -- win)
+            if roi is not None and (self._dm.has_groupnorm or np.prod(np.subtract(roi[1], roi[0])) > 0.8 * np.prod([w[1] for w in win])):
+                roi = None                       # (nearly the whole window is kept: whole-tile kernels -- the fused level-0 decoder -- win;
+                                                 # GroupNorm networks: the library ignores the box, it would only split launch sets)
             by_window.setdefault((tuple(w[1] for w in win), roi), []).append((lo, start, w0, w1))
         if zero:                                 # beyond the dataset `out` reads zero, whatever was skipped or clipped
             out.zero_()
@@ -268,11 +276,23 @@ class Predictor:
         if not self._fallback:
             raise L.ActivationOverflowError(
                 f"fp16 activation overflow (a stored activation exceeded 65504): results invalid; use act_dtype='{nxt}'")
-        log_main.warning(f'syconn_amd.Predictor: fp16 activation overflow detected -- switching this Predictor from '
-                         f'{self.act_dtype} to {nxt} storage and repeating the prediction')
-        self.act_dtype = nxt
-        self._dm = DenseModel(self.model, act_dtype=nxt, device=self.device, group_norm_groups=self._gn_groups)
-        run()
+        self.n_fallbacks += 1
+        if self._dm_fallback is None:
+            self._dm_fallback = DenseModel(self.model, act_dtype=nxt, device=self.device, group_norm_groups=self._gn_groups)
+        if self.sticky_fallback:
+            log_main.warning(f'syconn_amd.Predictor: fp16 activation overflow detected -- switching this Predictor from '
+                             f'{self.act_dtype} to {nxt} storage and repeating the prediction')
+            self.act_dtype = nxt
+            self._dm, self._dm_fallback = self._dm_fallback, None
+            run()
+            return
+        log_main.warning(f'syconn_amd.Predictor: fp16 activation overflow detected -- repeating this prediction in {nxt} storage '
+                         f'(fallback {self.n_fallbacks}); the next one runs in {self.act_dtype} again')
+        main, self._dm = self._dm, self._dm_fallback
+        try:
+            run()
+        finally:
+            self._dm = main
 
     def overflowed(self) -> bool:
         """fp16 range guard of the predictions since the last call (synchronises the current stream); for `defer_guard`."""
@@ -297,10 +317,13 @@ class Predictor:
         tb = [torch.zeros((nb, *shape), dtype=torch.uint8, device=self.device) for _ in range(ring.n)]
         ob = [torch.empty((nb, self.out_channels, *shape), dtype=torch.uint8, device=self.device) for _ in range(ring.n)]
         roi = (tuple(int(v) for v in ol), tuple(int(v) for v in ol + tile)) if (self.clip_tiles and np.any(ol > 0)) else None
+        # (a tile with another box -- boundary tiles keep whole windows, the level-0 decoder is replaced by its layers -- may need a
+        # larger workspace than the interior one: reserve for both forms, inside the caller's tile-halving try block)
         with ring:
-            for k in range(ring.n):
-                with ring.stream(k):
-                    self._dm.forward_batch(tb[k], L.SD_OUT_PROBS_U8, ob[k], slot=ring.slot(k), roi=roi)
+            for r in ([roi, None] if roi is not None else [None]):
+                for k in range(ring.n):
+                    with ring.stream(k):
+                        self._dm.forward_batch(tb[k], L.SD_OUT_PROBS_U8, ob[k], slot=ring.slot(k), roi=r)
         torch.cuda.current_stream(self.device).synchronize()
         self._dm.overflowed()                    # (clears the range-guard flag; zeros cannot overflow)
         del out, tb, ob
@@ -430,6 +453,7 @@ def dense_predictor(args):
     act_dtype = global_params.config['dense_prediction']['act_dtype'] if _wd_set() else 'f16x2'
     skip_outside = bool(global_params.config['dense_prediction'].get('skip_tiles_outside_dataset', True)) if _wd_set() else True
     clip_tiles = bool(global_params.config['dense_prediction'].get('clip_boundary_tiles', True)) if _wd_set() else True
+    sticky = bool(global_params.config['dense_prediction'].get('sticky_overflow_fallback', False)) if _wd_set() else False
     log_main.info(f'dense_predictor: activation storage type {act_dtype} '
                   f'({"reference precision" if act_dtype in ("f16x2", "f32") else "reduced precision, fast plan"})')
     while True:
@@ -438,7 +462,7 @@ def dense_predictor(args):
             out_shape = np.insert(out_shape, 0, n_channel)  # output must equal chunk size
             predictor = Predictor(model_p, strict_shapes=True, tile_shape=tile_shape[::-1], out_shape=out_shape,
                                   overlap_shape=overlap_shape_tiles[::-1], apply_softmax=True, act_dtype=act_dtype,
-                                  overflow_fallback=True, clip_tiles=clip_tiles)
+                                  overflow_fallback=True, clip_tiles=clip_tiles, sticky_fallback=sticky)
             try:
                 predictor.model.ae = False
             except Exception:  # ScriptModules refuse new attributes; elektronn3's flag has no meaning here
@@ -605,6 +629,9 @@ def dense_predictor(args):
     for tkd in target_kd_dict.values():
         tkd.flush()
     spent['write'] += _time.perf_counter() - t0
+    if predictor.n_fallbacks:
+        log_main.warning(f'dense_predictor: {predictor.n_fallbacks} of {len(chunk_ids)} chunk(s) overflowed fp16 storage and were predicted '
+                         f'in the fallback plan ({_FALLBACK.get(act_dtype, "?")})')
     if os.environ.get('SYCONN_AMD_IO_TIMING'):
         log_main.warning('dense_predictor stages over %d chunk(s): read + H2D %.2f s (reader thread), launch %.2f s (main thread), '
                          'D2H + write %.2f s (writer thread)', len(chunk_ids), spent['read'], spent['gpu'], spent['write'])

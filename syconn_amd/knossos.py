@@ -128,6 +128,10 @@ class KnossosDataset:
         return self._knossos_path
 
     @property
+    def available_mags(self):
+        return list(self._mags)
+
+    @property
     def cube_shape(self):
         return tuple(int(c) for c in self._cube_shape)
 
@@ -149,6 +153,8 @@ class KnossosDataset:
         m = re.search(r'magnification\s+(\d+)', txt)
         if m:
             out['mag'] = int(m.group(1))
+        if out['name'] is None or not np.all(out['boundary'] > 0):
+            raise ValueError(f'{path}: not a knossos.conf (needs `experiment name` and a positive `boundary x/y/z`)')
         return out
 
     def initialize_from_knossos_path(self, path: str, **_):
@@ -175,8 +181,52 @@ class KnossosDataset:
         self._initialized = True
         return self
 
-    initialize_from_conf = initialize_from_knossos_path
-    initialize_from_pyknossos_path = initialize_from_knossos_path
+    def initialize_from_pyknossos_path(self, path: str, **_):
+        """`path`: a ``*.pyk.conf`` (the INI file pyKNOSSOS / knossos_utils write next to the ``mag*`` folders; format recalled from
+        knossos_utils, un-vendored: section ``[Dataset]`` with ``_BaseName``, ``_DataScale`` = one x,y,z triple per magnification,
+        ``_Extent`` = mag-1 boundary, optional ``_CubeSize`` / ``_BaseExt``).  Anything that does not carry these keys is refused --
+        a silently empty dataset (boundary 0,0,0) would make every prediction a no-op."""
+        import configparser
+        path = os.path.expanduser(path)
+        cp = configparser.ConfigParser()
+        cp.optionxform = str
+        try:
+            with open(path) as f:
+                cp.read_file(f)
+        except (configparser.Error, OSError) as e:
+            raise ValueError(f'{path}: not a readable pyknossos conf ({e})') from None
+        if 'Dataset' not in cp:
+            raise ValueError(f'{path}: no [Dataset] section -- not a pyknossos conf')
+        ds = cp['Dataset']
+        missing = [k for k in ('_BaseName', '_DataScale', '_Extent') if k not in ds]
+        if missing:
+            raise ValueError(f'{path}: pyknossos conf without {missing}')
+        try:
+            scales = [float(v) for v in ds['_DataScale'].replace(';', ',').split(',') if v.strip()]
+            extent = [int(float(v)) for v in ds['_Extent'].split(',')]
+            cube = [int(v) for v in ds.get('_CubeSize', '128,128,128').split(',')]
+        except ValueError:
+            raise ValueError(f'{path}: malformed _DataScale / _Extent / _CubeSize') from None
+        if len(scales) < 3 or len(scales) % 3 or len(extent) != 3 or len(cube) != 3 or min(extent) <= 0:
+            raise ValueError(f'{path}: _DataScale needs x,y,z per magnification and _Extent a positive x,y,z')
+        if ds.get('_ServerFormat', 'knossos').strip().lower() not in ('knossos', 'pyknossos', ''):
+            raise ValueError(f'{path}: server format {ds["_ServerFormat"]!r} is not a local cube store')
+        root = os.path.dirname(os.path.abspath(path))
+        self._knossos_path = root + '/'
+        self._experiment_name = ds['_BaseName'].strip()
+        self._boundary = np.asarray(extent, dtype=np.int64)
+        self._scale = np.asarray(scales[:3], dtype=np.float64)
+        # magnifications: the scale triples relative to the first one (isotropic powers of two in every SyConn dataset)
+        self._mags = sorted({int(round(scales[3 * i] / scales[0])) for i in range(len(scales) // 3)})
+        self._cube_shape = tuple(cube)
+        self._initialized = True
+        return self
+
+    def initialize_from_conf(self, path: str, **_):
+        """A ``knossos.conf`` or a ``*.pyk.conf`` file (by name, then by content)."""
+        if str(path).endswith('.pyk.conf') or (os.path.isfile(path) and '[Dataset]' in open(path).read(4096)):
+            return self.initialize_from_pyknossos_path(path)
+        return self.initialize_from_knossos_path(path)
 
     def initialize_without_conf(self, path: str, boundary, scale, experiment_name: str, mags=None,
                                 make_mag_folders: bool = True, create_knossos_conf: bool = True,
@@ -203,6 +253,14 @@ class KnossosDataset:
                     for i, ax in enumerate('xyz'):
                         f.write(f'scale {ax} {float(s[i])};\n')
                     f.write(f'magnification {mag};\n')
+        if create_pyk_conf:
+            with open(f'{self._knossos_path}{experiment_name}.pyk.conf', 'w') as f:
+                f.write('[Dataset]\n')
+                f.write(f'_BaseName = {experiment_name}\n_ServerFormat = knossos\n')
+                f.write('_DataScale = ' + ', '.join(','.join(str(float(v)) for v in self._scale * mag) for mag in self._mags) + '\n')
+                f.write('_Extent = ' + ','.join(str(int(v)) for v in self._boundary) + '\n')
+                f.write('_CubeSize = ' + ','.join(str(int(c)) for c in self._cube_shape) + '\n')
+                f.write('_BaseExt = .raw\n_FileType = 2\n_Origin = 0,0,0\n')
         self._initialized = True
         return self
 
@@ -246,7 +304,9 @@ class KnossosDataset:
         if out is None:
             out = np.zeros(tuple(size[::-1]), dtype=dtype)   # z,y,x
         else:                                             # caller-owned (e.g. page-locked) buffer, reused chunk after chunk
-            assert tuple(out.shape) == tuple(size[::-1]) and out.dtype == np.dtype(dtype) and out.flags.c_contiguous
+            if tuple(out.shape) != tuple(size[::-1]) or out.dtype != np.dtype(dtype) or not out.flags.c_contiguous:
+                raise ValueError(f'load(out=...): need a C-contiguous {np.dtype(dtype)} array of shape {tuple(int(v) for v in size[::-1])}, got '
+                                 f'{out.dtype} {tuple(out.shape)}')
             out.fill(0)
         cs = np.asarray(self._cube_shape, dtype=np.int64)
         bnd = self._boundary // mag

@@ -5,6 +5,7 @@ import sys
 import zipfile
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -75,3 +76,29 @@ def test_mag_pyramid_levels_written_one_by_one_equal_one_call(tmp_path):
         assert x.shape == tuple(s // mag for s in size[::-1]) and np.array_equal(x, y)
         assert np.array_equal(x[:-(-90 // mag), :-(-130 // mag), 128 // mag:128 // mag - (-170 // mag)],
                               data[::mag, ::mag, ::mag])
+
+
+def test_pyknossos_conf_is_parsed_or_refused(tmp_path):
+    """kd_factory prefers a *.pyk.conf (basics.py:58-60): it must open the dataset it describes, or raise -- never an empty dataset."""
+    from syconn_amd.handler.basics import kd_factory
+    from syconn_amd.knossos import KnossosDataset
+    root = tmp_path / 'kd'
+    kd = KnossosDataset()
+    kd.initialize_without_conf(str(root), boundary=(200, 150, 70), scale=(10., 10., 25.), experiment_name='pyk', mags=[1, 2, 4],
+                               create_pyk_conf=True, create_knossos_conf=False)
+    raw = np.random.default_rng(0).integers(0, 256, (70, 150, 200), dtype=np.uint8)
+    kd.save_raw(offset=(0, 0, 0), mags=[1, 2, 4], data=raw, data_mag=1, fast_resampling=True)
+    k2 = kd_factory(str(root))
+    assert tuple(k2.boundary) == (200, 150, 70) and k2.experiment_name == 'pyk' and list(k2.available_mags) == [1, 2, 4]
+    assert np.allclose(k2.scale, (10., 10., 25.))
+    assert np.array_equal(k2.load_raw(size=(200, 150, 70), offset=(0, 0, 0), mag=1), raw)
+    assert np.array_equal(k2.load_raw(size=(50, 40, 10), offset=(8, 4, 4), mag=2), raw[::2, ::2, ::2][2:7, 2:22, 4:29])      # (size / offset in mag-1 voxels)
+    bad = tmp_path / 'bad.pyk.conf'
+    bad.write_text('[Dataset]\n_BaseName = x\n')
+    with pytest.raises(ValueError):
+        KnossosDataset().initialize_from_pyknossos_path(str(bad))
+    bad.write_text('experiment name "x";\n')
+    with pytest.raises(ValueError):
+        KnossosDataset().initialize_from_conf(str(bad))
+    with pytest.raises(ValueError):
+        k2.load_raw(size=(8, 8, 8), offset=(0, 0, 0), mag=1, out=np.empty((8, 8, 9), np.uint8))

@@ -13,7 +13,8 @@ export TMPDIR=/tmp
 cd /tmp
 python3 $REPO/bench.py --steps 20 --warmup 3 "$@" > $OUT/bench.json 2> $OUT/bench.err
 B="$REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline $*"
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python3 $B > $OUT/trace.log 2>&1
+# (the kernel trace runs long enough -- > 100 launches of the dominant kernel -- for its average to agree with the HIP events of the bench line)
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python3 $REPO/bench.py --steps 12 --warmup 2 --no-cpu-baseline "$@" > $OUT/trace_bench.json 2> $OUT/trace.log
 python3 $REPO/tools/rocprof_summary.py $(ls $OUT/trace/*/*.db $OUT/trace/*.db 2>/dev/null | head -1) $OUT/kernel_stats.txt > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/sq1 -o s -- python3 $B > $OUT/sq1.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS SQ_INSTS_VALU --output-format csv -d $OUT/sq2 -o s -- python3 $B > $OUT/sq2.log 2>&1
@@ -21,7 +22,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w -- python3 $B > $OUT/write.log 2>&1
 F=$(ls $OUT/fetch/*/*counter_collection.csv $OUT/fetch/*counter_collection.csv 2>/dev/null | head -1)
 W=$(ls $OUT/write/*/*counter_collection.csv $OUT/write/*counter_collection.csv 2>/dev/null | head -1)
-python3 $REPO/tools/pmc_traffic.py $F $W 8 $OUT/pmc_hbm_traffic.json > $OUT/pmc_hbm_traffic.txt 2>&1
+python3 $REPO/tools/pmc_traffic.py $F $W 8 $OUT/pmc_hbm_traffic.json $OUT/traffic.json > $OUT/pmc_hbm_traffic.txt 2>&1
 for s in sq1 sq2; do
   C=$(ls $OUT/$s/*/*counter_collection.csv $OUT/$s/*counter_collection.csv 2>/dev/null | head -1)
   python3 $REPO/tools/pmc_sq_summary.py $C > $OUT/pmc_$s.txt 2>&1
