@@ -265,9 +265,11 @@ def main():
             reps += 1
         torch.cuda.synchronize(dev)
         return (time.perf_counter() - t1) / reps / n_tiles * 1e3      # ms per tile
-    single_tile_ms = resident_rate(dm, 1)
+    # (not in the rocprofv3 passes, which run with --no-cpu-baseline: their per-kernel averages must be those of the timed launch sets)
+    extras = not args.no_cpu_baseline
+    single_tile_ms = resident_rate(dm, 1) if extras else None
     ref_prec = None
-    if world == 1 and args.act != 'f16x2':
+    if extras and world == 1 and args.act != 'f16x2':
         m2 = DenseModel(sd, act_dtype='f16x2', device=dev)
         ref_prec = resident_rate(m2, T)
         del m2
@@ -345,7 +347,8 @@ def main():
                            'tiles_per_gpu_per_step': T, 'tile': [S, S, S], 'parallelism': f'tile-sharded x{world}',
                            'hip_streams_per_gpu': 3,
                            'collective': 'RCCL gather of uint8 labels to rank 0, D2H there' if world > 1 else 'none',
-                           'single_tile_ms': single_tile_ms, 'single_tile_mvox_per_s': S ** 3 / single_tile_ms / 1e3,
+                           'single_tile_ms': single_tile_ms,
+                           'single_tile_mvox_per_s': None if single_tile_ms is None else S ** 3 / single_tile_ms / 1e3,
                            'reference_precision_f16x2_mvox_per_s': None if ref_prec is None else S ** 3 / ref_prec / 1e3,
                            'reference_precision_f16x2_ms_per_tile': ref_prec,
                            'device_resident_value': value_res,
@@ -430,13 +433,16 @@ def volume_main(args):
             r = pred.predict_proba_u8_device(ch, halo_included=in_halo, valid_box=vb)[1:2]
         return r if in_halo else _crop(r, halo)
     vol = torch.from_numpy(synthetic_volume(vol_shape, seed=3)).pin_memory() if rank == 0 else None
+    # (the result arrives in ONE page-locked host tensor, reused by every step: rank 0's part of a step is two contiguous PCIe streams,
+    # volume in and result out -- chunk + halo boxes are cut and results placed on its GPU, parallel.predict_volume_distributed)
+    res_host = torch.empty((1, *vol_shape), dtype=torch.uint8).pin_memory() if rank == 0 else None
     steps, warm = (args.steps if args.steps != 20 else 2), min(args.warmup, 1)
     for _ in range(warm):
-        par.predict_volume_distributed(vol, vol_shape, chunk, halo, predict_fn, n_out=1, device=dev)
+        par.predict_volume_distributed(vol, vol_shape, chunk, halo, predict_fn, n_out=1, device=dev, out=res_host)
     out = [None]
 
     def step():
-        out[0] = par.predict_volume_distributed(vol, vol_shape, chunk, halo, predict_fn, n_out=1, device=dev)
+        out[0] = par.predict_volume_distributed(vol, vol_shape, chunk, halo, predict_fn, n_out=1, device=dev, out=res_host)
     elapsed = timed(step, lambda: None, steps, par, dev)
     if pred.overflowed():
         raise SystemExit('fp16 activation overflow during the volume workload: rerun with bf16')
@@ -453,7 +459,9 @@ def volume_main(args):
                            'output_distinct_values': int(torch.unique(out[0][0, ::4, ::8, ::8]).numel()),      # (a strided sample)
                            'labels_sha256': (__import__('hashlib').sha256(out[0].numpy().tobytes()).hexdigest()
                                              if args.labels_sha else None),
-                           'collective': 'RCCL scatter of uint8 chunks / gather of uint8 results, rank 0 host memory' if world > 1 else 'none'}}
+                           'host_box_copies': par.HOST_BOX_COPIES,      # (0: rank 0's CPU cut and stitched nothing)
+                           'collective': 'RCCL scatter of uint8 chunks / gather of uint8 results; volume and result resident in rank 0\'s HBM, '
+                                         'one contiguous PCIe stream each way' if world > 1 else 'none'}}
         print(json.dumps(line))
     if world > 1:
         par.barrier()

@@ -234,6 +234,20 @@ int sd_segstats_compact_pairs(const void* pair_table, size_t cap_pair, const voi
                               size_t cap_obj, uint64_t* sub_ids_dev, uint64_t* cell_ids_dev, uint64_t* counts_dev,
                               size_t max_out, uint64_t* count_dev, void* stream);
 
+/* ---- globally unique objects across chunks (the steps behind the per-chunk first stage) ----------------
+ * make_unique_labels (/root/reference/syconn/extraction/object_extraction_steps.py:369-443: `matrix[matrix > 0] += offset` on the
+ * chunk's component labels widened to uint64, offset = number of components in all earlier chunks,
+ * object_extraction_wrapper.py:300-312): labels_dev int32[n] -> out_dev uint64[n]. */
+int sd_labels_make_unique(const int32_t* labels_dev, size_t n, uint64_t offset, uint64_t* out_dev, void* stream);
+/* Cut the box [x0, x0+nx) x [y0, y0+ny) x [z0, z0+nz) out of an (X,Y,Z) uint64 label volume (z fastest) into a contiguous
+ * (nx,ny,nz) array, optionally through a look-up table: dst = lut[src] (lut_dev NULL: dst = src).  Serves
+ *   * apply_merge_list (object_extraction_steps.py:717-731): crop the chunk's overlap margin and map every id through the
+ *     merge list (`id_changer[this_cc]`), lut_len = max_label + 1;
+ *   * the face slabs make_stitch_list compares (:560-575, cut_array_in_one_dim), whose co-occurring id pairs sd_segstats_scan counts.
+ * status_dev (optional int32): set to 1 when an id >= lut_len was met (it passes through unmapped). */
+int sd_labels_box_lut(const uint64_t* src_dev, int X, int Y, int Z, int x0, int y0, int z0, int nx, int ny, int nz,
+                      const uint64_t* lut_dev, size_t lut_len, uint64_t* dst_dev, int32_t* status_dev, void* stream);
+
 /* ---- probability map -> object segmentation, first stage ---------------------------------
  * Non-watershed branches of _object_segmentation_thread (/root/reference/syconn/extraction/object_extraction_steps.py:
  * 316-317 threshold, 354-358 morphology + scipy.ndimage.label) with the morphology semantics of

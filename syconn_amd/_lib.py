@@ -23,7 +23,7 @@ EXPORTS = ['sd_init', 'sd_device_count', 'sd_model_create', 'sd_model_destroy', 
            'sd_objtable_bytes', 'sd_pairtable_bytes', 'sd_segstats_scan', 'sd_segstats_compact_objects',
            'sd_segstats_compact_pairs', 'sd_objseg_workspace_bytes', 'sd_object_segmentation', 'sd_objseg_watershed_workspace_bytes',
            'sd_object_segmentation_watershed', 'sd_marker_flood', 'sd_host_box_copy', 'sd_host_zero', 'sd_plan_clip_window',
-           'sd_gauss_workspace_bytes', 'sd_gaussian_threshold', 'sd_model_set_roi']
+           'sd_gauss_workspace_bytes', 'sd_gaussian_threshold', 'sd_model_set_roi', 'sd_labels_make_unique', 'sd_labels_box_lut']
 
 
 class OpDesc(C.Structure):
@@ -105,6 +105,8 @@ def load():
     lib.sd_gauss_workspace_bytes.argtypes = [i32, i32, i32]; lib.sd_gauss_workspace_bytes.restype = sz
     lib.sd_gaussian_threshold.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_double), C.c_double, vp, vp, vp, sz, vp]
     lib.sd_gaussian_threshold.restype = i32
+    lib.sd_labels_make_unique.argtypes = [vp, sz, C.c_uint64, vp, vp]; lib.sd_labels_make_unique.restype = i32
+    lib.sd_labels_box_lut.argtypes = [vp] + [i32] * 9 + [vp, sz, vp, vp, vp]; lib.sd_labels_box_lut.restype = i32
     i64 = C.c_int64
     lib.sd_host_box_copy.argtypes = [vp, i64, i64, vp, i64, i64, i64, i64, i64, i32]; lib.sd_host_box_copy.restype = i32
     lib.sd_host_zero.argtypes = [vp, i64, i32]; lib.sd_host_zero.restype = i32

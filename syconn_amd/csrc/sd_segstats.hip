@@ -322,6 +322,32 @@ __global__ __launch_bounds__(256) void k_pair_compact(const u64* pkeys, const u6
 }
 
 inline bool pow2(u64 v) { return v && !(v & (v - 1)); }
+// ---- globally unique object ids across chunks (object_extraction_steps.py:369-443 make_unique_labels, :658-736 apply_merge_list)
+// per-chunk int32 component labels -> uint64 ids shifted by the chunk's offset (background stays 0)
+__global__ __launch_bounds__(256) void k_labels_offset(const int32_t* __restrict__ lab, u64 n, u64 offset, u64* __restrict__ out) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
+        const int32_t v = lab[i];
+        out[i] = v > 0 ? (u64)v + offset : 0ull;
+    }
+}
+// dst (nx,ny,nz contiguous, z fastest) = lut[src[x0 + i, y0 + j, z0 + k]] (lut == nullptr: the ids themselves); ids beyond the table
+// raise the flag and pass through
+__global__ __launch_bounds__(256) void k_labels_box_lut(const u64* __restrict__ src, int Y, int Z, int x0, int y0, int z0, int nx, int ny,
+                                                        int nz, const u64* __restrict__ lut, u64 lut_len, u64* __restrict__ dst,
+                                                        int32_t* status) {
+    const u64 n = (u64)nx * ny * nz;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
+        const unsigned k = (unsigned)(i % (unsigned)nz), ij = (unsigned)(i / (unsigned)nz);
+        const unsigned j = ij % (unsigned)ny, ii = ij / (unsigned)ny;
+        u64 v = src[((size_t)(x0 + ii) * Y + (y0 + j)) * Z + (z0 + k)];
+        if (lut) {
+            if (v < lut_len) v = lut[v];
+            else if (status) *status = 1;
+        }
+        dst[i] = v;
+    }
+}
+
 inline int grid_for(u64 n, int cap = 4096) { u64 g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > (u64)cap ? (u64)cap : g)); }
 
 }  // namespace
@@ -374,6 +400,29 @@ int sd_segstats_scan(const void* cell_dev, const void* const* sub_devs, int n_su
     if (dtype == SD_U64) hipLaunchKernelGGL(k_segstats_scan<uint64_t>, dim3(grid), dim3(256), 0, s, p, lcap);
     else hipLaunchKernelGGL(k_segstats_scan<uint32_t>, dim3(grid), dim3(256), 0, s, p, lcap);
     return hipGetLastError() == hipSuccess ? SD_OK : sd_fail_msg(SD_ERR_HIP, "sd_segstats_scan: launch failed");
+}
+
+int sd_labels_make_unique(const int32_t* labels_dev, size_t n, uint64_t offset, uint64_t* out_dev, void* stream) {
+    if (!labels_dev || !out_dev) return sd_fail_msg(SD_ERR_INVALID, "sd_labels_make_unique: null argument");
+    if (n == 0) return SD_OK;
+    hipLaunchKernelGGL(k_labels_offset, dim3(grid_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), labels_dev, (u64)n,
+                       (u64)offset, reinterpret_cast<u64*>(out_dev));
+    return hipGetLastError() == hipSuccess ? SD_OK : sd_fail_msg(SD_ERR_HIP, "sd_labels_make_unique: launch failed");
+}
+
+int sd_labels_box_lut(const uint64_t* src_dev, int X, int Y, int Z, int x0, int y0, int z0, int nx, int ny, int nz,
+                      const uint64_t* lut_dev, size_t lut_len, uint64_t* dst_dev, int32_t* status_dev, void* stream) {
+    if (!src_dev || !dst_dev || X <= 0 || Y <= 0 || Z <= 0 || x0 < 0 || y0 < 0 || z0 < 0 || nx < 0 || ny < 0 || nz < 0 ||
+        (long)x0 + nx > X || (long)y0 + ny > Y || (long)z0 + nz > Z)
+        return sd_fail_msg(SD_ERR_INVALID, "sd_labels_box_lut: box outside the volume");
+    const u64 n = (u64)nx * ny * nz;
+    if (n == 0) return SD_OK;
+    if (n >= (1ull << 32)) return sd_fail_msg(SD_ERR_INVALID, "sd_labels_box_lut: box must have < 2^32 voxels");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (status_dev && hipMemsetAsync(status_dev, 0, sizeof(int32_t), s) != hipSuccess) return sd_fail_msg(SD_ERR_HIP, "memset failed");
+    hipLaunchKernelGGL(k_labels_box_lut, dim3(grid_for(n)), dim3(256), 0, s, reinterpret_cast<const u64*>(src_dev), Y, Z, x0, y0, z0, nx, ny,
+                       nz, reinterpret_cast<const u64*>(lut_dev), (u64)lut_len, reinterpret_cast<u64*>(dst_dev), status_dev);
+    return hipGetLastError() == hipSuccess ? SD_OK : sd_fail_msg(SD_ERR_HIP, "sd_labels_box_lut: launch failed");
 }
 
 int sd_segstats_compact_objects(const void* table, size_t cap_obj, uint64_t* ids_dev, uint64_t* first_dev, uint64_t* size_dev,

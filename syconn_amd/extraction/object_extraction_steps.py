@@ -203,7 +203,7 @@ def auto_overlap(morph_ops: dict, scaling, sigmas=None) -> np.ndarray:
 def object_segmentation(cset, hdf5names: Sequence[str], prob_kd_path_dict: dict, thresholds: Sequence[float],
                         overlap="auto", chunk_list: Optional[Sequence[int]] = None, morph_ops: Optional[dict] = None,
                         min_seed_vx: Optional[dict] = None, scaling=None, with_properties: bool = True, device=None,
-                        sigmas=None):
+                        sigmas=None, keep_labels: bool = False, labels_on_device_bytes: int = 128 << 30):
     """``object_segmentation`` + ``_object_segmentation_thread`` (object_extraction_steps.py:42-201, 204-366) for the branch
     SyConn's pipeline takes after the dense prediction (object_extraction_wrapper.py:58-150: probability maps in
     KnossosDatasets ``prob_kd_path_dict``, ``load_raw``): per chunk of `cset` load size + 2 * overlap around the chunk from every
@@ -217,7 +217,10 @@ def object_segmentation(cset, hdf5names: Sequence[str], prob_kd_path_dict: dict,
     them back for the statistics.  `sigmas` (object_extraction_steps.py:77-81, 135-138, 296-298: a vigra ``gaussianSmoothing`` of the
     probability map before the threshold, one sigma or (x,y,z) triple per name; SyConn's pipeline passes none): maps with a
     non-zero sigma are smoothed and thresholded on the device (`gaussian_threshold`; vigra's algorithm restated, parity
-    unpinned).  Not reproduced: the membrane hooks, `swapdata`, overlay-cube input."""
+    unpinned).  `keep_labels`: a fourth result ``labels[(chunk.number, hdf5_name)]`` = the int32 (x,y,z) label volume incl. the
+    overlap margin (what the reference writes to ``*_connected_components.h5``), a device tensor while all of them fit in
+    `labels_on_device_bytes`, else a host tensor -- the input of the stitching steps (``from_probabilities_to_kd``).
+    Not reproduced: the membrane hooks, `swapdata`, overlay-cube input."""
     from .. import global_params
     from ..knossos import KnossosDataset
     from .find_object_properties import find_object_properties
@@ -240,7 +243,7 @@ def object_segmentation(cset, hdf5names: Sequence[str], prob_kd_path_dict: dict,
         kds[k] = KnossosDataset()
         kds[k].initialize_from_knossos_path(path)
     chunk_ids = list(cset.chunk_dict.keys()) if chunk_list is None else list(chunk_list)
-    results, props = [], {}
+    results, props, kept, kept_bytes = [], {}, {}, 0
     for nb in chunk_ids:
         chunk = cset.chunk_dict[nb]
         box_offset = np.array(chunk.coordinates) - overlap
@@ -258,4 +261,145 @@ def object_segmentation(cset, hdf5names: Sequence[str], prob_kd_path_dict: dict,
             if with_properties:
                 props[(chunk.number, name)] = find_object_properties(labels)
             results.append([chunk.number, name, int(max_label.item())])
+            if keep_labels:
+                kept_bytes += labels.numel() * 4
+                kept[(chunk.number, name)] = labels if kept_bytes <= labels_on_device_bytes else labels.cpu()
+    if keep_labels:
+        return results, [overlap, stitch_overlap], props, kept
     return results, [overlap, stitch_overlap], props
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Globally unique objects: the steps of ``from_probabilities_to_kd`` behind the per-chunk first stage
+# (/root/reference/syconn/extraction/object_extraction_wrapper.py:296-352; object_extraction_steps.py:369-736).  The reference keeps
+# every intermediate in one h5 file per chunk and step; here a chunk's label volume stays a device tensor from the connected
+# components to the stitched uint64 volume.  Pinned by tests/golden/g11_stitch.npz (the reference's own thread functions, executed
+# with in-memory stand-ins for their h5 / ChunkDataset I/O).
+def label_offsets(n_components: Sequence[int]) -> Tuple[np.ndarray, int]:
+    """object_extraction_wrapper.py:300-312: ``max_nb_dict`` -- what is added to the labels of chunk i -- is the number of components
+    of all chunks before it (in chunk-list order); ``max_labels`` = the total.  Returns (offsets int64[n], max_label)."""
+    nb = np.asarray(n_components, dtype=np.int64)
+    off = np.zeros(len(nb), dtype=np.int64)
+    if len(nb) > 1:
+        off[1:] = np.cumsum(nb[:-1])
+    return off, int(off[-1] + nb[-1]) if len(nb) else 0
+
+
+def make_unique_labels(labels: torch.Tensor, offset: int) -> torch.Tensor:
+    """``_make_unique_labels_thread`` (object_extraction_steps.py:425-443) for one chunk: int32 (x,y,z) component labels on the
+    device -> uint64 (stored as int64 bits) with `offset` added to every non-zero label (`sd_labels_make_unique`)."""
+    lib = L.load()
+    if not (labels.is_cuda and labels.dtype == torch.int32 and labels.is_contiguous()):
+        raise TypeError('expected a contiguous int32 device tensor (the labels of object_segmentation_first_stage(return_device=True))')
+    out = torch.empty(labels.shape, dtype=torch.int64, device=labels.device)
+    with torch.cuda.device(labels.device):
+        L.check(lib.sd_labels_make_unique(labels.data_ptr(), labels.numel(), int(offset), out.data_ptr(),
+                                          torch.cuda.current_stream(labels.device).cuda_stream), 'sd_labels_make_unique')
+    return out
+
+
+def labels_box(vol: torch.Tensor, lo, size, lut: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Contiguous copy of the box ``vol[lo : lo + size]`` of a uint64 (int64 bits) (x,y,z) device volume, optionally mapped through a
+    look-up table (`sd_labels_box_lut`); an id beyond the table raises."""
+    lib = L.load()
+    if not (vol.is_cuda and vol.dtype == torch.int64 and vol.is_contiguous() and vol.dim() == 3):
+        raise TypeError('expected a contiguous 3D int64 / uint64 device tensor')
+    lo, size = [int(v) for v in lo], [int(v) for v in size]
+    out = torch.empty(size, dtype=torch.int64, device=vol.device)
+    status = torch.zeros(1, dtype=torch.int32, device=vol.device) if lut is not None else None
+    with torch.cuda.device(vol.device):
+        L.check(lib.sd_labels_box_lut(vol.data_ptr(), *[int(v) for v in vol.shape], *lo, *size,
+                                      lut.data_ptr() if lut is not None else None, lut.numel() if lut is not None else 0,
+                                      out.data_ptr(), status.data_ptr() if status is not None else None,
+                                      torch.cuda.current_stream(vol.device).cuda_stream), 'sd_labels_box_lut')
+    if status is not None and int(status.item()):
+        raise ValueError('apply_merge_list: a label exceeds the merge list (max_label too small)')
+    return out
+
+
+def stitch_pairs(chunk_a: torch.Tensor, chunk_b: torch.Tensor, dim: int, overlap, stitch_overlap) -> set:
+    """The inner part of ``_make_stitch_list_thread`` (object_extraction_steps.py:555-611, ``overlap_thresh == 0``) for one chunk
+    and its neighbour in +`dim`: both are unique-label volumes of size chunk + 2 * overlap; the slab of `stitch_overlap` voxels
+    on either side of the common chunk face is ``a[-overlap - stitch : -overlap + stitch]`` in the first and ``b[overlap - stitch :
+    overlap + stitch]`` in the second (``cut_array_in_one_dim``, proc/general.py:45-82) -- the same voxels, labelled twice.
+    Returns the set of ``tuple(sorted((id_a, id_b)))`` over the voxels where both are non-zero.  The co-occurrence table is the
+    device native behind ``map_subcell_C`` (`sd_segstats_scan`: one pass over the two slabs)."""
+    from .find_object_properties import segstats
+    ol, so = int(overlap[dim]), int(stitch_overlap[dim])
+    if so > ol or so < 1:
+        raise ValueError('stitch overlap has to be >= 1 and <= the chunk overlap')
+    na, nb = int(chunk_a.shape[dim]), int(chunk_b.shape[dim])
+    lo_a, lo_b, size = [0, 0, 0], [0, 0, 0], [int(v) for v in chunk_a.shape]
+    if any(int(chunk_a.shape[d]) != int(chunk_b.shape[d]) for d in range(3) if d != dim):
+        raise ValueError('neighbouring chunks differ in the face extents')
+    lo_a[dim], lo_b[dim], size[dim] = na - ol - so, ol - so, 2 * so
+    if lo_a[dim] < 0 or lo_b[dim] + 2 * so > nb:
+        raise ValueError('chunk smaller than its overlap')
+    sa, sb = labels_box(chunk_a, lo_a, size), labels_box(chunk_b, lo_b, size)
+    r = segstats(sa, [sb], want_props=False)
+    ids_b, ids_a, _ = r.pairs[0]
+    return {(int(min(x, y)), int(max(x, y))) for x, y in zip(ids_a.tolist(), ids_b.tolist())}
+
+
+def make_stitch_list(chunks: dict, grid_pos: dict, overlap, stitch_overlap) -> list:
+    """``make_stitch_list`` / ``_make_stitch_list_thread`` (object_extraction_steps.py:446-617) for one label name: `chunks` maps a
+    chunk number to its unique-label device volume, `grid_pos` a chunk number to its (ix, iy, iz) position in the chunk grid; every
+    chunk is compared with its neighbours in +x, +y, +z (the upper half of the 6-neighbourhood, :548-554).  Returns the list of
+    id pairs that belong to one object."""
+    by_pos = {tuple(int(v) for v in p): n for n, p in grid_pos.items() if n in chunks}
+    pairs = set()
+    for n, vol in chunks.items():
+        p = tuple(int(v) for v in grid_pos[n])
+        for dim in range(3):
+            q = list(p)
+            q[dim] += 1
+            m = by_pos.get(tuple(q))
+            if m is not None:
+                pairs |= stitch_pairs(vol, chunks[m], dim, overlap, stitch_overlap)
+    return sorted(pairs)
+
+
+def make_merge_list(stitch_list: Sequence, max_label: int) -> Tuple[dict, np.ndarray]:
+    """``make_merge_list`` (object_extraction_steps.py:620-655) for one label name: ids connected through `stitch_list` pairs collapse
+    to ONE id of their component.  The reference takes ``list(component)[0]`` of networkx's set -- an arbitrary member; here it is the
+    smallest id (same partition, canonical representative).  Returns (merge_dict: id -> representative for every id that occurs in
+    a pair, merge_list: uint64[max_label + 1] with ``merge_list[id]`` = representative, identity elsewhere).  Union-find on the
+    host: the list has one entry per pair of touching objects, not per voxel."""
+    ml = np.arange(int(max_label) + 1, dtype=np.uint64)
+    if len(stitch_list) == 0:
+        return {}, ml
+    pr = np.asarray(stitch_list, dtype=np.int64).reshape(-1, 2)
+    if pr.min() < 1 or pr.max() > max_label:
+        raise ValueError('stitch list holds ids outside 1..max_label')
+    parent = np.arange(int(max_label) + 1, dtype=np.int64)
+
+    def find(a):
+        r = a
+        while parent[r] != r:
+            r = parent[r]
+        while parent[a] != r:
+            parent[a], a = r, parent[a]
+        return r
+    for a, b in pr.tolist():
+        ra, rb = find(a), find(b)
+        if ra != rb:
+            if ra < rb:
+                parent[rb] = ra
+            else:
+                parent[ra] = rb
+    ids = np.unique(pr)
+    merge_dict = {int(i): int(find(int(i))) for i in ids}
+    for i, r in merge_dict.items():
+        ml[i] = r
+    return merge_dict, ml
+
+
+def apply_merge_list(chunk_vol: torch.Tensor, chunk_size, merge_list) -> torch.Tensor:
+    """``_apply_merge_list_thread`` (object_extraction_steps.py:717-731) for one chunk: crop the overlap margin
+    (``offset = (shape - chunk.size) // 2``) and map every id through the merge list; uint64 (int64 bits) device tensor of
+    ``chunk_size``."""
+    shape = np.asarray(chunk_vol.shape, dtype=np.int64)
+    size = np.asarray(chunk_size, dtype=np.int64)
+    off = (shape - size) // 2
+    lut = merge_list if isinstance(merge_list, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(merge_list).view(np.int64)).to(chunk_vol.device)
+    return labels_box(chunk_vol, off, shape - 2 * off, lut)

@@ -1,0 +1,147 @@
+"""Probability maps -> globally unique object segmentation in KnossosDatasets
+(/root/reference/syconn/extraction/object_extraction_wrapper.py:23-377: ``calculate_chunk_numbers_for_box``,
+``from_probabilities_to_kd``).  The reference runs six batch-job stages that hand h5 files of every
+chunk to each other (connected components -> max labels -> unique labels -> stitch list -> merge list -> apply merge list ->
+export); here a chunk's label volume is produced on the GPU and stays a device tensor until its stitched uint64 volume is written
+into the target KnossosDataset's overlay cubes.  Per-chunk arithmetic: ``object_extraction_steps`` (HIP library, no CPU fallback).
+Not reproduced: overlay-cube input (`load_from_kd_overlaycubes`), `transform_func`, the membrane hooks, `swapdata`,
+``overlap_thresh > 0`` (a cKDTree test on whole objects; the default is 0)."""
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import object_extraction_steps as oes
+from ..handler.basics import kd_factory
+
+
+def calculate_chunk_numbers_for_box(cset, offset, size):
+    """object_extraction_wrapper.py:23-55: chunk ids (partly) inside the box, in x-outermost order, and the reverse mapping.  (The
+    reference grows `offset` / `size` in place to chunk multiples; copies are used here.)"""
+    offset, size = np.array(offset, dtype=np.int64), np.array(size, dtype=np.int64)
+    cs = np.asarray(cset.chunk_size, dtype=np.int64)
+    for dim in range(3):
+        offset_overlap = offset[dim] % cs[dim]
+        offset[dim] -= offset_overlap
+        size[dim] += offset_overlap
+        size[dim] += (cs[dim] - size[dim]) % cs[dim]
+    coord_dict = {tuple(int(v) for v in c.coordinates): n for n, c in cset.chunk_dict.items()}
+    chunk_list, translator = [], {}
+    for x in range(int(offset[0]), int(offset[0] + size[0]), int(cs[0])):
+        for y in range(int(offset[1]), int(offset[1] + size[1]), int(cs[1])):
+            for z in range(int(offset[2]), int(offset[2] + size[2]), int(cs[2])):
+                chunk_list.append(coord_dict[(x, y, z)])
+                translator[chunk_list[-1]] = len(chunk_list) - 1
+    return chunk_list, translator
+
+
+def from_probabilities_to_kd(target_kd_paths: Optional[Dict[str, str]], cset, filename: str, hdf5names: List[str],
+                             prob_kd_path_dict: Optional[Dict[str, str]] = None, load_from_kd_overlaycubes: bool = False,
+                             transf_func_kd_overlay=None, log=None, overlap="auto", sigmas: Optional[list] = None,
+                             thresholds: Optional[list] = None, debug: bool = False, swapdata: bool = False,
+                             offset: Optional[np.ndarray] = None, size: Optional[np.ndarray] = None, suffix: str = "",
+                             transform_func=None, func_kwargs: Optional[dict] = None, n_cores: Optional[int] = None,
+                             overlap_thresh: Optional[int] = 0, stitch_overlap=None, membrane_filename: str = None,
+                             membrane_kd_path: str = None, hdf5_name_membrane: str = None, n_chunk_jobs: int = None,
+                             device=None, labels_on_device_bytes: int = 128 << 30, morph_ops: Optional[dict] = None,
+                             min_seed_vx: Optional[dict] = None, scaling=None):
+    """The reference's signature (object_extraction_wrapper.py:153-173).  `target_kd_paths`: name -> already initialised target
+    KnossosDataset (``initialize_without_conf``); `cset`: the chunk grid; `prob_kd_path_dict`: name -> KnossosDataset with the
+    uint8 probability map; `thresholds` one per name (fractions <= 1 are scaled by 255, :251-253).  Returns a dict with the
+    intermediate results the reference pickles next to the ChunkDataset: ``cc_info_list``, ``overlap_info``, ``max_labels``,
+    ``stitch_list``, ``merge_dict`` / ``merge_list_dict`` (per name).
+
+    Extensions: `morph_ops` / `min_seed_vx` / `scaling` override ``config['cell_objects']['extract_morph_op']``, ``['min_seed_vx']`` and
+    ``config['scaling']`` (the reference reads them from the working directory's config inside its worker).
+    `labels_on_device_bytes`: the int32 component labels of all chunks are kept in HBM up to this budget (a 2048 x 2048 x 512
+    dataset in 512^3 chunks with three organelles: 29 GB of 288), beyond it in host memory."""
+    unsupported = {'load_from_kd_overlaycubes': load_from_kd_overlaycubes, 'transf_func_kd_overlay': transf_func_kd_overlay,
+                   'transform_func': transform_func, 'membrane_filename': membrane_filename, 'membrane_kd_path': membrane_kd_path,
+                   'swapdata': swapdata}
+    for k, v in unsupported.items():
+        if v:
+            raise NotImplementedError(f'from_probabilities_to_kd: `{k}` is not part of the dense-prediction consumers built here')
+    if overlap_thresh:
+        raise NotImplementedError('from_probabilities_to_kd: overlap_thresh > 0 (whole-object cKDTree test) is not built')
+    if prob_kd_path_dict is None:
+        raise NotImplementedError('from_probabilities_to_kd: source data inside the ChunkDataset (h5 files) is not built')
+    kd_keys = list(prob_kd_path_dict.keys())
+    assert len(kd_keys) == len(hdf5names)
+    for kd_key in kd_keys:
+        assert kd_key in hdf5names
+    if size is not None and offset is not None:
+        chunk_list, chunk_translator = calculate_chunk_numbers_for_box(cset, offset, size)
+    else:
+        chunk_list = [ii for ii in range(len(cset.chunk_dict))]
+        chunk_translator = {ii: ii for ii in chunk_list}
+    device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+
+    # ---- connected components per chunk (object_segmentation), labels kept
+    cc_info_list, overlap_info, _, labels = oes.object_segmentation(
+        cset, hdf5names, prob_kd_path_dict, thresholds, overlap=overlap, chunk_list=chunk_list, with_properties=False,
+        device=device, sigmas=sigmas, keep_labels=True, labels_on_device_bytes=labels_on_device_bytes, morph_ops=morph_ops,
+        min_seed_vx=min_seed_vx, scaling=scaling)
+    if stitch_overlap is None:
+        stitch_overlap = overlap_info[1]
+    else:
+        stitch_overlap = np.asarray(stitch_overlap)
+        overlap_info[1] = stitch_overlap
+    if not np.all(stitch_overlap <= overlap_info[0]):
+        raise ValueError("Stitch overlap ({}) has to be <= than chunk overlap ({}).".format(overlap_info[1], overlap_info[0]))
+    overlap = overlap_info[0]
+
+    # ---- max labels (:296-312)
+    nb_cc = {name: np.zeros(len(chunk_list), dtype=np.int64) for name in hdf5names}
+    for nb_chunk, name, n in cc_info_list:
+        nb_cc[name][chunk_translator[nb_chunk]] = n
+    offsets, max_labels = {}, {}
+    for name in hdf5names:
+        offsets[name], max_labels[name] = oes.label_offsets(nb_cc[name])
+
+    cs = np.asarray(cset.chunk_size, dtype=np.int64)
+    box0 = np.asarray(cset.box_coords if cset.box_coords is not None else np.zeros(3), dtype=np.int64)
+    grid_pos = {n: tuple(int(v) for v in (np.asarray(cset.chunk_dict[n].coordinates, dtype=np.int64) - box0) // cs) for n in chunk_list}
+
+    def unique(n, name):                                   # make_unique_labels, on the fly (the uint64 volume is transient)
+        return oes.make_unique_labels(labels[(n, name)].to(device), int(offsets[name][chunk_translator[n]]))
+
+    stitch_list, merge_dict, merge_list_dict = {}, {}, {}
+    targets = {name: kd_factory(target_kd_paths[name]) for name in hdf5names} if target_kd_paths else {}
+    for name in hdf5names:
+        # ---- stitch list (:330-337): every chunk against its +x, +y, +z neighbours.  Unique volumes are made once per chunk and kept
+        # only while a later neighbour still needs them.
+        by_pos = {p: n for n, p in grid_pos.items()}
+        cache, pairs = {}, set()
+        for n in chunk_list:
+            p = grid_pos[n]
+            nbrs = [(d, by_pos.get(tuple(p[k] + (1 if k == d else 0) for k in range(3)))) for d in range(3)]
+            if not any(m is not None for _, m in nbrs):
+                cache.pop(n, None)
+                continue
+            a = cache.pop(n) if n in cache else unique(n, name)
+            for d, m in nbrs:
+                if m is None:
+                    continue
+                if m not in cache:
+                    cache[m] = unique(m, name)
+                pairs |= oes.stitch_pairs(a, cache[m], d, overlap, stitch_overlap)
+            # (x-outermost chunk order: the +x neighbour is the farthest ahead; drop what no later chunk compares against)
+            for m in [k for k in cache if all(grid_pos[k][i] <= p[i] for i in range(3))]:
+                del cache[m]
+        cache.clear()
+        stitch_list[name] = sorted(pairs)
+        # ---- merge list (:343-347) and its application + export (:352-366)
+        merge_dict[name], merge_list_dict[name] = oes.make_merge_list(stitch_list[name], max_labels[name])
+        lut = torch.from_numpy(merge_list_dict[name].view(np.int64)).to(device)
+        for n in chunk_list:
+            chunk = cset.chunk_dict[n]
+            stitched = oes.apply_merge_list(unique(n, name), chunk.size, lut)                # (x,y,z) uint64, chunk.size
+            if name in targets:
+                zyx = stitched.permute(2, 1, 0).contiguous().cpu().numpy().view(np.uint64)
+                targets[name].save_seg(offset=[int(v) for v in chunk.coordinates], mags=[1], data=zyx, data_mag=1)
+        del lut
+    for kd in targets.values():
+        if hasattr(kd, 'flush'):
+            kd.flush()
+    return {'cc_info_list': cc_info_list, 'overlap_info': overlap_info, 'max_labels': max_labels, 'stitch_list': stitch_list,
+            'merge_dict': merge_dict, 'merge_list_dict': merge_list_dict, 'chunk_list': chunk_list}

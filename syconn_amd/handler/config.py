@@ -47,6 +47,8 @@ DEFAULTS = {
     'cell_objects': {
         'probathresholds': {'mi': 0.428571429, 'sj': 0.19047619, 'vc': 0.285714286, 'er': 0.5, 'golgi': 0.5},
         'min_seed_vx': {'mi': 50, 'sj': 10, 'vc': 10, 'er': 30, 'golgi': 30},
+        # size threshold applied during object extraction (config.yml:80-89); sv: all cell supervoxels are extracted
+        'min_obj_vx': {'mi': 500, 'sj': 100, 'vc': 100, 'er': 100, 'golgi': 100, 'sv': 1, 'cs': 10, 'syn': 10, 'syn_ssv': 100},
         'extract_morph_op': {
             'mi': ['binary_opening', 'binary_closing', 'binary_erosion', 'binary_erosion', 'binary_erosion', 'binary_erosion'],
             'sj': ['binary_opening', 'binary_closing', 'binary_erosion'],

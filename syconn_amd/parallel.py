@@ -19,7 +19,10 @@ import torch.distributed as dist
 from ._lib import host_box_copy, host_zero
 from .handler.basics import chunkify
 
-# host threads of the strided box copies (pack / stitch on rank 0): measured on the 128-thread GPU box for the config-4 volume in
+# strided host box copies issued by predict_volume_distributed since import (tests: the device path must not add any)
+HOST_BOX_COPIES = 0
+
+# host threads of the strided box copies (pack / stitch on rank 0, HOST path only -- CPU tensors, the gloo unit tests): measured on the 128-thread GPU box for the config-4 volume in
 # 128^3-tile chunks, pack + stitch sustain 4.4 Gvox/s with 16 threads and 6.8 Gvox/s with 64 (tools/host_pack_rate.py)
 HOST_THREADS = min(64, max(4, (os.cpu_count() or 8) // 2))
 
@@ -198,13 +201,20 @@ def _pinned_give(t: torch.Tensor, pin: bool) -> None:
 def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Sequence[int], chunk_shape: Sequence[int],
                                halo: Sequence[int], predict_fn, n_out: int, device=None,
                                pipelined: bool = True, root_computes: bool = True,
-                               trace: Optional[list] = None) -> Optional[torch.Tensor]:
+                               trace: Optional[list] = None, out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """Chunk-parallel dense prediction of one (z,y,x) uint8 volume over all ranks of the process group: the RCCL
     variant of the reference's "one worker per GPU, chunk ids dealt round-robin" (prediction.py:708-719), with the
     file system replaced by collectives.
 
-    Rank 0 holds `volume_u8` in HOST memory (other ranks pass None); the (n_out, *vol_shape) uint8 result is assembled
-    in host memory on rank 0 as well (None elsewhere) -- rank 0's device only ever holds the payloads of two rounds.
+    Rank 0 holds `volume_u8` in HOST memory (other ranks pass None) and receives the (n_out, *vol_shape) uint8 result in host
+    memory as well (None elsewhere; `out`: a caller-owned -- ideally page-locked -- tensor to fill instead of a fresh pinned one).
+    On a ROCm device rank 0's CPU does no per-chunk work at all: the volume is uploaded ONCE in contiguous z-slabs (one per row
+    of chunks, each just before the first round that reads it) into rank 0's HBM, chunk + halo boxes are cut there by
+    `sd_tile_gather` straight into the scatter staging buffer (zeros outside the volume), gathered results are placed by
+    `sd_tile_scatter` into a device-resident result volume, and every row of chunks is downloaded as one contiguous slab per
+    output channel as soon as its last chunk has arrived -- 2 x 2 GiB over rank 0's PCIe link per 2048 x 2048 x 512 volume,
+    under the kernels (rounds 1-4 packed and stitched every chunk with host threads: 6.3-6.9 Gvox/s on the GPU box, below what
+    8 GPUs predict).  CPU tensors (the gloo unit tests of the sharding logic) keep the host pack / stitch.
     Chunks of `chunk_shape` are enumerated z-major and dealt round-robin over the WORKER ranks (== ``chunkify``): all
     ranks, or ranks 1 .. world-1 with ``root_computes=False`` (rank 0 then only packs, uploads, downloads and stitches --
     for volumes where its host threads and PCIe link are the bottleneck).  Per round rank 0 cuts one chunk per worker
@@ -258,16 +268,30 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
 
     in_buf = [torch.empty(in_shape, dtype=torch.uint8, device=device) for _ in range(2)]
     res_buf = [torch.empty(out_shape, dtype=torch.uint8, device=device) for _ in range(2)]
-    out = vol = None
+    vol = None
     taken = []
-    if root:
-        vol = (volume_u8.cpu() if volume_u8.is_cuda else volume_u8).contiguous()
-        out = torch.empty((n_out, *[int(v) for v in vs]), dtype=torch.uint8)
+    full_shape = (n_out, *[int(v) for v in vs])
+    if root and out is not None and (tuple(out.shape) != full_shape or out.dtype != torch.uint8 or out.is_cuda or not out.is_contiguous()):
+        raise ValueError(f'out: need a contiguous uint8 host tensor of shape {full_shape}')
+    if root and cuda:
+        from .engine import tile_gather, tile_scatter
+        vol = volume_u8.contiguous()
+        vol_dev = vol if vol.is_cuda else torch.empty(tuple(int(v) for v in vs), dtype=torch.uint8, device=device)
+        out_dev = torch.empty(full_shape, dtype=torch.uint8, device=device)
+        if out is None:
+            out = torch.empty(full_shape, dtype=torch.uint8, pin_memory=True)
+        stage = [torch.empty((world, *in_shape), dtype=torch.uint8, device=device) for _ in range(2)] if world > 1 else None
+        recv = [torch.empty((world, *out_shape), dtype=torch.uint8, device=device) for _ in range(2)] if world > 1 else None
+        up_next = [0 if not vol.is_cuda else int(vs[0])]          # first z-plane of the volume not yet uploaded
+        rows_left = [grid[1] * grid[2]] * grid[0]                 # chunks of every row of chunks that are not in out_dev yet
+    elif root:
+        vol = volume_u8.contiguous()
+        if out is None:
+            out = torch.empty(full_shape, dtype=torch.uint8)
         pin_in = [_pinned_take((world, *in_shape), cuda) for _ in range(2)]       # packed payloads of a round, by RANK
         pin_out = [_pinned_take((world, *out_shape), cuda) for _ in range(2)]     # gathered results of a round, by RANK
         taken = pin_in + pin_out
-        stage = [torch.empty((world, *in_shape), dtype=torch.uint8, device=device) for _ in range(2)] if world > 1 else None
-        recv = [torch.empty((world, *out_shape), dtype=torch.uint8, device=device) for _ in range(2)] if world > 1 else None
+        stage = recv = None
     else:
         recv = None
     if cuda:
@@ -289,8 +313,24 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
         if not root or r >= nr or packed[r & 1] == r:
             return
         s = r & 1
-        if cuda and packed[s] >= 0:
-            ev_h2d[s].synchronize()                              # the upload of round r-2 has left this staging buffer
+        if cuda:
+            # device path: no host work.  On the copy-in stream: the z-slabs of the volume this round reads that are not in HBM yet
+            # (uploads stay in z order, one contiguous copy each), then one sd_tile_gather per chunk of the round
+            with torch.cuda.stream(s_in):
+                if r >= 2:       # round r-2's scatter has consumed stage[s] (world > 1) / its kernels have consumed in_buf[s]
+                    s_in.wait_event(ev_scat[s] if world > 1 else ev_pred[s])
+                need = min(int(vs[0]), max((int(c[0]) + 1) * int(cs[0]) + int(ol[0]) for c in rounds[r]))
+                while up_next[0] < need:
+                    z1 = min(int(vs[0]), (up_next[0] // int(cs[0]) + 1) * int(cs[0]))
+                    vol_dev[up_next[0]:z1].copy_(vol[up_next[0]:z1], non_blocking=True)
+                    up_next[0] = z1
+                for k, c in enumerate(rounds[r]):
+                    lo = np.asarray(c, dtype=np.int64) * cs - ol
+                    tile_gather(vol_dev, lo, in_shape, stage[s][workers[k]] if world > 1 else in_buf[s])
+                ev_h2d[s].record(s_in)
+            packed[s] = r
+            return
+        global HOST_BOX_COPIES
         for k, w in enumerate(workers):
             dst = pin_in[s][w]
             if k >= len(rounds[r]):
@@ -302,18 +342,11 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
             if np.any(a > lo) or np.any(b < hi):
                 host_zero(dst, HOST_THREADS)
             if np.all(b > a):       # strided box copy on host threads (C helper; numpy / torch slicing runs on one core)
+                HOST_BOX_COPIES += 1
                 host_box_copy(dst[a[0] - lo[0]:b[0] - lo[0], a[1] - lo[1]:b[1] - lo[1], a[2] - lo[2]:b[2] - lo[2]],
                               vol[a[0]:b[0], a[1]:b[1], a[2]:b[2]], HOST_THREADS)
-        target = stage[s] if world > 1 else in_buf[s]
-        src = pin_in[s] if world > 1 else pin_in[s][0]
-        if cuda:
-            with torch.cuda.stream(s_in):
-                if r >= 2:       # round r-2's scatter has consumed stage[s] (world > 1) / its kernels have consumed in_buf[s]
-                    s_in.wait_event(ev_scat[s] if world > 1 else ev_pred[s])
-                target.copy_(src, non_blocking=True)
-                ev_h2d[s].record(s_in)
-        else:
-            target.copy_(src)
+        if world == 1:
+            in_buf[s].copy_(pin_in[s][0])
         packed[s] = r
 
     def issue_scatter(r):
@@ -332,8 +365,8 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
                     s_comm.wait_event(ev_h2d[s])
                 if r >= 2:
                     s_comm.wait_event(ev_pred[s])                # the kernels of round r-2 have consumed in_buf[s]
-            _, work = scatter_from_root(list(stage[s].unbind(0)) if root else None, in_buf[s], src=0, async_op=True,
-                                        out=in_buf[s])
+            _, work = scatter_from_root(list((stage[s] if cuda else pin_in[s]).unbind(0)) if root else None, in_buf[s], src=0,
+                                        async_op=True, out=in_buf[s])
         return work
 
     def issue_gather(r):
@@ -346,29 +379,35 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
                     s_comm.wait_event(ev_pred[s])
                     if root and r >= 2:
                         s_comm.wait_event(ev_d2h[s])             # the download of round r-2 has left recv[s]
-                _, work = gather_to_root(res_buf[s], dst=0, async_op=True, out=recv[s] if root else None)
+                _, work = gather_to_root(res_buf[s], dst=0, async_op=True, out=(recv[s] if cuda else pin_out[s]) if root else None)
                 work.wait()                                      # NCCL: orders s_comm behind the collective; gloo: host wait
                 if cuda:
                     ev_gath[s].record(s_comm)
-        if root:
-            src = recv[s] if world > 1 else res_buf[s]
-            dst = pin_out[s] if world > 1 else pin_out[s][0]
-            if cuda:
-                with torch.cuda.stream(s_out):
-                    s_out.wait_event(ev_gath[s] if world > 1 else ev_pred[s])
-                    dst.copy_(src, non_blocking=True)
-                    ev_d2h[s].record(s_out)
-            else:
-                dst.copy_(src)
+        if root and cuda:
+            # device path: place the round's results in the device-resident result volume (copy-out stream), and download every
+            # row of chunks that is complete now -- one contiguous slab per output channel
+            with torch.cuda.stream(s_out):
+                s_out.wait_event(ev_gath[s] if world > 1 else ev_pred[s])
+                for k, c in enumerate(rounds[r]):
+                    lo = np.asarray(c, dtype=np.int64) * cs
+                    tile_scatter(recv[s][workers[k]] if world > 1 else res_buf[s], (0, 0, 0), np.minimum(cs, vs - lo), out_dev, lo)
+                    rows_left[c[0]] -= 1
+                    if rows_left[c[0]] == 0:
+                        z0, z1 = int(c[0]) * int(cs[0]), min(int(vs[0]), (int(c[0]) + 1) * int(cs[0]))
+                        for ch in range(n_out):
+                            out[ch, z0:z1].copy_(out_dev[ch, z0:z1], non_blocking=True)
+                ev_d2h[s].record(s_out)                          # (recv[s] / res_buf[s] are free again)
+        elif root and world == 1:
+            pin_out[s][0].copy_(res_buf[s])
 
     def stitch(r):
         """host: results of round r (pin_out[r % 2]) -> output volume"""
         note('stitch', r)
-        if not root:
+        if not root or cuda:                                     # (device path: done by the copy-out stream, see issue_gather)
             return
         s = r & 1
-        if cuda:
-            ev_d2h[s].synchronize()
+        global HOST_BOX_COPIES
+        HOST_BOX_COPIES += len(rounds[r]) * n_out
         for k in range(len(rounds[r])):
             w = workers[k]
             lo = np.asarray(rounds[r][k], dtype=np.int64) * cs
@@ -413,6 +452,9 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
         if cuda:
             cur.wait_stream(s_comm)                              # nothing of this call is still in flight when it returns
             cur.wait_stream(s_in)
+            cur.wait_stream(s_out)
+            if root:
+                s_out.synchronize()                              # host: every slab of the result has arrived
     finally:
         for t in taken:
             _pinned_give(t, cuda)

@@ -461,11 +461,21 @@ def test_chunked_volume_prediction_equals_whole_volume_tiling(gpu):
 
     def predict_fn(ch):
         return pred.predict_labels_u8_device(ch, ids, thr, halo_included=True)[None]
+    copies0 = par.HOST_BOX_COPIES
     for pipelined in (True, False):
         got = par.predict_volume_distributed(vol, vol_shape, chunk, halo, predict_fn, n_out=1, device=gpu,
                                              pipelined=pipelined)
         assert got.shape == (1, *vol_shape) and torch.equal(got[0], whole)
     assert len(torch.unique(whole)) >= 2
+    # on the device rank 0's CPU cuts and stitches nothing: the volume goes up in contiguous z-slabs, chunk + halo boxes are cut by
+    # sd_tile_gather, results placed by sd_tile_scatter in a device-resident volume and downloaded as slabs (no host box copy per round)
+    assert par.HOST_BOX_COPIES == copies0
+    # a caller-owned (page-locked) result tensor is filled in place; a volume that is already on the device needs no upload
+    mine = torch.empty((1, *vol_shape), dtype=torch.uint8).pin_memory()
+    got = par.predict_volume_distributed(vol.to(gpu), vol_shape, chunk, halo, predict_fn, n_out=1, device=gpu, out=mine)
+    assert got is mine and torch.equal(mine[0], whole) and par.HOST_BOX_COPIES == copies0
+    with pytest.raises(ValueError):
+        par.predict_volume_distributed(vol, vol_shape, chunk, halo, predict_fn, n_out=1, device=gpu, out=mine[:, :-1])
 
 
 def test_two_concurrent_workers_write_the_same_dataset_as_one(gpu, tmp_path, monkeypatch):

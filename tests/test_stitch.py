@@ -1,0 +1,108 @@
+"""Globally unique objects across chunks (the steps behind the per-chunk first stage):
+make_unique_labels / make_stitch_list / make_merge_list / apply_merge_list against tests/golden/g11_stitch.npz -- outputs of the
+reference's own thread functions (tests/golden/make_golden_stitch.py) -- and from_probabilities_to_kd end to end."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+G = np.load(os.path.join(ROOT, 'tests', 'golden', 'g11_stitch.npz'))
+NAMES = [str(n) for n in G['names']]
+
+
+def _grid(name):
+    grid = tuple(int(v) for v in G[f'{name}_grid'])
+    pos, n = {}, 0
+    for x in range(grid[0]):
+        for y in range(grid[1]):
+            for z in range(grid[2]):
+                pos[n] = (x, y, z)
+                n += 1
+    return pos
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_label_offsets_and_merge_list_host(name):
+    """object_extraction_wrapper.py:300-312 and make_merge_list (object_extraction_steps.py:620-655): the same offsets, and the same
+    partition of the ids with the smallest member as the representative."""
+    from syconn_amd.extraction.object_extraction_steps import label_offsets, make_merge_list
+    off, mx = label_offsets(G[f'{name}_nb_cc'])
+    assert np.array_equal(off, G[f'{name}_offsets']) and mx == int(G[f'{name}_max_label'])
+    md, ml = make_merge_list([tuple(p) for p in G[f'{name}_pairs'].tolist()], mx)
+    assert ml.dtype == np.uint64 and np.array_equal(ml, G[f'{name}_canon'])
+    assert set(md) == set(np.unique(G[f'{name}_pairs']).tolist()) and all(ml[k] == v for k, v in md.items())
+    with pytest.raises(ValueError):
+        make_merge_list([(1, mx + 1)], mx)
+
+
+def test_calculate_chunk_numbers_for_box_host():
+    from syconn_amd.extraction.object_extraction_wrapper import calculate_chunk_numbers_for_box
+    from syconn_amd.knossos import ChunkDataset
+    cd = ChunkDataset()
+    cd.initialize(None, (40, 30, 20), (10, 10, 10), '/tmp/x/', box_coords=[0, 0, 0], fit_box_size=True)
+    lst, tr = calculate_chunk_numbers_for_box(cd, np.array([12, 0, 5]), np.array([10, 10, 10]))
+    want = [n for n, c in cd.chunk_dict.items() if 10 <= c.coordinates[0] < 30 and c.coordinates[1] == 0 and c.coordinates[2] < 20]
+    assert lst == want and all(tr[n] == i for i, n in enumerate(lst))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', NAMES)
+def test_unique_stitch_apply_against_reference(gpu, name):
+    """Device kernels (sd_labels_make_unique, sd_labels_box_lut, the co-occurrence table of sd_segstats_scan) against the outputs of
+    _make_unique_labels_thread, _make_stitch_list_thread and _apply_merge_list_thread: bit-exact unique volumes, the same set of
+    id pairs, the same stitched volumes up to the choice of the representative (golden: canonicalised to the smallest member)."""
+    from syconn_amd.extraction import object_extraction_steps as oes
+    pos = _grid(name)
+    ol, so, cs = G[f'{name}_overlap'], G[f'{name}_stitch_overlap'], G[f'{name}_chunk_size']
+    uniq = {}
+    for n in pos:
+        lab = torch.from_numpy(G[f'{name}_labels_{n}']).to(gpu)
+        uniq[n] = oes.make_unique_labels(lab, int(G[f'{name}_offsets'][n]))
+        assert np.array_equal(uniq[n].cpu().numpy().view(np.uint64), G[f'{name}_unique_{n}'])
+    pairs = oes.make_stitch_list(uniq, pos, ol, so)
+    assert pairs == [tuple(p) for p in G[f'{name}_pairs'].tolist()]
+    _, ml = oes.make_merge_list(pairs, int(G[f'{name}_max_label']))
+    for n in pos:
+        st = oes.apply_merge_list(uniq[n], cs, ml)
+        assert tuple(st.shape) == tuple(cs) and np.array_equal(st.cpu().numpy().view(np.uint64), G[f'{name}_stitched_canon_{n}'])
+    last = max(pos)
+    if int(uniq[last].max()) > 1:                # a merge list that is too short for the ids of a chunk is refused
+        with pytest.raises(ValueError):
+            oes.apply_merge_list(uniq[last], cs, ml[:int(uniq[last].max())])
+
+
+@pytest.mark.gpu
+def test_from_probabilities_to_kd_gives_the_connected_components_of_the_whole_volume(gpu, tmp_path):
+    """End to end on a KnossosDataset: per-chunk components (no morphology) + stitching = the 6-connected components of the
+    thresholded WHOLE volume, as a partition of the voxels; ids are globally unique; the target dataset holds them."""
+    import scipy.ndimage
+    from scipy import ndimage
+    from syconn_amd.extraction.object_extraction_wrapper import from_probabilities_to_kd
+    from syconn_amd.knossos import ChunkDataset, KnossosDataset
+    shape_xyz = (96, 80, 40)
+    rng = np.random.default_rng(7)
+    v = ndimage.gaussian_filter(rng.random(shape_xyz[::-1]), 2.5)
+    prob = (255 * (v - v.min()) / (v.max() - v.min())).astype(np.uint8)          # (z,y,x)
+    src = KnossosDataset()
+    src.initialize_without_conf(str(tmp_path / 'prob'), boundary=shape_xyz, scale=(10., 10., 20.), experiment_name='p', mags=[1])
+    src.save_raw(offset=(0, 0, 0), mags=[1], data=prob, data_mag=1)
+    tgt = KnossosDataset()
+    tgt.initialize_without_conf(str(tmp_path / 'seg'), boundary=shape_xyz, scale=(10., 10., 20.), experiment_name='s', mags=[1])
+    cd = ChunkDataset()
+    cd.initialize(src, np.array(shape_xyz), (48, 40, 20), str(tmp_path / 'cd') + '/', box_coords=[0, 0, 0], fit_box_size=True)
+    thr = float(np.quantile(prob, 0.7))
+    res = from_probabilities_to_kd({'obj': str(tmp_path / 'seg')}, cd, 'obj', ['obj'], prob_kd_path_dict={'obj': str(tmp_path / 'prob')},
+                                   thresholds=[thr], overlap=np.array([2, 2, 2]), device=gpu,
+                                   morph_ops={'obj': []}, min_seed_vx={'obj': 0}, scaling=(10, 10, 20))
+    seg = KnossosDataset().initialize_from_knossos_path(str(tmp_path / 'seg')).load_seg(size=shape_xyz, offset=(0, 0, 0), mag=1)
+    want, n_want = scipy.ndimage.label(prob > thr)
+    assert seg.dtype == np.uint64 and np.array_equal(seg > 0, want > 0)
+    # the same partition: every reference component carries exactly one id and vice versa
+    a, b = want[want > 0].astype(np.int64), seg[seg > 0].astype(np.int64)
+    pairs = np.unique(np.stack([a, b], 1), axis=0)
+    assert len(pairs) == n_want == len(np.unique(b)) and len(np.unique(pairs[:, 0])) == len(np.unique(pairs[:, 1]))
+    assert n_want >= 4 and len(res['stitch_list']['obj']) > 0 and res['max_labels']['obj'] > n_want
