@@ -968,7 +968,13 @@ static int launch_conv_knt(const ConvParams& p, int NB, hipStream_t s) {
     const long vox = (long)p.D * p.H * p.W * (p.batch_total > 0 ? p.batch_total : p.batch);      // all tiles of a batched launch set
     const int nstages = (p.nchunk0 + p.nchunk1) * KZ;
     // 512-voxel workgroups when they still give every CU work, else 256-voxel workgroups
-    const bool big = (vox / 512) * NB >= 512;
+    // (round 5: 256 instead of 512 workgroups.  The deep layers of small launch sets -- mivcsj's 768-channel layers at 32 x 8 x 8, every
+    // net's level 2 / 3 on a single tile -- stream their whole weight tensor from L2 once per workgroup: 512-voxel workgroups halve that
+    // traffic at the same eight waves per CU.  mivcsj 384 -> 768 / 768 -> 768: 53.5 / 104.1 -> 42.1 / 81.7 us per tile at 8 tiles; one
+    // 128^3 tile: semseg_spine 0.81 -> 0.79 ms, mivcsj 3.37 -> 3.16 ms; 8-tile sets of the 32-filter nets: no layer changes form.)
+    const char* const big_env = getenv("SD_BIG_MIN");      // (A/B switch, read per launch)
+    const long big_min = big_env ? atol(big_env) : 256;
+    const bool big = (vox / 512) * NB >= big_min;
     // Resident weights + persistent blocks where the whole layer's weights fit beside a 2-slot halo ring and two
     // workgroups still share a CU (level-0 layers); else streamed weights, one block per workgroup.  Deeper rings
     // (NSLOT 4/6, one workgroup per CU) were measured SLOWER on the level-0 layers (1.32 vs 1.23 ms per tile): those
