@@ -203,7 +203,9 @@ def auto_overlap(morph_ops: dict, scaling, sigmas=None) -> np.ndarray:
 def object_segmentation(cset, hdf5names: Sequence[str], prob_kd_path_dict: dict, thresholds: Sequence[float],
                         overlap="auto", chunk_list: Optional[Sequence[int]] = None, morph_ops: Optional[dict] = None,
                         min_seed_vx: Optional[dict] = None, scaling=None, with_properties: bool = True, device=None,
-                        sigmas=None, keep_labels: bool = False, labels_on_device_bytes: int = 128 << 30):
+                        sigmas=None, keep_labels: bool = False, labels_on_device_bytes: int = 128 << 30,
+                        load_from_kd_overlaycubes: bool = False, transf_func_kd_overlay: Optional[dict] = None,
+                        membrane_kd_path: Optional[str] = None):
     """``object_segmentation`` + ``_object_segmentation_thread`` (object_extraction_steps.py:42-201, 204-366) for the branch
     SyConn's pipeline takes after the dense prediction (object_extraction_wrapper.py:58-150: probability maps in
     KnossosDatasets ``prob_kd_path_dict``, ``load_raw``): per chunk of `cset` load size + 2 * overlap around the chunk from every
@@ -220,7 +222,11 @@ def object_segmentation(cset, hdf5names: Sequence[str], prob_kd_path_dict: dict,
     unpinned).  `keep_labels`: a fourth result ``labels[(chunk.number, hdf5_name)]`` = the int32 (x,y,z) label volume incl. the
     overlap margin (what the reference writes to ``*_connected_components.h5``), a device tensor while all of them fit in
     `labels_on_device_bytes`, else a host tensor -- the input of the stitching steps (``from_probabilities_to_kd``).
-    Not reproduced: the membrane hooks, `swapdata`, overlay-cube input."""
+    `load_from_kd_overlaycubes` (object_extraction_steps.py:254-270): the source datasets hold SEGMENTATION (overlay cubes, ``load_seg``)
+    instead of probability maps; ``transf_func_kd_overlay[name]`` (a callable on the (x,y,z) uint64 array) is applied if given, no
+    threshold is (:316), every non-zero voxel is foreground.  `membrane_kd_path` (:309-314, experimental in the reference): for the
+    names 'p4' and 'vc' voxels whose membrane probability exceeds ``255 * .4`` are cleared before the threshold.
+    Not reproduced: the membrane hook on h5 chunk files (`membrane_filename`), `swapdata`, source data inside the ChunkDataset."""
     from .. import global_params
     from ..knossos import KnossosDataset
     from .find_object_properties import find_object_properties
@@ -235,13 +241,12 @@ def object_segmentation(cset, hdf5names: Sequence[str], prob_kd_path_dict: dict,
         overlap = auto_overlap(morph_ops, scaling, sigmas)
     overlap = np.asarray(overlap, dtype=np.int64)
     stitch_overlap = np.max([overlap.copy(), [1, 1, 1]], axis=0)
-    thresholds = np.array(thresholds, dtype=np.float64)
+    thresholds = np.zeros(len(hdf5names)) if thresholds is None else np.array(thresholds, dtype=np.float64)
     if len(thresholds) and thresholds[0] <= 1.:
         thresholds = thresholds * 255
-    kds = {}
-    for k, path in prob_kd_path_dict.items():
-        kds[k] = KnossosDataset()
-        kds[k].initialize_from_knossos_path(path)
+    from ..handler.basics import kd_factory
+    kds = {k: kd_factory(path) for k, path in prob_kd_path_dict.items()}
+    kd_bar = kd_factory(membrane_kd_path) if membrane_kd_path is not None else None
     chunk_ids = list(cset.chunk_dict.keys()) if chunk_list is None else list(chunk_list)
     results, props, kept, kept_bytes = [], {}, {}, 0
     for nb in chunk_ids:
@@ -249,10 +254,22 @@ def object_segmentation(cset, hdf5names: Sequence[str], prob_kd_path_dict: dict,
         box_offset = np.array(chunk.coordinates) - overlap
         size = np.array(chunk.size) + 2 * overlap
         for i, name in enumerate(hdf5names):
-            tmp_data = np.ascontiguousarray(kds[name].load_raw(size=size, offset=box_offset, mag=1).swapaxes(0, 2))
+            if load_from_kd_overlaycubes:                                                    # :254-267
+                data_k = kds[name].load_seg(size=size, offset=box_offset, mag=1).swapaxes(0, 2)
+                if transf_func_kd_overlay is not None:
+                    data_k = transf_func_kd_overlay[name](data_k)
+                tmp_data = np.ascontiguousarray(np.asarray(data_k) != 0).astype(np.uint8)      # (labelled / eroded as a binary volume)
+            else:
+                tmp_data = np.ascontiguousarray(kds[name].load_raw(size=size, offset=box_offset, mag=1).swapaxes(0, 2))
             ops = list(morph_ops.get(name, [])) if name in morph_ops else []
             seed = int(min_seed_vx.get(name, 0)) if name in min_seed_vx else 0
-            thr = float(thresholds[i])
+            thr = 0.0 if load_from_kd_overlaycubes else float(thresholds[i])                 # :316 (no threshold on overlay input)
+            if name in ("p4", "vc") and kd_bar is not None:                                  # :309-314
+                if sigmas is not None and float(np.sum(sigmas[i])) != 0.0:
+                    raise NotImplementedError('membrane masking behind a Gaussian pre-smoothing is not built')
+                membrane_data = kd_bar.load_raw(size=size, offset=box_offset, mag=1).swapaxes(0, 2)
+                tmp_data[membrane_data > 255 * .4] = 0
+                del membrane_data
             if sigmas is not None and float(np.sum(sigmas[i])) != 0.0:                      # :296-297
                 tmp_data = gaussian_threshold(tmp_data, sigmas[i], thr, device=device, return_device=True)
                 thr = 0.0                                                                    # (a 0/1 mask from here on)

@@ -4,7 +4,7 @@
 chunk to each other (connected components -> max labels -> unique labels -> stitch list -> merge list -> apply merge list ->
 export); here a chunk's label volume is produced on the GPU and stays a device tensor until its stitched uint64 volume is written
 into the target KnossosDataset's overlay cubes.  Per-chunk arithmetic: ``object_extraction_steps`` (HIP library, no CPU fallback).
-Not reproduced: overlay-cube input (`load_from_kd_overlaycubes`), `transform_func`, the membrane hooks, `swapdata`,
+Not reproduced: `transform_func`, the membrane hook on h5 chunk files (`membrane_filename`; `membrane_kd_path` is), `swapdata`,
 ``overlap_thresh > 0`` (a cKDTree test on whole objects; the default is 0)."""
 from typing import Dict, List, Optional
 
@@ -55,9 +55,7 @@ def from_probabilities_to_kd(target_kd_paths: Optional[Dict[str, str]], cset, fi
     ``config['scaling']`` (the reference reads them from the working directory's config inside its worker).
     `labels_on_device_bytes`: the int32 component labels of all chunks are kept in HBM up to this budget (a 2048 x 2048 x 512
     dataset in 512^3 chunks with three organelles: 29 GB of 288), beyond it in host memory."""
-    unsupported = {'load_from_kd_overlaycubes': load_from_kd_overlaycubes, 'transf_func_kd_overlay': transf_func_kd_overlay,
-                   'transform_func': transform_func, 'membrane_filename': membrane_filename, 'membrane_kd_path': membrane_kd_path,
-                   'swapdata': swapdata}
+    unsupported = {'transform_func': transform_func, 'membrane_filename': membrane_filename, 'swapdata': swapdata}
     for k, v in unsupported.items():
         if v:
             raise NotImplementedError(f'from_probabilities_to_kd: `{k}` is not part of the dense-prediction consumers built here')
@@ -80,7 +78,8 @@ def from_probabilities_to_kd(target_kd_paths: Optional[Dict[str, str]], cset, fi
     cc_info_list, overlap_info, _, labels = oes.object_segmentation(
         cset, hdf5names, prob_kd_path_dict, thresholds, overlap=overlap, chunk_list=chunk_list, with_properties=False,
         device=device, sigmas=sigmas, keep_labels=True, labels_on_device_bytes=labels_on_device_bytes, morph_ops=morph_ops,
-        min_seed_vx=min_seed_vx, scaling=scaling)
+        min_seed_vx=min_seed_vx, scaling=scaling, load_from_kd_overlaycubes=load_from_kd_overlaycubes,
+        transf_func_kd_overlay=transf_func_kd_overlay, membrane_kd_path=membrane_kd_path)
     if stitch_overlap is None:
         stitch_overlap = overlap_info[1]
     else:

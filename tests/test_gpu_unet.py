@@ -548,3 +548,32 @@ def test_groupnorm_raw_pooling_in_conv_epilogue_is_bit_identical(gpu, monkeypatc
             if '.norm' in k and k.endswith('.weight'):
                 v.mul_((torch.randint(0, 2, v.shape, generator=g) * 2 - 1).to(v.dtype))
     _run_case(gpu, model, (12, 35, 41), act)
+
+
+def test_op_kernels_report_what_ran(gpu, monkeypatch):
+    """sd_debug_op_kernel: every plan op names the launch that computed it and that launch's kernel symbol -- the fused first
+    convolution (uint8 input: MODE 5, float32 input: MODE 1), poolings in conv epilogues, the level-0 decoder's members."""
+    from syconn_amd import _lib as L
+    from syconn_amd.cnn import random_state_dict
+    from syconn_amd.engine import DenseModel
+    dm = DenseModel(random_state_dict('semseg_spine', seed=0, final_scale=8.0), 'bf16', gpu)
+    x = torch.randint(0, 256, (4, 64, 128, 128), dtype=torch.uint8, device=gpu)
+    ids = list(range(1, dm.out_channels))
+    dm.forward_labels_batch(x, ids, [127.5] * len(ids))
+    ks = dm.op_kernels()
+    kinds = dm.op_kinds
+    assert len(ks) == dm.n_ops and all(e >= 0 and name for e, name in ks)
+    assert ks[0][0] == 1 and 'MODE=5' in ks[1][1] and ks[1][0] == 1                      # first conv inside the second
+    for i, k in enumerate(kinds):
+        if k == L.SD_OP_POOL:
+            assert ks[i][0] == i - 1 and ks[i][1].startswith('k_conv_mfma')             # pooled in the producing conv's epilogue
+    up = max(i for i, k in enumerate(kinds) if k == L.SD_OP_UPCONV)
+    assert all(ks[i] == (up, 'k_dec0<labels>') for i in range(up, dm.n_ops))           # level-0 decoder: one streaming launch
+    dm.forward_batch(x.float() / 255., L.SD_OUT_PROBS_U8)
+    ks = dm.op_kernels()
+    assert 'MODE=1' in ks[1][1] and ks[-1] == (up, 'k_dec0<probs u8>')
+    monkeypatch.setenv('SD_NO_FUSE', '1')
+    plain = DenseModel(random_state_dict('semseg_spine', seed=0, final_scale=8.0), 'bf16', gpu)
+    plain.forward_batch(x, L.SD_OUT_PROBS_U8)
+    kp = plain.op_kernels()
+    assert all(e == i for i, (e, _) in enumerate(kp)) and kp[0][1].startswith('k_conv_first<uint8 input, bf16 MFMA')
