@@ -223,7 +223,11 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
                 cur_adv(cl, 32, 0, PW / 2, HP1);
             }
             D0_T(1);
+#ifdef SD_PROBE_DEC0_NO_MERGE
+            if (false) {
+#else
             if (k >= 0) {
+#endif
                 f32x16 acc = bias_c1;
                 // 36 fragments (chunks U0, U1, S0, S1 x 9 taps: the summation order of k_conv_mfma) through PF registers: fragment
                 // i + PF is requested right behind the MFMA that read fragment i's register; LDS returns in order -> counted waits
@@ -401,11 +405,18 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
 #ifdef SD_DEC0_TIMING
             tsk = k;
 #endif
+#ifdef SD_PROBE_DEC0_NO_FINAL      // (timing probes, tools/build_probe_libs.sh: WRONG results)
+            pending = 0;
+#endif
             if (pending) { final_pair(); pending = 0; }
 #ifdef SD_DEC0_TIMING
             long long t_final = __builtin_readcyclecounter();
 #endif
+#ifdef SD_PROBE_DEC0_NO_UP
+            if (false) {
+#else
             if (u >= 0) {
+#endif
                 // ---- one output parity (py, px) of the up-convolution of level-1 tile u
                 f32x16 acc = bias_up;
                 const uint32_t lt = LDS_L + (u & 3) * 4096 + rec_off(l31, half);
@@ -427,7 +438,11 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
             cur_adv(cu, 32, 0, PW / 2, HP1);
             uB += ST; if (uB >= RU) uB -= RU;
             D0_T(1);
+#ifdef SD_PROBE_DEC0_NO_SECOND
+            if (false) {
+#else
             if (k >= 2) {
+#endif
                 // ---- second conv of tile ow, two steps behind the merge conv
                 f32x16 acc = bias_c2;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the up-conv's ring writes are out: the counted waits below start from zero

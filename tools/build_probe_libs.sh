@@ -6,6 +6,7 @@ set -e
 REPO=$(cd $(dirname $0)/.. && pwd)
 for P in ${PROBES:-nodma nobar}; do
   T=/tmp/sd_probe_$P; rm -rf $T; mkdir -p $T/syconn_amd; cp -r $REPO/include $T/; cp -r $REPO/syconn_amd/csrc $T/syconn_amd/; rm -f $T/syconn_amd/csrc/*.o
+  EXTRA_FLAGS=
   if [ $P = nodma ]; then
     python3 - $T/syconn_amd/csrc/sd_device.h <<'PY'
 import sys
@@ -28,10 +29,13 @@ s = s.replace(anchor, anchor + '''    for (unsigned i = threadIdx.x; i < (unsign
 ''', 1)
 open(p, 'w').write(s)
 PY
+  elif [ ${P#dec0_} != $P ]; then
+    X=$(echo ${P#dec0_} | tr a-z A-Z)      # dec0_no_final -> -DSD_PROBE_DEC0_NO_FINAL etc. (k_dec0 without one of its pieces)
+    EXTRA_FLAGS="-DSD_PROBE_DEC0_$X"
   else
     sed -i 's/\\n\\ts_barrier//g; s/asm volatile("s_barrier" ::: "memory");/asm volatile("s_nop 0" ::: "memory");/g' $T/syconn_amd/csrc/sd_conv_mfma.h
   fi
-  make -C $T/syconn_amd/csrc -j4 > $T/build.log 2>&1
+  make -C $T/syconn_amd/csrc -j4 EXTRA="${EXTRA_FLAGS:-}" > $T/build.log 2>&1; EXTRA_FLAGS=
   cp $T/syconn_amd/libsyconn_dense_hip.so $REPO/syconn_amd/libsd_probe_$P.so
   echo built $REPO/syconn_amd/libsd_probe_$P.so
 done
