@@ -1603,7 +1603,9 @@ static int launch_conv_k(ConvParams p, int NB, hipStream_t s) {
                        (MODE == 2 ? (size_t)p.batch * conv_gn_lds_per_tile(p.nchunk0 + p.nchunk1) : 0);
     if (lds > (size_t)SD_LDS_BYTES) return SD_ERR_INVALID;
     p.nbx = (p.W + G::BX - 1) / G::BX; p.nby = (p.H + G::BY - 1) / G::BY; p.nbz = (p.D + G::BZ - 1) / G::BZ;
-    if (KZ == 3 && getenv("SD_TIMING_NO_STORE")) { p.store_main = 0; p.pool_dst = nullptr; }      // (timing probe: WRONG results)
+    if (const char* ns = getenv("SD_TIMING_NO_STORE")) {      // (timing probe: WRONG results; 1 = the 3x3x3 forms, 2 = every form)
+        if (KZ == 3 || atoi(ns) >= 2) { p.store_main = 0; p.pool_dst = nullptr; }
+    }
     static const int order = getenv("SD_BLOCK_ORDER") ? atoi(getenv("SD_BLOCK_ORDER")) : 1;
     p.block_order = order;
     // per-DEVICE cache of the dynamic-LDS attribute and the occupancy answer of this instantiation (a function attribute

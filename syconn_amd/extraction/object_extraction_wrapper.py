@@ -30,9 +30,67 @@ def calculate_chunk_numbers_for_box(cset, offset, size):
     for x in range(int(offset[0]), int(offset[0] + size[0]), int(cs[0])):
         for y in range(int(offset[1]), int(offset[1] + size[1]), int(cs[1])):
             for z in range(int(offset[2]), int(offset[2] + size[2]), int(cs[2])):
+                if (x, y, z) not in coord_dict:      # (generate_subcell_kd_from_proba asks for boundary + 1 voxels: on a dataset whose
+                    continue                          # boundary is a multiple of the chunk size that row of chunks does not exist)
                 chunk_list.append(coord_dict[(x, y, z)])
                 translator[chunk_list[-1]] = len(chunk_list) - 1
     return chunk_list, translator
+
+
+def generate_subcell_kd_from_proba(subcell_names: List[str], chunk_size=None, transf_func_kd_overlay=None,
+                                   load_cellorganelles_from_kd_overlaycubes: bool = False, cube_of_interest_bb=None,
+                                   cube_shape=None, log=None, overwrite=False, **kwargs):
+    """object_extraction_wrapper.py:58-150: connected-component segmentation of the sub-cellular structures `subcell_names` (e.g.
+    ['mi', 'vc', 'sj']) as KnossosDatasets at ``config.kd_organelle_seg_paths[co]``; sources are the probability-map datasets
+    ``config.kd_<co>_path``, thresholds ``config['cell_objects']['probathresholds'][co]``; the chunk grid covers the cell segmentation
+    dataset ``config.kd_seg_path`` in `chunk_size` chunks ([512, 512, 512]).  Existing targets need ``overwrite=True``
+    (``FileExistsError`` otherwise)."""
+    import os
+    import shutil
+    from .. import global_params
+    from ..knossos import ChunkDataset, KnossosDataset
+    conf = global_params.config
+    if chunk_size is None:
+        chunk_size = [512, 512, 512]
+    if cube_shape is None:
+        cube_shape = (256, 256, 256)
+    kd = kd_factory(conf.kd_seg_path)
+    if cube_of_interest_bb is None:
+        cube_of_interest_bb = [np.zeros(3, dtype=np.int32), np.asarray(kd.boundary)]
+    size = np.asarray(cube_of_interest_bb[1]) - np.asarray(cube_of_interest_bb[0]) + 1
+    offset = np.asarray(cube_of_interest_bb[0])
+    cd_dir = "{}/chunkdatasets/{}/".format(conf.working_dir, "_".join(subcell_names))
+    if os.path.isdir(cd_dir):
+        if not overwrite:
+            raise FileExistsError(f'Could not start generation of sub-cellular objects "{subcell_names}" ChunkDataset because it '
+                                  f'already exists at "{cd_dir}" and overwrite was not set to True.')
+        shutil.rmtree(cd_dir)
+    cd = ChunkDataset()
+    cd.initialize(kd, np.asarray(kd.boundary), chunk_size, cd_dir, box_coords=[0, 0, 0], fit_box_size=True)
+    prob_kd_path_dict = {co: getattr(conf, 'kd_{}_path'.format(co)) for co in subcell_names}
+    prob_threshs = []
+    seg_paths = {co: "{}/knossosdatasets/{}_seg/".format(conf.working_dir, co) for co in subcell_names}
+    for co in subcell_names:
+        prob_threshs.append(conf['cell_objects']["probathresholds"][co])
+        path = seg_paths[co]
+        if os.path.isdir(path):
+            if not overwrite:
+                raise FileExistsError(f'Could not start generation of sub-cellular object "{co}" KnossosDataset because it already '
+                                      f'exists at "{path}" and overwrite was not set to True.')
+            shutil.rmtree(path)
+        target_kd = KnossosDataset()
+        target_kd._cube_shape = tuple(cube_shape)
+        target_kd.initialize_without_conf(path, kd.boundary, np.array(conf['scaling'], dtype=np.float32), kd.experiment_name, mags=[1],
+                                          create_pyk_conf=True, create_knossos_conf=False)
+    if load_cellorganelles_from_kd_overlaycubes:      # no thresholds needed
+        prob_threshs = None
+    # (the box of interest restricts the chunks as the reference does: calculate_chunk_numbers_for_box)
+    res = from_probabilities_to_kd(seg_paths, cd, "_".join(subcell_names), prob_kd_path_dict=prob_kd_path_dict, thresholds=prob_threshs,
+                                   hdf5names=list(subcell_names), size=size, offset=offset,
+                                   load_from_kd_overlaycubes=load_cellorganelles_from_kd_overlaycubes,
+                                   transf_func_kd_overlay=transf_func_kd_overlay, log=log, **kwargs)
+    shutil.rmtree(cd_dir, ignore_errors=True)
+    return res
 
 
 def from_probabilities_to_kd(target_kd_paths: Optional[Dict[str, str]], cset, filename: str, hdf5names: List[str],

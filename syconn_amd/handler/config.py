@@ -10,7 +10,7 @@ with a "TODO: these should be config parameters" (prediction.py:671-677).
 """
 import logging
 import os
-from typing import Any, Optional
+from typing import Dict, Any, Optional
 
 import yaml
 
@@ -24,6 +24,7 @@ DEFAULTS = {
     'default_log_dir': None,
     'disable_file_logging': True,
     'paths': {'kd_seg': None},
+    'process_cell_organelles': ['mi', 'vc'],      # config.yml:15
     'dense_prediction': {
         'overlap_shape_tiles': [30, 31, 20],   # xyz, prediction.py:672
         'chunk_size': [482, 481, 236],         # prediction.py:674
@@ -117,6 +118,30 @@ class DynConfig:
     @property
     def kd_seg_path(self) -> str:
         return self['paths']['kd_seg']
+
+    def __getattr__(self, name: str):
+        # kd_<name>_path (config.py:300-360: kd_sym / kd_asym / kd_sj / kd_vc / kd_mi / kd_er / kd_golgi): the probability-map datasets
+        if name.startswith('kd_') and name.endswith('_path') and name != 'kd_seg_path':
+            key = name[:-len('_path')]
+            try:
+                return self['paths'][key]
+            except KeyError:
+                raise AttributeError(f"config['paths'] has no '{key}'") from None
+        raise AttributeError(name)
+
+    @property
+    def kd_organelles_paths(self) -> Dict[str, str]:
+        """config.py:362-373: probability-map KnossosDatasets of ``config['process_cell_organelles']``."""
+        return {k: self['paths']['kd_{}'.format(k)] for k in self['process_cell_organelles']}
+
+    @property
+    def kd_organelle_seg_paths(self) -> Dict[str, str]:
+        """config.py:375-386: where the organelle SEGMENTATION KnossosDatasets live."""
+        return {k: "{}/knossosdatasets/{}_seg/".format(self.working_dir, k) for k in self['process_cell_organelles']}
+
+    @property
+    def temp_path(self) -> str:
+        return "{}/tmp/".format(self.working_dir)
 
     @property
     def model_dir(self) -> str:
