@@ -202,7 +202,10 @@ def test_generate_subcell_kd_from_proba_from_the_working_directory(gpu, tmp_path
                                            ('cell_objects', {'probathresholds': {'mi': thr}, 'extract_morph_op': {'mi': []},
                                                              'min_seed_vx': {'mi': 0}})])
     global_params.wd = wd
-    res = generate_subcell_kd_from_proba(['mi'], chunk_size=[32, 24, 32], device=gpu)
+    with pytest.raises(ValueError):      # (no erosion, no sigma: the automatic chunk overlap is 0 < the stitch overlap of 1, as in the reference)
+        generate_subcell_kd_from_proba(['mi'], chunk_size=[32, 24, 32], device=gpu)
+    ol = np.array([2, 2, 2])
+    res = generate_subcell_kd_from_proba(['mi'], chunk_size=[32, 24, 32], device=gpu, overlap=ol, overwrite=True)
     seg = KnossosDataset().initialize_from_pyknossos_path(
         [str(tmp_path / 'wd' / 'knossosdatasets' / 'mi_seg' / f) for f in os.listdir(tmp_path / 'wd' / 'knossosdatasets' / 'mi_seg')
          if f.endswith('.pyk.conf')][0]).load_seg(size=shape_xyz, offset=(0, 0, 0), mag=1)
@@ -211,5 +214,5 @@ def test_generate_subcell_kd_from_proba_from_the_working_directory(gpu, tmp_path
     pairs = np.unique(np.stack([want[want > 0], seg[seg > 0].astype(np.int64)], 1), axis=0)
     assert len(pairs) == n_want and len(res['chunk_list']) == 4
     with pytest.raises(FileExistsError):
-        generate_subcell_kd_from_proba(['mi'], chunk_size=[32, 24, 32], device=gpu)
-    generate_subcell_kd_from_proba(['mi'], chunk_size=[32, 24, 32], device=gpu, overwrite=True)
+        generate_subcell_kd_from_proba(['mi'], chunk_size=[32, 24, 32], device=gpu, overlap=ol)
+    generate_subcell_kd_from_proba(['mi'], chunk_size=[32, 24, 32], device=gpu, overlap=ol, overwrite=True)
