@@ -974,7 +974,10 @@ static int launch_conv_knt(const ConvParams& p, int NB, hipStream_t s) {
     // 128^3 tile: semseg_spine 0.81 -> 0.79 ms, mivcsj 3.37 -> 3.16 ms; 8-tile sets of the 32-filter nets: no layer changes form.)
     const char* const big_env = getenv("SD_BIG_MIN");      // (A/B switch, read per launch)
     const long big_min = big_env ? atol(big_env) : 256;
-    const bool big = (vox / 512) * NB >= big_min;
+    // (planar layers with 96-column workgroups -- levels 2+ of the 48-filter family -- run faster as 4-wave workgroups at every size
+    // measured: mivcsj's GroupNorm layers at 32 x 16 x 16 20.5 / 31.0 / 58.1 / 30.7 -> 15.1 / 17.3 / 33.4 / 17.6 us per tile, semseg_axon's at
+    // 64 x 32 x 32 18.7 / 35.2 -> 17.4 / 32.3; SD_PLANAR_NT3_BIG=1 restores the 8-wave forms)
+    const bool big = (vox / 512) * NB >= big_min && !(KZ == 1 && NT == 3 && !getenv("SD_PLANAR_NT3_BIG"));
     // Resident weights + persistent blocks where the whole layer's weights fit beside a 2-slot halo ring and two
     // workgroups still share a CU (level-0 layers); else streamed weights, one block per workgroup.  Deeper rings
     // (NSLOT 4/6, one workgroup per CU) were measured SLOWER on the level-0 layers (1.32 vs 1.23 ms per tile): those
