@@ -105,7 +105,8 @@ class HostToHostPipeline:
         self.out_host = [torch.empty((n_out, T, S, S, S), dtype=torch.uint8).pin_memory() for _ in range(2)]
         self.in_dev = [torch.empty((T, S, S, S), dtype=torch.uint8, device=dev) for _ in range(2)]
         self.lab_dev = [torch.empty((T, S, S, S), dtype=torch.uint8, device=dev) for _ in range(2)]
-        self.recv = [torch.empty((world, T, S, S, S), dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
+        self.coll = par.collectives_active()          # world > 1 (or SD_DIST_SINGLE_RANK_GROUP=1: a group of one, tests)
+        self.recv = [torch.empty((world, T, S, S, S), dtype=torch.uint8, device=dev) if (self.coll and rank == 0) else None
                      for _ in range(2)]
         self.s_in, self.s_comp, self.s_out = (torch.cuda.Stream(device=dev) for _ in range(3))
         self.ev_in = [torch.cuda.Event() for _ in range(2)]       # H2D of the set finished
@@ -133,7 +134,7 @@ class HostToHostPipeline:
             self.ev_comp[s].record(self.s_comp)
         with torch.cuda.stream(self.s_out):
             self.s_out.wait_event(self.ev_comp[s])
-            if self.world > 1:
+            if self.coll:
                 _, work = self.par.gather_to_root(self.lab_dev[s], dst=0, async_op=True, out=self.recv[s])
                 work.wait()                             # stream-level dependency of s_out on the collective
                 if self.rank == 0:
@@ -346,7 +347,7 @@ def main():
                            'tiles_per_launch_set': B,
                            'tiles_per_gpu_per_step': T, 'tile': [S, S, S], 'parallelism': f'tile-sharded x{world}',
                            'hip_streams_per_gpu': 3,
-                           'collective': 'RCCL gather of uint8 labels to rank 0, D2H there' if world > 1 else 'none',
+                           'collective': 'RCCL gather of uint8 labels to rank 0, D2H there' if par.collectives_active() else 'none',
                            'single_tile_ms': single_tile_ms,
                            'single_tile_mvox_per_s': None if single_tile_ms is None else S ** 3 / single_tile_ms / 1e3,
                            'reference_precision_f16x2_mvox_per_s': None if ref_prec is None else S ** 3 / ref_prec / 1e3,
@@ -356,7 +357,7 @@ def main():
                            'pcie_bytes_per_step_each_way': T * S ** 3, 'labels_sha256': labels_sha},
                 'roofline': roof, 'network': net, 'cpu_baseline': cpu}
         print(json.dumps(line))
-    if world > 1:
+    if par.collectives_active():
         par.barrier()
         torch.distributed.destroy_process_group()
 
@@ -461,9 +462,9 @@ def volume_main(args):
                                              if args.labels_sha else None),
                            'host_box_copies': par.HOST_BOX_COPIES,      # (0: rank 0's CPU cut and stitched nothing)
                            'collective': 'RCCL scatter of uint8 chunks / gather of uint8 results; volume and result resident in rank 0\'s HBM, '
-                                         'one contiguous PCIe stream each way' if world > 1 else 'none'}}
+                                         'one contiguous PCIe stream each way' if par.collectives_active() else 'none'}}
         print(json.dumps(line))
-    if world > 1:
+    if par.collectives_active():
         par.barrier()
         torch.distributed.destroy_process_group()
 

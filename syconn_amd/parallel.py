@@ -27,13 +27,31 @@ HOST_BOX_COPIES = 0
 HOST_THREADS = min(64, max(4, (os.cpu_count() or 8) // 2))
 
 
+def _single_rank_group() -> bool:
+    """``SD_DIST_SINGLE_RANK_GROUP=1``: create a process group even for ONE rank and send every payload through it.  A one-rank
+    job needs no collective; the switch exists because a one-GPU box is the only hardware the test suite gets, RCCL refuses
+    two ranks on one device, and a group of one is then the only way to run the "nccl" branches (device tensors handed to
+    ``dist.scatter`` / ``dist.gather`` / ``dist.broadcast``, asynchronous work handles, the communication stream) on RCCL
+    itself rather than on the host-staged gloo stand-in."""
+    return os.environ.get('SD_DIST_SINGLE_RANK_GROUP') == '1'
+
+
+def collectives_active() -> bool:
+    """True when payloads travel through the process group: more than one rank, or a one-rank group made on purpose."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _single_rank_group())
+
+
+_collectives = collectives_active
+
+
 def init_distributed(backend: Optional[str] = None):
     """Initialise from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).
-    Returns (rank, world_size, local_rank).  World size 1 needs no process group."""
+    Returns (rank, world_size, local_rank).  World size 1 needs no process group (but see `_single_rank_group`)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _single_rank_group()) and not dist.is_initialized():
+        os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend is None:
@@ -116,8 +134,7 @@ def unflatten_state(model, flat: torch.Tensor) -> None:
 
 def broadcast_weights(model, src: int = 0, device: Optional[torch.device] = None) -> None:
     """Make every rank's `model` (``nn.Module`` or ``state_dict``) equal to rank `src`'s (Coll-1 of SURVEY.md 2.2)."""
-    _, world = world_info()
-    if world == 1:
+    if not _collectives():
         return
     flat = flatten_state(model)
     if device is not None:
@@ -134,7 +151,7 @@ def gather_to_root(local: torch.Tensor, dst: int = 0, async_op: bool = False, ou
     buffer so that steady-state steps allocate nothing.  A failing collective propagates: there is no fallback to
     another collective (a rank that switched alone would mismatch the others and hang the job)."""
     rank, world = world_info()
-    if world == 1:
+    if not _collectives():
         return [local], None
     bufs = None
     if rank == dst:
@@ -159,7 +176,7 @@ def scatter_from_root(payloads: Optional[Sequence[torch.Tensor]], like: torch.Te
     """Coll-2: rank `src` hands payloads[r] (all shaped like `like`) to rank r; returns this rank's payload (and the
     work handle when `async_op`)."""
     rank, world = world_info()
-    if world == 1:
+    if not _collectives():
         return (payloads[0], None) if async_op else payloads[0]
     if out is None:
         out = torch.empty_like(like)
@@ -236,6 +253,7 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
     import itertools
     import numpy as np
     rank, world = world_info()
+    coll = _collectives()          # payloads go through the process group (world > 1, or a one-rank group made on purpose)
     vs, cs, ol = (np.asarray(v, dtype=np.int64) for v in (vol_shape, chunk_shape, halo))
     grid = [int(-(-vs[i] // cs[i])) for i in range(3)]
     ids = list(itertools.product(*[range(g) for g in grid]))
@@ -280,8 +298,8 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
         out_dev = torch.empty(full_shape, dtype=torch.uint8, device=device)
         if out is None:
             out = torch.empty(full_shape, dtype=torch.uint8, pin_memory=True)
-        stage = [torch.empty((world, *in_shape), dtype=torch.uint8, device=device) for _ in range(2)] if world > 1 else None
-        recv = [torch.empty((world, *out_shape), dtype=torch.uint8, device=device) for _ in range(2)] if world > 1 else None
+        stage = [torch.empty((world, *in_shape), dtype=torch.uint8, device=device) for _ in range(2)] if coll else None
+        recv = [torch.empty((world, *out_shape), dtype=torch.uint8, device=device) for _ in range(2)] if coll else None
         up_next = [0 if not vol.is_cuda else int(vs[0])]          # first z-plane of the volume not yet uploaded
         rows_left = [grid[1] * grid[2]] * grid[0]                 # chunks of every row of chunks that are not in out_dev yet
     elif root:
@@ -318,7 +336,7 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
             # (uploads stay in z order, one contiguous copy each), then one sd_tile_gather per chunk of the round
             with torch.cuda.stream(s_in):
                 if r >= 2:       # round r-2's scatter has consumed stage[s] (world > 1) / its kernels have consumed in_buf[s]
-                    s_in.wait_event(ev_scat[s] if world > 1 else ev_pred[s])
+                    s_in.wait_event(ev_scat[s] if coll else ev_pred[s])
                 need = min(int(vs[0]), max((int(c[0]) + 1) * int(cs[0]) + int(ol[0]) for c in rounds[r]))
                 while up_next[0] < need:
                     z1 = min(int(vs[0]), (up_next[0] // int(cs[0]) + 1) * int(cs[0]))
@@ -326,7 +344,7 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
                     up_next[0] = z1
                 for k, c in enumerate(rounds[r]):
                     lo = np.asarray(c, dtype=np.int64) * cs - ol
-                    tile_gather(vol_dev, lo, in_shape, stage[s][workers[k]] if world > 1 else in_buf[s])
+                    tile_gather(vol_dev, lo, in_shape, stage[s][workers[k]] if coll else in_buf[s])
                 ev_h2d[s].record(s_in)
             packed[s] = r
             return
@@ -345,7 +363,7 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
                 HOST_BOX_COPIES += 1
                 host_box_copy(dst[a[0] - lo[0]:b[0] - lo[0], a[1] - lo[1]:b[1] - lo[1], a[2] - lo[2]:b[2] - lo[2]],
                               vol[a[0]:b[0], a[1]:b[1], a[2]:b[2]], HOST_THREADS)
-        if world == 1:
+        if not coll:
             in_buf[s].copy_(pin_in[s][0])
         packed[s] = r
 
@@ -355,7 +373,7 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
         s = r & 1
         pack_upload(r)
         note('scatter', r)
-        if world == 1:
+        if not coll:
             if cuda:
                 cur.wait_event(ev_h2d[s])
             return None
@@ -373,7 +391,7 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
         """gather round r's results to rank 0 (communication stream) and download them into pin_out[r % 2] (copy-out stream)"""
         s = r & 1
         note('gather', r)
-        if world > 1:
+        if coll:
             with comm_ctx():
                 if cuda:
                     s_comm.wait_event(ev_pred[s])
@@ -387,17 +405,17 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
             # device path: place the round's results in the device-resident result volume (copy-out stream), and download every
             # row of chunks that is complete now -- one contiguous slab per output channel
             with torch.cuda.stream(s_out):
-                s_out.wait_event(ev_gath[s] if world > 1 else ev_pred[s])
+                s_out.wait_event(ev_gath[s] if coll else ev_pred[s])
                 for k, c in enumerate(rounds[r]):
                     lo = np.asarray(c, dtype=np.int64) * cs
-                    tile_scatter(recv[s][workers[k]] if world > 1 else res_buf[s], (0, 0, 0), np.minimum(cs, vs - lo), out_dev, lo)
+                    tile_scatter(recv[s][workers[k]] if coll else res_buf[s], (0, 0, 0), np.minimum(cs, vs - lo), out_dev, lo)
                     rows_left[c[0]] -= 1
                     if rows_left[c[0]] == 0:
                         z0, z1 = int(c[0]) * int(cs[0]), min(int(vs[0]), (int(c[0]) + 1) * int(cs[0]))
                         for ch in range(n_out):
                             out[ch, z0:z1].copy_(out_dev[ch, z0:z1], non_blocking=True)
                 ev_d2h[s].record(s_out)                          # (recv[s] / res_buf[s] are free again)
-        elif root and world == 1:
+        elif root and not coll:
             pin_out[s][0].copy_(res_buf[s])
 
     def stitch(r):
@@ -429,7 +447,7 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
             pend = issue_scatter(r + 1) if (pipelined and r + 1 < nr) else None
             note('predict', r)
             if cuda and r >= 2:          # res_buf[s] is free again: round r-2's gather (download for world size 1) has read it
-                cur.wait_event(ev_gath[s] if world > 1 else ev_d2h[s])
+                cur.wait_event(ev_gath[s] if coll else ev_d2h[s])
             if my_slot >= 0 and my_slot < len(rounds[r]):
                 if wants_box:
                     res_buf[s].copy_(predict_fn(in_buf[s], valid_box=valid_box_of(rounds[r][my_slot])))
@@ -462,14 +480,12 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
 
 
 def barrier():
-    _, world = world_info()
-    if world > 1:
+    if _collectives():
         dist.barrier()
 
 
 def max_over_ranks(value: float, device: Optional[torch.device] = None) -> float:
-    _, world = world_info()
-    if world == 1:
+    if not _collectives():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else 'cpu')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -2,7 +2,10 @@
 ``predict_volume_distributed`` ON THE DEVICE -- copy streams, communication stream, buffer-reuse events, scatter(r+1) issued before
 predict(r), ``root_computes=False``, the pinned pool -- compared bit for bit with the single-process result for every combination
 of `pipelined` and `root_computes`, with >= 5 rounds and a ragged last round.  Backend: RCCL when the box has two GPUs, otherwise
-gloo with host-staged payloads and both ranks on cuda:0 (syconn_amd.parallel._staged)."""
+gloo with host-staged payloads and both ranks on cuda:0 (syconn_amd.parallel._staged).  Launched as ONE rank with
+``SD_DIST_SINGLE_RANK_GROUP=1`` the same protocol runs through a process group of one on RCCL (device tensors in ``dist.scatter`` /
+``dist.gather``, asynchronous work handles waited on from the compute / communication stream): the "nccl" branches a one-GPU box can
+execute."""
 import os
 import sys
 
@@ -15,8 +18,16 @@ sys.path.insert(0, ROOT)
 
 def main():
     from syconn_amd import parallel as par
-    two = torch.cuda.device_count() >= 2
+    single = os.environ.get('SD_DIST_SINGLE_RANK_GROUP') == '1' and int(os.environ.get('WORLD_SIZE', '1')) == 1
+    two = torch.cuda.device_count() >= 2 or single
     rank, world, local_rank = par.init_distributed('nccl' if two else 'gloo')
+    if single:
+        assert torch.distributed.is_initialized() and torch.distributed.get_backend() == 'nccl' and par._collectives()
+        # Coll-1 on RCCL: the broadcast of the flat weight vector as a DEVICE tensor
+        sd = {'a.weight': torch.arange(24, dtype=torch.float32).reshape(2, 3, 4), 'a.bias': torch.ones(2)}
+        par.broadcast_weights(sd, src=0, device=torch.device('cuda', 0))
+        assert torch.equal(sd['a.weight'], torch.arange(24, dtype=torch.float32).reshape(2, 3, 4))
+        assert par.max_over_ranks(3.5, torch.device('cuda', 0)) == 3.5
     dev = torch.device('cuda', local_rank if two else 0)
     torch.cuda.set_device(dev)
     from syconn_amd.engine import require_gpu
@@ -66,7 +77,7 @@ def main():
                 out = par.predict_volume_distributed(vol if rank == 0 else None, vol_shape, chunk, halo, predict_fn, n_out=2,
                                                      device=dev, pipelined=pipelined, root_computes=root_computes, trace=trace)
                 torch.cuda.synchronize(dev)
-                nr = -(-27 // (2 if root_computes else 1))
+                nr = -(-27 // (world if root_computes else max(1, world - 1)))
                 assert nr >= 5
                 if rank == 0:
                     assert out is not None and torch.equal(out, want), (pipelined, root_computes, rep)
@@ -81,7 +92,7 @@ def main():
                         assert pos[('stitch', r)] < pos[('scatter', r + 1)]
     par.barrier()
     if rank == 0:
-        print('DIST_GPU_WORKER_OK backend=%s' % ('nccl' if two else 'gloo-staged'))
+        print('DIST_GPU_WORKER_OK backend=%s world=%d' % ('nccl' if two else 'gloo-staged', world))
     torch.distributed.destroy_process_group()
     return 0 if ok else 1
 

@@ -92,13 +92,16 @@ def test_shard_units_matches_reference_partition():
     assert par.shard_units(range(3), 5, 8) == []
 
 
-def _worker_volume(rank, world, port, q):
+def _worker_volume(rank, world, port, q, single=False):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
                       MASTER_PORT=str(port))
+    if single:
+        os.environ['SD_DIST_SINGLE_RANK_GROUP'] = '1'
     import torch.distributed as dist
     from syconn_amd import parallel as par
     par.init_distributed('gloo')
+    assert par._collectives() and dist.get_world_size() == world
     vol_shape, chunk, halo = (20, 30, 26), (8, 16, 12), (2, 3, 1)
     vol = torch.from_numpy(np.random.default_rng(0).integers(0, 200, vol_shape, dtype=np.uint8)) if rank == 0 else None
 
@@ -149,6 +152,18 @@ def test_two_rank_chunk_scatter_predict_gather():
         p.join(60)
         assert p.exitcode == 0
     assert ok, 'distributed chunk prediction does not reproduce the single-process result'
+
+
+def test_group_of_one_sends_every_payload_through_the_process_group():
+    """``SD_DIST_SINGLE_RANK_GROUP=1``: a process group of ONE rank through which every payload still travels (how the GPU suite
+    runs the collectives on RCCL on a one-GPU box, tests/test_gpu_multirank.py); here on gloo: same volume, same issue order."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_volume, args=(0, 1, _free_port(), q, True))
+    p.start()
+    ok = q.get(timeout=120)
+    p.join(60)
+    assert p.exitcode == 0 and ok
 
 
 def test_single_process_volume_prediction_is_the_same_code_path():
