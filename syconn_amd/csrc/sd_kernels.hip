@@ -1138,10 +1138,10 @@ static int launch_upconv_t(const UpconvParams& p, int NB, hipStream_t s) {
     // the store-bound full-resolution shapes get the row-coalescing kernel (64 -> 32 channels: 77 -> 52 us at 128^3);
     // at 128 -> 64 channels it needs its weights in LDS (plain rows kernel 85 us, k_upconv_mfma 63 us, LDS weights with
     // one tap pair per workgroup and two workgroups per CU 51 us; 48 -> 33 us per tile at 8 tiles per launch)
-    if (p.nchunk == 4 && p.Cd == 32) return launch_upconv_rows<T, 4, 2>(p, s);
+    static const bool no_wl = getenv("SD_NO_UPCONV_WL") != nullptr;
+    if (p.nchunk == 4 && p.Cd == 32) return (no_wl || getenv("SD_UPCONV32_NO_WL")) ? launch_upconv_rows<T, 4, 2>(p, s) : launch_upconv_rows_wl<T, 4, 2>(p, s);
     if (p.nchunk == 3 && p.Cd == 32) return launch_upconv_rows<T, 3, 2>(p, s);
     if (p.nchunk == 2 && p.Cd == 16) return launch_upconv_rows<T, 2, 1>(p, s);
-    static const bool no_wl = getenv("SD_NO_UPCONV_WL") != nullptr;
     if (p.nchunk == 8 && p.Cd == 64 && !no_wl) return launch_upconv_rows_wl<T, 8, 4>(p, s);
     // (192 -> 96 channels: k_upconv_mfma 76 us, LDS-weight rows kernel 83 us per tile in the channel-blocked layout)
     if (p.nchunk == 6 && p.Cd == 48) return no_wl ? launch_upconv_rows<T, 6, 3>(p, s) : launch_upconv_rows_wl<T, 6, 3>(p, s);
@@ -1161,7 +1161,7 @@ int launch_upconv(const UpconvParams& p, int act_dtype, int NB, hipStream_t s) {
         const long M = (long)p.D * p.H * p.W;
         if (M >= (1l << 31) || p.gn) return SD_ERR_INVALID;
         static const bool no_rows = getenv("SD_SPLIT_NO_ROWS") != nullptr;      // A/B switch
-        if (!no_rows && p.nchunk == 12 && p.Cd == 32) {       // 64 -> 32 channels (level 0)
+        if (!no_rows && p.nchunk == 12 && p.Cd == 32 && getenv("SD_SPLIT_ROWS32_NO_WL")) {       // 64 -> 32 channels (level 0), weights from L2
             dim3 grid((unsigned)((M + 127) / 128), 1, p.batch), block(256);
             hipLaunchKernelGGL((k_upconv_rows<f16_t, 4, 2, false, false, true>), grid, block, 4 * 32 * 64 * 2, s, p);
             return SD_LAUNCH_CHECK();
@@ -1179,6 +1179,10 @@ int launch_upconv(const UpconvParams& p, int act_dtype, int NB, hipStream_t s) {
             hipLaunchKernelGGL(kern, grid, block, lds, s, p);
             return SD_LAUNCH_CHECK();
         };
+        // 64 -> 32 channels (level 0) with the weights in LDS as well: without them every wave fetched 24 KiB of weight fragments from L2
+        // per 32 input voxels and y-tap, three times the 8 KiB it writes (SD_SPLIT_ROWS32_NO_WL: the round-4 form, A/B)
+        if (!no_rows && p.nchunk == 12 && p.Cd == 32 && !getenv("SD_SPLIT_ROWS32_NO_WL"))
+            return rows_wl(k_upconv_rows<f16_t, 4, 2, true, false, true>, 2, 12);
         if (!no_rows && p.nchunk == 24 && p.Cd == 64) return rows_wl(k_upconv_rows<f16_t, 8, 4, true, false, true>, 4, 24);     // 128 -> 64
         if (!no_rows && p.nchunk == 18 && p.Cd == 48) return rows_wl(k_upconv_rows<f16_t, 6, 3, true, false, true>, 3, 18);     // 96 -> 48
         // (192 -> 96 channels: 36 weight groups per column tile do not fit the LDS beside the transpose tiles: weights from L2)

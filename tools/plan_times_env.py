@@ -31,6 +31,9 @@ ref = None
 for rep in range(3):
     for e in envs:
         dm = models[e]
+        kv = [p.split('=') for p in e.split(',') if p]
+        for k, v in kv:                      # (launch-time switches are read per launch)
+            os.environ[k] = v
         for _ in range(2):
             lab = dm.forward_labels_batch(x, ids, thr)
         torch.cuda.synchronize()
@@ -44,6 +47,8 @@ for rep in range(3):
             dm.forward_labels_batch(x, ids, thr)
         res[e].append(sum(dm.profile_read(k) for k in range(8)) / 8 / 8 * 1e3)
         dm.profile(0)
+        for k, v in kv:
+            os.environ.pop(k)
 for e in envs:
     us = np.mean(res[e], axis=0)
     print(f'{e or "(default)":28s}', ' '.join(f'{i}:{u:.1f}' for i, u in enumerate(us) if u > 0), f'sum {us.sum():.1f}',
