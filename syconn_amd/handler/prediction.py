@@ -429,6 +429,8 @@ def dense_predictor(args):
     from ..engine import mag_pyramid, postproc_labels, tile_scatter
     chunk_ids, kd_p, target_p, model_p, overlap_shape, overlap_shape_tiles, tile_shape, chunk_size, n_channel, \
         target_channels, target_kd_path_list, channel_thresholds, mag, cube_of_interest = args
+    import time as _time
+    t_start = _time.perf_counter()
 
     kd = KnossosDataset()
     kd.initialize_from_knossos_path(kd_p)
@@ -495,8 +497,8 @@ def dense_predictor(args):
     torch.cuda.set_device(dev)
     s_in, s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
 
-    import time as _time
     spent = {'read': 0.0, 'gpu': 0.0, 'write': 0.0}       # seconds per pipeline stage (SYCONN_AMD_IO_TIMING=1 logs them)
+    t_setup = _time.perf_counter() - t_start              # datasets opened, model planned, workspace reserved
 
     read_bufs = {}
 
@@ -628,13 +630,15 @@ def dense_predictor(args):
     t0 = _time.perf_counter()
     for tkd in target_kd_dict.values():
         tkd.flush()
-    spent['write'] += _time.perf_counter() - t0
+    t_flush = _time.perf_counter() - t0
+    spent['write'] += t_flush
     if predictor.n_fallbacks:
         log_main.warning(f'dense_predictor: {predictor.n_fallbacks} of {len(chunk_ids)} chunk(s) overflowed fp16 storage and were predicted '
                          f'in the fallback plan ({_FALLBACK.get(act_dtype, "?")})')
     if os.environ.get('SYCONN_AMD_IO_TIMING'):
         log_main.warning('dense_predictor stages over %d chunk(s): read + H2D %.2f s (reader thread), launch %.2f s (main thread), '
-                         'D2H + write %.2f s (writer thread)', len(chunk_ids), spent['read'], spent['gpu'], spent['write'])
+                         'D2H + write %.2f s (writer thread; includes waiting for the kernels and %.2f s of final flush); setup %.2f s, total %.2f s',
+                         len(chunk_ids), spent['read'], spent['gpu'], spent['write'], t_flush, t_setup, _time.perf_counter() - t_start)
 
 
 def _wd_set() -> bool:

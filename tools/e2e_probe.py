@@ -8,7 +8,7 @@ from syconn_amd.handler.config import generate_default_conf
 from syconn_amd.handler import prediction as P
 from syconn_amd.knossos import KnossosDataset
 
-shape_xyz = (1024, 1024, 256)
+shape_xyz = tuple(int(v) for v in os.environ.get('E2E_SHAPE', '1024,1024,256').split(','))      # x, y, z
 geo = {'overlap_shape_tiles': [16, 16, 8], 'chunk_size': [480, 480, 240], 'tile_shape': [256, 256, 128], 'act_dtype': 'bf16'}
 if os.environ.get('E2E_DEFAULT'):      # the reference's own chunk / tile geometry and the default storage type (f16x2)
     geo = {}
