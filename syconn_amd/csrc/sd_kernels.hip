@@ -305,15 +305,24 @@ __global__ __launch_bounds__(256) void k_upconv_mfma(const UpconvParams p) {
 // WL every wave re-reads all its weights from L2 for each 32 voxels, which bounds the 128 -> 64 channel up-convolution.
 // SPLIT (split-fp16 plan): NCH counts the REAL input chunks n; the 2n planes [hi | lo] of the input stay in registers and meet the
 // 3n weight groups [lo | hi | hi] (virtual chunks [hi | hi | lo]); every output row is written twice, hi planes then lo planes.
-template <typename T, int NCH, int NTAB, bool WL, bool GN, bool SPLIT = false>
+// G > 1 (needs WL): the output channels are dealt to G workgroups per (z-tap, y-tap) pair, CD / G channels (a multiple of 32) of BOTH
+// x-taps each -- blockIdx.y = pair * G + group.  A workgroup then keeps NTAB / G column tiles of weights in LDS: the split plan's
+// 192 -> 96 channel shape has 36 weight groups per tile, 216 KiB for all six tiles but 72 KiB for two; with its weights left in L2
+// every wave fetched 864 KiB of fragments per 32 input voxels (500 us per 128^3 tile, 9 % of semseg_axon's split plan).  The
+// price is that the input planes are read by G times as many workgroups.
+template <typename T, int NCH, int NTAB, bool WL, bool GN, bool SPLIT = false, int G = 1>
 __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
     constexpr int NX = SPLIT ? 2 * NCH : NCH;      // activation planes held in registers
     constexpr int NV = SPLIT ? 3 * NCH : NCH;      // weight groups per column tile
     static_assert(!(SPLIT && GN), "split plan: no deferred GroupNorm");
+    static_assert(G == 1 || (WL && NTAB % (2 * G) == 0), "channel groups: LDS weights, whole tiles of each x-tap per group");
     using v8 = typename Act<T>::v8;
     using v4 = typename Act<T>::v4;
     typedef __attribute__((ext_vector_type(4))) unsigned u4;
-    constexpr int CD = NTAB * 16;            // channel stride of the output
+    constexpr int CDR = NTAB * 16;           // channels of the output tensor
+    constexpr int NTL = NTAB / G;            // column tiles of this workgroup
+    constexpr int TPT = NTL / 2;             // ... per x-tap (G > 1)
+    constexpr int CD = NTL * 16;             // channels this workgroup computes
     constexpr int ROW = 4 * CD;              // bytes per input voxel per (a,b): 2 taps * CD * 2 B
     constexpr int PPV = ROW / 16;            // 16-byte pieces per voxel
     constexpr int SWM = (PPV % 8 == 0) ? 7 : (PPV % 4 == 0) ? 3 : (PPV % 2 == 0) ? 1 : 0;   // XOR mask must divide the row
@@ -338,8 +347,19 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
     // weight fragments of one (z-tap, y-tap) pair: the NTAB column tiles [ab*NTAB, ab*NTAB + NTAB) live in blocks of two
     // tiles (NCH * 2 KiB each); an odd NTAB straddles one block more (the launcher sizes the LDS for NTAB/2 + 2 blocks)
     const char* const wlds = smem + 4 * 32 * ROW;
-    const int a_wg = WL ? (int)blockIdx.y : 0;
-    if constexpr (WL) {
+    const int a_wg = WL ? (int)blockIdx.y / G : 0;
+    const int grp = G > 1 ? (int)blockIdx.y % G : 0;
+    // tile of the (pair, x-tap, channel) numbering n = tap * CDR + co that local tile jl of this workgroup is
+    auto tile_of = [&](int ab, int jl) { return G == 1 ? ab * NTAB + jl : ab * NTAB + (jl / TPT) * (NTAB / 2) + grp * TPT + jl % TPT; };
+    if constexpr (WL && G > 1) {
+        // [local tile][weight group][64 lanes] x 16 bytes; in the packed image tile t is half (t & 1) of block t >> 1, [block][group][half]
+        for (int i = tid; i < NTL * NV * 64; i += 256) {
+            const int piece = i >> 6, jl = piece / NV, c = piece - jl * NV, tl = tile_of(a_wg, jl);
+            *reinterpret_cast<u4*>(smem + 4 * 32 * ROW + (size_t)i * 16) =
+                *reinterpret_cast<const u4*>(reinterpret_cast<const char*>(wp) + ((((size_t)(tl >> 1) * NV + c) * 2 + (tl & 1)) * 64 + (i & 63)) * 16);
+        }
+        __syncthreads();
+    } else if constexpr (WL) {
         const int first_blk = (a_wg * NTAB) >> 1, last_blk = (a_wg * NTAB + NTAB - 1) >> 1;
         const int nbytes = (last_blk - first_blk + 1) * NV * 2048;
         const char* const wsrc = reinterpret_cast<const char*>(wp) + (size_t)first_blk * NV * 2048;
@@ -372,22 +392,24 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
     for (int ab = ab0; ab < nab; ++ab) {
         // the accumulators start from the folded bias (the summation order of k_conv_mfma and of the fused level-0 decoder:
         // bias, then the input chunks in order -- the three plans must agree bit for bit)
-        f32x16 acc[NTAB];
+        f32x16 acc[NTL];
 #pragma unroll
-        for (int j = 0; j < NTAB; ++j)
+        for (int j = 0; j < NTL; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + ab * 2 * CD + 32 * j + 8 * q + 4 * half);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + 32 * tile_of(ab, j) + 8 * q + 4 * half);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[j][4 * q + e] = b[e];
             }
 #pragma unroll
         for (int c = 0; c < NV; ++c) {
 #pragma unroll
-            for (int j = 0; j < NTAB; ++j) {
+            for (int j = 0; j < NTL; ++j) {
                 const int tl = ab * NTAB + j;             // global 32-column tile (n = tap*CD + co ordering)
                 v8 wf;
-                if constexpr (WL) {
+                if constexpr (WL && G > 1) {
+                    wf = *reinterpret_cast<const v8*>(wlds + (((j * NV + c) * 64 + lane) * 16));
+                } else if constexpr (WL) {
                     const int tloc = ab * NTAB + j - 2 * ((ab0 * NTAB) >> 1);
                     wf = *reinterpret_cast<const v8*>(wlds + ((((tloc >> 1) * NV + c) * 2 + (tloc & 1)) * 64 + lane) * 16);
                 } else {
@@ -400,7 +422,7 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
         for (int pass = 0; pass < (SPLIT ? 2 : 1); ++pass) {      // (split plan: hi planes, then lo planes, through the same LDS tile)
         // accumulators -> rounded rows in the wave's LDS tile: voxel vl, columns 32j + 8q + 4*half + e
 #pragma unroll
-        for (int j = 0; j < NTAB; ++j) {
+        for (int j = 0; j < NTL; ++j) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 v4 o;
@@ -450,7 +472,7 @@ __global__ __launch_bounds__(256) void k_upconv_rows(const UpconvParams p) {
             if (okv[it & 1]) {
                 const size_t ov = ovv[it & 1] + tap;
                 const u4 val = *reinterpret_cast<const u4*>(tile + v * ROW + ((piece ^ (v & SWM)) * 16));
-                *reinterpret_cast<u4*>(dst + (((size_t)(chunk + pass * (CD / 16)) * p.Pd + ov) * SD_CHUNK + hf * 8) * sizeof(T)) = val;
+                *reinterpret_cast<u4*>(dst + (((size_t)(grp * (CD / 16) + chunk + pass * (CDR / 16)) * p.Pd + ov) * SD_CHUNK + hf * 8) * sizeof(T)) = val;
             }
         }
         }
@@ -1185,7 +1207,20 @@ int launch_upconv(const UpconvParams& p, int act_dtype, int NB, hipStream_t s) {
             return rows_wl(k_upconv_rows<f16_t, 4, 2, true, false, true>, 2, 12);
         if (!no_rows && p.nchunk == 24 && p.Cd == 64) return rows_wl(k_upconv_rows<f16_t, 8, 4, true, false, true>, 4, 24);     // 128 -> 64
         if (!no_rows && p.nchunk == 18 && p.Cd == 48) return rows_wl(k_upconv_rows<f16_t, 6, 3, true, false, true>, 3, 18);     // 96 -> 48
-        // (192 -> 96 channels: 36 weight groups per column tile do not fit the LDS beside the transpose tiles: weights from L2)
+        // 192 -> 96 channels: the 36 weight groups of all six column tiles do not fit the LDS; three workgroups per tap pair with the
+        // two tiles of 32 channels each (k_upconv_rows<G = 3>: 72 KiB of weights + 16 KiB of transpose tiles)
+        if (!no_rows && p.nchunk == 36 && p.Cd == 96 && !getenv("SD_SPLIT_NO_ROWS96") && !getenv("SD_SPLIT_ROWS96_L2")) {
+            auto kern = k_upconv_rows<f16_t, 12, 6, true, false, true, 3>;
+            const size_t lds = (size_t)4 * 32 * 128 + (size_t)2 * 36 * 1024;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return SD_ERR_HIP;
+            const int per_cu = std::max(1, (int)(SD_LDS_BYTES / lds));
+            const long want = std::max(1L, (long)SD_NUM_CU * per_cu * 2 / (2 * p.kz * 3 * p.batch));
+            dim3 grid((unsigned)std::min((M + 127) / 128, want), 2 * p.kz * 3, p.batch), block(256);
+            hipLaunchKernelGGL(kern, grid, block, lds, s, p);
+            return SD_LAUNCH_CHECK();
+        }
+        // (SD_SPLIT_ROWS96_L2: the round-4 form of that shape, weights from L2 -- A/B)
         if (!no_rows && p.nchunk == 36 && p.Cd == 96 && !getenv("SD_SPLIT_NO_ROWS96")) {
             auto kern = k_upconv_rows<f16_t, 12, 6, false, false, true>;
             const size_t lds = (size_t)4 * 32 * 64 * 6;
