@@ -25,7 +25,11 @@ template <int KZ, int NT>
 int launch_conv_split_knt(const ConvParams& p, int NB, hipStream_t s) {
     const long vox = (long)p.D * p.H * p.W * p.batch;
     const int nstages = (p.nchunk0 + p.nchunk1) * KZ;
-    const bool big = (vox / 512) * NB >= 512;      // the form rules of launch_conv_knt (sd_kernels.hip)
+    // the form rules of launch_conv_knt (sd_kernels.hip), incl. round 5's: 512-voxel workgroups from 256 of them on (deep layers stream
+    // their weights once per workgroup), planar 96-column layers always as 4-wave workgroups
+    const char* const big_env = getenv("SD_BIG_MIN");      // (A/B switches, read per launch)
+    const long big_min = big_env ? atol(big_env) : 256;
+    const bool big = (vox / 512) * NB >= big_min && !(KZ == 1 && NT == 3 && !getenv("SD_PLANAR_NT3_BIG"));
     const bool ff = p.final_wfrag != nullptr;
     static const size_t wres8 = (size_t)(getenv("SD_SPLIT_WRES8_KB") ? atoi(getenv("SD_SPLIT_WRES8_KB")) : 96) * 1024;
     if (big) {
