@@ -632,7 +632,7 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
         for (size_t i = 0; i + 1 < m->ops.size(); ++i) {
             Op& f = m->ops[i];
             Op& c = m->ops[i + 1];
-            if (f.d.kind == SD_OP_CONV && f.first && f.d.kz == 1 && m->bufCp[f.d.dst] == 32 && f.d.cout == 32 &&
+            if (f.d.kind == SD_OP_CONV && f.first && f.d.kz == 1 && m->bufCp[f.d.dst] == 32 &&      // (17 ... 32 filters: padding channels have zero weights and bias)
                 c.d.kind == SD_OP_CONV && !c.first && c.d.kz == 1 && c.d.src0 == f.d.dst && c.d.src1 < 0 &&
                 !getenv("SD_NO_FIRST_FUSE")) {
                 bool other_reader = false;
@@ -723,7 +723,7 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
             Op& f = m->ops[i];
             Op& c = m->ops[i + 1];
             if (f.d.kind == SD_OP_CONV && f.first && f.d.kz == 1 &&
-                ((m->bufCp[f.d.dst] == 32 && f.d.cout == 32) || (m->bufCp[f.d.dst] == 48 && f.d.cout == 48)) &&
+                (m->bufCp[f.d.dst] == 32 || m->bufCp[f.d.dst] == 48) &&      // (17 ... 32 / 33 ... 48 filters: padding channels have zero weights and bias)
                 c.d.kind == SD_OP_CONV && !c.first && c.d.kz == 1 && c.d.src0 == f.d.dst && c.d.src1 < 0 &&
                 !getenv("SD_NO_FIRST_FUSE")) {
                 bool other_reader = false;
