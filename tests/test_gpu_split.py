@@ -239,3 +239,27 @@ def test_split_fusions_agree_with_the_layer_wise_split_plan(gpu, monkeypatch):
         # (GroupNorm nets: the fused statistics sum in another order than the separate pass -- both within 1e-5 of the oracle)
         assert err <= (5e-6 if arch == 'mivcsj' else 2e-6), (arch, err)
         assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 1e-3, (arch, int(d.max()))
+
+
+@pytest.mark.parametrize('arch,act,ntiles,shape,switches', [
+    ('semseg_axon', 'f16x2', 1, (128, 128, 128), ('SD_SPLIT_ROWS96_L2', 'SD_PLANAR_NT3_BIG')),
+    ('mivcsj', 'f16x2', 4, (128, 128, 128), ('SD_SPLIT_ROWS96_L2', 'SD_PLANAR_NT3_BIG')),
+    ('semseg_spine', 'f16x2', 4, (8, 96, 128), ('SD_SPLIT_ROWS32_NO_WL',)),
+    ('semseg_spine', 'bf16', 4, (8, 96, 128), ('SD_UPCONV32_NO_WL',)),
+])
+def test_round5_up_convolution_and_workgroup_forms_are_bit_identical(gpu, monkeypatch, arch, act, ntiles, shape, switches):
+    """The forms picked in round 5 -- up-convolutions with LDS-resident weights (64 -> 32 channels; 192 -> 96 in three channel groups,
+    k_upconv_rows<G = 3>), planar 96-column layers as 4-wave workgroups in the split plan (sizes at which the 8-wave form used to be
+    picked) -- against the forms they replaced (launch-time switches): same logits, bit for bit."""
+    from syconn_amd import _lib as L
+    from syconn_amd.engine import DenseModel
+    from syconn_amd.cnn import random_state_dict
+    monkeypatch.setenv('SD_NO_DEC0', '1')            # (plain plan: the level-0 up-convolution as its own launch)
+    dm = DenseModel(random_state_dict(arch, seed=2, final_scale=4.0), act_dtype=act, device=gpu)
+    raw = torch.stack([_input(shape, 11 + k) for k in range(ntiles)]).to(gpu)
+    new = dm.forward_batch(raw, L.SD_OUT_LOGITS_F32).clone()
+    for sw in switches:
+        monkeypatch.setenv(sw, '1')
+    old = dm.forward_batch(raw, L.SD_OUT_LOGITS_F32)
+    assert torch.equal(new, old)
+    assert float(new.abs().max()) > 0 and not dm.overflowed()
