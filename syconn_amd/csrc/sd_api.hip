@@ -183,10 +183,12 @@ int infer_shapes(const sd_model* m, int D, int H, int W, std::vector<Dims>& dims
 // row arithmetic, H >= 8 for the cursor wraps -- are part of it, so a shape that passes here never fails in the launcher after
 // the intermediate buffers have been dropped from the workspace)
 bool dec0_shape_ok(const Dims& o) {
-    const int nstrip = (o.w + 63) / 64;
+    // (round 5: strips of 56 columns where they cover the width with fewer stream positions -- launch_dec0 picks; the fill rule
+    // counts positions: strips x (width + 4), 68 per 64-column strip)
+    const long cost = std::min<long>((long)((o.w + 63) / 64) * 68, (long)((o.w + 55) / 56) * 60);
     const long hp = 2 * (o.h / 2 + 1);
     return o.h >= 8 && (long)o.d * o.h < (1l << 24) && o.w < (1 << 24) && (long)o.d * hp * 68 <= (1l << 30) &&
-           (long)o.d * o.h * o.w < (1l << 31) && o.w * 10 >= nstrip * 64 * 7;
+           (long)o.d * o.h * o.w < (1l << 31) && (long)o.w * 10 * 68 >= cost * 64 * 7;
 }
 
 struct Box { int lo[3], hi[3]; bool any; };      // z,y,x; hi exclusive; any == false: "the whole tensor" / "nothing yet" by context

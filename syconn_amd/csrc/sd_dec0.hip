@@ -39,7 +39,9 @@
 
 namespace {
 
-constexpr int PW = 68;          // positions per stream row
+template <typename X> struct TypeTag { using type = X; };
+constexpr int PW_WIDE = 68;     // positions per stream row: 64 columns + 2 halo columns per conv and side (template parameter PW of k_dec0;
+constexpr int PW_NARROW = 60;   // 56 + 4 for widths that 64-column strips cover badly, e.g. 331 = 6 x 56 - 5 instead of 6 x 64 - 53)
 constexpr int ST = 128;         // positions per step
 constexpr int RU = 768;         // ring sizes in positions (multiples of 32; see the header of k_dec0 for the spans)
 constexpr int RS = 640;
@@ -74,8 +76,11 @@ __device__ __forceinline__ uint32_t wrap(uint32_t v, uint32_t ring) { return min
 // VIEW: the launch computes a sub-box of the tile (sd_model_set_roi): D, H, W, H1, W1 are the box, sH, sW, sH1, sW1 the y / x extents of
 // the tensors it lies in (the bases are shifted by the host); zero padding at a box border that is not the tensor's only reaches the
 // two outermost voxel shells, which the host keeps outside what it needs.
-template <typename T, int KIND, bool VIEW = false>
+// PW: positions per stream row = strip width + 4 (68 in the text above; every span there scales with it: a tap reaches PW + 1 positions,
+// a level-1 row of PW / 2 positions yields 2 * PW positions, up-conv tile u starts at or behind position 128u - 2 * PW).
+template <typename T, int KIND, bool VIEW = false, int PW = PW_WIDE>
 __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
+    static_assert(PW % 4 == 0 && PW <= PW_WIDE && PW >= 36, "ring sizes are laid out for rows of at most 68 positions");
     using v8 = typename Act<T>::v8;
     typedef __attribute__((ext_vector_type(4))) unsigned u4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
     const int zg = b % p.nzg; b /= p.nzg;
     const int strip = b % p.nstrip, tile = b / p.nstrip;
     const int z0 = zg * p.zsplit, nz = min(p.zsplit, p.D - z0);
-    const int c0 = strip * 64;
+    const int c0 = strip * (PW - 4);
     const int HP = p.HP, HP1 = p.HP1;
     const int PT = nz * HP * PW;
     const int nsteps = ((PT + ST - 1) / ST + 1) / 2 * 2 + 2;      // second conv runs in steps 2 .. nsteps-1: an even count
@@ -184,8 +189,8 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
 #pragma unroll
         for (int t9 = 0; t9 < 9; ++t9) {
             const int off = (t9 / 3) * PW + (t9 % 3);
-            aU[t9] = LDS_U + rec_off(wrap((uint32_t)(QOFF + 32 * cw - 69) % RU + off + l31, RU), half);
-            aS[t9] = LDS_S + rec_off(wrap((uint32_t)(QOFF + 32 * cw - 69) % RS + off + l31, RS), half);
+            aU[t9] = LDS_U + rec_off(wrap((uint32_t)(QOFF + 32 * cw - (PW + 1)) % RU + off + l31, RU), half);
+            aS[t9] = LDS_S + rec_off(wrap((uint32_t)(QOFF + 32 * cw - (PW + 1)) % RS + off + l31, RS), half);
         }
         uint32_t dS = (uint32_t)(QOFF + ST * (-5 + 3) + 32 * cw) % RS;          // ring index of the skip piece (uniform)
         Cur cs = cur_at(ST * (-5 + 3) + 32 * cw + (lane >> 1), PW, HP);        // ... its position handled by this lane
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
                 glds16(s0, smem + LDS_S + dS * 32);
                 glds16(s1, smem + LDS_S + RS * 32 + dS * 32);
                 dS += ST; if (dS >= RS) dS -= RS;
-                cur_adv(cs, ST - PW, 1, PW, HP);
+                cur_adv(cs, ST % PW, ST / PW, PW, HP);
             }
             {   // level-1 piece: chunk cw of up-conv tile u = k + 5
                 const int u = k + 5;
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
                     s0 = lvl1 + chunk_l1 + (((size_t)__umul24(row, sW1) + x1) * 32 + dh * 16);
                 }
                 glds16(s0, smem + LDS_L + ((u & 3) * 4 + cw) * 1024);
-                cur_adv(cl, 32, 0, PW / 2, HP1);
+                cur_adv(cl, 32 % (PW / 2), 32 / (PW / 2), PW / 2, HP1);
             }
             D0_T(1);
 #ifdef SD_PROBE_DEC0_NO_MERGE
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
                 const bool ok = (unsigned)cm.plane < (unsigned)nz && cm.y < gH && (unsigned)(c0 - 2 + cm.xx) < (unsigned)gW;
                 write_tile(acc, ok, cC, cCsw);
                 cC = (cC & ~(uint32_t)(RC * 32 - 1)) | ((cC + ST * 32) & (RC * 32 - 1));
-                cur_adv(cm, ST - PW, 1, PW, HP);
+                cur_adv(cm, ST % PW, ST / PW, PW, HP);
             }
             D0_T(3);
             // everything this wave DMA'd in the PREVIOUS step has landed (3 instructions per step, in order)
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)      // up-conv fragments: [tap pair][chunk][tap & 1][64 lanes][8]
             wu[c] = reinterpret_cast<const v8*>(p.wup)[(((ow >> 1) * 4 + c) * 2 + (ow & 1)) * 64 + lane];
-        uint32_t uB = (uint32_t)(QOFF + ST * (-5 + 3) - 136) % RU;      // ring index of position 128u - 136, u = k + 3
+        uint32_t uB = (uint32_t)(QOFF + ST * (-5 + 3) - 2 * PW) % RU;      // ring index of position 128u - 2 PW, u = k + 3
         uint32_t aC[9];      // tap fragment addresses of the second conv's tile (chunk 0), for k = 2
 #pragma unroll
         for (int t9 = 0; t9 < 9; ++t9) {
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
                         if (c < gcout) out[(size_t)c * nvox + v] = l[c];
                 }
             }
-            cur_adv(co, 2 * ST - 3 * PW, 3, PW, HP);
+            cur_adv(co, (2 * ST) % PW, (2 * ST) / PW, PW, HP);
         };
         for (int k = -5; k < nsteps; ++k) {
             const int u = k + 3;
@@ -430,12 +435,12 @@ __global__ __launch_bounds__(512, 2) void k_dec0(const Dec0Params p) {
                 });
                 const int y = 2 * cu.y + py, xx = 2 * cu.xx + px;
                 const bool ok = (unsigned)cu.plane < (unsigned)nz && y < gH && (unsigned)(c0 - 2 + xx) < (unsigned)gW;
-                // position relative to 128u - 136 (>= 0, < 396 for every lane of the tile), then the ring index
-                const int qrel = (cu.plane * HP + y) * PW + xx - (ST * u - 136);
+                // position relative to 128u - 2 PW (>= 0, < 396 for every lane of the tile), then the ring index
+                const int qrel = (cu.plane * HP + y) * PW + xx - (ST * u - 2 * PW);
                 const uint32_t idx = wrap(uB + (uint32_t)qrel, RU);
                 write_tile(acc, ok, LDS_U + half * (RU * 32) + (idx << 5), ((idx >> 3) & 1u) << 4);
             }
-            cur_adv(cu, 32, 0, PW / 2, HP1);
+            cur_adv(cu, 32 % (PW / 2), 32 / (PW / 2), PW / 2, HP1);
             uB += ST; if (uB >= RU) uB -= RU;
             D0_T(1);
 #ifdef SD_PROBE_DEC0_NO_SECOND
@@ -496,7 +501,14 @@ int launch_dec0(Dec0Params p, int act_dtype, hipStream_t s) {
     p.HP1 = p.HP / 2;
     p.magic_hp = (unsigned)(0x100000000ull / (unsigned)p.HP) + 1u;
     p.magic_hp1 = (unsigned)(0x100000000ull / (unsigned)p.HP1) + 1u;
-    p.nstrip = (p.W + 63) / 64;
+    // strip width: 64 columns, or 56 where that covers the width with fewer stream positions (strips x (width + 4): 331 columns =
+    // 6 x 68 or 6 x 60; 128 = 2 x 68 or 3 x 60).  Same arithmetic per voxel either way: bit-identical results.
+    const char* const pw_env = getenv("SD_DEC0_PW");      // (A/B switch, read per launch: 68 or 60)
+    const int force_pw = pw_env ? atoi(pw_env) : 0;
+    const int nsw = (p.W + PW_WIDE - 5) / (PW_WIDE - 4), nsn = (p.W + PW_NARROW - 5) / (PW_NARROW - 4);
+    const bool narrow = force_pw ? force_pw == PW_NARROW : nsn * PW_NARROW < nsw * PW_WIDE;
+    const int pw = narrow ? PW_NARROW : PW_WIDE;
+    p.nstrip = narrow ? nsn : nsw;
     p.lab_fast = 0;
     for (int c = 0; c < 8; ++c) p.lab_cls[c] = 0u;
     if (p.final_kind == SD_OUT_LABELS_U8) {
@@ -527,7 +539,7 @@ int launch_dec0(Dec0Params p, int act_dtype, hipStream_t s) {
     }
     p.nzg = (p.D + p.zsplit - 1) / p.zsplit;
     p.prio = getenv("SD_DEC0_PRIO") ? atoi(getenv("SD_DEC0_PRIO")) : 0;
-    if ((long)p.zsplit * p.HP * PW > (1l << 30) || p.H < 8 || (long)p.D * p.H >= (1l << 24) || p.W >= (1 << 24))
+    if ((long)p.zsplit * p.HP * pw > (1l << 30) || p.H < 8 || (long)p.D * p.H >= (1l << 24) || p.W >= (1 << 24))
         return SD_ERR_INVALID;      // 32-bit positions, 24-bit row arithmetic, cursor wraps once per advance (== dec0_shape_ok, sd_api.hip)
     if ((long)p.D * p.H * p.W >= (1l << 31)) return SD_ERR_INVALID;
     if (p.final_kind < 0 || p.final_kind > SD_OUT_LABELS_U8) return SD_ERR_INVALID;
@@ -538,20 +550,25 @@ int launch_dec0(Dec0Params p, int act_dtype, hipStream_t s) {
     if (p.out_nvox == 0) p.out_nvox = (long)p.D * p.H * p.W;
     const bool vw = p.sH != p.H || p.sW != p.W || p.sH1 != p.H1 || p.sW1 != p.W1;
     void (*kern)(const Dec0Params) = nullptr;
-    if (act_dtype == SD_BF16) {
-        if (vw) kern = kind == 0 ? k_dec0<bf16_t, 0, true> : kind == 1 ? k_dec0<bf16_t, 1, true> : kind == 2 ? k_dec0<bf16_t, 2, true> : kind == 3 ? k_dec0<bf16_t, 3, true> : k_dec0<bf16_t, 4, true>;
-        else kern = kind == 0 ? k_dec0<bf16_t, 0> : kind == 1 ? k_dec0<bf16_t, 1> : kind == 2 ? k_dec0<bf16_t, 2> : kind == 3 ? k_dec0<bf16_t, 3> : k_dec0<bf16_t, 4>;
-    } else {
-        if (vw) kern = kind == 0 ? k_dec0<f16_t, 0, true> : kind == 1 ? k_dec0<f16_t, 1, true> : kind == 2 ? k_dec0<f16_t, 2, true> : kind == 3 ? k_dec0<f16_t, 3, true> : k_dec0<f16_t, 4, true>;
-        else kern = kind == 0 ? k_dec0<f16_t, 0> : kind == 1 ? k_dec0<f16_t, 1> : kind == 2 ? k_dec0<f16_t, 2> : kind == 3 ? k_dec0<f16_t, 3> : k_dec0<f16_t, 4>;
-    }
+    auto pick = [&](auto tc, auto vc, auto pc) -> void (*)(const Dec0Params) {
+        using TT = typename decltype(tc)::type;
+        constexpr bool V = decltype(vc)::value;
+        constexpr int P = decltype(pc)::value;
+        return kind == 0 ? k_dec0<TT, 0, V, P> : kind == 1 ? k_dec0<TT, 1, V, P> : kind == 2 ? k_dec0<TT, 2, V, P> : kind == 3 ? k_dec0<TT, 3, V, P>
+                                                                                                                                  : k_dec0<TT, 4, V, P>;
+    };
+    auto pick_pw = [&](auto tc, auto vc) {
+        return narrow ? pick(tc, vc, std::integral_constant<int, PW_NARROW>{}) : pick(tc, vc, std::integral_constant<int, PW_WIDE>{});
+    };
+    auto pick_view = [&](auto tc) { return vw ? pick_pw(tc, std::true_type{}) : pick_pw(tc, std::false_type{}); };
+    kern = act_dtype == SD_BF16 ? pick_view(TypeTag<bf16_t>{}) : pick_view(TypeTag<f16_t>{});
     static std::mutex mu;
-    static bool attr_done[20][64] = {};      // the attribute is per kernel and device
+    static bool attr_done[40][64] = {};      // the attribute is per kernel and device
     {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return SD_ERR_HIP;
         std::lock_guard<std::mutex> g(mu);
-        bool& done = attr_done[(act_dtype == SD_BF16 ? 0 : 5) + kind + (vw ? 10 : 0)][dev];
+        bool& done = attr_done[(act_dtype == SD_BF16 ? 0 : 5) + kind + (vw ? 10 : 0) + (narrow ? 20 : 0)][dev];
         if (!done) {
             const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
             if (ea != hipSuccess) {
