@@ -581,10 +581,15 @@ int launch_dec0(Dec0Params p, int act_dtype, hipStream_t s) {
         }
     }
     {
-        static const char* const names[2][5] = {{"k_dec0<logits>", "k_dec0<probs f32>", "k_dec0<probs u8>", "k_dec0<labels>", "k_dec0<labels, generic id list>"},
-                                                {"k_dec0<logits, sub-box>", "k_dec0<probs f32, sub-box>", "k_dec0<probs u8, sub-box>", "k_dec0<labels, sub-box>",
-                                                 "k_dec0<labels, generic id list, sub-box>"}};
-        SD_NOTE_KERNEL(names[vw ? 1 : 0][kind]);
+        static const char* const names[2][2][5] = {
+            {{"k_dec0<logits>", "k_dec0<probs f32>", "k_dec0<probs u8>", "k_dec0<labels>", "k_dec0<labels, generic id list>"},
+             {"k_dec0<logits, sub-box>", "k_dec0<probs f32, sub-box>", "k_dec0<probs u8, sub-box>", "k_dec0<labels, sub-box>",
+              "k_dec0<labels, generic id list, sub-box>"}},
+            {{"k_dec0<logits, 56-column strips>", "k_dec0<probs f32, 56-column strips>", "k_dec0<probs u8, 56-column strips>",
+              "k_dec0<labels, 56-column strips>", "k_dec0<labels, generic id list, 56-column strips>"},
+             {"k_dec0<logits, sub-box, 56-column strips>", "k_dec0<probs f32, sub-box, 56-column strips>", "k_dec0<probs u8, sub-box, 56-column strips>",
+              "k_dec0<labels, sub-box, 56-column strips>", "k_dec0<labels, generic id list, sub-box, 56-column strips>"}}};
+        SD_NOTE_KERNEL(names[narrow ? 1 : 0][vw ? 1 : 0][kind]);
     }
     hipLaunchKernelGGL(kern, dim3(combos * p.nzg), dim3(512), LDS_TOTAL, s, p);
     const hipError_t e = hipGetLastError();

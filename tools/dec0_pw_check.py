@@ -32,7 +32,7 @@ for shape in ((6, 40, 331), (5, 33, 166), (4, 24, 112), (3, 50, 57), (2, 18, 200
         os.environ.pop('SD_DEC0_PW', None)
     ok = all(torch.equal(r[0], ref) and torch.equal(r[1], ref_l) for r in res.values()) and torch.equal(res['68'][2], res['60'][2])
     bad += not ok
-    print(shape, 'kernel:', [k for k in fused.op_kernels() if 'dec0' in k][:1], 'OK' if ok else 'MISMATCH')
+    print(shape, 'kernel:', fused.op_kernels()[-1][1], '|', layers.op_kernels()[-1][1], 'OK' if ok else 'MISMATCH')
 print('mismatching shapes:', bad)
 x = torch.randint(0, 256, (3, 178, 243, 331), dtype=torch.uint8, device=dev)
 for rep in range(2):
