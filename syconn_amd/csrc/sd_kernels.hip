@@ -1051,7 +1051,10 @@ static int launch_conv_knt(const ConvParams& p, int NB, hipStream_t s) {
             // wave, 4-wave workgroups of 1 x 32 x 16 voxels, two per CU -- 0.75 instead of 1.0 LDS fragment reads per MFMA (at 1.0
             // the four SIMDs of a CU ask for 128 B per cycle: all the LDS has) and a barrier per 72 instead of 36 MFMAs
             const bool no_p4 = getenv("SD_NO_PLANAR4") != nullptr;      // A/B switch (read per launch)
-            if (!no_p4 && !p.final_wfrag && (p.H % 32 == 0 || p.H >= 128) && (vox / 512) * NB >= 1024)
+            // (rounds 2-4 asked for H % 32 == 0 || H >= 128; the 8-wave form this falls back to has 32-row blocks as well, so a ragged
+            // height costs both the same: at 89 x 61 x 83 -- the reference tile's level 2 -- the four layers 631 -> 600 us per tile.
+            // SD_PLANAR4_H_RULE restores the rule)
+            if (!no_p4 && !p.final_wfrag && (p.H % 32 == 0 || p.H >= 128 || !getenv("SD_PLANAR4_H_RULE")) && (vox / 512) * NB >= 1024)
                 return launch_conv_k<T, KZ, NT, 4, 0, 4>(p, NB, s);
         }
         if constexpr (KZ == 1 && NT == 3) {

@@ -38,7 +38,7 @@ int launch_conv_split_knt(const ConvParams& p, int NB, hipStream_t s) {
             if (!ff && (vox / 1024) * NB >= 256 && (p.D % 8 == 0 || p.D >= 96)) return launch_conv_k<T, KZ, NT, 8, 0, 4, 3>(p, NB, s);
         }
         if constexpr (KZ == 1 && NT == 2) {      // (the planar 4-tile form of launch_conv_knt)
-            if (!getenv("SD_NO_PLANAR4") && !ff && !p.gn_sums && (p.H % 32 == 0 || p.H >= 128) && (vox / 512) * NB >= 1024)
+            if (!getenv("SD_NO_PLANAR4") && !ff && !p.gn_sums && (p.H % 32 == 0 || p.H >= 128 || !getenv("SD_PLANAR4_H_RULE")) && (vox / 512) * NB >= 1024)
                 return launch_conv_k<T, KZ, NT, 4, 0, 4, 3>(p, NB, s);
         }
         return launch_conv_k<T, KZ, NT, 8, 0, 2, 3>(p, NB, s);

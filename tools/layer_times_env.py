@@ -14,7 +14,8 @@ arch, act = sys.argv[1], sys.argv[2]
 envs = sys.argv[3:] or ['']
 dev = torch.device('cuda', 0)
 dm = DenseModel(random_state_dict(arch, seed=0, final_scale=8.0), act, dev)
-x = torch.randint(0, 256, (8, 128, 128, 128), dtype=torch.uint8, device=dev)
+shape = tuple(int(v) for v in os.environ.get('LAYER_SHAPE', '8,128,128,128').split(','))      # tiles, z, y, x
+x = torch.randint(0, 256, shape, dtype=torch.uint8, device=dev)
 ids, thr = list(range(1, dm.out_channels)), [127.5] * (dm.out_channels - 1)
 res = {e: [] for e in envs}
 for rep in range(3):
@@ -28,7 +29,7 @@ for rep in range(3):
         dm.profile(8)
         for _ in range(8):
             dm.forward_labels_batch(x, ids, thr)
-        res[e].append(sum(dm.profile_read(k) for k in range(8)) / 8 / 8 * 1e3)
+        res[e].append(sum(dm.profile_read(k) for k in range(8)) / 8 / shape[0] * 1e3)
         dm.profile(0)
         for k, v in kv:
             os.environ.pop(k)
