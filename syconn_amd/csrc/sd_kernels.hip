@@ -1043,7 +1043,10 @@ static int launch_conv_knt(const ConvParams& p, int NB, hipStream_t s) {
             // stage barriers and block boundaries per MFMA (32->64 channels 52.6 -> 48.7 us per tile, 64->64 88 -> 85 us,
             // 128->64 164 -> 162 us).  Taller blocks waste more on a ragged z extent, hence the rule on D.
             const bool mt2 = getenv("SD_MT2") != nullptr;      // A/B switch (read per launch): the 4x8x16 / 2-tile form everywhere
-            if (!mt2 && !p.final_wfrag && (vox / 1024) * NB >= 256 && (p.D % 8 == 0 || p.D >= 96))
+            // (the z extent: 8-plane blocks may cover at most 5 % more planes than 4-plane blocks would -- 89 planes: 96 vs 92, the
+            // reference tile's level 3, 517 -> 506 us per tile; rounds 2-4 asked for D % 8 == 0 || D >= 96: SD_MT4_D_RULE)
+            const bool z_ok = getenv("SD_MT4_D_RULE") ? (p.D % 8 == 0 || p.D >= 96) : ((p.D + 7) / 8 * 8) * 100 <= ((p.D + 3) / 4 * 4) * 105;
+            if (!mt2 && !p.final_wfrag && (vox / 1024) * NB >= 256 && z_ok)
                 return launch_conv_k<T, KZ, NT, 8, 0, 4>(p, NB, s);
         }
         if constexpr (KZ == 1 && NT == 2) {

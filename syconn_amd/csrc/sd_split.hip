@@ -35,7 +35,8 @@ int launch_conv_split_knt(const ConvParams& p, int NB, hipStream_t s) {
     if (big) {
         if (conv_lds_bytes<KZ, NT, 8, 2, 2>(nstages, ff) <= wres8) return launch_conv_k<T, KZ, NT, 8, 2, 2, 3>(p, NB, s);
         if constexpr (KZ == 3 && NT == 2) {
-            if (!ff && (vox / 1024) * NB >= 256 && (p.D % 8 == 0 || p.D >= 96)) return launch_conv_k<T, KZ, NT, 8, 0, 4, 3>(p, NB, s);
+            const bool z_ok = getenv("SD_MT4_D_RULE") ? (p.D % 8 == 0 || p.D >= 96) : ((p.D + 7) / 8 * 8) * 100 <= ((p.D + 3) / 4 * 4) * 105;
+            if (!ff && (vox / 1024) * NB >= 256 && z_ok) return launch_conv_k<T, KZ, NT, 8, 0, 4, 3>(p, NB, s);
         }
         if constexpr (KZ == 1 && NT == 2) {      // (the planar 4-tile form of launch_conv_knt)
             if (!getenv("SD_NO_PLANAR4") && !ff && !p.gn_sums && (p.H % 32 == 0 || p.H >= 128 || !getenv("SD_PLANAR4_H_RULE")) && (vox / 512) * NB >= 1024)
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(256) void k_maxpool_split(const PoolParams p) {
 
 // Final 1x1x1 convolution to <= 8 classes in fp32 FMA arithmetic on the exact values of the split tensor, softmax with full-
 // precision expf and a true division (like the fp32 plan's k32_final), uint8 / label epilogues of the other plans.
+template <int NCO>      // classes computed: 2, 4 or 8 >= p.cout (a 4-class net does not pay for 8 accumulator chains)
 __global__ __launch_bounds__(256) void k_final_split(const FinalParams p) {
     const T* const src = reinterpret_cast<const T*>(reinterpret_cast<const char*>(p.src) + blockIdx.z * p.tstride);
     const size_t slo = (size_t)(p.Cs >> 4) * p.nvox * SD_CHUNK;
@@ -117,9 +119,9 @@ __global__ __launch_bounds__(256) void k_final_split(const FinalParams p) {
     const float* const gss = p.gn_scale_shift
         ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.gn_scale_shift) + blockIdx.z * p.tstride) : nullptr;
     for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < p.nvox; v += (long)gridDim.x * 256) {
-        float acc[8];
+        float acc[NCO];
 #pragma unroll
-        for (int co = 0; co < 8; ++co) acc[co] = 0.f;
+        for (int co = 0; co < NCO; ++co) acc[co] = 0.f;
         const int nc8 = p.Cs / 8;
         for (int g0 = 0; g0 < nc8; g0 += 4) {
             v8 xh[4], xl[4];
@@ -148,23 +150,26 @@ __global__ __launch_bounds__(256) void k_final_split(const FinalParams p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
 #pragma unroll
-                    for (int co = 0; co < 8; ++co) acc[co] = fmaf(f[e], w[co * p.Cs + c8 * 8 + e], acc[co]);
+                    for (int co = 0; co < NCO; ++co) acc[co] = fmaf(f[e], w[co * p.Cs + c8 * 8 + e], acc[co]);
             }
         }
         float mx = -INFINITY;
 #pragma unroll
-        for (int co = 0; co < 8; ++co)
+        for (int co = 0; co < NCO; ++co)
             if (co < p.cout) { acc[co] += p.bias[co]; mx = fmaxf(mx, acc[co]); }
         if (p.out_kind != SD_OUT_LOGITS_F32) {
             float sum = 0.f;
 #pragma unroll
-            for (int co = 0; co < 8; ++co)
+            for (int co = 0; co < NCO; ++co)
                 if (co < p.cout) { acc[co] = expf(acc[co] - mx); sum += acc[co]; }
             range_guard<T>(sum, p.ovf);
 #pragma unroll
-            for (int co = 0; co < 8; ++co) acc[co] = acc[co] / sum;
+            for (int co = 0; co < NCO; ++co) acc[co] = acc[co] / sum;
         } else {
-            range_guard<T>(logit_probe<T>(acc, p.cout), p.ovf);
+            float l8[8];
+#pragma unroll
+            for (int co = 0; co < 8; ++co) l8[co] = co < NCO ? acc[co < NCO ? co : 0] : 0.f;
+            range_guard<T>(logit_probe<T>(l8, p.cout), p.ovf);
         }
         if (p.out_kind == SD_OUT_LABELS_U8) {
             uint8_t lab = 0;
@@ -172,19 +177,19 @@ __global__ __launch_bounds__(256) void k_final_split(const FinalParams p) {
                 const int id = p.lab.ids[k];
                 float pv = 0.f;
 #pragma unroll
-                for (int co = 0; co < 8; ++co) pv = (co == id) ? acc[co] : pv;
+                for (int co = 0; co < NCO; ++co) pv = (co == id) ? acc[co] : pv;
                 if ((int)(uint8_t)(pv * 255.f) >= p.lab.cuts[k]) lab = (uint8_t)id;
             }
             (reinterpret_cast<uint8_t*>(p.out) + blockIdx.z * p.out_tstride)[v] = lab;
         } else if (p.out_kind == SD_OUT_PROBS_U8) {
             uint8_t* out = reinterpret_cast<uint8_t*>(p.out) + blockIdx.z * p.out_tstride;
 #pragma unroll
-            for (int co = 0; co < 8; ++co)
+            for (int co = 0; co < NCO; ++co)
                 if (co < p.cout) out[(size_t)co * p.nvox + v] = (uint8_t)(acc[co] * 255.f);
         } else {
             float* out = reinterpret_cast<float*>(reinterpret_cast<char*>(p.out) + blockIdx.z * p.out_tstride);
 #pragma unroll
-            for (int co = 0; co < 8; ++co)
+            for (int co = 0; co < NCO; ++co)
                 if (co < p.cout) out[(size_t)co * p.nvox + v] = acc[co];
         }
     }
@@ -368,7 +373,9 @@ int launch_pool_split(const PoolParams& p, hipStream_t s) {
 }
 
 int launch_final_split(const FinalParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(k_final_split, dim3(grid_for(p.nvox), 1, p.batch), dim3(256), 0, s, p);
+    if (p.cout <= 2) hipLaunchKernelGGL(k_final_split<2>, dim3(grid_for(p.nvox), 1, p.batch), dim3(256), 0, s, p);
+    else if (p.cout <= 4) hipLaunchKernelGGL(k_final_split<4>, dim3(grid_for(p.nvox), 1, p.batch), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_final_split<8>, dim3(grid_for(p.nvox), 1, p.batch), dim3(256), 0, s, p);
     return SD_LAUNCH_CHECK();
 }
 
