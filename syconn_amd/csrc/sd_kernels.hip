@@ -1037,7 +1037,12 @@ static int launch_conv_knt(const ConvParams& p, int NB, hipStream_t s) {
         return launch_conv_k<T, KZ, NT, 4, 0, 2, 2>(p, NB, s);
     }
     if (big) {
-        if (conv_lds_bytes<KZ, NT, 8, 2, 2>(nstages, p.final_wfrag != nullptr) <= 96 * 1024) return launch_conv_k<T, KZ, NT, 8, 2>(p, NB, s);
+        // (full-resolution layers, round 5: resident weights up to 150 KiB -- one workgroup per CU either way from 80 KiB on.  The 48-filter
+        // family's level-0 decoder convs: 96 -> 48 187 -> 180 us, 48 -> 48 + final 141 -> 130 us per tile; the 32-filter nets' level-2 layers,
+        // which would fit as well, are no faster that way (9.7 -> 10.0 us) and keep the 96 KiB rule.  SD_WRES_CAP_KB: A/B, read per launch)
+        const char* const cap_env = getenv("SD_WRES_CAP_KB");
+        const size_t wres_cap = (size_t)(cap_env ? atoi(cap_env) : ((long)p.D * p.H * p.W >= (1l << 20) ? 150 : 96)) * 1024;
+        if (conv_lds_bytes<KZ, NT, 8, 2, 2>(nstages, p.final_wfrag != nullptr) <= wres_cap) return launch_conv_k<T, KZ, NT, 8, 2>(p, NB, s);
         if constexpr (KZ == 3 && NT == 2) {
             // 8x8x16 blocks, 4 z-stacked voxel tiles per wave: 0.75 LDS fragment reads per MFMA instead of 1.0, half as many
             // stage barriers and block boundaries per MFMA (32->64 channels 52.6 -> 48.7 us per tile, 64->64 88 -> 85 us,
