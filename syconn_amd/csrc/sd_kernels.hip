@@ -1030,7 +1030,11 @@ static int launch_conv_knt(const ConvParams& p, int NB, hipStream_t s) {
     if (p.gn0 || p.gn1) {      // deferred GroupNorm apply: same shape rules, MODE 2 kernels (LDS incl. the scale / shift table)
         const size_t gl = (size_t)p.batch * conv_gn_lds_per_tile(p.nchunk0 + p.nchunk1);
         if (big) {
-            if (conv_lds_bytes<KZ, NT, 8, 2, 2>(nstages, p.final_wfrag != nullptr) + gl <= 80 * 1024) return launch_conv_k<T, KZ, NT, 8, 2, 2, 2>(p, NB, s);
+            // (full-resolution layers: resident weights as far as the LDS reaches, like the plain form below -- mivcsj's level-0 convs
+            // 194.7 / 273.8 / 163.9 -> 186.9 / 263.4 / 155.2 us per tile.  SD_WRES_GN_CAP_KB: A/B switch, read per launch)
+            const char* const gcap_env = getenv("SD_WRES_GN_CAP_KB");
+            const size_t gn_cap = (size_t)(gcap_env ? atoi(gcap_env) : ((long)p.D * p.H * p.W >= (1l << 20) ? 158 : 80)) * 1024;
+            if (conv_lds_bytes<KZ, NT, 8, 2, 2>(nstages, p.final_wfrag != nullptr) + gl <= gn_cap) return launch_conv_k<T, KZ, NT, 8, 2, 2, 2>(p, NB, s);
             return launch_conv_k<T, KZ, NT, 8, 0, 2, 2>(p, NB, s);
         }
         if (conv_lds_bytes<KZ, NT, 4, 2, 2>(nstages, p.final_wfrag != nullptr) + gl <= 80 * 1024) return launch_conv_k<T, KZ, NT, 4, 2, 2, 2>(p, NB, s);
