@@ -1160,6 +1160,23 @@ static int launch_upconv_rows_wl(const UpconvParams& p, hipStream_t s) {      //
     hipLaunchKernelGGL(kern, grid, block, lds, s, p);
     return SD_LAUNCH_CHECK();
 }
+// LDS-resident weights with G channel groups per tap pair (k_upconv_rows<G>): NTAB / G column tiles of weights per workgroup
+template <typename T, int NCH, int NTAB, int G>
+static int launch_upconv_rows_wl_g(const UpconvParams& p, hipStream_t s) {
+    { static const std::string name = "k_upconv_rows<NCH=" + std::to_string(NCH) + ",NTAB=" + std::to_string(NTAB) + ",LDS weights,G=" + std::to_string(G) + ">"; SD_NOTE_KERNEL(name.c_str()); }
+    const long M = (long)p.D * p.H * p.W;
+    if (M >= (1l << 31) || p.gn) return SD_ERR_INVALID;
+    constexpr int NTL = NTAB / G;
+    const size_t lds = (size_t)4 * 32 * (4 * NTL * 16) + (size_t)NTL * NCH * 1024;
+    auto kern = k_upconv_rows<T, NCH, NTAB, true, false, false, G>;
+    if (lds > (size_t)SD_LDS_BYTES) return SD_ERR_INVALID;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SD_ERR_HIP;
+    const int per_cu = std::max(1, (int)(SD_LDS_BYTES / lds));
+    const long want = std::max(1L, (long)SD_NUM_CU * per_cu * 2 / (2 * p.kz * G * p.batch));
+    dim3 grid((unsigned)std::min((M + 127) / 128, want), 2 * p.kz * G, p.batch), block(256);
+    hipLaunchKernelGGL(kern, grid, block, lds, s, p);
+    return SD_LAUNCH_CHECK();
+}
 // true when launch_upconv runs this shape with the row-coalescing kernel (activations of all chunks in registers): the form
 // into which a deferred GroupNorm apply folds for less than the separate apply pass costs (the generic MFMA kernel pays
 // more for it than the pass it replaces: 192 -> 96 channels 80 -> 108 us vs a 10 us pass)
@@ -1185,6 +1202,10 @@ static int launch_upconv_t(const UpconvParams& p, int NB, hipStream_t s) {
     // 192 -> 96 channels: the generic kernel re-reads the input for each of its 12 column blocks (PMC: 1.0 GB read for 0.2 GB
     // algorithmic per 8 tiles) and writes partial lines; rows kernel with LDS-resident weights 70 -> 60 us per tile
     if (p.nchunk == 12 && p.Cd == 96 && !no_wl) return launch_upconv_rows_wl<T, 12, 6>(p, s);
+    // 256 -> 128 channels: rows kernel, weights in LDS, two channel groups per tap pair (64 KiB of weights each).  The generic kernel
+    // slows down on shapes that are not powers of two: 89 x 31 x 42 -> 89 x 62 x 84 (the reference tile) 129.9 -> 77.6 us per tile, at
+    // 64 x 16 x 16 -> 64 x 32 x 32 12.4 -> 11.5 us (SD_UPCONV128_MFMA: the generic kernel, A/B)
+    if (p.nchunk == 16 && p.Cd == 128 && !p.gn && !no_wl && !getenv("SD_UPCONV128_MFMA")) return launch_upconv_rows_wl_g<T, 16, 8, 2>(p, s);
     const long M = (long)p.D * p.H * p.W;
     if (M >= (1l << 31)) return SD_ERR_INVALID;        // (32-bit voxel decode in the kernel)
     dim3 grid((unsigned)((M + 255) / 256), NB, p.batch), block(256);
