@@ -1206,6 +1206,9 @@ static int launch_upconv_t(const UpconvParams& p, int NB, hipStream_t s) {
     // slows down on shapes that are not powers of two: 89 x 31 x 42 -> 89 x 62 x 84 (the reference tile) 129.9 -> 77.6 us per tile, at
     // 64 x 16 x 16 -> 64 x 32 x 32 12.4 -> 11.5 us (SD_UPCONV128_MFMA: the generic kernel, A/B)
     if (p.nchunk == 16 && p.Cd == 128 && !p.gn && !no_wl && !getenv("SD_UPCONV128_MFMA")) return launch_upconv_rows_wl_g<T, 16, 8, 2>(p, s);
+    // 384 -> 192 channels (48-filter BatchNorm nets): six channel groups of 32 (48 KiB of weights each): 26.8 -> 17.3 us per 128^3 tile
+    // (three groups of 64: 22.3; SD_UPCONV192_MFMA: the generic kernel, A/B)
+    if (p.nchunk == 24 && p.Cd == 192 && !p.gn && !no_wl && !getenv("SD_UPCONV192_MFMA")) return launch_upconv_rows_wl_g<T, 24, 12, 6>(p, s);
     const long M = (long)p.D * p.H * p.W;
     if (M >= (1l << 31)) return SD_ERR_INVALID;        // (32-bit voxel decode in the kernel)
     dim3 grid((unsigned)((M + 255) / 256), NB, p.batch), block(256);
@@ -1215,7 +1218,7 @@ static int launch_upconv_t(const UpconvParams& p, int NB, hipStream_t s) {
 }
 int launch_upconv(const UpconvParams& p, int act_dtype, int NB, hipStream_t s) {
     if (act_dtype == SD_F16X2) {      // split-fp16 plan: row kernel for the full-resolution shapes, else the generic kernel (3n virtual chunks)
-        SD_NOTE_KERNEL(p.nchunk == 12 || p.nchunk == 24 || p.nchunk == 18 || p.nchunk == 36 ? "k_upconv_rows<split-fp16> / k_upconv_mfma<split-fp16>" : "k_upconv_mfma<split-fp16>");
+        SD_NOTE_KERNEL(p.nchunk == 12 || p.nchunk == 24 || p.nchunk == 18 || p.nchunk == 36 || p.nchunk == 48 ? "k_upconv_rows<split-fp16> / k_upconv_mfma<split-fp16>" : "k_upconv_mfma<split-fp16>");
         const long M = (long)p.D * p.H * p.W;
         if (M >= (1l << 31) || p.gn) return SD_ERR_INVALID;
         static const bool no_rows = getenv("SD_SPLIT_NO_ROWS") != nullptr;      // A/B switch
@@ -1241,6 +1244,16 @@ int launch_upconv(const UpconvParams& p, int act_dtype, int NB, hipStream_t s) {
         // per 32 input voxels and y-tap, three times the 8 KiB it writes (SD_SPLIT_ROWS32_NO_WL: the round-4 form, A/B)
         if (!no_rows && p.nchunk == 12 && p.Cd == 32 && !getenv("SD_SPLIT_ROWS32_NO_WL"))
             return rows_wl(k_upconv_rows<f16_t, 4, 2, true, false, true>, 2, 12);
+        if (!no_rows && p.nchunk == 48 && p.Cd == 128 && !getenv("SD_SPLIT_UPCONV128_MFMA")) {      // 256 -> 128: four channel groups of 32 (96 KiB of weights each)
+            auto kern = k_upconv_rows<f16_t, 16, 8, true, false, true, 4>;
+            const size_t lds = (size_t)4 * 32 * 128 + (size_t)2 * 48 * 1024;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return SD_ERR_HIP;
+            const long want = std::max(1L, (long)SD_NUM_CU * 2 / (2 * p.kz * 4 * p.batch));
+            dim3 grid((unsigned)std::min((M + 127) / 128, want), 2 * p.kz * 4, p.batch), block(256);
+            hipLaunchKernelGGL(kern, grid, block, lds, s, p);
+            return SD_LAUNCH_CHECK();
+        }
         if (!no_rows && p.nchunk == 24 && p.Cd == 64) return rows_wl(k_upconv_rows<f16_t, 8, 4, true, false, true>, 4, 24);     // 128 -> 64
         if (!no_rows && p.nchunk == 18 && p.Cd == 48) return rows_wl(k_upconv_rows<f16_t, 6, 3, true, false, true>, 3, 18);     // 96 -> 48
         // 192 -> 96 channels: the 36 weight groups of all six column tiles do not fit the LDS; three workgroups per tap pair with the
