@@ -244,13 +244,16 @@ def test_split_fusions_agree_with_the_layer_wise_split_plan(gpu, monkeypatch):
 @pytest.mark.parametrize('arch,act,ntiles,shape,switches', [
     ('semseg_axon', 'f16x2', 1, (128, 128, 128), ('SD_SPLIT_ROWS96_L2', 'SD_PLANAR_NT3_BIG')),
     ('mivcsj', 'f16x2', 4, (128, 128, 128), ('SD_SPLIT_ROWS96_L2', 'SD_PLANAR_NT3_BIG')),
-    ('semseg_spine', 'f16x2', 4, (8, 96, 128), ('SD_SPLIT_ROWS32_NO_WL',)),
-    ('semseg_spine', 'bf16', 4, (8, 96, 128), ('SD_UPCONV32_NO_WL',)),
+    ('semseg_spine', 'f16x2', 4, (8, 96, 128), ('SD_SPLIT_ROWS32_NO_WL', 'SD_SPLIT_UPCONV128_MFMA')),
+    ('semseg_spine', 'bf16', 4, (8, 96, 128), ('SD_UPCONV32_NO_WL', 'SD_UPCONV128_MFMA')),
+    ('myelin', 'bf16', 1, (178, 243, 331), ('SD_UPCONV32_NO_WL', 'SD_UPCONV128_MFMA', 'SD_PLANAR4_H_RULE', 'SD_MT4_D_RULE')),      # the reference's tile
+    ('semseg_axon', 'bf16', 2, (16, 96, 128), ('SD_UPCONV192_MFMA',)),
 ])
 def test_round5_up_convolution_and_workgroup_forms_are_bit_identical(gpu, monkeypatch, arch, act, ntiles, shape, switches):
-    """The forms picked in round 5 -- up-convolutions with LDS-resident weights (64 -> 32 channels; 192 -> 96 in three channel groups,
-    k_upconv_rows<G = 3>), planar 96-column layers as 4-wave workgroups in the split plan (sizes at which the 8-wave form used to be
-    picked) -- against the forms they replaced (launch-time switches): same logits, bit for bit."""
+    """The forms picked in round 5 -- up-convolutions with LDS-resident weights (64 -> 32 channels; 256 -> 128, 384 -> 192 and the split
+    plan's 192 -> 96 / 256 -> 128 in channel groups, k_upconv_rows<G>), planar 96-column layers as 4-wave workgroups in the split plan
+    (sizes at which the 8-wave form used to be picked), the relaxed height / depth rules of the four-tile forms -- against the forms
+    they replaced (launch-time switches): same logits, bit for bit."""
     from syconn_amd import _lib as L
     from syconn_amd.engine import DenseModel
     from syconn_amd.cnn import random_state_dict
