@@ -1205,10 +1205,13 @@ static int launch_upconv_t(const UpconvParams& p, int NB, hipStream_t s) {
     // 256 -> 128 channels: rows kernel, weights in LDS, two channel groups per tap pair (64 KiB of weights each).  The generic kernel
     // slows down on shapes that are not powers of two: 89 x 31 x 42 -> 89 x 62 x 84 (the reference tile) 129.9 -> 77.6 us per tile, at
     // 64 x 16 x 16 -> 64 x 32 x 32 12.4 -> 11.5 us (SD_UPCONV128_MFMA: the generic kernel, A/B)
-    if (p.nchunk == 16 && p.Cd == 128 && !p.gn && !no_wl && !getenv("SD_UPCONV128_MFMA")) return launch_upconv_rows_wl_g<T, 16, 8, 2>(p, s);
+    // (a workgroup of these forms loads 48-64 KiB of weights: they pay from ~6 tiles of 128^3 per launch set on -- 256 -> 128 on ONE such
+    // tile 21.0 -> 33.2 us, on two 16.1 -> 18.9 per tile: small launch sets keep the generic kernel)
+    const bool many = (long)p.D * p.H * p.W * p.batch >= 98304;
+    if (p.nchunk == 16 && p.Cd == 128 && !p.gn && !no_wl && many && !getenv("SD_UPCONV128_MFMA")) return launch_upconv_rows_wl_g<T, 16, 8, 2>(p, s);
     // 384 -> 192 channels (48-filter BatchNorm nets): six channel groups of 32 (48 KiB of weights each): 26.8 -> 17.3 us per 128^3 tile
     // (three groups of 64: 22.3; SD_UPCONV192_MFMA: the generic kernel, A/B)
-    if (p.nchunk == 24 && p.Cd == 192 && !p.gn && !no_wl && !getenv("SD_UPCONV192_MFMA")) return launch_upconv_rows_wl_g<T, 24, 12, 6>(p, s);
+    if (p.nchunk == 24 && p.Cd == 192 && !p.gn && !no_wl && many && !getenv("SD_UPCONV192_MFMA")) return launch_upconv_rows_wl_g<T, 24, 12, 6>(p, s);
     const long M = (long)p.D * p.H * p.W;
     if (M >= (1l << 31)) return SD_ERR_INVALID;        // (32-bit voxel decode in the kernel)
     dim3 grid((unsigned)((M + 255) / 256), NB, p.batch), block(256);
@@ -1244,7 +1247,7 @@ int launch_upconv(const UpconvParams& p, int act_dtype, int NB, hipStream_t s) {
         // per 32 input voxels and y-tap, three times the 8 KiB it writes (SD_SPLIT_ROWS32_NO_WL: the round-4 form, A/B)
         if (!no_rows && p.nchunk == 12 && p.Cd == 32 && !getenv("SD_SPLIT_ROWS32_NO_WL"))
             return rows_wl(k_upconv_rows<f16_t, 4, 2, true, false, true>, 2, 12);
-        if (!no_rows && p.nchunk == 48 && p.Cd == 128 && !getenv("SD_SPLIT_UPCONV128_MFMA")) {      // 256 -> 128: four channel groups of 32 (96 KiB of weights each)
+        if (!no_rows && p.nchunk == 48 && p.Cd == 128 && M * p.batch >= 98304 && !getenv("SD_SPLIT_UPCONV128_MFMA")) {      // 256 -> 128: four channel groups of 32 (96 KiB of weights each)
             auto kern = k_upconv_rows<f16_t, 16, 8, true, false, true, 4>;
             const size_t lds = (size_t)4 * 32 * 128 + (size_t)2 * 48 * 1024;
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
