@@ -247,7 +247,8 @@ def test_split_fusions_agree_with_the_layer_wise_split_plan(gpu, monkeypatch):
     ('semseg_spine', 'f16x2', 4, (8, 96, 128), ('SD_SPLIT_ROWS32_NO_WL', 'SD_SPLIT_UPCONV128_MFMA')),
     ('semseg_spine', 'bf16', 4, (8, 96, 128), ('SD_UPCONV32_NO_WL', 'SD_UPCONV128_MFMA')),
     ('myelin', 'bf16', 1, (178, 243, 331), ('SD_UPCONV32_NO_WL', 'SD_UPCONV128_MFMA', 'SD_PLANAR4_H_RULE', 'SD_MT4_D_RULE')),      # the reference's tile
-    ('semseg_axon', 'bf16', 2, (16, 96, 128), ('SD_UPCONV192_MFMA',)),
+    ('semseg_axon', 'bf16', 6, (128, 128, 128), ('SD_UPCONV192_MFMA', 'SD_WRES_CAP_KB')),      # (the grouped forms need >= 6 such tiles per launch set)
+    ('myelin', 'f16x2', 1, (178, 243, 331), ('SD_SPLIT_UPCONV128_MFMA', 'SD_SPLIT_ROWS32_NO_WL', 'SD_PLANAR4_H_RULE', 'SD_MT4_D_RULE')),
 ])
 def test_round5_up_convolution_and_workgroup_forms_are_bit_identical(gpu, monkeypatch, arch, act, ntiles, shape, switches):
     """The forms picked in round 5 -- up-convolutions with LDS-resident weights (64 -> 32 channels; 256 -> 128, 384 -> 192 and the split
@@ -262,7 +263,7 @@ def test_round5_up_convolution_and_workgroup_forms_are_bit_identical(gpu, monkey
     raw = torch.stack([_input(shape, 11 + k) for k in range(ntiles)]).to(gpu)
     new = dm.forward_batch(raw, L.SD_OUT_LOGITS_F32).clone()
     for sw in switches:
-        monkeypatch.setenv(sw, '1')
+        monkeypatch.setenv(sw, '96' if sw == 'SD_WRES_CAP_KB' else '1')
     old = dm.forward_batch(raw, L.SD_OUT_LOGITS_F32)
     assert torch.equal(new, old)
     assert float(new.abs().max()) > 0 and not dm.overflowed()
