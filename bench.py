@@ -10,9 +10,13 @@ step     : one pass of the hot path over one batch of `--tiles` tiles per GPU, H
            SURVEY.md section 8d: "uint8 input in host memory to uint8 output in host memory"; the reference does one PCIe
            round trip per tile, /root/reference/syconn/handler/prediction.py:806-809, 863):
                pinned host uint8 tiles --H2D--> [normalise, U-Net, softmax, floor(255 p), label rule
-               (prediction.py:813-833)] --D2H--> pinned host uint8 label volume
+               (prediction.py:813-833)] --> pinned host uint8 label volume
            on three HIP streams (copy-in / compute / copy-out) with two buffer sets, so the copies of steps k-1 and k+1
-           overlap the kernels of step k.  With N > 1 every rank feeds its own tiles over its own PCIe link, the label
+           overlap the kernels of step k.  On one rank the last kernel of a launch set stores its labels (1 byte per voxel)
+           STRAIGHT INTO the page-locked host buffer: the runtime executes a device-to-host hipMemcpyAsync as a blit KERNEL
+           here (rocprofv3: __amd_rocclr_copyBuffer, 572 us per 16 MiB; the host-to-device copies go through SDMA), which took
+           CUs from the persistent compute kernels -- 2850-2874 -> 2900-2920 Mvox/s on one box, same sha256 of the labels
+           (SD_BENCH_D2H_COPY=1: labels into HBM + an explicit copy, the pipeline of rounds 1-4).  With N > 1 every rank feeds its own tiles over its own PCIe link, the label
            volumes are gathered on rank 0 over RCCL / xGMI and leave through rank 0's link (one writer, as the north
            star's "gather of per-chunk logits").
 value    = tiles * 128^3 * N * K / (max over ranks of the wall time of K steps), in Mvox/s.  Weak scaling.
@@ -112,6 +116,9 @@ class HostToHostPipeline:
         self.ev_in = [torch.cuda.Event() for _ in range(2)]       # H2D of the set finished
         self.ev_comp = [torch.cuda.Event() for _ in range(2)]     # kernels of the set finished
         self.ev_out = [torch.cuda.Event() for _ in range(2)]      # D2H (and gather) of the set finished
+        # one rank: the last kernel stores the labels straight into the page-locked host buffer (module docstring); with a process group
+        # the gather needs them in HBM
+        self.zero_copy = not os.environ.get('SD_BENCH_D2H_COPY') and not self.coll
         self.k = 0
 
     def step(self):
@@ -130,7 +137,8 @@ class HostToHostPipeline:
             self.s_comp.wait_event(self.ev_in[s])
             for t0 in range(0, self.T, self.B):
                 n = min(self.B, self.T - t0)
-                self.dm.forward_labels_batch(self.in_dev[s][t0:t0 + n], self.ids, self.thr, out=self.lab_dev[s][t0:t0 + n])
+                dst = self.out_host[s][0] if self.zero_copy else self.lab_dev[s]
+                self.dm.forward_labels_batch(self.in_dev[s][t0:t0 + n], self.ids, self.thr, out=dst[t0:t0 + n])
             self.ev_comp[s].record(self.s_comp)
         with torch.cuda.stream(self.s_out):
             self.s_out.wait_event(self.ev_comp[s])
@@ -139,7 +147,7 @@ class HostToHostPipeline:
                 work.wait()                             # stream-level dependency of s_out on the collective
                 if self.rank == 0:
                     self.out_host[s].copy_(self.recv[s], non_blocking=True)
-            else:
+            elif not self.zero_copy:
                 self.out_host[s][0].copy_(self.lab_dev[s], non_blocking=True)
             self.ev_out[s].record(self.s_out)
 
@@ -342,8 +350,9 @@ def main():
                 'vs_baseline': None, 'dtype': args.act, 'data': 'synthetic',
                 'config': {'workload': f'BASELINE configs[1]: {args.arch} 3D U-Net on {S}^3 uint8 tiles, {T} tiles per GPU '
                                        f'per step in launch sets of {B} (sd_forward_labels_batch), random-init weights, '
-                                       f'HOST TO HOST: pinned host uint8 tiles -> H2D -> kernels -> D2H -> pinned host '
-                                       f'uint8 labels, 3 HIP streams, 2 buffer sets',
+                                       f'HOST TO HOST: pinned host uint8 tiles -> H2D -> kernels -> '
+                                       + ('pinned host uint8 labels (stored by the last kernel, no copy)' if pipe.zero_copy
+                                          else 'D2H -> pinned host uint8 labels') + ', 3 HIP streams, 2 buffer sets',
                            'tiles_per_launch_set': B,
                            'tiles_per_gpu_per_step': T, 'tile': [S, S, S], 'parallelism': f'tile-sharded x{world}',
                            'hip_streams_per_gpu': 3,
