@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark of the dense 3D-CNN prediction path on MI355X (contract: see the task statement / DESIGN.md).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched through torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: bench.py starts torch.distributed.run itself as a
+                                                           child process; under a launcher -- WORLD_SIZE set -- it is one of the ranks)
 
 metric   : segmented Mvoxels/s (whole node) on synthetic 128^3 uint8 EM tiles  (BASELINE.json `metric`)
 workload : BASELINE.json configs[1] -- `semseg_spine` 3D U-Net (myelin trunk, 5 classes),
@@ -157,6 +158,39 @@ class HostToHostPipeline:
         torch.cuda.synchronize(self.dev)
 
 
+def self_launch(n: int) -> int:
+    """``python bench.py --gpus N`` (N > 1) without a launcher: start ``torch.distributed.run`` with one rank per GPU as a CHILD process --
+    this process has not touched the GPU (``import torch`` alone does not), it never execs, it only relays the child's output and
+    return code.  The reference's counterpart is one worker process per GPU (/root/reference/syconn/handler/prediction.py:708-719)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env)
+    sys.stdout.flush()
+    raise SystemExit(proc.returncode)
+
+
+def dist_info(par):
+    """What the process group looks like from inside (so that a reader of the JSON line sees that RCCL saw N ranks)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return {'world_size': 1, 'backend': None, 'rccl_version': None}
+    backend = dist.get_backend()
+    ver = None
+    if backend == 'nccl':
+        try:
+            ver = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:      # noqa: BLE001  (a version string is decoration, never a reason to fail the run)
+            ver = 'unknown'
+    return {'world_size': dist.get_world_size(), 'backend': backend, 'rccl_version': ver}
+
+
 def timed(fn_step, fn_drain, steps, par, dev):
     torch.cuda.synchronize(dev)
     par.barrier()
@@ -176,12 +210,13 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--tiles', type=int, default=8, help='128^3 tiles per GPU per step')
+    ap.add_argument('--tiles', type=int, default=96, help='128^3 tiles per GPU per step (96 tiles in launch sets of 8: 20 steps are a\n'
+                    '                    timed region of >= 1.3 s -- long enough for the clock to settle and for an SMI sampler to see the load)')
     ap.add_argument('--tile', type=int, default=128)
     ap.add_argument('--arch', default='semseg_spine')
     ap.add_argument('--act', default=None, choices=['bf16', 'f16', 'f16x2', 'f32'],
                     help="activation storage type (default: bf16 = what BASELINE configs[1] names; volume workloads: their config's)")
-    ap.add_argument('--batch', type=int, default=0, help='tiles per sd_forward_batch launch set (0 = all tiles of a step)')
+    ap.add_argument('--batch', type=int, default=8, help='tiles per sd_forward_batch launch set (0 = all tiles of a step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--predict-outside', action='store_true',
                     help='volume workloads: also predict model tiles that lie entirely beyond the volume, as the reference does')
@@ -193,7 +228,10 @@ def main():
     ap.add_argument('--geometry', default='tile128', choices=['tile128', 'reference'],
                     help='volume workloads: 128^3 model tiles (SURVEY 8d) or the reference chunk / tile geometry')
     ap.add_argument('--volume', type=int, nargs=3, default=None, help='volume workloads: z y x of the synthetic volume')
+    ap.add_argument('--zmajor-rounds', action='store_true', help='volume workloads: deal the chunks in z-major order (A/B against cost-sorted rounds)')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return self_launch(args.gpus)
     if args.workload != 'config2':
         return volume_main(args)
     args.act = args.act or 'bf16'
@@ -245,6 +283,13 @@ def main():
     for k in range(n_fw):
         per_op += dm.profile_read(k)
     per_op /= n_fw                                # ms per launch, averaged over the timed region
+    # shader clock of every convolution launch of the timed region (stamped by the launch's first workgroup): (n_fw, n_ops) GHz, 0 = no stamp
+    clk = np.zeros((n_fw, dm.n_ops))
+    for k in range(n_fw):
+        st = dm.profile_read_clocks(k).astype(np.float64)
+        dt = st[:, 3] - st[:, 1]
+        ok = dt > 0
+        clk[k, ok] = (st[ok, 2] - st[ok, 0]) / (dt[ok] * 10.0)
     dm.profile(0)
 
     # ---- the same K steps with inputs / outputs resident in HBM (kernel throughput; NOT `value`) ------------------
@@ -313,6 +358,21 @@ def main():
         # algorithmic (what the bench contract asks for), the matrix pipe does three times that
         roof['mfma_passes_per_product'] = 3
         roof['executed_frac_of_peak'] = 3 * roof['frac'] if roof['bound'] == 'mfma' else None
+    # the same run's view of THIS box: shader clock of the dominant kernel's launches inside the timed region, and what a chip-wide pure
+    # MFMA loop sustains here right after it (the part is power-limited under matrix load and boxes differ: DESIGN.md section 5) --
+    # `frac` is against the nominal 2.5 PFLOP/s, `frac_of_sustained` against what this box's matrix pipes deliver at their own clock
+    dom_ops = [i for i in range(dm.n_ops) if executed[i][1] == dom and executed[i][0] == i]
+    dom_clk = clk[:, dom_ops][clk[:, dom_ops] > 0] if dom_ops else np.zeros(0)
+    roof['clock_ghz_timed_region'] = float(dom_clk.mean()) if dom_clk.size else None
+    roof['clock_ghz_timed_region_min_max'] = [float(dom_clk.min()), float(dom_clk.max())] if dom_clk.size else None
+    all_clk = clk[clk > 0]
+    roof['clock_ghz_all_conv_launches'] = float(all_clk.mean()) if all_clk.size else None
+    if roof['bound'] == 'mfma' and rank == 0:
+        from syconn_amd.engine import probe_mfma_rate
+        sus_tf, sus_ghz = probe_mfma_rate(dev)
+        roof['sustained_mfma_tflops_this_box'] = sus_tf
+        roof['sustained_clock_ghz_this_box'] = sus_ghz
+        roof['frac_of_sustained'] = roof['achieved'] / sus_tf if sus_tf > 0 else None
     roof['traffic'] = None
     tr_file = os.path.join(ROOT, 'profiles', 'traffic.json')
     if os.path.isfile(tr_file):
@@ -334,7 +394,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, sd, dm, tiles_host, ids, L)
+        cpu = cpu_baseline(args, sd, dm, tiles_host[:B], ids, L)
 
     labels_sha = None
     if rank == 0 and args.labels_sha:
@@ -364,7 +424,7 @@ def main():
                            'device_resident_value': value_res,
                            'device_resident_ms_per_step': elapsed_res / args.steps * 1e3,
                            'pcie_bytes_per_step_each_way': T * S ** 3, 'labels_sha256': labels_sha},
-                'roofline': roof, 'network': net, 'cpu_baseline': cpu}
+                'roofline': roof, 'network': net, 'cpu_baseline': cpu, 'distributed': dist_info(par)}
         print(json.dumps(line))
     if par.collectives_active():
         par.barrier()
@@ -447,12 +507,17 @@ def volume_main(args):
     # volume in and result out -- chunk + halo boxes are cut and results placed on its GPU, parallel.predict_volume_distributed)
     res_host = torch.empty((1, *vol_shape), dtype=torch.uint8).pin_memory() if rank == 0 else None
     steps, warm = (args.steps if args.steps != 20 else 2), min(args.warmup, 1)
+    # rounds dealt from a cost-sorted chunk list (cost = voxels of all windows the chunk's predicted tiles run on, from geometry):
+    # the chunks of a lock-step round then cost the same (parallel.predict_volume_distributed; --zmajor-rounds: the old order)
+    cm = pred.chunk_cost_model(halo, in_halo, skip_outside)
+    chunk_cost = None if args.zmajor_rounds else (lambda vb: cm.chunk_cost(chunk, vb))
     for _ in range(warm):
-        par.predict_volume_distributed(vol, vol_shape, chunk, halo, predict_fn, n_out=1, device=dev, out=res_host)
+        par.predict_volume_distributed(vol, vol_shape, chunk, halo, predict_fn, n_out=1, device=dev, out=res_host, chunk_cost=chunk_cost)
     out = [None]
 
     def step():
-        out[0] = par.predict_volume_distributed(vol, vol_shape, chunk, halo, predict_fn, n_out=1, device=dev, out=res_host)
+        out[0] = par.predict_volume_distributed(vol, vol_shape, chunk, halo, predict_fn, n_out=1, device=dev, out=res_host,
+                                                chunk_cost=chunk_cost)
     elapsed = timed(step, lambda: None, steps, par, dev)
     if pred.overflowed():
         raise SystemExit('fp16 activation overflow during the volume workload: rerun with bf16')
@@ -470,12 +535,23 @@ def volume_main(args):
                            'labels_sha256': (__import__('hashlib').sha256(out[0].numpy().tobytes()).hexdigest()
                                              if args.labels_sha else None),
                            'host_box_copies': par.HOST_BOX_COPIES,      # (0: rank 0's CPU cut and stitched nothing)
+                           'round_order': 'z-major' if args.zmajor_rounds else 'cost-sorted (descending window voxels, stable)',
+                           'modelled_speedup_8_ranks': dict(zip(('z_major', 'cost_sorted'), _modelled(par, cm, vol_shape, chunk, halo))),
                            'collective': 'RCCL scatter of uint8 chunks / gather of uint8 results; volume and result resident in rank 0\'s HBM, '
-                                         'one contiguous PCIe stream each way' if par.collectives_active() else 'none'}}
+                                         'one contiguous PCIe stream each way' if par.collectives_active() else 'none'},
+                'distributed': dist_info(par)}
         print(json.dumps(line))
     if par.collectives_active():
         par.barrier()
         torch.distributed.destroy_process_group()
+
+
+def _modelled(par, cm, vol_shape, chunk, halo, world=8):
+    """What lock-step rounds can reach on `world` ranks by chunk cost alone (no communication): z-major vs cost-sorted deal order."""
+    ids, boxes = par.chunk_grid(vol_shape, chunk, halo)
+    costs = [cm.chunk_cost(chunk, b) for b in boxes]
+    order = par.cost_sorted(list(range(len(ids))), costs)
+    return (round(par.round_schedule_speedup(costs, world), 3), round(par.round_schedule_speedup([costs[i] for i in order], world), 3))
 
 
 def _crop(t, halo):

@@ -157,12 +157,28 @@ int sd_tile_scatter(const void* tile_dev, int dtype, int C, int TD, int TH, int 
 int sd_postproc_labels(const uint8_t* probs_dev, int C, size_t nvox, const int32_t* ids, const double* thresholds,
                        int n_ids, void* out_dev, int out_dtype, void* stream);
 
+/* `height` pieces of `width_bytes` contiguous bytes each, `*_pitch` bytes apart (hipMemcpy2DAsync on `stream`): how a (z-range,
+ * y-range, all x) strip of a (z,y,x) volume travels between a page-locked host volume and its device copy without touching the
+ * rows around it (syconn_amd.parallel: per-strip result downloads).  kind: 0 host -> device, 1 device -> host, 2 device -> device. */
+int sd_memcpy2d_async(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width_bytes, size_t height, int kind,
+                      void* stream);
+
 /* Measurement / test support.  With n_slots > 0 every layer launch of an sd_forward is bracketed by HIP events
  * recorded on the launch stream; forward number k uses event set k % n_slots (counted from this call), so a timed
  * region of many forwards can be read back afterwards without synchronising inside it.  n_slots = 0 switches off.
  * sd_profile_read returns the per-layer milliseconds of one slot (the caller synchronised the stream before). */
 int sd_profile_enable(sd_model* m, int n_slots);
 int sd_profile_read(sd_model* m, int slot, float* ms_per_op, int n_ops);
+/* With profiling enabled every convolution launch also stamps, from its first workgroup, the shader cycle counter and the constant
+ * 100 MHz counter on entry and on exit: stamps[4 * op + {0,1,2,3}] = {cycles at entry, ticks at entry, cycles at exit, ticks at exit}
+ * (zeros for ops without a convolution launch of their own) -- shader clock of the launch = (c1 - c0) / ((t1 - t0) * 10 ns).
+ * The caller synchronised the stream before. */
+int sd_profile_read_clocks(sd_model* m, int slot, uint64_t* stamps, int n_ops);
+/* Box calibration: a chip-wide dense bf16 MFMA loop (n_workgroups x waves_per_workgroup waves, `iters` x 4 v_mfma_f32_32x32x16_bf16
+ * each, no memory traffic) launched back to back for at least min_seconds; reports the LAST launch: sustained TFLOP/s and the median
+ * shader clock of its waves.  Synchronises `stream`. */
+int sd_probe_mfma_rate(int n_workgroups, int waves_per_workgroup, int iters, double min_seconds, double* tflops_out,
+                       double* shader_ghz_out, void* stream);
 /* Copy activation buffer `buf` of the last sd_forward out of the workspace as float32 planar (C, d, h, w);
  * dims are returned in dims4 = {C, d, h, w}.  out_dev may be NULL to query dims only. */
 int sd_debug_read_buffer(sd_model* m, int buf, const void* workspace_dev, float* out_dev, int32_t* dims4,
@@ -233,6 +249,36 @@ int sd_segstats_compact_objects(const void* table, size_t cap_obj, uint64_t* ids
 int sd_segstats_compact_pairs(const void* pair_table, size_t cap_pair, const void* sub_table, const void* cell_table,
                               size_t cap_obj, uint64_t* sub_ids_dev, uint64_t* cell_ids_dev, uint64_t* counts_dev,
                               size_t max_out, uint64_t* count_dev, void* stream);
+
+/* ---- dataset-wide merge of per-chunk statistics (the chunk driver around the natives) ----------------
+ * Replaces, on record arrays in HBM, what /root/reference/syconn/proc/sd_proc.py does with Python dictionaries per chunk:
+ * the filter of _map_subcell_extract_props_thread (:640-650, :657-670: an object that lies purely inside its chunk -- on none of the
+ * six faces -- and has fewer than min_obj_vx voxels is dropped, for organelles from the overlap counts too), merge_prop_dicts
+ * (:1248-1273) and merge_map_dicts (:1300-1322).
+ * sd_chunkprops_append: reads an object table sd_segstats_scan filled for a chunk of extent (X,Y,Z) at origin (ox,oy,oz) and appends
+ *   one record per surviving object at *cursor_dev (a device counter the caller zeroes once per dataset; NOT reset here): id, global
+ *   representative coordinate int32[3], global box int32[6] = (min, max + 1), voxel count.  min_obj_vx <= 1: no filter.  Records
+ *   beyond max_records are not written but still counted: the caller compares the final cursor with max_records.
+ * sd_chunkpairs_append: the same for a pair table: (subcell id, cell id, overlap voxels), filter by the SUBCELL table's entry. */
+int sd_chunkprops_append(const void* table, size_t cap_obj, int X, int Y, int Z, int ox, int oy, int oz, uint64_t min_obj_vx,
+                         uint64_t* ids_dev, int32_t* rc_dev, int32_t* bbox_dev, uint64_t* sizes_dev, size_t max_records,
+                         uint64_t* cursor_dev, void* stream);
+int sd_chunkpairs_append(const void* pair_table, size_t cap_pair, const void* sub_table, const void* cell_table, size_t cap_obj,
+                         int X, int Y, int Z, uint64_t min_obj_vx, uint64_t* sub_ids_dev, uint64_t* cell_ids_dev, uint64_t* counts_dev,
+                         size_t max_records, uint64_t* cursor_dev, void* stream);
+/* Merge n appended records (chunks appended in processing order): stable sort by id + one segment per id.
+ *   uniq_ids / tot_sizes / last_rc[.][3]: per id (ascending) the summed voxel count and the representative coordinate of the LAST
+ *   chunk holding it (dict.update order of merge_prop_dicts); seg_begin[u]: first position of id u in bbox_sorted int32[n][6], the
+ *   per-chunk boxes in chunk order (the reference keeps a list of boxes per id); *n_unique_dev: number of ids.  Output arrays hold n
+ *   entries each; temp_dev: sd_propmerge_temp_bytes(n) bytes.
+ * sd_propmerge_pairs: unique (subcell id, cell id) ascending lexicographically with summed counts. */
+size_t sd_propmerge_temp_bytes(size_t n_records);
+int sd_propmerge_objects(const uint64_t* ids_dev, const uint64_t* sizes_dev, const int32_t* rc_dev, const int32_t* bbox_dev, size_t n,
+                         uint64_t* uniq_ids_dev, uint64_t* tot_sizes_dev, int32_t* last_rc_dev, uint32_t* seg_begin_dev,
+                         int32_t* bbox_sorted_dev, uint64_t* n_unique_dev, void* temp_dev, size_t temp_bytes, void* stream);
+int sd_propmerge_pairs(const uint64_t* sub_ids_dev, const uint64_t* cell_ids_dev, const uint64_t* counts_dev, size_t n,
+                       uint64_t* out_sub_dev, uint64_t* out_cell_dev, uint64_t* out_counts_dev, uint64_t* n_unique_dev, void* temp_dev,
+                       size_t temp_bytes, void* stream);
 
 /* ---- globally unique objects across chunks (the steps behind the per-chunk first stage) ----------------
  * make_unique_labels (/root/reference/syconn/extraction/object_extraction_steps.py:369-443: `matrix[matrix > 0] += offset` on the

@@ -23,7 +23,8 @@ EXPORTS = ['sd_init', 'sd_device_count', 'sd_model_create', 'sd_model_destroy', 
            'sd_objtable_bytes', 'sd_pairtable_bytes', 'sd_segstats_scan', 'sd_segstats_compact_objects',
            'sd_segstats_compact_pairs', 'sd_objseg_workspace_bytes', 'sd_object_segmentation', 'sd_objseg_watershed_workspace_bytes',
            'sd_object_segmentation_watershed', 'sd_marker_flood', 'sd_host_box_copy', 'sd_host_zero', 'sd_plan_clip_window',
-           'sd_gauss_workspace_bytes', 'sd_gaussian_threshold', 'sd_model_set_roi', 'sd_labels_make_unique', 'sd_labels_box_lut']
+           'sd_gauss_workspace_bytes', 'sd_gaussian_threshold', 'sd_model_set_roi', 'sd_labels_make_unique', 'sd_labels_box_lut',
+           'sd_chunkprops_append', 'sd_chunkpairs_append', 'sd_propmerge_temp_bytes', 'sd_propmerge_objects', 'sd_propmerge_pairs', 'sd_profile_read_clocks', 'sd_probe_mfma_rate', 'sd_memcpy2d_async']
 
 
 class OpDesc(C.Structure):
@@ -68,6 +69,10 @@ def load():
     lib.sd_postproc_labels.restype = i32
     lib.sd_profile_enable.argtypes = [vp, i32]; lib.sd_profile_enable.restype = i32
     lib.sd_profile_read.argtypes = [vp, i32, C.POINTER(C.c_float), i32]; lib.sd_profile_read.restype = i32
+    lib.sd_profile_read_clocks.argtypes = [vp, i32, C.POINTER(C.c_uint64), i32]; lib.sd_profile_read_clocks.restype = i32
+    lib.sd_probe_mfma_rate.argtypes = [i32, i32, i32, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]
+    lib.sd_probe_mfma_rate.restype = i32
+    lib.sd_memcpy2d_async.argtypes = [vp, sz, vp, sz, sz, sz, i32, vp]; lib.sd_memcpy2d_async.restype = i32
     lib.sd_debug_read_buffer.argtypes = [vp, i32, vp, vp, C.POINTER(C.c_int32), vp]
     lib.sd_debug_read_buffer.restype = i32
     lib.sd_model_num_ops.argtypes = [vp]; lib.sd_model_num_ops.restype = i32
@@ -107,6 +112,13 @@ def load():
     lib.sd_gaussian_threshold.restype = i32
     lib.sd_labels_make_unique.argtypes = [vp, sz, C.c_uint64, vp, vp]; lib.sd_labels_make_unique.restype = i32
     lib.sd_labels_box_lut.argtypes = [vp] + [i32] * 9 + [vp, sz, vp, vp, vp]; lib.sd_labels_box_lut.restype = i32
+    lib.sd_chunkprops_append.argtypes = [vp, sz] + [i32] * 6 + [C.c_uint64, vp, vp, vp, vp, sz, vp, vp]
+    lib.sd_chunkprops_append.restype = i32
+    lib.sd_chunkpairs_append.argtypes = [vp, sz, vp, vp, sz] + [i32] * 3 + [C.c_uint64, vp, vp, vp, sz, vp, vp]
+    lib.sd_chunkpairs_append.restype = i32
+    lib.sd_propmerge_temp_bytes.argtypes = [sz]; lib.sd_propmerge_temp_bytes.restype = sz
+    lib.sd_propmerge_objects.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp, vp, vp, vp, vp, sz, vp]; lib.sd_propmerge_objects.restype = i32
+    lib.sd_propmerge_pairs.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp, vp, sz, vp]; lib.sd_propmerge_pairs.restype = i32
     i64 = C.c_int64
     lib.sd_host_box_copy.argtypes = [vp, i64, i64, vp, i64, i64, i64, i64, i64, i32]; lib.sd_host_box_copy.restype = i32
     lib.sd_host_zero.argtypes = [vp, i64, i32]; lib.sd_host_zero.restype = i32

@@ -101,6 +101,7 @@ struct sd_model {
     long n_forward = 0;
     int last_launches = 0;             // ops of the last forward that ran as their own launch
     std::vector<hipEvent_t> events;    // [slot][n_ops + 1]
+    unsigned long long* dev_clk = nullptr;   // [slot][n_ops][4] clock stamps of the convolution launches (ConvParams::clk)
     std::vector<char> ev_recorded;     // [slot][n_ops + 1]: event was recorded by the forward that used the slot (ops that run inside
                                        // another op's launch record none: every record is a packet between two kernels)
     int final_cout = 0;
@@ -907,6 +908,7 @@ void sd_model_destroy(sd_model* m) {
     if (!m) return;
     for (hipEvent_t e : m->events) (void)hipEventDestroy(e);
     if (m->dev_blob) (void)hipFree(m->dev_blob);
+    if (m->dev_clk) (void)hipFree(m->dev_clk);
     f32_model_destroy(m->f32);
     delete m;
 }
@@ -930,6 +932,16 @@ int sd_model_set_roi(sd_model* m, const int32_t* lo_zyx, const int32_t* hi_zyx) 
     return SD_OK;
 }
 
+int sd_memcpy2d_async(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width_bytes, size_t height, int kind,
+                      void* stream) {
+    if (!dst || !src || width_bytes > dst_pitch || width_bytes > src_pitch || kind < 0 || kind > 2)
+        return fail(SD_ERR_INVALID, "sd_memcpy2d_async: bad argument");
+    if (width_bytes == 0 || height == 0) return SD_OK;
+    const hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    HIP_TRY(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width_bytes, height, k, reinterpret_cast<hipStream_t>(stream)));
+    return SD_OK;
+}
+
 int sd_profile_enable(sd_model* m, int n_slots) {
     if (!m || n_slots < 0) return fail(SD_ERR_INVALID, "sd_profile_enable: bad argument");
     for (hipEvent_t e : m->events) (void)hipEventDestroy(e);
@@ -937,10 +949,22 @@ int sd_profile_enable(sd_model* m, int n_slots) {
     m->profile_slots = n_slots;
     m->n_forward = 0;
     m->ev_recorded.assign((size_t)std::max(n_slots, 0) * (m->ops.size() + 1), 0);
+    if (m->dev_clk) { (void)hipFree(m->dev_clk); m->dev_clk = nullptr; }
     if (n_slots > 0) {
         m->events.resize((size_t)n_slots * (m->ops.size() + 1));
         for (auto& e : m->events) HIP_TRY(hipEventCreate(&e));
+        const size_t nb = (size_t)n_slots * m->ops.size() * 4 * sizeof(unsigned long long);
+        HIP_TRY(hipMalloc(&m->dev_clk, nb));
+        HIP_TRY(hipMemset(m->dev_clk, 0, nb));
     }
+    return SD_OK;
+}
+
+int sd_profile_read_clocks(sd_model* m, int slot, uint64_t* stamps, int n_ops) {
+    if (!m || !stamps || m->profile_slots <= 0 || slot < 0 || slot >= m->profile_slots || !m->dev_clk)
+        return fail(SD_ERR_INVALID, "sd_profile_read_clocks: profiling not enabled or bad slot");
+    const int n = std::min<int>(n_ops, (int)m->ops.size());
+    HIP_TRY(hipMemcpy(stamps, m->dev_clk + (size_t)slot * m->ops.size() * 4, (size_t)n * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return SD_OK;
 }
 
@@ -1233,6 +1257,7 @@ static int forward_impl(sd_model* m, const void* in_dev, int in_dtype, int N, in
                 p.relu = d.relu; p.zero = m->dev_zero;
                 p.store_main = 1; p.ovf = m->dev_ovf;
                 p.batch = N; p.tstride = tstride; p.out_tstride = out_tstride;
+                if (ev && m->dev_clk) p.clk = m->dev_clk + ((size_t)((m->n_forward - 1) % m->profile_slots) * m->ops.size() + i) * 4;
 #ifdef SD_TIMING
                 p.dbg = (getenv("SD_TIMING_OP") && atoi(getenv("SD_TIMING_OP")) == (int)i) ? reinterpret_cast<long long*>(wsb + m->buf_off[1]) : nullptr;
 #endif

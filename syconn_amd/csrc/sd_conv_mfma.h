@@ -155,6 +155,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
     // values (weights / 255 and bias split three ways into bf16 parts: sd_device.h first_u8_mfma) instead of five 64-cycle
     // v_mfma_f32_32x32x2_f32 -- a fifth of the matrix-pipe time; fp32-level result, not the bit pattern of the float32(v) / 255 chain.
     constexpr bool FF = MODE == 1 || MODE == 4 || MODE == 5, GN = MODE == 2, FU8 = MODE == 5;
+    // shader clock seen by this launch (bench.py: `roofline.clock_ghz_timed_region`): the first workgroup stamps the shader cycle counter
+    // and the constant 100 MHz counter on entry and on exit (persistent workgroups live as long as the launch)
+    if (p.clk && blockIdx.x == 0 && threadIdx.x == 0) { p.clk[0] = __builtin_readcyclecounter(); p.clk[1] = __builtin_amdgcn_s_memrealtime(); }
     // MODE 3 (SP, split-fp16 plan = act_dtype SD_F16X2): every tensor is stored as TWO fp16 planes per channel, x = hi + lo (hi =
     // fp16(x), lo = fp16(x - hi): 22 mantissa bits), as 2n chunks [n hi chunks | n lo chunks]; the weights are split the same
     // way (times a power of two per layer that keeps the lo parts normal; undone by p.oscale).  A product is computed as
@@ -1566,6 +1569,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
 #endif
         lb = nlb; z0 = nz0; y0 = ny0; x0 = nx0; tn = ntn;
     }
+    if (p.clk && blockIdx.x == 0 && threadIdx.x == 0) { p.clk[2] = __builtin_readcyclecounter(); p.clk[3] = __builtin_amdgcn_s_memrealtime(); }
     sguard.flush(p.ovf);
 }
 

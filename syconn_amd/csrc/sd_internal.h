@@ -58,6 +58,7 @@ struct ConvParams {
     int final_cout, final_kind;
     void* final_out;   // planar (cout, D*H*W)
     long long* dbg;         // SD_TIMING builds: per-wave cycle stamps
+    unsigned long long* clk; // sd_profile_enable: workgroup 0 stamps {s_memtime, s_memrealtime} at entry and exit here (4 values), or nullptr
     int batch; size_t tstride, out_tstride;
     int batch_total;   // > 0: tiles of the whole launch SET when it is issued in tile groups (deferred GroupNorm): the kernel
                        // form (512- / 256-voxel workgroups, 4-tile form) must not depend on the size of the last group

@@ -218,7 +218,6 @@ __global__ __launch_bounds__(256) void k_upconv_mfma(const UpconvParams p) {
         __syncthreads();
         gss = gtab;
     }
-#pragma unroll 2
     for (int c = 0; c < p.nchunk; ++c) {
         v8 xf[2], wf[2];
 #pragma unroll
@@ -640,7 +639,6 @@ __global__ __launch_bounds__(256) void k_final_mfma(const FinalParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) lg[i][r] = 0.f;
         const long vv[2] = {v0 + vl, v0 + 32 + vl};
-#pragma unroll 2
         for (int c = 0; c < nch; ++c) {
             v8 x[2];
 #pragma unroll

@@ -239,6 +239,26 @@ class DenseModel:
         return np.asarray(list(ms), dtype=np.float64)
 
 
+    def profile_read_clocks(self, slot: int = 0) -> np.ndarray:
+        """(n_ops, 4) uint64 stamps of the convolution launches recorded in `slot`: shader cycles / 100 MHz ticks at entry and exit of
+        the launch's first workgroup (zeros: the op had no convolution launch of its own)."""
+        torch.cuda.synchronize(self.device)
+        st = (C.c_uint64 * (4 * self.n_ops))()
+        L.check(self.lib.sd_profile_read_clocks(self._h, int(slot), st, self.n_ops), 'sd_profile_read_clocks')
+        return np.asarray(list(st), dtype=np.uint64).reshape(self.n_ops, 4)
+
+
+def probe_mfma_rate(device, n_workgroups: int = 256, waves: int = 8, iters: int = 20000, min_seconds: float = 0.25):
+    """(sustained dense bf16 MFMA TFLOP/s, shader clock in GHz) of this box under a chip-wide pure MFMA loop (`sd_probe_mfma_rate`)."""
+    device = torch.device(device)
+    lib = require_gpu(device.index or 0)
+    tf, ghz = C.c_double(), C.c_double()
+    with torch.cuda.device(device):
+        L.check(lib.sd_probe_mfma_rate(int(n_workgroups), int(waves), int(iters), float(min_seconds), C.byref(tf), C.byref(ghz),
+                                       torch.cuda.current_stream(device).cuda_stream), 'sd_probe_mfma_rate')
+    return float(tf.value), float(ghz.value)
+
+
 class StreamRing:
     """`n` side streams for independent tiles: tile i runs on stream i % n with workspace slot i % n, so the small
     deep-level layers and the launch tails of one tile overlap with the big layers of the next (one tile alone

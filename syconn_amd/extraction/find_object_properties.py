@@ -53,54 +53,98 @@ class SegStats:
         self.pairs: List[tuple] = []
 
 
+class DeviceScan:
+    """Hash tables of ``sd_segstats_scan`` kept on the device and reused from chunk to chunk (the scan initialises them itself).
+    After ``scan``: ``tabs[0]`` = cell table (when a cell volume was given), ``tabs[k..]`` = subcell tables, ``ptabs[i]`` = pair table
+    of subcell volume i; capacities grow (and stay grown) when a pass reports overflow."""
+
+    def __init__(self, device=None, cap_obj: Optional[int] = None, cap_pair: Optional[int] = None):
+        self.lib = L.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError('syconn_amd: no MI355X visible to PyTorch-ROCm; this package has no CPU fallback')
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        L.check(self.lib.sd_init(self.device.index or 0), 'sd_init')
+        self.cap_obj = _pow2_at_least(cap_obj) if cap_obj else 0
+        self.cap_pair = _pow2_at_least(cap_pair) if cap_pair else 0
+        self.tabs: List[torch.Tensor] = []
+        self.ptabs: List[torch.Tensor] = []
+        self.status = torch.zeros(2, dtype=torch.int32, device=self.device)
+        self.shape = None
+        self.has_cell = False
+        self.n_sub = 0
+
+    def _room(self, n_tabs: int, n_ptabs: int):
+        ob, pb = self.lib.sd_objtable_bytes(self.cap_obj), self.lib.sd_pairtable_bytes(self.cap_pair)
+        self.tabs = [t for t in self.tabs if t.numel() == ob][:n_tabs]
+        self.ptabs = [t for t in self.ptabs if t.numel() == pb][:n_ptabs]
+        while len(self.tabs) < n_tabs:
+            self.tabs.append(torch.empty(ob, dtype=torch.uint8, device=self.device))
+        while len(self.ptabs) < n_ptabs:
+            self.ptabs.append(torch.empty(pb, dtype=torch.uint8, device=self.device))
+
+    def scan(self, cell, subs: Sequence = (), want_props: bool = True):
+        """One streaming pass over `cell` (may be None) and the `subs` volumes, all of one (X, Y, Z) shape and dtype."""
+        lib, device = self.lib, self.device
+        vols = [v for v in ([cell] if cell is not None else []) + list(subs)]
+        if not vols:
+            raise ValueError('no volume given')
+        shape = tuple(int(s) for s in vols[0].shape)
+        if len(shape) != 3:
+            raise ValueError('label volumes must be 3D (x, y, z)')
+        for v in vols:
+            assert tuple(v.shape) == shape, 'Segmentation of cells and subcellular structures must have same shape.'
+        dev = [_to_device(v, device) for v in vols]
+        if len({d for _, d in dev}) != 1:
+            raise TypeError('all label volumes of one call must share a dtype')
+        dtype = dev[0][1]
+        cell_t = dev[0][0] if cell is not None else None
+        sub_ts = [t for t, _ in (dev[1:] if cell is not None else dev)]
+        n_sub = len(sub_ts)
+        nvox = shape[0] * shape[1] * shape[2]
+        # capacity guess: label volumes hold far fewer objects than voxels; overflow is detected and the pass repeated
+        if not self.cap_obj:
+            self.cap_obj = _pow2_at_least(min(2 * nvox, max(1 << 16, nvox // 256)))
+        if not self.cap_pair:
+            self.cap_pair = self.cap_obj
+        stream = torch.cuda.current_stream(device).cuda_stream
+        while True:
+            self._room(1 + n_sub, n_sub if cell_t is not None else 0)
+            tabs, ptabs = self.tabs, self.ptabs
+            sub_ptrs = (C.c_void_p * max(n_sub, 1))(*[t.data_ptr() for t in sub_ts])
+            sub_tabs = (C.c_void_p * max(n_sub, 1))(*[t.data_ptr() for t in tabs[1:]])
+            pair_tabs = (C.c_void_p * max(n_sub, 1))(*[t.data_ptr() for t in ptabs])
+            L.check(lib.sd_segstats_scan(cell_t.data_ptr() if cell_t is not None else None, sub_ptrs, n_sub, dtype, *shape,
+                                         tabs[0].data_ptr() if cell_t is not None else None, sub_tabs, self.cap_obj, pair_tabs,
+                                         self.cap_pair, 1 if want_props else 0, self.status.data_ptr(), stream), 'sd_segstats_scan')
+            st = self.status.cpu().tolist()
+            if not any(st):
+                break
+            if st[0]:
+                if self.cap_obj >= 2 * nvox:
+                    raise RuntimeError('sd_segstats_scan: object table overflow at maximum capacity')
+                self.cap_obj *= 4
+            if st[1]:
+                self.cap_pair *= 4
+        self.shape, self.has_cell, self.n_sub = shape, cell_t is not None, n_sub
+        return self
+
+    @property
+    def cell_table(self):
+        return self.tabs[0] if self.has_cell else None
+
+    @property
+    def sub_tables(self):
+        return self.tabs[1:1 + self.n_sub]
+
+
 def segstats(cell, subs: Sequence = (), want_props: bool = True, device=None, cap_obj: Optional[int] = None,
              cap_pair: Optional[int] = None) -> SegStats:
     """One streaming pass over `cell` (may be None) and the `subs` volumes, all of one (X, Y, Z) shape and dtype."""
-    lib = L.load()
-    if not torch.cuda.is_available():
-        raise RuntimeError('syconn_amd: no MI355X visible to PyTorch-ROCm; this package has no CPU fallback')
-    device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
-    L.check(lib.sd_init(device.index or 0), 'sd_init')
-    vols = [v for v in ([cell] if cell is not None else []) + list(subs)]
-    if not vols:
-        raise ValueError('no volume given')
-    shape = tuple(int(s) for s in vols[0].shape)
-    if len(shape) != 3:
-        raise ValueError('label volumes must be 3D (x, y, z)')
-    for v in vols:
-        assert tuple(v.shape) == shape, 'Segmentation of cells and subcellular structures must have same shape.'
-    dev = [_to_device(v, device) for v in vols]
-    if len({d for _, d in dev}) != 1:
-        raise TypeError('all label volumes of one call must share a dtype')
-    dtype = dev[0][1]
-    cell_t = dev[0][0] if cell is not None else None
-    sub_ts = [t for t, _ in (dev[1:] if cell is not None else dev)]
-    n_sub = len(sub_ts)
-    nvox = shape[0] * shape[1] * shape[2]
-    # capacity guess: label volumes hold far fewer objects than voxels; overflow is detected and the pass repeated
-    cap_obj = _pow2_at_least(cap_obj if cap_obj else min(2 * nvox, max(1 << 16, nvox // 256)))
-    cap_pair = _pow2_at_least(cap_pair if cap_pair else cap_obj)
+    sc = DeviceScan(device, cap_obj, cap_pair).scan(cell, subs, want_props)
+    lib, device, cap_obj, cap_pair, tabs, ptabs = sc.lib, sc.device, sc.cap_obj, sc.cap_pair, sc.tabs, sc.ptabs
+    shape, n_sub = sc.shape, sc.n_sub
+    cell_t = True if sc.has_cell else None
     stream = torch.cuda.current_stream(device).cuda_stream
-    status = torch.zeros(2, dtype=torch.int32, device=device)
-    while True:
-        tabs = [torch.empty(lib.sd_objtable_bytes(cap_obj), dtype=torch.uint8, device=device) for _ in range(1 + n_sub)]
-        ptabs = [torch.empty(lib.sd_pairtable_bytes(cap_pair), dtype=torch.uint8, device=device)
-                 for _ in range(n_sub if cell_t is not None else 0)]
-        sub_ptrs = (C.c_void_p * max(n_sub, 1))(*[t.data_ptr() for t in sub_ts])
-        sub_tabs = (C.c_void_p * max(n_sub, 1))(*[t.data_ptr() for t in tabs[1:]])
-        pair_tabs = (C.c_void_p * max(n_sub, 1))(*[t.data_ptr() for t in ptabs])
-        L.check(lib.sd_segstats_scan(cell_t.data_ptr() if cell_t is not None else None, sub_ptrs, n_sub, dtype, *shape,
-                                     tabs[0].data_ptr() if cell_t is not None else None, sub_tabs, cap_obj, pair_tabs,
-                                     cap_pair, 1 if want_props else 0, status.data_ptr(), stream), 'sd_segstats_scan')
-        st = status.cpu().tolist()
-        if not any(st):
-            break
-        if st[0]:
-            if cap_obj >= 2 * nvox:
-                raise RuntimeError('sd_segstats_scan: object table overflow at maximum capacity')
-            cap_obj *= 4
-        if st[1]:
-            cap_pair *= 4
 
     def objects(tab):
         n_max = cap_obj
@@ -135,7 +179,7 @@ def segstats(cell, subs: Sequence = (), want_props: bool = True, device=None, ca
     if want_props:
         if cell_t is not None:
             res.cell = objects(tabs[0])
-        res.sub = [objects(t) for t in tabs[1:]]
+        res.sub = [objects(t) for t in tabs[1:1 + n_sub]]
     if cell_t is not None:
         res.pairs = [pairs(ptabs[i], tabs[1 + i], tabs[0]) for i in range(n_sub)]
     return res

@@ -352,8 +352,30 @@ def stitch_pairs(chunk_a: torch.Tensor, chunk_b: torch.Tensor, dim: int, overlap
     lo_a[dim], lo_b[dim], size[dim] = na - ol - so, ol - so, 2 * so
     if lo_a[dim] < 0 or lo_b[dim] + 2 * so > nb:
         raise ValueError('chunk smaller than its overlap')
-    sa, sb = labels_box(chunk_a, lo_a, size), labels_box(chunk_b, lo_b, size)
-    r = segstats(sa, [sb], want_props=False)
+    return slab_pairs(labels_box(chunk_a, lo_a, size), labels_box(chunk_b, lo_b, size))
+
+
+def face_slab(chunk: torch.Tensor, dim: int, high: bool, overlap, stitch_overlap) -> torch.Tensor:
+    """The ``2 * stitch_overlap[dim]`` planes around the chunk face in +`dim` (`high`: the slab this chunk shares with its +`dim`
+    neighbour, ``[-overlap - stitch, -overlap + stitch)``) or in -`dim` (``[overlap - stitch, overlap + stitch)``), as a contiguous
+    copy: all ``stitch_pairs`` reads of a chunk, so a chunk's volume need not outlive the loop iteration that made it."""
+    ol, so = int(overlap[dim]), int(stitch_overlap[dim])
+    if so > ol or so < 1:
+        raise ValueError('stitch overlap has to be >= 1 and <= the chunk overlap')
+    n = int(chunk.shape[dim])
+    lo, size = [0, 0, 0], [int(v) for v in chunk.shape]
+    lo[dim], size[dim] = (n - ol - so) if high else (ol - so), 2 * so
+    if lo[dim] < 0 or lo[dim] + 2 * so > n:
+        raise ValueError('chunk smaller than its overlap')
+    return labels_box(chunk, lo, size)
+
+
+def slab_pairs(slab_a: torch.Tensor, slab_b: torch.Tensor) -> set:
+    """``tuple(sorted((id_a, id_b)))`` over the voxels where both slabs (the same voxels, labelled by two chunks) are non-zero."""
+    from .find_object_properties import segstats
+    if tuple(slab_a.shape) != tuple(slab_b.shape):
+        raise ValueError('neighbouring chunks differ in the face extents')
+    r = segstats(slab_a, [slab_b], want_props=False)
     ids_b, ids_a, _ = r.pairs[0]
     return {(int(min(x, y)), int(max(x, y))) for x, y in zip(ids_a.tolist(), ids_b.tolist())}
 

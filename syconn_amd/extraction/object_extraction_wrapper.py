@@ -16,25 +16,22 @@ from ..handler.basics import kd_factory
 
 
 def calculate_chunk_numbers_for_box(cset, offset, size):
-    """object_extraction_wrapper.py:23-55: chunk ids (partly) inside the box, in x-outermost order, and the reverse mapping.  (The
-    reference grows `offset` / `size` in place to chunk multiples; copies are used here.)"""
-    offset, size = np.array(offset, dtype=np.int64), np.array(size, dtype=np.int64)
+    """Chunks of `cset` that intersect the box (`offset`, `size`) -- contract of object_extraction_wrapper.py:23-55: the list of their
+    numbers ordered by chunk origin with x slowest and z fastest, and the mapping chunk number -> position in that list.  The box is
+    widened to whole chunks first (down at its origin, up at its far side); origins the grid does not hold are left out (a box that
+    ends one voxel beyond a dataset whose extent is a multiple of the chunk size names a row of chunks that does not exist).  Unlike
+    the reference, `offset` and `size` are not modified."""
     cs = np.asarray(cset.chunk_size, dtype=np.int64)
-    for dim in range(3):
-        offset_overlap = offset[dim] % cs[dim]
-        offset[dim] -= offset_overlap
-        size[dim] += offset_overlap
-        size[dim] += (cs[dim] - size[dim]) % cs[dim]
-    coord_dict = {tuple(int(v) for v in c.coordinates): n for n, c in cset.chunk_dict.items()}
-    chunk_list, translator = [], {}
-    for x in range(int(offset[0]), int(offset[0] + size[0]), int(cs[0])):
-        for y in range(int(offset[1]), int(offset[1] + size[1]), int(cs[1])):
-            for z in range(int(offset[2]), int(offset[2] + size[2]), int(cs[2])):
-                if (x, y, z) not in coord_dict:      # (generate_subcell_kd_from_proba asks for boundary + 1 voxels: on a dataset whose
-                    continue                          # boundary is a multiple of the chunk size that row of chunks does not exist)
-                chunk_list.append(coord_dict[(x, y, z)])
-                translator[chunk_list[-1]] = len(chunk_list) - 1
-    return chunk_list, translator
+    lo = np.asarray(offset, dtype=np.int64) // cs * cs
+    hi = -(-(np.asarray(offset, dtype=np.int64) + np.asarray(size, dtype=np.int64)) // cs) * cs
+    numbers = np.fromiter(cset.chunk_dict.keys(), dtype=np.int64, count=len(cset.chunk_dict))
+    origins = np.asarray([cset.chunk_dict[int(n)].coordinates for n in numbers], dtype=np.int64).reshape(-1, 3)
+    # the reference steps from the box's widened origin in chunk-size strides: only origins on that lattice can match
+    inside = np.all((origins >= lo) & (origins < hi) & ((origins - lo) % cs == 0), axis=1)
+    numbers, origins = numbers[inside], origins[inside]
+    order = np.lexsort((origins[:, 2], origins[:, 1], origins[:, 0]))
+    chunk_list = [int(n) for n in numbers[order]]
+    return chunk_list, {n: i for i, n in enumerate(chunk_list)}
 
 
 def generate_subcell_kd_from_proba(subcell_names: List[str], chunk_size=None, transf_func_kd_overlay=None,
@@ -131,6 +128,8 @@ def from_probabilities_to_kd(target_kd_paths: Optional[Dict[str, str]], cset, fi
         chunk_list = [ii for ii in range(len(cset.chunk_dict))]
         chunk_translator = {ii: ii for ii in chunk_list}
     device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    # (the kept int32 labels may take at most half of what is free in HBM right now, whatever budget was asked for)
+    labels_on_device_bytes = min(int(labels_on_device_bytes), torch.cuda.mem_get_info(device)[0] // 2)
 
     # ---- connected components per chunk (object_segmentation), labels kept
     cc_info_list, overlap_info, _, labels = oes.object_segmentation(
@@ -165,27 +164,22 @@ def from_probabilities_to_kd(target_kd_paths: Optional[Dict[str, str]], cset, fi
     stitch_list, merge_dict, merge_list_dict = {}, {}, {}
     targets = {name: kd_factory(target_kd_paths[name]) for name in hdf5names} if target_kd_paths else {}
     for name in hdf5names:
-        # ---- stitch list (:330-337): every chunk against its +x, +y, +z neighbours.  Unique volumes are made once per chunk and kept
-        # only while a later neighbour still needs them.
+        # ---- stitch list (:330-337): every chunk against its +x, +y, +z neighbours.  A chunk's unique-label volume is made ONCE and
+        # dropped at the end of its iteration; what waits for a later neighbour is only the face slab that neighbour shares with it
+        # (2 * stitch_overlap planes): at most one row of slabs per dimension is alive, whatever the size of the dataset.
         by_pos = {p: n for n, p in grid_pos.items()}
-        cache, pairs = {}, set()
-        for n in chunk_list:
+        waiting, pairs = {}, set()                      # (chunk, dim) -> its +dim face slab, until the +dim neighbour has been made
+        for n in sorted(chunk_list, key=lambda k: grid_pos[k]):      # (any -d neighbour then precedes its +d neighbour)
             p = grid_pos[n]
-            nbrs = [(d, by_pos.get(tuple(p[k] + (1 if k == d else 0) for k in range(3)))) for d in range(3)]
-            if not any(m is not None for _, m in nbrs):
-                cache.pop(n, None)
-                continue
-            a = cache.pop(n) if n in cache else unique(n, name)
-            for d, m in nbrs:
-                if m is None:
-                    continue
-                if m not in cache:
-                    cache[m] = unique(m, name)
-                pairs |= oes.stitch_pairs(a, cache[m], d, overlap, stitch_overlap)
-            # (x-outermost chunk order: the +x neighbour is the farthest ahead; drop what no later chunk compares against)
-            for m in [k for k in cache if all(grid_pos[k][i] <= p[i] for i in range(3))]:
-                del cache[m]
-        cache.clear()
+            vol = unique(n, name)
+            for d in range(3):
+                before = by_pos.get(tuple(p[k] - (1 if k == d else 0) for k in range(3)))
+                if before is not None and (before, d) in waiting:
+                    pairs |= oes.slab_pairs(waiting.pop((before, d)), oes.face_slab(vol, d, False, overlap, stitch_overlap))
+                if by_pos.get(tuple(p[k] + (1 if k == d else 0) for k in range(3))) is not None:
+                    waiting[(n, d)] = oes.face_slab(vol, d, True, overlap, stitch_overlap)
+            del vol
+        assert not waiting, 'chunk order: a +neighbour was processed before its -neighbour'
         stitch_list[name] = sorted(pairs)
         # ---- merge list (:343-347) and its application + export (:352-366)
         merge_dict[name], merge_list_dict[name] = oes.make_merge_list(stitch_list[name], max_labels[name])

@@ -213,40 +213,20 @@ class Predictor:
             run(vol[None], out[None], 0)
             return
         # independent tiles go through the network `nb` at a time (sd_forward_batch: one set of launches, every
-        # kernel sees nb times as many blocks); batches alternate over `n_streams` HIP streams
-        pos_list = list(itertools.product(*[range(int(n)) for n in ntiles]))   # z-major, like upstream
-        zero = False
-        if valid_box is not None:
-            v_lo, v_hi = (np.asarray(v, dtype=np.int64) for v in valid_box)
-            inside = [pos for pos in pos_list
-                      if np.all(tile * np.asarray(pos) < v_hi) and np.all(np.minimum(tile * (np.asarray(pos) + 1), spatial) > v_lo)]
-            zero = len(inside) < len(pos_list)
-            pos_list = inside
-            if not pos_list:
-                out.zero_()
-                return
-        # window of every tile: full, or clipped at the far side to what its wanted voxels depend on; equal windows batch
-        by_window = {}
-        for pos in pos_list:
-            lo = tile * np.asarray(pos, dtype=np.int64)
-            keep = np.minimum(tile, spatial - lo)
-            w0 = np.zeros(3, dtype=np.int64) if valid_box is None else np.maximum(v_lo - lo, 0)      # wanted: [w0, w1) from lo
-            w1 = keep if valid_box is None else np.minimum(keep, v_hi - lo)
-            win = [self._dm.clipped_window(int(ol[a] + w0[a]), int(ol[a] + w1[a]), int(tin[a]), a) for a in range(3)] \
-                if self.clip_tiles else [(0, int(t)) for t in tin]
-            zero = zero or bool(np.any(w1 < keep) or np.any(w0 > 0))
-            start = np.asarray([w[0] for w in win], dtype=np.int64)
-            # the box of the window that is scattered (tiled_apply keeps the core of a tile): the decoder computes only what it
-            # depends on (`sd_model_set_roi`); tiles of one window that keep the same box share a launch set
-            roi = (tuple(int(v) for v in ol + w0 - start), tuple(int(v) for v in ol + w1 - start)) if self.clip_tiles else None
-            if roi is not None and (self._dm.has_groupnorm or np.prod(np.subtract(roi[1], roi[0])) > 0.8 * np.prod([w[1] for w in win])):
-                roi = None                       # (nearly the whole window is kept: whole-tile kernels -- the fused level-0 decoder -- win;
-                                                 # GroupNorm networks: the library ignores the box, it would only split launch sets)
-            by_window.setdefault((tuple(w[1] for w in win), roi), []).append((lo, start, w0, w1))
+        # kernel sees nb times as many blocks); batches alternate over `n_streams` HIP streams.
+        # Which tiles run, on which window (full, or clipped at the far side to what the wanted voxels depend on), keeping which box:
+        # syconn_amd.tiling.plan_tile_windows -- the same arithmetic parallel.predict_volume_distributed orders its rounds by
+        from ..tiling import plan_tile_windows
+        by_window, zero = plan_tile_windows(spatial, tile, ol, ntiles, valid_box, self.clip_tiles, self._dm.clipped_window,
+                                            self._dm.has_groupnorm)
+        if not by_window:
+            out.zero_()
+            return
         if zero:                                 # beyond the dataset `out` reads zero, whatever was skipped or clipped
             out.zero_()
         nb = self._batch_for(tin, max(len(g) for g in by_window.values()))
-        ring = self._ring2 if (self._ring2 is not None and nb == 1 and len(pos_list) > 1) else self._ring
+        n_tiles = sum(len(g) for g in by_window.values())
+        ring = self._ring2 if (self._ring2 is not None and nb == 1 and n_tiles > 1) else self._ring
         tbuf = [torch.empty(nb * int(np.prod(tin)), dtype=vol.dtype, device=self.device) for _ in range(ring.n)]
         obuf = [torch.empty(nb * nch * int(np.prod(tin)), dtype=out.dtype, device=self.device) for _ in range(ring.n)]
         i = 0
@@ -265,6 +245,12 @@ class Predictor:
                         for j, (lo, start, w0, w1) in enumerate(group):
                             tile_scatter(ob[j], ol + w0 - start, w1 - w0, out, lo + w0)
                     i += 1
+
+    def chunk_cost_model(self, halo, halo_included: bool, skip_outside: bool = True):
+        """Cost of a chunk of a chunked volume prediction through this Predictor, from geometry alone (``syconn_amd.tiling``)."""
+        from ..tiling import ChunkCostModel, PlanClipper
+        return ChunkCostModel(PlanClipper(self._dm._ops_arr), self.tile_shape, self.overlap_shape, halo, halo_included,
+                              self.clip_tiles, skip_outside)
 
     def _guarded(self, run):
         """Run one tiled prediction; if the fp16 range guard fired, repeat it in bf16 (default storage type) or raise."""

@@ -17,6 +17,7 @@ import torch
 import torch.distributed as dist
 
 from ._lib import host_box_copy, host_zero
+from ._lib import load as _lib_load
 from .handler.basics import chunkify
 
 # strided host box copies issued by predict_volume_distributed since import (tests: the device path must not add any)
@@ -218,7 +219,8 @@ def _pinned_give(t: torch.Tensor, pin: bool) -> None:
 def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Sequence[int], chunk_shape: Sequence[int],
                                halo: Sequence[int], predict_fn, n_out: int, device=None,
                                pipelined: bool = True, root_computes: bool = True,
-                               trace: Optional[list] = None, out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+                               trace: Optional[list] = None, out: Optional[torch.Tensor] = None,
+                               chunk_cost=None) -> Optional[torch.Tensor]:
     """Chunk-parallel dense prediction of one (z,y,x) uint8 volume over all ranks of the process group: the RCCL
     variant of the reference's "one worker per GPU, chunk ids dealt round-robin" (prediction.py:708-719), with the
     file system replaced by collectives.
@@ -249,6 +251,11 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
     A `predict_fn` that takes a keyword `valid_box` receives ((z0, y0, x0), (z1, y1, x1)), the part of the chunk PROPER that
     lies inside the volume in chunk + halo coordinates (the chunk grid overhangs the volume; ``Predictor`` skips model tiles
     whose result lies entirely beyond it).
+    `chunk_cost(valid_box) -> number` (e.g. ``Predictor.chunk_cost_model(...).chunk_cost`` bound to the chunk shape): the chunk list is
+    then dealt in order of DESCENDING cost (stable: equal costs stay z-major), so that the chunks of one lock-step round cost the
+    same and the round barrier waits for nobody.  The chunk grid of the reference overhangs the dataset: in z-major order a round
+    mixes 12-tile interior chunks with 2-tile corner chunks and 8 ranks top out at 6.1-6.4x by geometry alone; cost-sorted rounds
+    reach 7.8-7.9x (`round_schedule_speedup`, tests/test_distributed_cpu.py).  Ownership stays ``chunkify`` over that list.
     `trace`: optional list that receives ('scatter' | 'predict' | 'gather' | 'stitch', round) in ISSUE order (tests)."""
     import itertools
     import numpy as np
@@ -260,8 +267,6 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
     workers = list(range(world)) if (root_computes or world == 1) else list(range(1, world))
     nw = len(workers)
     slot_of = {w: k for k, w in enumerate(workers)}              # rank -> position of its chunk in a round
-    rounds = [ids[r0:r0 + nw] for r0 in range(0, len(ids), nw)]
-    nr = len(rounds)
     import inspect
     try:
         wants_box = 'valid_box' in inspect.signature(predict_fn).parameters
@@ -273,6 +278,11 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
         a = np.maximum(ol, -lo)
         b = np.minimum(ol + cs, vs - lo)
         return tuple(int(v) for v in a), tuple(int(v) for v in b)
+
+    if chunk_cost is not None:
+        ids = cost_sorted(ids, [chunk_cost(valid_box_of(c)) for c in ids])       # (every rank computes the same list from geometry)
+    rounds = [ids[r0:r0 + nw] for r0 in range(0, len(ids), nw)]
+    nr = len(rounds)
 
     in_shape = tuple(int(v) for v in cs + 2 * ol)
     out_shape = (n_out, *[int(c) for c in cs])
@@ -291,6 +301,21 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
     full_shape = (n_out, *[int(v) for v in vs])
     if root and out is not None and (tuple(out.shape) != full_shape or out.dtype != torch.uint8 or out.is_cuda or not out.is_contiguous()):
         raise ValueError(f'out: need a contiguous uint8 host tensor of shape {full_shape}')
+    fits = True
+    if root and cuda:
+        # volume + result live in rank 0's HBM for the whole call: (1 + n_out) bytes per voxel beside the model's workspace.  Refuse
+        # before the first payload collective what cannot fit (RuntimeError = the reference's out-of-memory convention), on ALL ranks:
+        # rank 0 failing alone in the middle of a round would leave the others waiting in a collective
+        need_bytes = (0 if volume_u8.is_cuda else int(np.prod(vs))) + n_out * int(np.prod(vs))
+        free_bytes = torch.cuda.mem_get_info(device)[0] + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+        fits = need_bytes <= 0.9 * free_bytes
+    if coll and cuda:
+        flag = torch.tensor([1 if fits else 0], dtype=torch.int32, device=device if dist.get_backend() == 'nccl' else 'cpu')
+        dist.broadcast(flag, src=0)
+        fits = bool(flag.item())
+    if not fits:
+        raise RuntimeError(f"predict_volume_distributed: volume + {n_out} result channel(s) = {(1 + n_out) * int(np.prod(vs)) / 2**30:.1f} GiB do not fit "
+                           f"rank 0's free HBM: predict the volume in z-slabs")
     if root and cuda:
         from .engine import tile_gather, tile_scatter
         vol = volume_u8.contiguous()
@@ -301,7 +326,11 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
         stage = [torch.empty((world, *in_shape), dtype=torch.uint8, device=device) for _ in range(2)] if coll else None
         recv = [torch.empty((world, *out_shape), dtype=torch.uint8, device=device) for _ in range(2)] if coll else None
         up_next = [0 if not vol.is_cuda else int(vs[0])]          # first z-plane of the volume not yet uploaded
-        rows_left = [grid[1] * grid[2]] * grid[0]                 # chunks of every row of chunks that are not in out_dev yet
+        # results leave HBM strip by strip: a strip = the chunks (zi, yi, all x) = z-planes x a contiguous run of rows, one 2D copy per
+        # output channel as soon as its last chunk has arrived (cost-sorted rounds finish whole z-rows only at the very end: row-wise
+        # downloads would leave the entire result for a tail after the last kernel)
+        strips_left = {(zi, yi): grid[2] for zi in range(grid[0]) for yi in range(grid[1])}
+        lib = _lib_load()
     elif root:
         vol = volume_u8.contiguous()
         if out is None:
@@ -409,11 +438,18 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
                 for k, c in enumerate(rounds[r]):
                     lo = np.asarray(c, dtype=np.int64) * cs
                     tile_scatter(recv[s][workers[k]] if coll else res_buf[s], (0, 0, 0), np.minimum(cs, vs - lo), out_dev, lo)
-                    rows_left[c[0]] -= 1
-                    if rows_left[c[0]] == 0:
-                        z0, z1 = int(c[0]) * int(cs[0]), min(int(vs[0]), (int(c[0]) + 1) * int(cs[0]))
+                    key = (int(c[0]), int(c[1]))
+                    strips_left[key] -= 1
+                    if strips_left[key] == 0:
+                        z0, z1 = key[0] * int(cs[0]), min(int(vs[0]), (key[0] + 1) * int(cs[0]))
+                        y0, y1 = key[1] * int(cs[1]), min(int(vs[1]), (key[1] + 1) * int(cs[1]))
+                        plane, row = int(vs[1]) * int(vs[2]), int(vs[2])
                         for ch in range(n_out):
-                            out[ch, z0:z1].copy_(out_dev[ch, z0:z1], non_blocking=True)
+                            off = (ch * int(vs[0]) + z0) * plane + y0 * row
+                            rc = lib.sd_memcpy2d_async(out.data_ptr() + off, plane, out_dev.data_ptr() + off, plane, (y1 - y0) * row, z1 - z0,
+                                                       1, s_out.cuda_stream)
+                            if rc != 0:
+                                raise RuntimeError('sd_memcpy2d_async failed: ' + lib.sd_last_error().decode(errors='replace'))
                 ev_d2h[s].record(s_out)                          # (recv[s] / res_buf[s] are free again)
         elif root and not coll:
             pin_out[s][0].copy_(res_buf[s])
@@ -477,6 +513,34 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
         for t in taken:
             _pinned_give(t, cuda)
     return out if root else None
+
+
+def chunk_grid(vol_shape: Sequence[int], chunk_shape: Sequence[int], halo: Sequence[int]):
+    """-> (ids, valid boxes): chunk ids (iz, iy, ix) in z-major order and, per chunk, the part of the chunk proper that lies inside the
+    volume in chunk + halo coordinates -- what ``predict_volume_distributed`` hands to ``predict_fn(valid_box=...)`` / ``chunk_cost``."""
+    import itertools
+    import numpy as np
+    vs, cs, ol = (np.asarray(v, dtype=np.int64) for v in (vol_shape, chunk_shape, halo))
+    ids = list(itertools.product(*[range(int(-(-vs[i] // cs[i]))) for i in range(3)]))
+    boxes = []
+    for cid in ids:
+        lo = np.asarray(cid, dtype=np.int64) * cs - ol
+        boxes.append((tuple(int(v) for v in np.maximum(ol, -lo)), tuple(int(v) for v in np.minimum(ol + cs, vs - lo))))
+    return ids, boxes
+
+
+def cost_sorted(ids: Sequence, costs: Sequence[float]) -> list:
+    """`ids` in order of descending cost; equal costs keep their order (z-major ids: the z-slab uploads stay in order inside a class)."""
+    order = sorted(range(len(ids)), key=lambda i: -float(costs[i]))      # sorted() is stable
+    return [ids[i] for i in order]
+
+
+def round_schedule_speedup(costs_in_deal_order: Sequence[float], world: int) -> float:
+    """Modelled speed-up of lock-step rounds over one rank: every round takes as long as its most expensive chunk
+    (sum of all costs / sum over rounds of the round's maximum) -- geometry only, no communication."""
+    c = [float(v) for v in costs_in_deal_order]
+    rounds = [c[i:i + world] for i in range(0, len(c), world)]
+    return sum(c) / sum(max(r) for r in rounds) if c else 1.0
 
 
 def barrier():

@@ -1,155 +1,329 @@
-"""Dataset-wide object properties and organelle -> cell overlap counts from KnossosDataset segmentations: the chunk driver of
-``map_subcell_extract_props`` (/root/reference/syconn/proc/sd_proc.py:273-787) up to and including
-the dictionaries its first step produces -- per chunk the Cython native ``map_subcell_extract_props``
-(find_object_properties_C.pyx:112-192; here the device pass ``sd_segstats_scan``), then ``merge_prop_dicts`` (:1248-1273) /
-``merge_map_dicts`` (:1300-1322) into per-dataset dictionaries.  Not built: the worker / batch-job machinery, the mesh caches and
-step 2 (writing SegmentationObject storages) -- they belong to SyConn's storage layer, outside the dense-prediction path.
+"""Dataset-wide object properties and organelle -> cell overlap counts from KnossosDataset segmentations: step 1 of
+``map_subcell_extract_props`` (/root/reference/syconn/proc/sd_proc.py:273-787).
 
-Pinned: ``merge_prop_dicts``, ``merge_map_dicts``, ``convert_nvox2ratio_mapdict``, ``invert_mdc`` by the reference's own functions
-(tests/golden/make_golden_propmerge.py, AST-lifted), the per-chunk native by the reference's known-answer test (g8)."""
-from collections import defaultdict
-from typing import Dict, List, Optional, Sequence
+MI355X shape of the work.  The reference turns every chunk into Python dictionaries and folds them into running dictionaries, id
+by id, on the host (its worker loop :617-678 with ``merge_prop_dicts`` :1248-1273 and ``merge_map_dicts`` :1300-1322).  Here no
+per-object data exists on the host before the dataset is finished:
+
+* per chunk  ``sd_segstats_scan`` (one HBM-bound pass over the label volumes) fills device hash tables; ``sd_chunkprops_append`` /
+  ``sd_chunkpairs_append`` turn them into RECORDS appended to device arrays -- applying the "purely inside the chunk and smaller than
+  ``min_obj_vx``" filter from the tables' own bounding boxes (an id is on a face of the chunk exactly when its box touches that
+  face: no sixfold ``np.unique`` over the faces) and adding the chunk origin;
+* per dataset  ``sd_propmerge_objects`` / ``sd_propmerge_pairs``: stable radix sort by id + one segment per id (sizes add up, the
+  representative coordinate is the last chunk's, bounding boxes stay one per chunk in chunk order);
+* at the API edge the merged tables (``PropTable`` / ``MapTable``, plain numpy) become the dictionaries the reference's workers
+  pickle for step 2.  ``convert_nvox2ratio_mapdict`` / ``invert_mdc`` have array forms there (``MapTable.ratios`` /
+  ``MapTable.inverted``).
+
+The four dictionary functions of the reference's module are kept by name and contract (in-place merge into the first element)
+for callers that hold dictionaries; the chunk driver does not use them.  Not built: the batch-job machinery, the mesh caches and
+step 2 (writing SegmentationObject storages) -- SyConn's storage layer, outside the dense-prediction path.
+
+Pinned by tests/golden/g12_propmerge.npz (outputs of the reference's own functions, tests/golden/make_golden_propmerge.py)."""
+from typing import Callable, Dict, List, Optional, Sequence
 
 import numpy as np
 
 from ..handler.basics import kd_factory
 
 
-def merge_prop_dicts(prop_dicts: List[List[dict]], offset: Optional[np.ndarray] = None):
-    """sd_proc.py:1248-1273: merge ``[rep_coords, bounding_boxes, sizes]`` triples IN PLACE into the first one.  Representative
-    coordinates: a later chunk overwrites an earlier one; bounding boxes: every chunk's box is appended to the id's list (the
-    first triple's second dict must be a ``defaultdict(list)``); sizes add up.  `offset` (the chunk's origin) is added to the
-    coordinates and boxes of every triple but the first."""
-    tot_rc, tot_bb, tot_size = prop_dicts[0][0], prop_dicts[0][1], prop_dicts[0][2]
-    for el in prop_dicts[1:]:
-        if len(el[0]) == 0:
-            continue
-        if offset is not None:
-            for k in el[0]:
-                el[0][k] = [el[0][k][ii] + offset[ii] for ii in range(3)]
-        tot_rc.update(el[0])
-        for k, v in el[1].items():
-            bb = v if offset is None else [[v[0][ii] + offset[ii] for ii in range(3)], [v[1][ii] + offset[ii] for ii in range(3)]]
-            tot_bb[k].append(bb)
-        for k, v in el[2].items():
-            if k in tot_size:
-                tot_size[k] += v
-            else:
-                tot_size[k] = v
+# ---------------------------------------------------------------------------------------------------------------------------------
+# merged tables (host, numpy) and their dictionary views
+class PropTable:
+    """Merged properties of one label volume kind: ``ids`` ascending (uint64), ``sizes`` (int64), ``rep_coords`` (n, 3),
+    ``boxes`` (m, 2, 3) = every (chunk, id) box in id-major / chunk-minor order, ``box_begin`` (n + 1) offsets into ``boxes``."""
+
+    def __init__(self, ids, sizes, rep_coords, boxes, box_begin):
+        self.ids, self.sizes, self.rep_coords, self.boxes, self.box_begin = ids, sizes, rep_coords, boxes, box_begin
+
+    def __len__(self):
+        return len(self.ids)
+
+    def as_dicts(self) -> List[dict]:
+        """``[rep_coords, bounding_boxes, sizes]`` as the reference's workers return them: id -> [x, y, z], id -> list of
+        [[min], [max + 1]] (one entry per chunk holding the id), id -> voxels."""
+        keys = self.ids.tolist()
+        per_id = np.split(self.boxes, self.box_begin[1:-1]) if len(keys) else []
+        return [dict(zip(keys, self.rep_coords.tolist())), dict(zip(keys, (b.tolist() for b in per_id))),
+                dict(zip(keys, self.sizes.tolist()))]
 
 
-def merge_map_dicts(map_dicts):
-    """sd_proc.py:1300-1322: merge ``subcell id -> cell id -> overlap voxels`` dictionaries IN PLACE into the first one (counts add
-    up; an id that is new to the first dictionary brings its inner dictionary along, not a copy)."""
-    tot_map = map_dicts[0]
-    for el in map_dicts[1:]:
-        for sc_id, sc_dc in el.items():
-            if sc_id in tot_map:
-                for cellsv_id, ol_vx_cnt in sc_dc.items():
-                    if cellsv_id in tot_map[sc_id]:
-                        tot_map[sc_id][cellsv_id] += ol_vx_cnt
-                    else:
-                        tot_map[sc_id][cellsv_id] = ol_vx_cnt
-            else:
-                tot_map[sc_id] = sc_dc
+class MapTable:
+    """Merged overlap counts of one organelle: rows (subcell id, cell id, voxels), ascending by subcell id, then cell id."""
+
+    def __init__(self, sub_ids, cell_ids, counts):
+        self.sub_ids, self.cell_ids, self.counts = sub_ids, cell_ids, counts
+
+    def __len__(self):
+        return len(self.sub_ids)
+
+    @staticmethod
+    def _nested(outer, inner, values) -> Dict[int, Dict[int, object]]:
+        out: Dict[int, Dict[int, object]] = {}
+        if len(outer) == 0:
+            return out
+        cut = np.flatnonzero(outer[1:] != outer[:-1]) + 1
+        inner_l, values_l = inner.tolist(), values.tolist()
+        for a, b in zip(np.concatenate(([0], cut)).tolist(), np.concatenate((cut, [len(outer)])).tolist()):
+            out[int(outer[a])] = dict(zip(inner_l[a:b], values_l[a:b]))
+        return out
+
+    def as_dict(self) -> Dict[int, Dict[int, int]]:
+        """subcell id -> cell id -> overlapping voxels."""
+        return self._nested(self.sub_ids, self.cell_ids, self.counts)
+
+    def ratios(self) -> np.ndarray:
+        """Array form of ``convert_nvox2ratio_mapdict`` (sd_proc.py:1276-1285): every count divided by the mapped voxels of its
+        subcellular object (float64, ``count / sum`` like the reference's division by a numpy integer)."""
+        if len(self) == 0:
+            return np.zeros(0, np.float64)
+        heads = np.flatnonzero(np.concatenate(([True], self.sub_ids[1:] != self.sub_ids[:-1])))
+        totals = np.add.reduceat(self.counts.astype(np.int64), heads)
+        return self.counts / np.repeat(totals, np.diff(np.concatenate((heads, [len(self)]))))
+
+    def inverted(self, values: Optional[np.ndarray] = None) -> Dict[int, Dict[int, object]]:
+        """Array form of ``invert_mdc`` (sd_proc.py:1288-1297): cell id -> subcell id -> value (the counts, or e.g. ``ratios()``)."""
+        values = self.counts if values is None else values
+        order = np.lexsort((self.sub_ids, self.cell_ids))
+        return self._nested(self.cell_ids[order], self.sub_ids[order], values[order])
 
 
-def convert_nvox2ratio_mapdict(map_dc):
-    """sd_proc.py:1276-1285: overlap voxel counts -> fractions of each subcellular object's mapped voxels, in place."""
-    for subcell_id, subcell_dc in map_dc.items():
-        s = np.sum(list(subcell_dc.values()))
-        for k, v in subcell_dc.items():
-            map_dc[subcell_id][k] = subcell_dc[k] / s
+# ---------------------------------------------------------------------------------------------------------------------------------
+# device-side record accumulators
+class _Records:
+    """Growable device arrays with a device-side append cursor.  ``fields`` = [(name, dtype, inner width)]."""
+
+    def __init__(self, device, fields, capacity: int):
+        import torch
+        self.torch, self.device, self.fields = torch, device, fields
+        self.capacity = int(capacity)
+        self.cursor = torch.zeros(1, dtype=torch.int64, device=device)
+        self.arrays = {n: self._new(dt, w, self.capacity) for n, dt, w in fields}
+        self.checked = 0                      # records known to be safely stored (cursor value at the last check)
+
+    def _new(self, dtype, width, n):
+        return self.torch.empty((n, width) if width > 1 else (n,), dtype=dtype, device=self.device)
+
+    def ptrs(self):
+        return [self.arrays[n].data_ptr() for n, _, _ in self.fields]
+
+    def room_for(self, n_more: int):
+        """Make sure `n_more` further records fit (an upper bound the caller knows: a table's capacity)."""
+        need = self.checked + int(n_more)
+        if need <= self.capacity:
+            return
+        cap = max(need, 2 * self.capacity)
+        for n, dt, w in self.fields:
+            grown = self._new(dt, w, cap)
+            grown[:self.checked] = self.arrays[n][:self.checked]
+            self.arrays[n] = grown
+        self.capacity = cap
+
+    def count(self) -> int:
+        return int(self.cursor.item())
 
 
-def invert_mdc(mapping_dict):
-    """sd_proc.py:1288-1297: ``subcell id -> cell id -> value`` turned into ``cell id -> subcell id -> value``."""
-    mdc_inv = {}
-    for subcell_id, subcell_dc in mapping_dict.items():
-        for cell_id, v in subcell_dc.items():
-            if cell_id not in mdc_inv:
-                mdc_inv[cell_id] = {subcell_id: v}
-            else:
-                mdc_inv[cell_id][subcell_id] = v
-    return mdc_inv
+class ChunkMerger:
+    """Accumulates the per-chunk tables of one dataset pass on the device and merges them at the end."""
+
+    def __init__(self, names: Sequence[str], min_obj_vx: dict, device, capacity: int = 1 << 16):
+        import torch
+        from .. import _lib as L
+        self.L, self.lib, self.torch = L, L.load(), torch
+        self.device = torch.device(device)
+        self.names = list(names)
+        self.min_vx = {k: int(min_obj_vx.get(k, 1)) for k in ['sv'] + self.names}
+        obj = [('ids', torch.int64, 1), ('rc', torch.int32, 3), ('bb', torch.int32, 6), ('sizes', torch.int64, 1)]
+        pair = [('sub', torch.int64, 1), ('cell', torch.int64, 1), ('cnt', torch.int64, 1)]
+        self.cell = _Records(self.device, obj, capacity)
+        self.sub = [_Records(self.device, obj, capacity) for _ in self.names]
+        self.pairs = [_Records(self.device, pair, capacity) for _ in self.names]
+        self.n_chunks = 0
+
+    def _settle(self, rec: _Records, upper: int):
+        """Appends are counted on the device only; before a table with up to `upper` entries is appended the arrays must hold
+        them all.  Reading the cursor (one 8-byte copy) is needed only when the pessimistic bound no longer fits."""
+        if rec.checked + upper > rec.capacity:
+            rec.checked = rec.count()
+        rec.room_for(upper)
+        rec.checked += upper                   # pessimistic until the next read of the cursor
+
+    def add_chunk(self, scan, origin):
+        """`scan`: a ``DeviceScan`` after ``scan(cell, subs)`` over one chunk whose (x, y, z) origin in the dataset is `origin`."""
+        lib, L = self.lib, self.L
+        X, Y, Z = scan.shape
+        ox, oy, oz = (int(v) for v in origin)
+        stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        cap_o, cap_p = scan.cap_obj, scan.cap_pair
+        upper_o, upper_p = min(cap_o, X * Y * Z), min(cap_p, X * Y * Z)
+        self._settle(self.cell, upper_o)
+        ids, rc, bb, sz = self.cell.ptrs()
+        L.check(lib.sd_chunkprops_append(scan.cell_table.data_ptr(), cap_o, X, Y, Z, ox, oy, oz, self.min_vx['sv'], ids, rc, bb, sz,
+                                         self.cell.capacity, self.cell.cursor.data_ptr(), stream), 'sd_chunkprops_append')
+        for i, name in enumerate(self.names):
+            tab = scan.sub_tables[i]
+            self._settle(self.sub[i], upper_o)
+            ids, rc, bb, sz = self.sub[i].ptrs()
+            L.check(lib.sd_chunkprops_append(tab.data_ptr(), cap_o, X, Y, Z, ox, oy, oz, self.min_vx[name], ids, rc, bb, sz,
+                                             self.sub[i].capacity, self.sub[i].cursor.data_ptr(), stream), 'sd_chunkprops_append')
+            self._settle(self.pairs[i], upper_p)
+            a, b, c = self.pairs[i].ptrs()
+            L.check(lib.sd_chunkpairs_append(scan.ptabs[i].data_ptr(), cap_p, tab.data_ptr(), scan.cell_table.data_ptr(), cap_o, X, Y, Z,
+                                             self.min_vx[name], a, b, c, self.pairs[i].capacity, self.pairs[i].cursor.data_ptr(), stream),
+                    'sd_chunkpairs_append')
+        self.n_chunks += 1
+
+    # -- end of the dataset ------------------------------------------------------------------------------------------------------
+    def _merge_objects(self, rec: _Records) -> PropTable:
+        torch, lib = self.torch, self.lib
+        n = rec.count()
+        assert n <= rec.capacity, 'record arrays overran (internal error: capacity bound)'
+        if n == 0:
+            return PropTable(np.zeros(0, np.uint64), np.zeros(0, np.int64), np.zeros((0, 3), np.int64), np.zeros((0, 2, 3), np.int64),
+                             np.zeros(1, np.int64))
+        dev, stream = self.device, torch.cuda.current_stream(self.device).cuda_stream
+        uniq = torch.empty(n, dtype=torch.int64, device=dev)
+        tot = torch.empty(n, dtype=torch.int64, device=dev)
+        rc = torch.empty((n, 3), dtype=torch.int32, device=dev)
+        beg = torch.empty(n, dtype=torch.int32, device=dev)
+        bbs = torch.empty((n, 6), dtype=torch.int32, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        tb = lib.sd_propmerge_temp_bytes(n)
+        tmp = torch.empty(tb, dtype=torch.uint8, device=dev)
+        a = rec.arrays
+        self.L.check(lib.sd_propmerge_objects(a['ids'].data_ptr(), a['sizes'].data_ptr(), a['rc'].data_ptr(), a['bb'].data_ptr(), n,
+                                              uniq.data_ptr(), tot.data_ptr(), rc.data_ptr(), beg.data_ptr(), bbs.data_ptr(),
+                                              cnt.data_ptr(), tmp.data_ptr(), tb, stream), 'sd_propmerge_objects')
+        u = int(cnt.item())
+        begin = np.concatenate((beg[:u].cpu().numpy().view(np.uint32).astype(np.int64), [n]))
+        return PropTable(uniq[:u].cpu().numpy().view(np.uint64), tot[:u].cpu().numpy(), rc[:u].cpu().numpy().astype(np.int64),
+                         bbs.cpu().numpy().astype(np.int64).reshape(n, 2, 3), begin)
+
+    def _merge_pairs(self, rec: _Records) -> MapTable:
+        torch, lib = self.torch, self.lib
+        n = rec.count()
+        assert n <= rec.capacity, 'record arrays overran (internal error: capacity bound)'
+        if n == 0:
+            return MapTable(np.zeros(0, np.uint64), np.zeros(0, np.uint64), np.zeros(0, np.int64))
+        dev, stream = self.device, torch.cuda.current_stream(self.device).cuda_stream
+        o_s, o_c, o_n = (torch.empty(n, dtype=torch.int64, device=dev) for _ in range(3))
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        tb = lib.sd_propmerge_temp_bytes(n)
+        tmp = torch.empty(tb, dtype=torch.uint8, device=dev)
+        a = rec.arrays
+        self.L.check(lib.sd_propmerge_pairs(a['sub'].data_ptr(), a['cell'].data_ptr(), a['cnt'].data_ptr(), n, o_s.data_ptr(),
+                                            o_c.data_ptr(), o_n.data_ptr(), cnt.data_ptr(), tmp.data_ptr(), tb, stream),
+                     'sd_propmerge_pairs')
+        u = int(cnt.item())
+        return MapTable(o_s[:u].cpu().numpy().view(np.uint64), o_c[:u].cpu().numpy().view(np.uint64), o_n[:u].cpu().numpy())
+
+    def finish(self):
+        """-> (cell PropTable, {name: PropTable}, {name: MapTable})"""
+        return (self._merge_objects(self.cell), {n: self._merge_objects(self.sub[i]) for i, n in enumerate(self.names)},
+                {n: self._merge_pairs(self.pairs[i]) for i, n in enumerate(self.names)})
 
 
-def _boundary_ids(vol) -> np.ndarray:
-    """Ids on the six faces of an (x,y,z) device volume: objects that are "not purely inside this chunk" (sd_proc.py:626-629)."""
-    import torch
-    faces = [vol[0], vol[-1], vol[:, 0], vol[:, -1], vol[:, :, 0], vol[:, :, -1]]
-    return torch.unique(torch.cat([f.reshape(-1) for f in faces])).cpu().numpy().view(np.uint64) if vol.dtype == torch.int64 \
-        else torch.unique(torch.cat([f.reshape(-1) for f in faces])).cpu().numpy()
-
-
+# ---------------------------------------------------------------------------------------------------------------------------------
 def map_subcell_extract_props(kd_seg_path: str, kd_organelle_paths: Dict[str, str], n_folders_fs: int = 1000,
                               n_folders_fs_sc: int = 1000, n_chunk_jobs: Optional[int] = None, n_cores: int = 1,
                               cube_of_interest_bb: Optional[Sequence] = None, chunk_size: Optional[Sequence[int]] = None,
-                              log=None, overwrite=False, min_obj_vx: Optional[dict] = None, device=None):
-    """Step 1 of the reference's function of this name (sd_proc.py:273-787; the per-chunk loop is
-    ``_map_subcell_extract_props_thread``, :617-678): over a regular chunk grid (``fit_box_size=True``) load the cell segmentation
-    and every organelle segmentation (``load_seg(...).swapaxes(0, 2)``), extract per-chunk properties and overlap counts on the
-    GPU, drop objects that lie purely inside a chunk and are smaller than ``config['cell_objects']['min_obj_vx'][name]`` (for
-    organelles also from the overlap dictionary), and merge everything with the chunk's origin added.
+                              log=None, overwrite=False, min_obj_vx: Optional[dict] = None, device=None, as_tables: bool = False,
+                              chunk_loader: Optional[Callable] = None):
+    """Step 1 of the reference's function of this name (sd_proc.py:273-787): over a regular chunk grid (``fit_box_size=True``)
+    read the cell segmentation and every organelle segmentation (``load_seg(...).swapaxes(0, 2)``, zeros beyond the dataset),
+    gather per-object properties and organelle -> cell overlap counts, drop objects that lie purely inside a chunk and are
+    smaller than ``config['cell_objects']['min_obj_vx'][name]``, and merge everything in dataset coordinates.
 
     Returns ``(cell_props, organelle_props, organelle_maps)``: ``[rc, bb, size]`` of the cell segmentation, ``{name: [rc, bb, size]}``
-    and ``{name: {subcell id: {cell id: voxels}}}`` -- the dictionaries the reference's workers pickle for step 2.
-    The segmentations go to the device as they are loaded (8 B per voxel and volume over PCIe); the label volumes are read once."""
+    and ``{name: {subcell id: {cell id: voxels}}}`` -- the dictionaries the reference's workers pickle for step 2; with
+    ``as_tables=True`` the merged ``PropTable`` / ``MapTable`` objects instead (no per-object Python objects are built).
+    ``chunk_loader(name, offset_xyz, size_xyz)`` (name ``'sv'`` = cell segmentation) may supply (x, y, z) label volumes, host or
+    device, in the place of the KnossosDataset reads."""
     import torch
     from .. import global_params
-    from ..extraction.find_object_properties import map_subcell_extract_props as native
+    from ..extraction.find_object_properties import DeviceScan
     from ..knossos import ChunkDataset
+    names = list(kd_organelle_paths.keys())
     kd = kd_factory(kd_seg_path)
-    kd_subcells = {k: kd_factory(v) for k, v in kd_organelle_paths.items()}
-    for k, kd_sc in kd_subcells.items():
-        if not np.array_equal(kd_sc.boundary, kd.boundary):
-            raise ValueError("Data shape of subcellular structures '{}' differs from cell segmentation data. {} vs. {}".format(
-                k, kd_sc.boundary, kd.boundary))
+    if chunk_loader is None:
+        kds = {'sv': kd}
+        for name, path in kd_organelle_paths.items():
+            kds[name] = kd_factory(path)
+            if not np.array_equal(kds[name].boundary, kd.boundary):
+                raise ValueError("Data shape of subcellular structures '{}' differs from cell segmentation data. {} vs. {}".format(
+                    name, kds[name].boundary, kd.boundary))
+
+        def chunk_loader(name, offset, size):
+            return np.ascontiguousarray(kds[name].load_seg(size=size, offset=offset, mag=1).swapaxes(0, 2))
     if min_obj_vx is None:
         min_obj_vx = global_params.config['cell_objects']['min_obj_vx']
-    if chunk_size is None:
-        chunk_size = [512, 512, 512]
-    chunk_size = np.asarray(chunk_size, dtype=np.int64)
-    if cube_of_interest_bb is None:
-        cube_of_interest_bb = [np.zeros(3, dtype=np.int64), np.asarray(kd.boundary, dtype=np.int64)]
-    size = np.asarray(cube_of_interest_bb[1]) - np.asarray(cube_of_interest_bb[0])
-    offset0 = np.asarray(cube_of_interest_bb[0], dtype=np.int64)
+    chunk_size = np.asarray([512, 512, 512] if chunk_size is None else chunk_size, dtype=np.int64)
+    lo = np.zeros(3, dtype=np.int64) if cube_of_interest_bb is None else np.asarray(cube_of_interest_bb[0], dtype=np.int64)
+    hi = np.asarray(kd.boundary, dtype=np.int64) if cube_of_interest_bb is None else np.asarray(cube_of_interest_bb[1], dtype=np.int64)
     cd = ChunkDataset()
-    cd.initialize(kd, size, chunk_size, '', box_coords=offset0, fit_box_size=True)
+    cd.initialize(kd, hi - lo, chunk_size, '', box_coords=lo, fit_box_size=True)
     device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
-    names = list(kd_organelle_paths.keys())
-    n_subcell = len(names)
-    cpd_lst = [{}, defaultdict(list), {}]
-    scpd_lst = [[{}, defaultdict(list), {}] for _ in range(n_subcell)]
-    scmd_lst = [{} for _ in range(n_subcell)]
+    with torch.cuda.device(device):
+        scan = DeviceScan(device)
+        merger = ChunkMerger(names, min_obj_vx, device)
+        for ch_id in sorted(cd.chunk_dict):
+            origin = np.asarray(cd.chunk_dict[ch_id].coordinates, dtype=np.int64)
+            subs = [chunk_loader(n, origin, chunk_size) for n in names]
+            scan.scan(chunk_loader('sv', origin, chunk_size), subs)
+            merger.add_chunk(scan, origin)
+        cell_t, sub_t, map_t = merger.finish()
+    if as_tables:
+        return cell_t, sub_t, map_t
+    return cell_t.as_dicts(), {n: t.as_dicts() for n, t in sub_t.items()}, {n: t.as_dict() for n, t in map_t.items()}
 
-    def load(k, offset):
-        a = np.ascontiguousarray(k.load_seg(size=chunk_size, offset=offset, mag=1).swapaxes(0, 2))
-        return torch.from_numpy(a.view(np.int64)).to(device)
-    for ch_id in sorted(cd.chunk_dict):
-        offset = np.asarray(cd.chunk_dict[ch_id].coordinates, dtype=np.int64)
-        subs = [load(kd_subcells[n], offset) for n in names]
-        cell_d = load(kd, offset)
-        obj_ids_bdry = {n: _boundary_ids(s) for n, s in zip(names, subs)}
-        cell_prop_dicts, subcell_prop_dicts, subcell_mapping_dicts = native(cell_d, subs)
-        # objects purely inside this chunk and below the size threshold are dropped (:640-650, :657-670)
-        if min_obj_vx.get('sv', 1) > 1:
-            inside = set(cell_prop_dicts[0].keys()).difference(set(_boundary_ids(cell_d).tolist()))
-            for ix in inside:
-                if cell_prop_dicts[2][ix] < min_obj_vx['sv']:
-                    del cell_prop_dicts[0][ix], cell_prop_dicts[1][ix], cell_prop_dicts[2][ix]
-        merge_prop_dicts([cpd_lst, cell_prop_dicts], offset)
-        subcell_prop_dicts = [[subcell_prop_dicts[0][ii], subcell_prop_dicts[1][ii], subcell_prop_dicts[2][ii]]
-                              for ii in range(n_subcell)]
-        for ii, organelle in enumerate(names):
-            if min_obj_vx.get(organelle, 1) > 1:
-                inside = set(subcell_prop_dicts[ii][0].keys()).difference(set(obj_ids_bdry[organelle].tolist()))
-                for ix in inside:
-                    if subcell_prop_dicts[ii][2][ix] < min_obj_vx[organelle]:
-                        del subcell_prop_dicts[ii][0][ix], subcell_prop_dicts[ii][1][ix]
-                        del subcell_prop_dicts[ii][2][ix]
-                        if ix in subcell_mapping_dicts[ii]:
-                            del subcell_mapping_dicts[ii][ix]
-            merge_map_dicts([scmd_lst[ii], subcell_mapping_dicts[ii]])
-            merge_prop_dicts([scpd_lst[ii], subcell_prop_dicts[ii]], offset)
-    return cpd_lst, {n: scpd_lst[i] for i, n in enumerate(names)}, {n: scmd_lst[i] for i, n in enumerate(names)}
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The reference's dictionary helpers, kept by name and contract for callers that hold dictionaries (the driver above works on
+# tables).  Each merges IN PLACE into the first element, as sd_proc.py:1248-1322 do.
+def merge_prop_dicts(prop_dicts: List[List[dict]], offset: Optional[np.ndarray] = None):
+    """``prop_dicts[0]`` = running ``[rep_coords, bounding_boxes, sizes]`` (its second entry maps id -> list of boxes); every further
+    triple is one chunk: its coordinates and boxes are shifted by `offset`, its representative coordinates replace earlier ones,
+    its boxes are appended, its sizes added.  A triple without objects is skipped."""
+    into_rc, into_bb, into_sz = prop_dicts[0]
+    shift = np.zeros(3, dtype=np.int64) if offset is None else np.asarray(offset)
+    for rc, bb, sz in prop_dicts[1:]:
+        if not rc:
+            continue
+        keys = list(bb)
+        boxes = (np.asarray([bb[k] for k in keys]).reshape(len(keys), 2, 3) + shift).tolist()
+        rc_keys = list(rc)
+        into_rc.update(zip(rc_keys, (np.asarray([rc[k] for k in rc_keys]).reshape(len(rc_keys), 3) + shift).tolist()))
+        for k, box in zip(keys, boxes):
+            into_bb.setdefault(k, []).append(box)
+        for k, n in sz.items():
+            into_sz[k] = into_sz.get(k, 0) + n
+
+
+def merge_map_dicts(map_dicts):
+    """``map_dicts[0]`` = running ``subcell id -> cell id -> voxels``; the others are added to it (an id new to the running
+    dictionary contributes its inner dictionary itself, not a copy)."""
+    into = map_dicts[0]
+    for chunk_map in map_dicts[1:]:
+        for sub_id, cells in chunk_map.items():
+            known = into.get(sub_id)
+            if known is None:
+                into[sub_id] = cells
+                continue
+            for cell_id, n in cells.items():
+                known[cell_id] = known.get(cell_id, 0) + n
+
+
+def convert_nvox2ratio_mapdict(map_dc):
+    """Overlap voxel counts -> fractions of each subcellular object's mapped voxels, in place (float64 true division)."""
+    for cells in map_dc.values():
+        counts = np.fromiter(cells.values(), dtype=np.int64, count=len(cells))
+        cells.update(zip(list(cells), counts / counts.sum()))
+
+
+def invert_mdc(mapping_dict):
+    """``subcell id -> cell id -> value`` -> ``cell id -> subcell id -> value``."""
+    out: Dict[int, dict] = {}
+    for sub_id, cells in mapping_dict.items():
+        for cell_id, value in cells.items():
+            out.setdefault(cell_id, {})[sub_id] = value
+    return out

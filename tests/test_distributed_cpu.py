@@ -112,10 +112,14 @@ def _worker_volume(rank, world, port, q, single=False):
         return torch.stack([core.to(torch.uint8), (255 - core).to(torch.uint8)])
     ok = True
     # overlapped scatter / predict / gather, the lock-step variant, and "rank 0 does not compute": same result
-    for pipelined, root_computes in ((True, True), (False, True), (True, False)):
+    # (the last combination deals the chunks from a cost-sorted list: cost = voxels of the chunk inside the volume, so the ragged
+    # edge chunks come last -- the result must not depend on the deal order)
+    def cost(valid_box):
+        return int(np.prod(np.subtract(valid_box[1], valid_box[0])))
+    for pipelined, root_computes, chunk_cost in ((True, True, None), (False, True, None), (True, False, None), (True, True, cost)):
         trace = []
         out = par.predict_volume_distributed(vol, vol_shape, chunk, halo, predict_fn, n_out=2, pipelined=pipelined,
-                                             root_computes=root_computes, trace=trace)
+                                             root_computes=root_computes, trace=trace, chunk_cost=chunk_cost)
         if rank == 0:
             ref = torch.nn.functional.max_pool3d(vol[None, None].float(), 3, stride=1, padding=1)[0, 0].to(torch.uint8)
             ok = ok and bool(torch.equal(out[0], ref) and torch.equal(out[1], 255 - ref))
@@ -179,3 +183,58 @@ def test_single_process_volume_prediction_is_the_same_code_path():
     for pipelined in (True, False):
         out = par.predict_volume_distributed(vol, vol_shape, chunk, halo, predict_fn, n_out=1, pipelined=pipelined)
         assert torch.equal(out[0], ref)
+
+
+@pytest.mark.parametrize('arch,geometry', [('myelin', 'reference'), ('myelin', 'tile128'), ('mivcsj', 'reference'), ('mivcsj', 'tile128')])
+def test_cost_sorted_rounds_reach_7_5x_on_8_ranks_by_geometry(arch, geometry):
+    """BASELINE configs[3] (myelin) and configs[4] (mivcsj) on the 2048 x 2048 x 512 volume: lock-step rounds dealt in z-major order
+    mix 12-tile interior chunks with 2-tile corner chunks of the overhanging chunk grid (6.1-6.4x of 8 by window voxels alone in the
+    reference geometry); dealt from the cost-sorted list every round holds chunks of one cost class.  Model: a round takes as long as
+    its most expensive chunk; cost = voxels of all windows the chunk's predicted tiles run on (syconn_amd.tiling, the arithmetic
+    Predictor._tiled runs).  No communication in the model (DESIGN.md section 6 has that budget)."""
+    from syconn_amd import parallel as par
+    from syconn_amd.cnn import random_state_dict
+    from syconn_amd.tiling import ChunkCostModel, PlanClipper
+    vol_shape = (512, 2048, 2048)
+    if geometry == 'reference':      # prediction.py:672-677 (x,y,z) -> (z,y,x)
+        chunk, halo, tile, inc = (236, 481, 482), (20, 31, 30), (138, 181, 271), False
+    else:
+        chunk, halo, tile, inc = (224, 192, 192), (8, 16, 16), (112, 96, 96), True
+    cm = ChunkCostModel(PlanClipper.for_model(random_state_dict(arch, seed=0)), tile, halo, halo, inc)
+    ids, boxes = par.chunk_grid(vol_shape, chunk, halo)
+    costs = [cm.chunk_cost(chunk, b) for b in boxes]
+    assert len(ids) == (75 if geometry == 'reference' else 363) and min(costs) > 0
+    order = par.cost_sorted(list(range(len(ids))), costs)
+    assert sorted(order) == list(range(len(ids)))
+    sorted_costs = [costs[i] for i in order]
+    assert all(a >= b for a, b in zip(sorted_costs, sorted_costs[1:]))
+    zmajor, dealt = par.round_schedule_speedup(costs, 8), par.round_schedule_speedup(sorted_costs, 8)
+    assert dealt >= 7.5 and dealt >= zmajor - 1e-9, (zmajor, dealt)
+    if geometry == 'reference':
+        assert zmajor < 6.5          # what the old order could reach at best
+    for world in (2, 4):
+        assert par.round_schedule_speedup(sorted_costs, world) >= 0.97 * world
+    # ownership is still chunkify over the dealt list: rank r predicts dealt[r::8]
+    assert [len(par.shard_units(order, r, 8)) for r in range(8)] == [len(order[r::8]) for r in range(8)]
+
+
+def test_tile_plan_skips_and_clips_like_the_predictor_contract():
+    """plan_tile_windows: tiles entirely beyond the valid box are skipped, the others keep full windows without clipping and never
+    larger ones with it; GroupNorm plans keep full windows."""
+    from syconn_amd.cnn import random_state_dict
+    from syconn_amd.tiling import PlanClipper, convolved_voxels, plan_tile_windows, tile_grid
+    cl = PlanClipper.for_model(random_state_dict('myelin', seed=0))
+    spatial = np.array([276, 543, 542])
+    tile, ol, nt = tile_grid(spatial, (138, 181, 271), (20, 31, 30))
+    assert tuple(nt) == (2, 3, 2)
+    full, z0 = plan_tile_windows(spatial, tile, ol, nt, None, False, None, False)
+    assert not z0 and convolved_voxels(full) == 12 * 178 * 243 * 331
+    vb = ((20, 31, 30), (60, 155, 150))                       # a corner chunk of the overhanging grid: 40 x 124 x 120 voxels inside
+    skipped, z1 = plan_tile_windows(spatial, tile, ol, nt, vb, False, None, False)
+    assert z1 and sum(len(v) for v in skipped.values()) == 1 and convolved_voxels(skipped) == 178 * 243 * 331
+    clipped, _ = plan_tile_windows(spatial, tile, ol, nt, vb, True, cl, False)
+    assert convolved_voxels(clipped) < convolved_voxels(skipped)
+    (win, roi), = clipped.keys()
+    assert all(w % 8 == 0 or w == f for w, f in zip(win, (178, 243, 331)))
+    gn = PlanClipper.for_model(random_state_dict('mivcsj', seed=0))
+    assert gn.has_groupnorm and gn(20, 60, 178, 0) == (0, 178)

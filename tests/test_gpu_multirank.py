@@ -106,6 +106,22 @@ def test_bench_volume_workloads_two_ranks_equal_one_rank(gpu, workload, geometry
     assert two['n_gpus'] == 2 and one['n_gpus'] == 1 and two['scaling'] == 'strong'
     assert two['config']['labels_sha256'] and two['config']['labels_sha256'] == one['config']['labels_sha256']
     assert one['config']['output_distinct_values'] >= 2            # (not a constant volume)
+    assert one['config']['round_order'].startswith('cost-sorted')
+    if geometry == 'reference':
+        # the deal order of the rounds (cost-sorted by default) does not change a voxel: same volume with the old z-major order
+        zmaj = _json_line(_torchrun(2, args + ['--gpus', '2', '--zmajor-rounds'], {'SD_BENCH_ONE_GPU_DEBUG': '1'}))
+        assert zmaj['config']['round_order'] == 'z-major' and zmaj['config']['labels_sha256'] == one['config']['labels_sha256']
+
+
+def test_bench_gpus_2_starts_its_own_ranks(gpu):
+    """`python3 bench.py --gpus 2` spelled like the driver's N = 1 command (no launcher): bench.py starts torch.distributed.run itself
+    as a child process before touching the GPU and relays the JSON line and the return code -- default workload and a volume workload;
+    the line says what the process group looked like from inside."""
+    for extra in ([], ['--workload', 'config3', '--volume', '160', '224', '224']):
+        args = ['bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--tiles', '2', '--batch', '2', '--no-cpu-baseline', '--labels-sha']
+        line = _json_line(_run([sys.executable] + args + extra, {'SD_BENCH_ONE_GPU_DEBUG': '1'}))
+        assert line['n_gpus'] == 2 and line['value'] > 0 and line['config']['labels_sha256']
+        assert line['distributed'] == {'world_size': 2, 'backend': 'gloo', 'rccl_version': None}
 
 
 def test_volume_workload_equals_per_tile_path(gpu):
@@ -170,4 +186,5 @@ def test_bench_default_and_volume_workload_through_rccl_group_of_one(gpu):
         plain = _json_line(_run([sys.executable] + args))
         rccl = _json_line(_torchrun(1, args, {'SD_DIST_SINGLE_RANK_GROUP': '1'}))
         assert plain['config']['collective'] == 'none' and rccl['config']['collective'].startswith('RCCL')
+        assert plain['distributed']['backend'] is None and rccl['distributed']['backend'] == 'nccl' and rccl['distributed']['rccl_version']
         assert plain['config']['labels_sha256'] and plain['config']['labels_sha256'] == rccl['config']['labels_sha256']
