@@ -284,12 +284,13 @@ def main():
         per_op += dm.profile_read(k)
     per_op /= n_fw                                # ms per launch, averaged over the timed region
     # shader clock of every convolution launch of the timed region (stamped by the launch's first workgroup): (n_fw, n_ops) GHz, 0 = no stamp
-    clk = np.zeros((n_fw, dm.n_ops))
+    # (cycles, 100 MHz ticks) between entry and exit of the first workgroup; a launch whose first workgroup lived < 10 us says nothing
+    clk_cyc, clk_tick = np.zeros((n_fw, dm.n_ops)), np.zeros((n_fw, dm.n_ops))
     for k in range(n_fw):
         st = dm.profile_read_clocks(k).astype(np.float64)
         dt = st[:, 3] - st[:, 1]
-        ok = dt > 0
-        clk[k, ok] = (st[ok, 2] - st[ok, 0]) / (dt[ok] * 10.0)
+        ok = dt >= 1000
+        clk_cyc[k, ok], clk_tick[k, ok] = (st[ok, 2] - st[ok, 0]), dt[ok]
     dm.profile(0)
 
     # ---- the same K steps with inputs / outputs resident in HBM (kernel throughput; NOT `value`) ------------------
@@ -362,11 +363,13 @@ def main():
     # MFMA loop sustains here right after it (the part is power-limited under matrix load and boxes differ: DESIGN.md section 5) --
     # `frac` is against the nominal 2.5 PFLOP/s, `frac_of_sustained` against what this box's matrix pipes deliver at their own clock
     dom_ops = [i for i in range(dm.n_ops) if executed[i][1] == dom and executed[i][0] == i]
-    dom_clk = clk[:, dom_ops][clk[:, dom_ops] > 0] if dom_ops else np.zeros(0)
-    roof['clock_ghz_timed_region'] = float(dom_clk.mean()) if dom_clk.size else None
-    roof['clock_ghz_timed_region_min_max'] = [float(dom_clk.min()), float(dom_clk.max())] if dom_clk.size else None
-    all_clk = clk[clk > 0]
-    roof['clock_ghz_all_conv_launches'] = float(all_clk.mean()) if all_clk.size else None
+    def ghz(cyc, tick):          # time-weighted: all cycles / all ticks (a tick = 10 ns)
+        return float(cyc.sum() / (tick.sum() * 10.0)) if tick.sum() > 0 else None
+    roof['clock_ghz_timed_region'] = ghz(clk_cyc[:, dom_ops], clk_tick[:, dom_ops]) if dom_ops else None
+    per_set = [ghz(clk_cyc[k, dom_ops], clk_tick[k, dom_ops]) for k in range(n_fw)] if dom_ops else []
+    per_set = [v for v in per_set if v]
+    roof['clock_ghz_timed_region_min_max_over_launch_sets'] = [min(per_set), max(per_set)] if per_set else None
+    roof['clock_ghz_all_conv_launches'] = ghz(clk_cyc, clk_tick)
     if roof['bound'] == 'mfma' and rank == 0:
         from syconn_amd.engine import probe_mfma_rate
         sus_tf, sus_ghz = probe_mfma_rate(dev)

@@ -29,14 +29,14 @@ pytestmark = pytest.mark.gpu
 # logit margin of the oracle / stated tolerance" (scale-invariant for a ReLU network).  Measured on MI355X (round 3):
 #   semseg_spine bf16: unsafe 0.171 / 0.017, agreement 0.99546 / 0.99949, margin 12.7
 #   semseg_spine f16 : unsafe 0.021 / 0.0020, agreement 0.99945 / 0.99994, margin 98
-#   mivcsj f16 (stated 2.09e-3 = the 44-rounding rule, measured 1.9e-3): agreement 0.9991 / 0.9992
+#   mivcsj f16 (stated 2.09e-3 = the 44-rounding rule, measured 1.99e-3; round 6): unsafe 0.025 / 0.024, agreement 0.9992 / 0.9992, margin 44
 # `unsafe_m`: bounds on the unsafe fractions when the margin is drawn A POSTERIORI at twice the measured error (how much of the
 # a-priori unsafe set is really at risk; bf16: 7.4e-3 measured -> the 17 % shrink to what 1.5e-2 of the logit range covers)
 BOUNDS = {
     ('semseg_spine', 'bf16'): dict(unsafe=(0.25, 0.03), agree=(0.993, 0.999), margin=8.0),
     ('semseg_spine', 'f16'): dict(unsafe=(0.035, 0.005), agree=(0.999, 0.9998), margin=60.0),
     ('semseg_axon', 'bf16'): dict(unsafe=(0.25, 0.03), agree=(0.993, 0.999), margin=8.0),
-    ('mivcsj', 'f16'): dict(unsafe=(0.08, 0.02), agree=(0.998, 0.998), margin=12.0),
+    ('mivcsj', 'f16'): dict(unsafe=(0.04, 0.04), agree=(0.998, 0.998), margin=30.0),
 }
 
 

@@ -181,6 +181,27 @@ def test_predictor_float16_flag_selects_the_plan_and_overflow_falls_back(gpu):
     assert torch.equal(p.predict_proba_u8_device(raw.to(gpu)), want32) and p.act_dtype == 'f32'
 
 
+def test_non_sticky_overflow_fallback_repeats_one_prediction_only(gpu):
+    """`sticky_fallback=False` (dense_predictor's default, `dense_prediction.sticky_overflow_fallback: false`): the prediction that
+    overflowed is repeated in the plan with fp32's exponent range -- bit-identical to that plan -- and the NEXT prediction runs in the
+    configured plan again; `n_fallbacks` counts the repeats."""
+    from syconn_amd.handler.prediction import Predictor
+    kw = dict(tile_shape=(4, 16, 32), overlap_shape=(2, 4, 4), out_shape=(2, 8, 32, 64), strict_shapes=True, apply_softmax=True)
+    model = _blow_up(build_unet('myelin', seed=3, final_scale=4.0))
+    raw = _input((8, 32, 64), 2).to(gpu)
+    want32 = Predictor(model, act_dtype='f32', **kw).predict_proba_u8_device(raw)
+    p = Predictor(model, sticky_fallback=False, **kw)
+    assert p.act_dtype == 'f16x2' and p.n_fallbacks == 0
+    for n in (1, 2):
+        got = p.predict_proba_u8_device(raw)
+        assert torch.equal(got, want32), 'the repeated prediction is not the f32 plan\'s'
+        assert p.act_dtype == 'f16x2' and p.n_fallbacks == n          # back in the configured plan, one more repeat counted
+    # an input that does not overflow is served by the configured plan without a repeat
+    quiet = torch.zeros_like(raw)
+    want_quiet = Predictor(model, act_dtype='f16x2', **kw).predict_proba_u8_device(quiet)
+    assert torch.equal(p.predict_proba_u8_device(quiet), want_quiet) and p.n_fallbacks == 2
+
+
 @pytest.mark.parametrize('arch', sorted(ARCHS))
 def test_split_plan_against_committed_golden_logits(gpu, arch):
     """the split plan against the COMMITTED fp32 logits of all 8 architectures (tests/golden/g4_unet_logits.npz: even and odd
