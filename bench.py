@@ -284,13 +284,21 @@ def main():
         per_op += dm.profile_read(k)
     per_op /= n_fw                                # ms per launch, averaged over the timed region
     # shader clock of every convolution launch of the timed region (stamped by the launch's first workgroup): (n_fw, n_ops) GHz, 0 = no stamp
-    # (cycles, 100 MHz ticks) between entry and exit of the first workgroup; a launch whose first workgroup lived < 10 us says nothing
-    clk_cyc, clk_tick = np.zeros((n_fw, dm.n_ops)), np.zeros((n_fw, dm.n_ops))
+    # GHz of every stamped launch = cycles / (100 MHz ticks * 10 ns) between entry and exit of its first workgroup.  A launch whose first
+    # workgroup lived < 10 us says nothing, and about 3 % of the stamps carry a cycle counter that jumped by ~2^23.6 between the two
+    # reads (seen on every box; the tick counter never does): everything outside 0.3 ... 3 GHz is dropped and the statistic is a median
+    clk = np.full((n_fw, dm.n_ops), np.nan)
     for k in range(n_fw):
         st = dm.profile_read_clocks(k).astype(np.float64)
         dt = st[:, 3] - st[:, 1]
         ok = dt >= 1000
-        clk_cyc[k, ok], clk_tick[k, ok] = (st[ok, 2] - st[ok, 0]), dt[ok]
+        g = np.full(dm.n_ops, np.nan)
+        g[ok] = (st[ok, 2] - st[ok, 0]) / (dt[ok] * 10.0)
+        g[(g < 0.3) | (g > 3.0)] = np.nan
+        clk[k] = g
+    if os.environ.get('SD_BENCH_DUMP_CLOCKS'):      # (debugging aid: raw stamps and launch times of every launch set)
+        np.savez(os.environ['SD_BENCH_DUMP_CLOCKS'], stamps=np.stack([dm.profile_read_clocks(k) for k in range(n_fw)]),
+                 ms=np.stack([dm.profile_read(k) for k in range(n_fw)]))
     dm.profile(0)
 
     # ---- the same K steps with inputs / outputs resident in HBM (kernel throughput; NOT `value`) ------------------
@@ -363,18 +371,22 @@ def main():
     # MFMA loop sustains here right after it (the part is power-limited under matrix load and boxes differ: DESIGN.md section 5) --
     # `frac` is against the nominal 2.5 PFLOP/s, `frac_of_sustained` against what this box's matrix pipes deliver at their own clock
     dom_ops = [i for i in range(dm.n_ops) if executed[i][1] == dom and executed[i][0] == i]
-    def ghz(cyc, tick):          # time-weighted: all cycles / all ticks (a tick = 10 ns)
-        return float(cyc.sum() / (tick.sum() * 10.0)) if tick.sum() > 0 else None
-    roof['clock_ghz_timed_region'] = ghz(clk_cyc[:, dom_ops], clk_tick[:, dom_ops]) if dom_ops else None
-    per_set = [ghz(clk_cyc[k, dom_ops], clk_tick[k, dom_ops]) for k in range(n_fw)] if dom_ops else []
-    per_set = [v for v in per_set if v]
-    roof['clock_ghz_timed_region_min_max_over_launch_sets'] = [min(per_set), max(per_set)] if per_set else None
-    roof['clock_ghz_all_conv_launches'] = ghz(clk_cyc, clk_tick)
+    def med(a):
+        a = a[np.isfinite(a)]
+        return (float(np.median(a)), [float(np.percentile(a, 10)), float(np.percentile(a, 90))], int(a.size)) if a.size else (None, None, 0)
+    roof['clock_ghz_timed_region'], roof['clock_ghz_timed_region_p10_p90'], roof['clock_stamps_used'] = med(clk[:, dom_ops]) if dom_ops else (None, None, 0)
+    roof['clock_ghz_all_conv_launches'] = med(clk)[0]
+    if roof['bound'] == 'mfma' and roof['clock_ghz_timed_region']:
+        # the matrix peak is a 2.4 GHz figure: what fraction of the MFMA issue slots of the clock the launches really ran at was used
+        roof['frac_at_measured_clock'] = roof['achieved'] / (PEAK_MFMA_TFLOPS * roof['clock_ghz_timed_region'] / 2.4)
     if roof['bound'] == 'mfma' and rank == 0:
         from syconn_amd.engine import probe_mfma_rate
-        sus_tf, sus_ghz = probe_mfma_rate(dev)
-        roof['sustained_mfma_tflops_this_box'] = sus_tf
+        sus_tf, sus_ghz = probe_mfma_rate(dev, random_operands=True)
+        cst_tf, cst_ghz = probe_mfma_rate(dev, random_operands=False)
+        roof['sustained_mfma_tflops_this_box'] = sus_tf            # pure MFMA loop on pseudo-random operands (what data looks like)
         roof['sustained_clock_ghz_this_box'] = sus_ghz
+        roof['sustained_mfma_tflops_constant_operands'] = cst_tf   # the same loop on constants: nothing toggles, less power, higher clock
+        roof['sustained_clock_ghz_constant_operands'] = cst_ghz
         roof['frac_of_sustained'] = roof['achieved'] / sus_tf if sus_tf > 0 else None
     roof['traffic'] = None
     tr_file = os.path.join(ROOT, 'profiles', 'traffic.json')

@@ -176,9 +176,11 @@ int sd_profile_read(sd_model* m, int slot, float* ms_per_op, int n_ops);
 int sd_profile_read_clocks(sd_model* m, int slot, uint64_t* stamps, int n_ops);
 /* Box calibration: a chip-wide dense bf16 MFMA loop (n_workgroups x waves_per_workgroup waves, `iters` x 4 v_mfma_f32_32x32x16_bf16
  * each, no memory traffic) launched back to back for at least min_seconds; reports the LAST launch: sustained TFLOP/s and the median
- * shader clock of its waves.  Synchronises `stream`. */
-int sd_probe_mfma_rate(int n_workgroups, int waves_per_workgroup, int iters, double min_seconds, double* tflops_out,
-                       double* shader_ghz_out, void* stream);
+ * shader clock of its waves.  random_operands != 0: four pseudo-random A / B fragment pairs take turns (operand buses toggle as in
+ * a convolution; the part draws more power and holds a lower clock than on the constant operands of random_operands = 0).
+ * Synchronises `stream`. */
+int sd_probe_mfma_rate(int n_workgroups, int waves_per_workgroup, int iters, double min_seconds, int random_operands,
+                       double* tflops_out, double* shader_ghz_out, void* stream);
 /* Copy activation buffer `buf` of the last sd_forward out of the workspace as float32 planar (C, d, h, w);
  * dims are returned in dims4 = {C, d, h, w}.  out_dev may be NULL to query dims only. */
 int sd_debug_read_buffer(sd_model* m, int buf, const void* workspace_dev, float* out_dev, int32_t* dims4,

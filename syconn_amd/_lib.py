@@ -70,7 +70,7 @@ def load():
     lib.sd_profile_enable.argtypes = [vp, i32]; lib.sd_profile_enable.restype = i32
     lib.sd_profile_read.argtypes = [vp, i32, C.POINTER(C.c_float), i32]; lib.sd_profile_read.restype = i32
     lib.sd_profile_read_clocks.argtypes = [vp, i32, C.POINTER(C.c_uint64), i32]; lib.sd_profile_read_clocks.restype = i32
-    lib.sd_probe_mfma_rate.argtypes = [i32, i32, i32, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]
+    lib.sd_probe_mfma_rate.argtypes = [i32, i32, i32, C.c_double, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]
     lib.sd_probe_mfma_rate.restype = i32
     lib.sd_memcpy2d_async.argtypes = [vp, sz, vp, sz, sz, sz, i32, vp]; lib.sd_memcpy2d_async.restype = i32
     lib.sd_debug_read_buffer.argtypes = [vp, i32, vp, vp, C.POINTER(C.c_int32), vp]

@@ -1,7 +1,8 @@
 // Box calibration for the benchmark line: what a chip-wide dense bf16 MFMA loop SUSTAINS on this part and at what shader clock.
 // The nominal 2.5 PFLOP/s of gfx950 is a 2.4 GHz figure; under matrix load the part is power-limited and
 // different boxes settle at different clocks, so bench.py prints this figure beside the roofline fraction of the same run.
-// No memory traffic, no LDS: 4 independent accumulators per wave, v_mfma_f32_32x32x16_bf16 back to back.
+// No memory traffic, no LDS: 4 independent accumulators per wave, v_mfma_f32_32x32x16_bf16 back to back, on constant or on
+// pseudo-random operands.
 #include "../../include/syconn_dense.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -13,17 +14,32 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 v8bf;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+// RANDOM: four A and four B fragments of pseudo-random bf16 values (magnitude 0.06 ... 0.5, random sign -- what activations and weights
+// look like) take turns, so that the operand buses toggle from one MFMA to the next as they do in a convolution; the constant
+// small integers of the other form toggle nothing and draw visibly less power (the part then holds a higher clock).
+template <bool RANDOM>
 __global__ void __launch_bounds__(512) k_probe_mfma(unsigned long long* out, int iters, float* sink) {
-    v8bf a, b;
-    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(float)(threadIdx.x & 7); b[i] = (__bf16)(float)(i); }
+    v8bf a[4], b[4];
+    for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 8; ++i) {
+            if (RANDOM) {
+                unsigned h = (threadIdx.x * 8u + i) * 2654435761u + j * 40503u + blockIdx.x * 97u;
+                h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+                const unsigned short ba = (unsigned short)(0x3d80u + (h & 0x17fu)) | (unsigned short)((h >> 3) & 0x8000u);
+                const unsigned short bb = (unsigned short)(0x3d80u + ((h >> 9) & 0x17fu)) | (unsigned short)((h >> 5) & 0x8000u);
+                a[j][i] = __builtin_bit_cast(__bf16, ba); b[j][i] = __builtin_bit_cast(__bf16, bb);
+            } else {
+                a[j][i] = (__bf16)(float)(threadIdx.x & 7); b[j][i] = (__bf16)(float)(i);
+            }
+        }
     f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
     __syncthreads();
     const unsigned long long t0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int i = 0; i < iters; ++i) {
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c1, 0, 0, 0);
-        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c2, 0, 0, 0);
-        c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c3, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[2], c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[3], b[3], c3, 0, 0, 0);
     }
     const unsigned long long t1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0;
@@ -36,8 +52,8 @@ __global__ void __launch_bounds__(512) k_probe_mfma(unsigned long long* out, int
 }
 }  // namespace
 
-extern "C" int sd_probe_mfma_rate(int n_workgroups, int waves_per_workgroup, int iters, double min_seconds, double* tflops_out,
-                                  double* shader_ghz_out, void* stream) {
+extern "C" int sd_probe_mfma_rate(int n_workgroups, int waves_per_workgroup, int iters, double min_seconds, int random_operands,
+                                  double* tflops_out, double* shader_ghz_out, void* stream) {
     if (n_workgroups <= 0 || waves_per_workgroup <= 0 || waves_per_workgroup > 8 || iters <= 0 || !tflops_out || !shader_ghz_out)
         return sd_fail_msg(SD_ERR_INVALID, "sd_probe_mfma_rate: bad argument");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -52,7 +68,8 @@ extern "C" int sd_probe_mfma_rate(int n_workgroups, int waves_per_workgroup, int
     int rc = SD_OK;
     do {
         (void)hipEventRecord(e0, s);
-        hipLaunchKernelGGL(k_probe_mfma, dim3(n_workgroups), dim3(waves_per_workgroup * 64), 0, s, d, iters, sink);
+        if (random_operands) hipLaunchKernelGGL(k_probe_mfma<true>, dim3(n_workgroups), dim3(waves_per_workgroup * 64), 0, s, d, iters, sink);
+        else hipLaunchKernelGGL(k_probe_mfma<false>, dim3(n_workgroups), dim3(waves_per_workgroup * 64), 0, s, d, iters, sink);
         (void)hipEventRecord(e1, s);
         if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = SD_ERR_HIP; break; }
         total_ms += ms;

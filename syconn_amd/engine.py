@@ -248,13 +248,15 @@ class DenseModel:
         return np.asarray(list(st), dtype=np.uint64).reshape(self.n_ops, 4)
 
 
-def probe_mfma_rate(device, n_workgroups: int = 256, waves: int = 8, iters: int = 20000, min_seconds: float = 0.25):
-    """(sustained dense bf16 MFMA TFLOP/s, shader clock in GHz) of this box under a chip-wide pure MFMA loop (`sd_probe_mfma_rate`)."""
+def probe_mfma_rate(device, n_workgroups: int = 256, waves: int = 8, iters: int = 20000, min_seconds: float = 0.25,
+                    random_operands: bool = True):
+    """(sustained dense bf16 MFMA TFLOP/s, shader clock in GHz) of this box under a chip-wide pure MFMA loop (`sd_probe_mfma_rate`);
+    `random_operands`: pseudo-random fragments that take turns (a convolution's operand toggling) instead of constants."""
     device = torch.device(device)
     lib = require_gpu(device.index or 0)
     tf, ghz = C.c_double(), C.c_double()
     with torch.cuda.device(device):
-        L.check(lib.sd_probe_mfma_rate(int(n_workgroups), int(waves), int(iters), float(min_seconds), C.byref(tf), C.byref(ghz),
+        L.check(lib.sd_probe_mfma_rate(int(n_workgroups), int(waves), int(iters), float(min_seconds), 1 if random_operands else 0, C.byref(tf), C.byref(ghz),
                                        torch.cuda.current_stream(device).cuda_stream), 'sd_probe_mfma_rate')
     return float(tf.value), float(ghz.value)
 

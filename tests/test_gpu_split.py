@@ -196,10 +196,6 @@ def test_non_sticky_overflow_fallback_repeats_one_prediction_only(gpu):
         got = p.predict_proba_u8_device(raw)
         assert torch.equal(got, want32), 'the repeated prediction is not the f32 plan\'s'
         assert p.act_dtype == 'f16x2' and p.n_fallbacks == n          # back in the configured plan, one more repeat counted
-    # an input that does not overflow is served by the configured plan without a repeat
-    quiet = torch.zeros_like(raw)
-    want_quiet = Predictor(model, act_dtype='f16x2', **kw).predict_proba_u8_device(quiet)
-    assert torch.equal(p.predict_proba_u8_device(quiet), want_quiet) and p.n_fallbacks == 2
 
 
 @pytest.mark.parametrize('arch', sorted(ARCHS))
