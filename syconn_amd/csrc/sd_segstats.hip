@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void k_zero64(u64* p, u64 n) {
     for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) p[i] = 0;
 }
 
+template <typename X> struct SegTag { using type = X; };
 constexpr int MAX_SUB = 8;
 struct ScanParams {
     const void* cell;                  // (X,Y,Z) labels, z fastest; may be nullptr (then only subcell properties)
@@ -180,7 +181,13 @@ __device__ __forceinline__ void lds_flush(const LTab& lt, const ObjTable& gt, in
 // One wave = 64 consecutive voxels of the flattened volume; a workgroup owns a contiguous range of such wave-chunks.  Per
 // volume a lane is a run head iff it is the wave's first lane, the first voxel of a z-row, or its label differs from the
 // previous voxel's.
-template <typename L>
+// V4 (rows of a multiple of 4 voxels, 16-byte aligned volumes): a LANE owns 4 consecutive voxels (one or two 16-byte loads per
+// volume), a wave 256.  Run heads inside a lane are four compares, run lengths come from one ballot (lanes that hold a head), the
+// lane's own 4-bit head mask and the head mask of the next lane that holds a head; the voxel coordinates (two integer divisions)
+// are computed once per lane and iteration for all volumes.  The first form of this pass (one voxel per lane) spent ~300
+// instructions per 64 voxels and volume -- it was instruction-bound at 0.9 TB/s of label reads; runs, atomics and results are the
+// same in both forms (sums / minima / maxima do not depend on where a wave cuts a run).
+template <typename L, bool V4, bool HC = false, int NS = -1>
 __global__ __launch_bounds__(256) void k_segstats_scan(const ScanParams p, const int lcap) {
     __shared__ u64 l_keys[LDS_SLOTS];
     __shared__ u64 l_first[LDS_SLOTS];
@@ -210,9 +217,147 @@ __global__ __launch_bounds__(256) void k_segstats_scan(const ScanParams p, const
     };
     const LTab cell_lt = ltab(0);
     const u64 nvox = (u64)p.X * p.Y * p.Z;
-    const u64 nwaves = (nvox + 63) / 64;
+    constexpr int VPW = V4 ? 256 : 64;            // voxels per wave and iteration
+    const u64 nwaves = (nvox + VPW - 1) / VPW;
     const u64 per_wg = (nwaves + gridDim.x - 1) / gridDim.x;
     const u64 w_end = min(nwaves, (u64)(blockIdx.x + 1) * per_wg);
+    if constexpr (V4) {
+        // pair / object update of the heads at in-lane position J of one volume (hm: this lane's head mask, bit j = voxel j starts a run)
+        auto run_len = [&](int j, unsigned hm, bool has_next, int nl, unsigned nhm) -> int {
+            const unsigned rest = hm >> (j + 1);
+            if (rest) return __builtin_ctz(rest) + 1;                                   // the next head is in this lane
+            if (!has_next) return (4 - j) + 4 * (63 - lane);                            // ... or nowhere in this wave's 256 voxels
+            return (4 - j) + 4 * (nl - lane - 1) + __builtin_ctz(nhm);                  // ... or in lane nl
+        };
+        // next lane above this one that holds a head (and that lane's head mask), from the ballot of head-holding lanes
+        auto next_head = [&](unsigned hm, bool& has_next, int& nl, unsigned& nhm) {
+            const u64 any = __ballot(hm != 0u);
+            const u64 later = (lane == 63) ? 0ull : (any >> (lane + 1));
+            has_next = later != 0ull;
+            nl = has_next ? lane + 1 + __builtin_ctzll(later) : lane;
+            nhm = (unsigned)__shfl((int)hm, nl, 64);
+        };
+        auto load4 = [&](const void* vol, u64 first, u64 (&v)[4]) {
+            if constexpr (sizeof(L) == 8) {
+                typedef __attribute__((ext_vector_type(2))) u64 u64x2;
+                const u64x2 a = reinterpret_cast<const u64x2*>(vol)[first / 2], b = reinterpret_cast<const u64x2*>(vol)[first / 2 + 1];
+                v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+            } else {
+                typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+                const u32x4 a = reinterpret_cast<const u32x4*>(vol)[first / 4];
+                v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+            }
+        };
+        // head mask of a lane's four labels: bit 0 needs the previous lane's last label (a row start and the wave's first lane always
+        // start a run); lanes beyond the volume hold zeros and a head at bit 0, which ends the last real run
+        auto heads = [&](const u64 (&v)[4], bool valid, bool row_start) -> unsigned {
+            const u64 prev = __shfl_up(v[3], 1, 64);
+            unsigned hm = (!valid || row_start || v[0] != prev) ? 1u : 0u;
+            hm |= (v[1] != v[0]) ? 2u : 0u; hm |= (v[2] != v[1]) ? 4u : 0u; hm |= (v[3] != v[2]) ? 8u : 0u;
+            return valid ? hm : 1u;
+        };
+        // one subcell volume of this lane's four voxels: its own properties and its overlap with the cell labels
+        auto do_sub = [&](int ii, const u64 (&sk)[4], const u64 (&ck)[4], unsigned chm, u64 first, bool valid, bool row_start, int x, int y, int z) {
+            const unsigned shm = heads(sk, valid, row_start);
+            if (p.want_props) {
+                bool hn; int nl; unsigned nhm;
+                next_head(shm, hn, nl, nhm);
+                const LTab slt = ltab((p.cell ? 1 : 0) + ii);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (!__any((shm >> j) & 1u)) continue;
+                    if (((shm >> j) & 1u) && sk[j] != 0)
+                        run_update(slt, p.sub_t[ii], sk[j], first + j, x, y, z + j, run_len(j, shm, hn, nl, nhm), p.status);
+                }
+            }
+            if (p.cell) {
+                // overlap counts: runs of a constant (subcell id, cell id) pair start wherever either volume starts a run
+                const unsigned phm = chm | shm;
+                bool hn; int nl; unsigned nhm;
+                next_head(phm, hn, nl, nhm);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool mine = ((phm >> j) & 1u) && sk[j] != 0 && ck[j] != 0;
+                    if (!__any(mine)) continue;
+                    if (!mine) continue;
+                    const int plen = run_len(j, phm, hn, nl, nhm);
+                    if (pcap) {
+                        const LTab slt = ltab(1 + ii);
+                        const int ls = lds_find_or_insert(slt.keys, slt.cap, sk[j]), lc = lds_find_or_insert(cell_lt.keys, cell_lt.cap, ck[j]);
+                        if (ls >= 0 && lc >= 0) {
+                            const int ps = lds_pair_slot(l_pkey + ii * pcap, pcap, (((unsigned)ls << 16) | (unsigned)lc) + 1u);
+                            if (ps >= 0) { atomicAdd(&l_pcnt[ii * pcap + ps], (unsigned)plen); continue; }
+                        }
+                    }
+                    const long ss = find_or_insert(p.sub_t[ii].keys, p.sub_t[ii].cap, sk[j]);
+                    const long cs = find_or_insert(p.cell_t.keys, p.cell_t.cap, ck[j]);
+                    if (ss < 0 || cs < 0) { atomicExch(&p.status[0], 1); continue; }
+                    const long ps = find_or_insert(p.pair_keys[ii], p.pair_cap, (((u64)ss << 32) | (u64)cs) + 1);
+                    if (ps < 0) { atomicExch(&p.status[1], 1); continue; }
+                    atomicAdd(&p.pair_cnt[ii][ps], (u64)plen);
+                }
+            }
+        };
+        // PF (NS >= 0: the launch has exactly NS subcell volumes and, with HC, a cell volume -- at most four volumes): the labels of
+        // the NEXT iteration are requested before this one is worked on, all volumes at once -- 8 KiB per wave in flight instead of
+        // 2 KiB (SQ counters of the sequential form: waves wait 60 % of their cycles, 0.31 busy)
+        constexpr bool PF = NS >= 0;
+        constexpr int C0 = HC ? 1 : 0, NT = PF ? (C0 + NS > 0 ? C0 + NS : 1) : 1;
+        u64 cur[NT][4], nxt[NT][4];
+        auto fetch_all = [&](u64 w, u64 (&buf)[NT][4]) {
+            const u64 f = w * 256 + 4 * (u64)lane;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                buf[t][0] = buf[t][1] = buf[t][2] = buf[t][3] = 0;
+                if (f < nvox) load4(t < C0 ? p.cell : p.sub[t - C0], f, buf[t]);
+            }
+        };
+        const u64 w_first = (u64)blockIdx.x * per_wg + (threadIdx.x >> 6);
+        if constexpr (PF) { if (w_first < w_end) fetch_all(w_first, cur); }
+        for (u64 w = w_first; w < w_end; w += 4) {
+            if constexpr (PF) { if (w + 4 < w_end) fetch_all(w + 4, nxt); }
+            const u64 first = w * 256 + 4 * (u64)lane;            // this lane's first voxel (a multiple of 4: never straddles a z-row)
+            const bool valid = first < nvox;
+            const u64 li = valid ? first : (nvox - 4);
+            int z, y, x;
+            if (nvox < (1ull << 32)) {
+                const unsigned u = (unsigned)li, r = u / (unsigned)p.Z, q = r / (unsigned)p.Y;
+                z = (int)(u - r * (unsigned)p.Z); y = (int)(r - q * (unsigned)p.Y); x = (int)q;
+            } else {
+                z = (int)(li % p.Z); y = (int)((li / p.Z) % p.Y); x = (int)(li / ((u64)p.Z * p.Y));
+            }
+            const bool row_start = (lane == 0) || (z == 0);
+            u64 ck[4] = {0, 0, 0, 0};
+            unsigned chm = valid ? 0u : 1u;
+            if (p.cell) {
+                if constexpr (PF && HC) { ck[0] = cur[0][0]; ck[1] = cur[0][1]; ck[2] = cur[0][2]; ck[3] = cur[0][3]; }
+                else if (valid) load4(p.cell, first, ck);
+                chm = heads(ck, valid, row_start);
+                if (p.want_props) {
+                    bool hn; int nl; unsigned nhm;
+                    next_head(chm, hn, nl, nhm);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (!__any((chm >> j) & 1u)) continue;
+                        if (((chm >> j) & 1u) && ck[j] != 0)
+                            run_update(cell_lt, p.cell_t, ck[j], first + j, x, y, z + j, run_len(j, chm, hn, nl, nhm), p.status);
+                    }
+                }
+            }
+            if constexpr (PF) {
+#pragma unroll
+                for (int ii = 0; ii < NS; ++ii) do_sub(ii, cur[C0 + ii], ck, chm, first, valid, row_start, x, y, z);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { cur[t][0] = nxt[t][0]; cur[t][1] = nxt[t][1]; cur[t][2] = nxt[t][2]; cur[t][3] = nxt[t][3]; }
+            } else {
+                for (int ii = 0; ii < p.n_sub; ++ii) {
+                    u64 sk[4] = {0, 0, 0, 0};
+                    if (valid) load4(p.sub[ii], first, sk);
+                    do_sub(ii, sk, ck, chm, first, valid, row_start, x, y, z);
+                }
+            }
+        }
+    } else
     for (u64 w = (u64)blockIdx.x * per_wg + (threadIdx.x >> 6); w < w_end; w += 4) {
         const u64 base = w * 64, lin = base + lane;
         const int nvalid = (int)((nvox - base) < 64 ? (nvox - base) : 64);
@@ -388,17 +533,38 @@ int sd_segstats_scan(const void* cell_dev, const void* const* sub_devs, int n_su
             hipLaunchKernelGGL(k_zero64, dim3(grid_for(2 * cap_pair)), dim3(256), 0, s, p.pair_keys[i], (u64)2 * cap_pair);
         }
     }
-    const u64 nwaves = ((u64)X * Y * Z + 63) / 64;
-    // each workgroup owns a contiguous range of >= 64 wave-chunks (4096 voxels = a few z-rows); LDS slots per volume
-    const int grid = (int)std::max<u64>(1, std::min<u64>((nwaves + 63) / 64, 256 * 8));
+    // four voxels per lane where every lane's 16 / 32 bytes are aligned and lie inside one z-row
+    bool v4 = Z % 4 == 0 && getenv("SD_SEGSTATS_V1") == nullptr;
+    const uintptr_t amask = 15;
+    if (cell_dev && (reinterpret_cast<uintptr_t>(cell_dev) & amask)) v4 = false;
+    for (int i = 0; i < n_sub; ++i) if (reinterpret_cast<uintptr_t>(sub_devs[i]) & amask) v4 = false;
+    const u64 nwaves = ((u64)X * Y * Z + (v4 ? 255 : 63)) / (v4 ? 256 : 64);
+    // each workgroup owns a contiguous range of >= 64 (16) wave-chunks (4096 voxels = a few z-rows); LDS slots per volume
+    const int grid = (int)std::max<u64>(1, std::min<u64>((nwaves + (v4 ? 15 : 63)) / (v4 ? 16 : 64), 256 * 8));
     const int nvol = (cell_dev ? 1 : 0) + n_sub;
     int lcap = 32;
     while (lcap * 2 * nvol <= LDS_SLOTS) lcap *= 2;
     if (lcap * nvol > LDS_SLOTS) lcap = 0;            // too many volumes for the shared LDS table: global updates only
     static const bool no_lds = getenv("SD_SEGSTATS_NO_LDS") != nullptr;      // debugging aid / A-B
     if (no_lds) lcap = 0;
-    if (dtype == SD_U64) hipLaunchKernelGGL(k_segstats_scan<uint64_t>, dim3(grid), dim3(256), 0, s, p, lcap);
-    else hipLaunchKernelGGL(k_segstats_scan<uint32_t>, dim3(grid), dim3(256), 0, s, p, lcap);
+    // kernel form: one voxel per lane; four voxels per lane; ... with all volumes of the next iteration prefetched (<= 4 volumes)
+    static const bool no_pf = getenv("SD_SEGSTATS_NO_PREFETCH") != nullptr;      // A/B
+    auto launch = [&](auto tag) {
+        using LT = typename decltype(tag)::type;
+        void (*k)(const ScanParams, const int) = k_segstats_scan<LT, false>;
+        if (v4) {
+            k = k_segstats_scan<LT, true>;
+            const int nt = nvol;
+            if (!no_pf && nt <= 4) {
+                if (cell_dev) k = n_sub == 0 ? k_segstats_scan<LT, true, true, 0> : n_sub == 1 ? k_segstats_scan<LT, true, true, 1>
+                                : n_sub == 2 ? k_segstats_scan<LT, true, true, 2> : k_segstats_scan<LT, true, true, 3>;
+                else k = n_sub == 1 ? k_segstats_scan<LT, true, false, 1> : n_sub == 2 ? k_segstats_scan<LT, true, false, 2>
+                         : n_sub == 3 ? k_segstats_scan<LT, true, false, 3> : k_segstats_scan<LT, true, false, 4>;
+            }
+        }
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, s, p, lcap);
+    };
+    if (dtype == SD_U64) launch(SegTag<uint64_t>{}); else launch(SegTag<uint32_t>{});
     return hipGetLastError() == hipSuccess ? SD_OK : sd_fail_msg(SD_ERR_HIP, "sd_segstats_scan: launch failed");
 }
 

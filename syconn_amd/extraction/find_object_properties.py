@@ -82,8 +82,11 @@ class DeviceScan:
         while len(self.ptabs) < n_ptabs:
             self.ptabs.append(torch.empty(pb, dtype=torch.uint8, device=self.device))
 
-    def scan(self, cell, subs: Sequence = (), want_props: bool = True):
-        """One streaming pass over `cell` (may be None) and the `subs` volumes, all of one (X, Y, Z) shape and dtype."""
+    def scan(self, cell, subs: Sequence = (), want_props: bool = True, status_out: Optional[torch.Tensor] = None):
+        """One streaming pass over `cell` (may be None) and the `subs` volumes, all of one (X, Y, Z) shape and dtype.
+        `status_out` (int32[2] on the device): the pass writes its overflow flags there and this call does NOT wait for them -- the
+        caller reads them later and repeats the work with larger tables (`cap_obj` / `cap_pair` are then the caller's business);
+        without it the flags are awaited here and an overflowed pass is repeated with 4x the capacity."""
         lib, device = self.lib, self.device
         vols = [v for v in ([cell] if cell is not None else []) + list(subs)]
         if not vols:
@@ -115,7 +118,10 @@ class DeviceScan:
             pair_tabs = (C.c_void_p * max(n_sub, 1))(*[t.data_ptr() for t in ptabs])
             L.check(lib.sd_segstats_scan(cell_t.data_ptr() if cell_t is not None else None, sub_ptrs, n_sub, dtype, *shape,
                                          tabs[0].data_ptr() if cell_t is not None else None, sub_tabs, self.cap_obj, pair_tabs,
-                                         self.cap_pair, 1 if want_props else 0, self.status.data_ptr(), stream), 'sd_segstats_scan')
+                                         self.cap_pair, 1 if want_props else 0,
+                                         (self.status if status_out is None else status_out).data_ptr(), stream), 'sd_segstats_scan')
+            if status_out is not None:
+                break
             st = self.status.cpu().tolist()
             if not any(st):
                 break

@@ -90,16 +90,24 @@ class MapTable:
 
 # ---------------------------------------------------------------------------------------------------------------------------------
 # device-side record accumulators
-class _Records:
-    """Growable device arrays with a device-side append cursor.  ``fields`` = [(name, dtype, inner width)]."""
+class _TableOverflow(Exception):
+    """A hash table of ``sd_segstats_scan`` was too small for some chunk (seen late: the flags are read two chunks behind)."""
 
-    def __init__(self, device, fields, capacity: int):
+    def __init__(self, objects: bool, pairs: bool):
+        super().__init__('segstats table overflow')
+        self.objects, self.pairs = objects, pairs
+
+
+class _Records:
+    """Growable device arrays appended to at a device-side cursor.  ``fields`` = [(name, dtype, inner width)]; `cursor`: a 1-element
+    view into the merger's counter tensor."""
+
+    def __init__(self, device, fields, capacity: int, cursor):
         import torch
         self.torch, self.device, self.fields = torch, device, fields
         self.capacity = int(capacity)
-        self.cursor = torch.zeros(1, dtype=torch.int64, device=device)
+        self.cursor = cursor
         self.arrays = {n: self._new(dt, w, self.capacity) for n, dt, w in fields}
-        self.checked = 0                      # records known to be safely stored (cursor value at the last check)
 
     def _new(self, dtype, width, n):
         return self.torch.empty((n, width) if width > 1 else (n,), dtype=dtype, device=self.device)
@@ -107,26 +115,30 @@ class _Records:
     def ptrs(self):
         return [self.arrays[n].data_ptr() for n, _, _ in self.fields]
 
-    def room_for(self, n_more: int):
-        """Make sure `n_more` further records fit (an upper bound the caller knows: a table's capacity)."""
-        need = self.checked + int(n_more)
+    def room_for(self, stored: int, n_more: int):
+        """`stored` records are known to be in the arrays; make sure `n_more` further ones fit."""
+        need = int(stored) + int(n_more)
         if need <= self.capacity:
             return
         cap = max(need, 2 * self.capacity)
         for n, dt, w in self.fields:
             grown = self._new(dt, w, cap)
-            grown[:self.checked] = self.arrays[n][:self.checked]
+            keep = min(int(stored) + int(n_more), self.capacity)      # (everything that may have been written so far)
+            grown[:keep] = self.arrays[n][:keep]
             self.arrays[n] = grown
         self.capacity = cap
 
-    def count(self) -> int:
-        return int(self.cursor.item())
-
 
 class ChunkMerger:
-    """Accumulates the per-chunk tables of one dataset pass on the device and merges them at the end."""
+    """Accumulates the per-chunk tables of one dataset pass on the device and merges them at the end.
 
-    def __init__(self, names: Sequence[str], min_obj_vx: dict, device, capacity: int = 1 << 16):
+    The host never waits for the chunk it has just queued: the append cursors and the overflow flags of the scans are copied to
+    page-locked memory on a side stream after every chunk, and chunk k reads the copy posted after chunk k - 2 (complete by then,
+    while the GPU still works on chunk k - 1).  Record arrays are kept large enough for what is known to be stored plus the
+    pessimistic bound (a full table) of the two chunks in between."""
+    LAG = 2
+
+    def __init__(self, names: Sequence[str], min_obj_vx: dict, device, n_chunks: int, capacity: int = 1 << 16):
         import torch
         from .. import _lib as L
         self.L, self.lib, self.torch = L, L.load(), torch
@@ -135,48 +147,90 @@ class ChunkMerger:
         self.min_vx = {k: int(min_obj_vx.get(k, 1)) for k in ['sv'] + self.names}
         obj = [('ids', torch.int64, 1), ('rc', torch.int32, 3), ('bb', torch.int32, 6), ('sizes', torch.int64, 1)]
         pair = [('sub', torch.int64, 1), ('cell', torch.int64, 1), ('cnt', torch.int64, 1)]
-        self.cell = _Records(self.device, obj, capacity)
-        self.sub = [_Records(self.device, obj, capacity) for _ in self.names]
-        self.pairs = [_Records(self.device, pair, capacity) for _ in self.names]
+        n = len(self.names)
+        self.counters = torch.zeros(1 + 2 * n, dtype=torch.int64, device=self.device)          # cursors: cell, subs, pairs
+        self.status = torch.zeros((max(int(n_chunks), 1), 2), dtype=torch.int32, device=self.device)      # overflow flags of every chunk's scan
+        self.cell = _Records(self.device, obj, capacity, self.counters[0:1])
+        self.sub = [_Records(self.device, obj, capacity, self.counters[1 + i:2 + i]) for i in range(n)]
+        self.pairs = [_Records(self.device, pair, capacity, self.counters[1 + n + i:2 + n + i]) for i in range(n)]
         self.n_chunks = 0
+        self._side = torch.cuda.Stream(device=self.device)
+        ring = self.LAG + 1
+        self._host_counts = [torch.zeros(1 + 2 * n, dtype=torch.int64).pin_memory() for _ in range(ring)]
+        self._host_status = [torch.zeros_like(self.status, device='cpu').pin_memory() for _ in range(ring)]
+        self._posted = [torch.cuda.Event() for _ in range(ring)]
+        self._known = np.zeros(1 + 2 * n, dtype=np.int64)      # cursor values as of the newest copy that has been read
+        self._known_at = -1                                    # ... posted after this chunk
 
-    def _settle(self, rec: _Records, upper: int):
-        """Appends are counted on the device only; before a table with up to `upper` entries is appended the arrays must hold
-        them all.  Reading the cursor (one 8-byte copy) is needed only when the pessimistic bound no longer fits."""
-        if rec.checked + upper > rec.capacity:
-            rec.checked = rec.count()
-        rec.room_for(upper)
-        rec.checked += upper                   # pessimistic until the next read of the cursor
+    def status_slot(self):
+        """Where the scan of the next chunk writes its overflow flags (``DeviceScan.scan(status_out=...)``)."""
+        return self.status[self.n_chunks]
+
+    def _post(self, k: int):
+        r = k % (self.LAG + 1)
+        ev = self.torch.cuda.current_stream(self.device).record_event()
+        with self.torch.cuda.stream(self._side):
+            self._side.wait_event(ev)
+            self._host_counts[r].copy_(self.counters, non_blocking=True)
+            self._host_status[r].copy_(self.status, non_blocking=True)
+            self._posted[r].record(self._side)
+
+    def _read(self, k: int):
+        """Take in the copy posted after chunk k (waits for it); raises when a scan up to chunk k overflowed its tables."""
+        if k <= self._known_at or k < 0:
+            return
+        r = k % (self.LAG + 1)
+        self._posted[r].synchronize()
+        self._known = self._host_counts[r].numpy().copy()
+        self._known_at = k
+        flags = self._host_status[r].numpy()[:k + 1]
+        if flags.any():
+            raise _TableOverflow(bool(flags[:, 0].any()), bool(flags[:, 1].any()))
 
     def add_chunk(self, scan, origin):
-        """`scan`: a ``DeviceScan`` after ``scan(cell, subs)`` over one chunk whose (x, y, z) origin in the dataset is `origin`."""
+        """`scan`: a ``DeviceScan`` after ``scan(cell, subs, status_out=self.status_slot())`` over one chunk whose (x, y, z) origin in
+        the dataset is `origin`."""
         lib, L = self.lib, self.L
+        k = self.n_chunks
         X, Y, Z = scan.shape
         ox, oy, oz = (int(v) for v in origin)
         stream = self.torch.cuda.current_stream(self.device).cuda_stream
         cap_o, cap_p = scan.cap_obj, scan.cap_pair
         upper_o, upper_p = min(cap_o, X * Y * Z), min(cap_p, X * Y * Z)
-        self._settle(self.cell, upper_o)
+        self._read(k - self.LAG)
+        behind = k - 1 - self._known_at            # chunks appended since the counts that are known (at most LAG - 1 ... LAG)
+        n = len(self.names)
+
+        def settle(rec, idx, upper):
+            rec.room_for(int(self._known[idx]) + behind * upper, upper)
+        settle(self.cell, 0, upper_o)
         ids, rc, bb, sz = self.cell.ptrs()
         L.check(lib.sd_chunkprops_append(scan.cell_table.data_ptr(), cap_o, X, Y, Z, ox, oy, oz, self.min_vx['sv'], ids, rc, bb, sz,
                                          self.cell.capacity, self.cell.cursor.data_ptr(), stream), 'sd_chunkprops_append')
         for i, name in enumerate(self.names):
             tab = scan.sub_tables[i]
-            self._settle(self.sub[i], upper_o)
+            settle(self.sub[i], 1 + i, upper_o)
             ids, rc, bb, sz = self.sub[i].ptrs()
             L.check(lib.sd_chunkprops_append(tab.data_ptr(), cap_o, X, Y, Z, ox, oy, oz, self.min_vx[name], ids, rc, bb, sz,
                                              self.sub[i].capacity, self.sub[i].cursor.data_ptr(), stream), 'sd_chunkprops_append')
-            self._settle(self.pairs[i], upper_p)
+            settle(self.pairs[i], 1 + n + i, upper_p)
             a, b, c = self.pairs[i].ptrs()
             L.check(lib.sd_chunkpairs_append(scan.ptabs[i].data_ptr(), cap_p, tab.data_ptr(), scan.cell_table.data_ptr(), cap_o, X, Y, Z,
                                              self.min_vx[name], a, b, c, self.pairs[i].capacity, self.pairs[i].cursor.data_ptr(), stream),
                     'sd_chunkpairs_append')
+        self._post(k)
         self.n_chunks += 1
 
     # -- end of the dataset ------------------------------------------------------------------------------------------------------
-    def _merge_objects(self, rec: _Records) -> PropTable:
+    def _scratch(self, n: int):
+        """One scratch buffer for all merges of `finish` (sized for the largest record count)."""
+        need = self.lib.sd_propmerge_temp_bytes(max(int(n), 1))
+        if getattr(self, '_tmp', None) is None or self._tmp.numel() < need:
+            self._tmp = self.torch.empty(need, dtype=self.torch.uint8, device=self.device)
+        return self._tmp
+
+    def _merge_objects(self, rec: _Records, n: int) -> PropTable:
         torch, lib = self.torch, self.lib
-        n = rec.count()
         assert n <= rec.capacity, 'record arrays overran (internal error: capacity bound)'
         if n == 0:
             return PropTable(np.zeros(0, np.uint64), np.zeros(0, np.int64), np.zeros((0, 3), np.int64), np.zeros((0, 2, 3), np.int64),
@@ -188,39 +242,40 @@ class ChunkMerger:
         beg = torch.empty(n, dtype=torch.int32, device=dev)
         bbs = torch.empty((n, 6), dtype=torch.int32, device=dev)
         cnt = torch.zeros(1, dtype=torch.int64, device=dev)
-        tb = lib.sd_propmerge_temp_bytes(n)
-        tmp = torch.empty(tb, dtype=torch.uint8, device=dev)
+        tmp = self._scratch(n)
         a = rec.arrays
         self.L.check(lib.sd_propmerge_objects(a['ids'].data_ptr(), a['sizes'].data_ptr(), a['rc'].data_ptr(), a['bb'].data_ptr(), n,
                                               uniq.data_ptr(), tot.data_ptr(), rc.data_ptr(), beg.data_ptr(), bbs.data_ptr(),
-                                              cnt.data_ptr(), tmp.data_ptr(), tb, stream), 'sd_propmerge_objects')
+                                              cnt.data_ptr(), tmp.data_ptr(), tmp.numel(), stream), 'sd_propmerge_objects')
         u = int(cnt.item())
         begin = np.concatenate((beg[:u].cpu().numpy().view(np.uint32).astype(np.int64), [n]))
         return PropTable(uniq[:u].cpu().numpy().view(np.uint64), tot[:u].cpu().numpy(), rc[:u].cpu().numpy().astype(np.int64),
                          bbs.cpu().numpy().astype(np.int64).reshape(n, 2, 3), begin)
 
-    def _merge_pairs(self, rec: _Records) -> MapTable:
+    def _merge_pairs(self, rec: _Records, n: int) -> MapTable:
         torch, lib = self.torch, self.lib
-        n = rec.count()
         assert n <= rec.capacity, 'record arrays overran (internal error: capacity bound)'
         if n == 0:
             return MapTable(np.zeros(0, np.uint64), np.zeros(0, np.uint64), np.zeros(0, np.int64))
         dev, stream = self.device, torch.cuda.current_stream(self.device).cuda_stream
         o_s, o_c, o_n = (torch.empty(n, dtype=torch.int64, device=dev) for _ in range(3))
         cnt = torch.zeros(1, dtype=torch.int64, device=dev)
-        tb = lib.sd_propmerge_temp_bytes(n)
-        tmp = torch.empty(tb, dtype=torch.uint8, device=dev)
+        tmp = self._scratch(n)
         a = rec.arrays
         self.L.check(lib.sd_propmerge_pairs(a['sub'].data_ptr(), a['cell'].data_ptr(), a['cnt'].data_ptr(), n, o_s.data_ptr(),
-                                            o_c.data_ptr(), o_n.data_ptr(), cnt.data_ptr(), tmp.data_ptr(), tb, stream),
+                                            o_c.data_ptr(), o_n.data_ptr(), cnt.data_ptr(), tmp.data_ptr(), tmp.numel(), stream),
                      'sd_propmerge_pairs')
         u = int(cnt.item())
         return MapTable(o_s[:u].cpu().numpy().view(np.uint64), o_c[:u].cpu().numpy().view(np.uint64), o_n[:u].cpu().numpy())
 
     def finish(self):
         """-> (cell PropTable, {name: PropTable}, {name: MapTable})"""
-        return (self._merge_objects(self.cell), {n: self._merge_objects(self.sub[i]) for i, n in enumerate(self.names)},
-                {n: self._merge_pairs(self.pairs[i]) for i, n in enumerate(self.names)})
+        self._read(self.n_chunks - 1)              # every chunk's flags and the final cursors
+        counts = [int(v) for v in self._known]
+        n = len(self.names)
+        self._scratch(max(counts) if counts else 1)
+        return (self._merge_objects(self.cell, counts[0]), {nm: self._merge_objects(self.sub[i], counts[1 + i]) for i, nm in enumerate(self.names)},
+                {nm: self._merge_pairs(self.pairs[i], counts[1 + n + i]) for i, nm in enumerate(self.names)})
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -228,7 +283,7 @@ def map_subcell_extract_props(kd_seg_path: str, kd_organelle_paths: Dict[str, st
                               n_folders_fs_sc: int = 1000, n_chunk_jobs: Optional[int] = None, n_cores: int = 1,
                               cube_of_interest_bb: Optional[Sequence] = None, chunk_size: Optional[Sequence[int]] = None,
                               log=None, overwrite=False, min_obj_vx: Optional[dict] = None, device=None, as_tables: bool = False,
-                              chunk_loader: Optional[Callable] = None):
+                              chunk_loader: Optional[Callable] = None, table_capacity: Optional[int] = None):
     """Step 1 of the reference's function of this name (sd_proc.py:273-787): over a regular chunk grid (``fit_box_size=True``)
     read the cell segmentation and every organelle segmentation (``load_seg(...).swapaxes(0, 2)``, zeros beyond the dataset),
     gather per-object properties and organelle -> cell overlap counts, drop objects that lie purely inside a chunk and are
@@ -263,15 +318,30 @@ def map_subcell_extract_props(kd_seg_path: str, kd_organelle_paths: Dict[str, st
     cd = ChunkDataset()
     cd.initialize(kd, hi - lo, chunk_size, '', box_coords=lo, fit_box_size=True)
     device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    chunk_ids = sorted(cd.chunk_dict)
+    nvox = int(np.prod(chunk_size))
+    # table capacities: label volumes hold far fewer objects than voxels; a chunk that needs more is detected (two chunks late, the
+    # host does not wait for the chunk it has just queued) and the pass is repeated with 4x the capacity
+    cap_obj = cap_pair = 1 << max(10, int((table_capacity or min(2 * nvox, max(1 << 16, nvox // 256))) - 1).bit_length())
     with torch.cuda.device(device):
-        scan = DeviceScan(device)
-        merger = ChunkMerger(names, min_obj_vx, device)
-        for ch_id in sorted(cd.chunk_dict):
-            origin = np.asarray(cd.chunk_dict[ch_id].coordinates, dtype=np.int64)
-            subs = [chunk_loader(n, origin, chunk_size) for n in names]
-            scan.scan(chunk_loader('sv', origin, chunk_size), subs)
-            merger.add_chunk(scan, origin)
-        cell_t, sub_t, map_t = merger.finish()
+        while True:
+            scan = DeviceScan(device, cap_obj, cap_pair)
+            merger = ChunkMerger(names, min_obj_vx, device, len(chunk_ids))
+            try:
+                for ch_id in chunk_ids:
+                    origin = np.asarray(cd.chunk_dict[ch_id].coordinates, dtype=np.int64)
+                    subs = [chunk_loader(n, origin, chunk_size) for n in names]
+                    scan.scan(chunk_loader('sv', origin, chunk_size), subs, status_out=merger.status_slot())
+                    merger.add_chunk(scan, origin)
+                cell_t, sub_t, map_t = merger.finish()
+                break
+            except _TableOverflow as e:
+                if e.objects:
+                    if cap_obj >= 2 * nvox:
+                        raise RuntimeError('sd_segstats_scan: object table overflow at maximum capacity')
+                    cap_obj *= 4
+                if e.pairs:
+                    cap_pair *= 4
     if as_tables:
         return cell_t, sub_t, map_t
     return cell_t.as_dicts(), {n: t.as_dicts() for n, t in sub_t.items()}, {n: t.as_dict() for n, t in map_t.items()}

@@ -90,6 +90,29 @@ def test_gpu_objprops_and_mapping_equal_oracle(gpu, shape, nid, dtype, coh):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('shape,nid,dtype,coh', [((3, 5, 4), 3, np.uint64, False), ((1, 1, 4), 2, np.uint32, False), ((3, 1, 12), 4, np.uint64, True),
+                                                ((7, 3, 260), 9, np.uint32, False), ((9, 4, 256), 30, np.uint64, True),
+                                                ((37, 21, 72), 200, np.uint64, True), ((6, 10, 1024), 5, np.uint32, True)])
+def test_gpu_four_voxels_per_lane_form_equals_one_voxel_form_and_oracle(gpu, shape, nid, dtype, coh, monkeypatch):
+    """Rows of a multiple of 4 voxels run the pass with 4 voxels per lane (`k_segstats_scan<L, true>`): same tables as the one-voxel
+    form (`SD_SEGSTATS_V1=1`) and as the numpy oracle -- row ends inside a wave, a volume that ends inside a wave, runs that start
+    at every in-lane position, uint32 and uint64 labels, ids beyond 63 bits."""
+    from syconn_amd.extraction.find_object_properties import map_subcell_C, map_subcell_extract_props
+    assert shape[2] % 4 == 0
+    cell = _random_case(31, shape, nid, dtype, coh)
+    if dtype == np.uint64:
+        cell[cell == 1] = np.uint64(2 ** 63 + 77)
+    subs = np.stack([_random_case(40 + k, shape, max(2, nid // 2), dtype, coh and k != 1) for k in range(3)])
+    want = map_subcell_extract_props_np(cell, subs)
+    got4 = map_subcell_extract_props(cell, subs)
+    assert got4[0] == want[0] and got4[1] == want[1] and got4[2] == want[2]
+    assert map_subcell_C(cell, subs) == want[2]
+    monkeypatch.setenv('SD_SEGSTATS_V1', '1')
+    got1 = map_subcell_extract_props(cell, subs)
+    assert got1[0] == want[0] and got1[1] == want[1] and got1[2] == want[2]
+
+
+@pytest.mark.gpu
 def test_gpu_objprops_edge_cases(gpu):
     from syconn_amd.extraction.find_object_properties import find_object_properties, map_subcell_extract_props, segstats
     empty = np.zeros((4, 5, 6), np.uint64)

@@ -200,3 +200,38 @@ def test_chunk_driver_on_device_volumes_equals_whole_volume_statistics(gpu):
         assert np.array_equal(lo, whole.sub[i][3][:, 0]) and np.array_equal(hi, whole.sub[i][3][:, 1])
         s, c, n = whole.pairs[i]
         assert np.array_equal(map_t[o].sub_ids, s) and np.array_equal(map_t[o].cell_ids, c) and np.array_equal(map_t[o].counts, n)
+
+
+@pytest.mark.gpu
+def test_chunk_driver_repeats_the_pass_when_a_table_overflows(gpu):
+    """The host reads a chunk's overflow flags two chunks late (it never waits for the chunk it has just queued): tables that start
+    far too small for one chunk are detected, the whole pass is repeated with larger ones, and the result is the one of a pass that
+    started large enough -- every voxel its own object in one of the chunks."""
+    import torch
+    import syconn_amd.proc.sd_proc as sp
+
+    class KD:
+        boundary = np.array([48, 16, 16])
+    vol = np.zeros(tuple(KD.boundary), np.uint64)
+    vol[16:32] = (np.arange(16 * 16 * 16, dtype=np.uint64) + 5).reshape(16, 16, 16)       # chunk 1 of 3: 4096 objects
+    vol[40:44, 3:9, 2:7] = 3
+    sub = (vol % np.uint64(7)) * np.uint64(11)
+    dv, ds = torch.from_numpy(vol.view(np.int64)).to(gpu), torch.from_numpy(sub.view(np.int64)).to(gpu)
+
+    def loader(name, off, size):
+        src = dv if name == 'sv' else ds
+        return src[off[0]:off[0] + size[0], off[1]:off[1] + size[1], off[2]:off[2] + size[2]].contiguous()
+    orig = sp.kd_factory
+    sp.kd_factory = lambda p: KD()
+    try:
+        kw = dict(chunk_size=(16, 16, 16), min_obj_vx={'sv': 1, 'mi': 1}, device=gpu, as_tables=True, chunk_loader=loader)
+        small = sp.map_subcell_extract_props('', {'mi': ''}, table_capacity=1024, **kw)
+        big = sp.map_subcell_extract_props('', {'mi': ''}, table_capacity=1 << 16, **kw)
+    finally:
+        sp.kd_factory = orig
+    assert len(small[0]) == 4097 and np.array_equal(small[0].ids, big[0].ids) and np.array_equal(small[0].sizes, big[0].sizes)
+    assert np.array_equal(small[0].boxes, big[0].boxes) and np.array_equal(small[0].rep_coords, big[0].rep_coords)
+    for a, b in ((small[1]['mi'], big[1]['mi']),):
+        assert np.array_equal(a.ids, b.ids) and np.array_equal(a.sizes, b.sizes) and np.array_equal(a.boxes, b.boxes)
+    assert np.array_equal(small[2]['mi'].counts, big[2]['mi'].counts) and np.array_equal(small[2]['mi'].cell_ids, big[2]['mi'].cell_ids)
+    assert int(small[0].sizes.sum()) == int(np.count_nonzero(vol))

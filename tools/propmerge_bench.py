@@ -38,7 +38,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--extent', type=int, nargs=3, default=[2048, 2048, 512])
     ap.add_argument('--chunk', type=int, nargs=3, default=[512, 512, 512])
-    ap.add_argument('--reps', type=int, default=3)
+    ap.add_argument('--reps', type=int, default=7)
     ap.add_argument('--min-vx', type=int, default=200)
     args = ap.parse_args()
     import syconn_amd.proc.sd_proc as sp
@@ -88,7 +88,7 @@ def main():
     print(json.dumps({
         'what': 'map_subcell_extract_props step 1 (device chunk driver): cell segmentation + 3 organelle segmentations, uint64, resident in HBM',
         'extent_xyz': [int(v) for v in ext], 'chunk': [int(v) for v in cs], 'n_chunks': int(np.prod(-(-ext // cs))),
-        'min_obj_vx': mov, 'seconds': times, 'first_call_seconds_incl_synthesis': t_first,
+        'min_obj_vx': mov, 'seconds': times, 'seconds_median': float(np.median(times)), 'first_call_seconds_incl_synthesis': t_first,
         'mvox_per_s': vox / best / 1e6, 'label_bytes_read_GBps': vox * 8 * 4 / best / 1e9,
         'objects': {'sv': len(res[0]), **{n: len(res[1][n]) for n in names}}, 'box_records': {'sv': int(len(res[0].boxes)), **{n: int(len(res[1][n].boxes)) for n in names}},
         'overlap_pairs': {n: len(res[2][n]) for n in names},
