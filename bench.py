@@ -120,6 +120,11 @@ class HostToHostPipeline:
         # one rank: the last kernel stores the labels straight into the page-locked host buffer (module docstring); with a process group
         # the gather needs them in HBM
         self.zero_copy = not os.environ.get('SD_BENCH_D2H_COPY') and not self.coll
+        # SD_BENCH_D2H_REPEAT=n (one rank with SD_BENCH_D2H_COPY=1, A/B only): the labels leave n times per step -- what rank 0's device-to-host
+        # leg carries at N = n ranks (measured, n = 8: 2986 -> 2845 Mvox/s = -4.7 %; a lean 8-workgroup copy kernel in the place of the
+        # runtime's blit kernel was WORSE, -12 %: tools/experiments/round6_notes.md)
+        self.d2h_repeat = max(1, int(os.environ.get('SD_BENCH_D2H_REPEAT', '1'))) if not self.coll else 1
+        self.extra_host = [[torch.empty((T, S, S, S), dtype=torch.uint8).pin_memory() for _ in range(self.d2h_repeat - 1)] for _ in range(2)]
         self.k = 0
 
     def step(self):
@@ -150,6 +155,8 @@ class HostToHostPipeline:
                     self.out_host[s].copy_(self.recv[s], non_blocking=True)
             elif not self.zero_copy:
                 self.out_host[s][0].copy_(self.lab_dev[s], non_blocking=True)
+                for extra in self.extra_host[s]:
+                    extra.copy_(self.lab_dev[s], non_blocking=True)
             self.ev_out[s].record(self.s_out)
 
     def drain(self):
@@ -427,7 +434,8 @@ def main():
                                        f'per step in launch sets of {B} (sd_forward_labels_batch), random-init weights, '
                                        f'HOST TO HOST: pinned host uint8 tiles -> H2D -> kernels -> '
                                        + ('pinned host uint8 labels (stored by the last kernel, no copy)' if pipe.zero_copy
-                                          else 'D2H -> pinned host uint8 labels') + ', 3 HIP streams, 2 buffer sets',
+                                          else 'D2H -> pinned host uint8 labels')
+                                       + (f' x{pipe.d2h_repeat}' if pipe.d2h_repeat > 1 else '') + ', 3 HIP streams, 2 buffer sets',
                            'tiles_per_launch_set': B,
                            'tiles_per_gpu_per_step': T, 'tile': [S, S, S], 'parallelism': f'tile-sharded x{world}',
                            'hip_streams_per_gpu': 3,
