@@ -495,6 +495,8 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
                 // the (block, chunk) groups are independent)
                 parallel_for(op.NB * nchunks, [&](int g0) {
                     const int nb = g0 / nchunks, c = g0 % nchunks;
+                        // weight groups in the order the kernel's stages read them: [kz][9 taps (ky, kx)]; 3x3x3 layers with NT <= 2 (ZROLL in
+                        // sd_conv_mfma.h): [stage ky][step (kx, kz)] -- those outputs are summed in the order (chunk, ky, kx, kz)
                         for (int kz = 0; kz < d.kz; ++kz)
                             for (int t9 = 0; t9 < 9; ++t9)
                                 for (int j = 0; j < op.NT; ++j)
@@ -509,7 +511,8 @@ int sd_model_create(const sd_op_desc* ops, int n_ops, const float* W, size_t n_f
                                                 const int k = (r % nsrc) * SD_CHUNK + (l >> 5) * 8 + e;
                                                 ci = s0 ? (k < d.cin0 ? k : -1) : (k < d.cin1 ? d.cin0 + k : -1);
                                             }
-                                            const float v = (n < d.cout && ci >= 0) ? wat(n, ci, kz, t9) * wscale : 0.f;
+                                            // (ZROLL layers: group index `kz` and in-group index `t9` name the tap (kz, ky, kx) = (t9 % 3, kz, t9 / 3))
+                                            const float v = (n < d.cout && ci >= 0) ? (d.kz == 3 && op.NT != 3 ? wat(n, ci, t9 % 3, kz * 3 + t9 / 3) : wat(n, ci, kz, t9)) * wscale : 0.f;
                                             const size_t idx =
                                                 ((((((size_t)nb * nchunks + c) * d.kz + kz) * 9 + t9) * op.NT + j) * 64 + l) * 8 + e;
                                             wp[idx] = split ? split_part(v, r, nsrc) : cvt(v, act_dtype);

@@ -149,12 +149,39 @@ constexpr int dma_count(int w, int waves, int a_instr, int j0, int j1) {
     for (int j = j0; j < j1; ++j) n += (w + j * waves < a_instr) ? 1 : 0;
     return n;
 }
+// 3x3x3 stage with z-neighbour tiles (MT = 4; see the tap loop): LDS reads of a stage in program order -- W(0), X(kx 0, planes 0..3), then per
+// step u = 3 kx + kz: W(u + 1), and per tile row i: [wait] MFMAs, refill (plane 4 after (kz 0, i 0), plane 5 after (kz 1, i 0), the next
+// kx's plane i after (kz 2, i)).  LDS returns in order: the wait in front of row (u, i) may leave as many reads in flight as were issued
+// after the youngest one it needs (X(kx, plane i + kz); for i = 0 also the last fragment of W(u)).
+constexpr int zroll_wait(int nt, int u_want, int i_want) {
+    int seq = 0;
+    int wseq[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};       // sequence number of the LAST fragment of W(u)
+    int xseq[3][6] = {{0}};
+    seq += nt; wseq[0] = seq - 1;
+    for (int m = 0; m < 4; ++m) xseq[0][m] = seq++;
+    for (int u = 0; u < 9; ++u) {
+        const int kx = u / 3, kz = u % 3;
+        if (u + 1 < 9) { seq += nt; wseq[u + 1] = seq - 1; }
+        for (int i = 0; i < 4; ++i) {
+            if (u == u_want && i == i_want) {
+                int need = xseq[kx][i + kz];
+                if (i == 0 && wseq[u] > need) need = wseq[u];
+                return seq - 1 - need;
+            }
+            if (kz == 0 && i == 0) xseq[kx][4] = seq++;
+            else if (kz == 1 && i == 0) xseq[kx][5] = seq++;
+            else if (kz == 2 && kx < 2) xseq[kx + 1][i] = seq++;
+        }
+    }
+    return 0;
+}
 template <typename T, int KZ, int NT, int WAVES, int NSLOT, int MT, int MODE>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(const ConvParams p) {
     // MODE 5 (FU8) = MODE 1 for UINT8 network input: the first convolution runs as two bf16 MFMAs per 32 halo voxels on the exact uint8
     // values (weights / 255 and bias split three ways into bf16 parts: sd_device.h first_u8_mfma) instead of five 64-cycle
     // v_mfma_f32_32x32x2_f32 -- a fifth of the matrix-pipe time; fp32-level result, not the bit pattern of the float32(v) / 255 chain.
     constexpr bool FF = MODE == 1 || MODE == 4 || MODE == 5, GN = MODE == 2, FU8 = MODE == 5;
+    constexpr bool ZROLL = KZ == 3 && NT != 3;      // 3x3x3 stages by ky, taps (kx, kz) inside: see the stage loop
     // shader clock seen by this launch (bench.py: `roofline.clock_ghz_timed_region`): the first workgroup stamps the shader cycle counter
     // and the constant 100 MHz counter on entry and on exit (persistent workgroups live as long as the launch)
     if (p.clk && blockIdx.x == 0 && threadIdx.x == 0) { p.clk[0] = __builtin_readcyclecounter(); p.clk[1] = __builtin_amdgcn_s_memrealtime(); }
@@ -880,13 +907,63 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                 }
                 if (s == SD_TS) SD_T(1);     // after the DMA issue of the probed stage
                 const char* const bcur = ldsB + (WRES ? s : RING ? gs % NW : (gs & 1)) * B_BYTES + lane * 16;
-                const char* const acur = abuf + kz * SLICE;
+                // ZROLL: the three stages of a chunk are the three KY rows of the stencil (the loop variable keeps its name); inside a stage
+                // the taps run kx-major, kz-minor -- every output is summed in the order (chunk, ky, kx, kz) (the weight groups are packed in
+                // that order, sd_api.hip).  A wave's voxel tiles are z-neighbours, so tile i at kz reads the halo plane
+                // tile i + 1 reads at kz - 1: with kz innermost a fragment serves up to three MFMA rows (MT = 4 below).
+                // (ZROLL = 3x3x3 layers with NT <= 2.  The NT = 3 forms -- the 48-filter family, two voxel tiles per wave, nothing to share --
+                // keep kz stages and the order (chunk, kz, ky, kx): which order a LAYER is summed in depends on its channel count alone,
+                // never on the launch, so a layer gives the same bits in every form that can run it.)
+                const char* const acur = ZROLL ? abuf + kz * (HX * 32) : abuf + kz * SLICE;
+                const bool odd_row = ZROLL && (kz & 1);      // (halo-row parity of the stage = which 16-byte half order the fragments have)
                 // software-pipelined over the 9 taps: the fragments of tap t+1 are in flight while tap t's MFMAs run.
                 // The LDS reads and their counted waits are inline asm: left to the compiler the reads are sunk next
                 // to their use behind an lgkmcnt(0) (it prefers reusing the fragment registers), which idles the
                 // matrix pipe for one LDS latency per tap.  LDS returns in order, so lgkmcnt(MT + NT) after issuing
                 // tap t+1 means tap t has landed; `tie` makes the MFMAs depend on the post-wait values.
-                if constexpr (MT == 4) {
+                if constexpr (MT == 4 && ZROLL) {
+                    // 4 z-neighbour tiles per wave, planes P0 ... P5 of the halo at this stage's ky row: step u = (kx, kz) runs the MFMA rows
+                    // (tile i) x (NT weight fragments of tap (kz, ky, kx)) on plane i + kz.  The four fragment registers rotate through the
+                    // six planes of a kx column -- P4 replaces P0 right behind P0's only row, P5 replaces P1 behind P1's last row, and behind
+                    // the kz = 2 rows the next column's P0 ... P3 come in: 6 x fragments + 3 NT weight fragments per 12 NT MFMAs (NT = 2:
+                    // 0.5 LDS fragment reads per MFMA; the kz-stage form read 0.75 -- every halo plane three times per chunk).  Same
+                    // registers as before (single-buffered x fragments refilled in place, double-buffered weight fragments), counted waits
+                    // from the replayed issue order (zroll_wait).
+                    v8 xq[4], wq[2][NT];
+                    const uint32_t bA = lds_addr(bcur);
+                    const uint32_t xb = lds_addr(acur) + (odd_row ? xoffO[0] : xoffE[0]);
+                    auto load_p = [&](auto kxc, auto mc) {
+                        constexpr int kx = decltype(kxc)::value, m = decltype(mc)::value;
+                        ds_read16<kx * 32 + m * SLICE>(xq[(m + 2 * kx) & 3], xb);
+                    };
+                    auto load_w = [&](auto uc) {
+                        constexpr int u = decltype(uc)::value;
+                        static_for<NT>([&](auto jc) {
+                            constexpr int j = decltype(jc)::value;
+                            ds_read16<(u * NT + j) * 1024>(wq[u & 1][j], bA);
+                        });
+                    };
+                    load_w(std::integral_constant<int, 0>{});
+                    static_for<4>([&](auto mc) { load_p(std::integral_constant<int, 0>{}, mc); });
+                    static_for<9>([&](auto uc) {
+                        constexpr int u = decltype(uc)::value, kx = u / 3, kzz = u % 3, buf = u & 1;
+                        if constexpr (u + 1 < 9) load_w(std::integral_constant<int, u + 1>{});
+                        static_for<4>([&](auto ic) {
+                            constexpr int i = decltype(ic)::value, slot = (i + kzz + 2 * kx) & 3;
+                            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(zroll_wait(NT, u, i)));
+                            tie(xq[slot]);
+                            if constexpr (i == 0) {
+#pragma unroll
+                                for (int j = 0; j < NT; ++j) tie(wq[buf][j]);
+                            }
+#pragma unroll
+                            for (int j = 0; j < NT; ++j) acc[i][j] = Act<T>::mfma(wq[buf][j], xq[slot], acc[i][j]);
+                            if constexpr (kzz == 0 && i == 0) load_p(std::integral_constant<int, kx>{}, std::integral_constant<int, 4>{});
+                            else if constexpr (kzz == 1 && i == 0) load_p(std::integral_constant<int, kx>{}, std::integral_constant<int, 5>{});
+                            else if constexpr (kzz == 2 && kx < 2) load_p(std::integral_constant<int, kx + 1>{}, ic);
+                        });
+                    });
+                } else if constexpr (MT == 4) {
                     // 4 voxel tiles per wave (KZ == 3: z-neighbours, so tile i's fragment sits i * SLICE bytes behind tile 0's:
                     // a ds_read offset immediate, ONE address register pair for all tiles).  Register budget: 128
                     // accumulator registers leave no room for double-buffered fragments, so the x fragments are single-
@@ -933,10 +1010,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                 const uint32_t aE = lds_addr(acur), bA = lds_addr(bcur);
                 uint32_t xaE[MT], xaO[MT];
 #pragma unroll
-                for (int i = 0; i < MT; ++i) { xaE[i] = aE + xoffE[i]; xaO[i] = aE + xoffO[i]; }
+                for (int i = 0; i < MT; ++i) {
+                    xaE[i] = aE + xoffE[i]; xaO[i] = aE + xoffO[i];
+                    if constexpr (ZROLL) { if (odd_row) { const uint32_t t = xaE[i]; xaE[i] = xaO[i]; xaO[i] = t; } }      // (the stage IS the ky row)
+                }
                 auto load_tap = [&](auto tc) {
-                    constexpr int t9 = decltype(tc)::value, ky = t9 / 3, kx = t9 % 3, buf = t9 & 1;
-                    constexpr int tapoff = (ky * HX + kx) * 32;
+                    // tap t9 = (ky, kx) of the stage's kz plane; ZROLL: step t9 = (kx, kz) of the stage's ky row
+                    constexpr int t9 = decltype(tc)::value, ky = ZROLL ? 0 : t9 / 3, kx = ZROLL ? t9 / 3 : t9 % 3, buf = t9 & 1;
+                    constexpr int tapoff = ZROLL ? kx * 32 + (t9 % 3) * SLICE : (ky * HX + kx) * 32;
 #pragma unroll
                     for (int i = 0; i < MT; ++i) ds_read16<tapoff>(xf[buf][i], (ky & 1) ? xaO[i] : xaE[i]);
                     static_for<NT>([&](auto jc) {

@@ -70,12 +70,16 @@ def main():
                     n = [min(c, v - l) for c, v, l in zip(chunk, vol_shape, lo)]
                     want[:, lo[0]:lo[0] + n[0], lo[1]:lo[1] + n[1], lo[2]:lo[2] + n[2]] = r[:, :n[0], :n[1], :n[2]]
     ok = True
+
+    def cost(valid_box):      # rounds dealt from a cost-sorted list (second repetition): ragged edge chunks last, same volume
+        return int(np.prod(np.subtract(valid_box[1], valid_box[0])))
     for pipelined in (True, False):
         for root_computes in (True, False):
             for rep in range(2):                  # twice: the second call reuses the pinned pool
                 trace = []
                 out = par.predict_volume_distributed(vol if rank == 0 else None, vol_shape, chunk, halo, predict_fn, n_out=2,
-                                                     device=dev, pipelined=pipelined, root_computes=root_computes, trace=trace)
+                                                     device=dev, pipelined=pipelined, root_computes=root_computes, trace=trace,
+                                                     chunk_cost=cost if rep else None)
                 torch.cuda.synchronize(dev)
                 nr = -(-27 // (world if root_computes else max(1, world - 1)))
                 assert nr >= 5

@@ -476,6 +476,14 @@ def test_chunked_volume_prediction_equals_whole_volume_tiling(gpu):
     assert got is mine and torch.equal(mine[0], whole) and par.HOST_BOX_COPIES == copies0
     with pytest.raises(ValueError):
         par.predict_volume_distributed(vol, vol_shape, chunk, halo, predict_fn, n_out=1, device=gpu, out=mine[:, :-1])
+    # rounds dealt from a cost-sorted chunk list (the Predictor's own cost model): the same volume
+    cm = pred.chunk_cost_model(halo, True)
+    got = par.predict_volume_distributed(vol, vol_shape, chunk, halo, predict_fn, n_out=1, device=gpu, chunk_cost=lambda vb: cm.chunk_cost(chunk, vb))
+    assert torch.equal(got[0], whole)
+    # a volume whose device copy + result cannot fit rank 0's HBM is refused before anything is allocated or sent (RuntimeError = the
+    # reference's out-of-memory convention)
+    with pytest.raises(RuntimeError, match='do not fit'):
+        par.predict_volume_distributed(vol, (200000, 200000, 64), chunk, halo, predict_fn, n_out=1, device=gpu)
 
 
 def test_two_concurrent_workers_write_the_same_dataset_as_one(gpu, tmp_path, monkeypatch):
