@@ -807,7 +807,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
             const char* pf_zero = reinterpret_cast<const char*>(p.zero);
             char* pf_dst = nullptr;
             int pf_Hs = 0, pf_Ws = 0, pf_z = 0, pf_y = 0, pf_x = 0, pf_D = p.D, pf_H = p.H, pf_W = p.W;
-            if constexpr (SPREAD) {
+            // (every wave runs this set-up in front of the chunk's first tap loop -- cycle stamps show that stage 600 cycles longer than the
+            // other two.  Round 6 moved it behind the first tap loop for the waves that issue their pieces there: 2 % SLOWER on the 3x3x3
+            // launches, tools/experiments/round6_notes.md: the lock-step start of a stage is worth more than the idle set-up costs.)
+            auto pf_setup = [&]() {
                 int pc = c + 1, pt = tn;
                 pf_real = true; pf_z = z0; pf_y = y0; pf_x = x0;
                 if (pc == nchunks) { pc = 0; pt = ntn; pf_z = nz0; pf_y = ny0; pf_x = nx0; pf_real = nlb >= 0; }
@@ -828,7 +831,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 12 ? 3 : 2) void k_conv_mfma(c
                 pf_Hs = rfl(pf_Hs); pf_Ws = rfl(pf_Ws); pf_z = rfl(pf_z); pf_y = rfl(pf_y); pf_x = rfl(pf_x);
                 asm volatile("" : "+s"(pf_sbase), "+s"(pf_zero), "+s"(pf_Hs), "+s"(pf_Ws), "+s"(pf_z), "+s"(pf_y), "+s"(pf_x),
                              "+s"(pf_D), "+s"(pf_H), "+s"(pf_W));
-            }
+            };
+            (void)pf_setup;
+            if constexpr (SPREAD) pf_setup();
             // halo coordinates of this lane's NEXT piece, advanced piece by piece (one piece = WAVES * 32 halo voxels further):
             // additions and two carries instead of the divisions of hpack_of (quarter-rate multiplies)
             constexpr int SV = WAVES * 32, SDZ = SV / (HY * HX), SDY = (SV % (HY * HX)) / HX, SDX = SV % HX;
