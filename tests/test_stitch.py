@@ -49,6 +49,22 @@ def test_calculate_chunk_numbers_for_box_host():
     assert lst == want and all(tr[n] == i for i, n in enumerate(lst))
 
 
+def test_calculate_chunk_numbers_for_box_against_the_reference_function():
+    """tests/golden/g13_chunk_numbers.npz: outputs of the reference's own calculate_chunk_numbers_for_box (its triple loop over the widened
+    box) on a stand-in chunk set; here the same lists come from lattice arithmetic over the chunk origins."""
+    from syconn_amd.extraction.object_extraction_wrapper import calculate_chunk_numbers_for_box
+    from syconn_amd.knossos import ChunkDataset
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g13_chunk_numbers.npz'))
+    for i in range(int(g['n_cases'])):
+        cd = ChunkDataset()
+        cd.initialize(None, g[f'c{i}_box'], g[f'c{i}_chunk'], '/tmp/x/', box_coords=[0, 0, 0], fit_box_size=True)
+        off, size = g[f'c{i}_offset'].copy(), g[f'c{i}_size'].copy()
+        lst, tr = calculate_chunk_numbers_for_box(cd, off, size)
+        assert lst == g[f'c{i}_list'].tolist(), i
+        assert tr == dict(zip(g[f'c{i}_tr_keys'].tolist(), g[f'c{i}_tr_vals'].tolist()))
+        assert np.array_equal(off, g[f'c{i}_offset']) and np.array_equal(size, g[f'c{i}_size'])        # (arguments untouched)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', NAMES)
 def test_unique_stitch_apply_against_reference(gpu, name):
