@@ -27,6 +27,9 @@ HOST_BOX_COPIES = 0
 # 128^3-tile chunks, pack + stitch sustain 4.4 Gvox/s with 16 threads and 6.8 Gvox/s with 64 (tools/host_pack_rate.py)
 HOST_THREADS = min(64, max(4, (os.cpu_count() or 8) // 2))
 
+# rows per upload piece of the device volume path (predict_volume_distributed): pieces = row block x the z-planes a round needs next
+UPLOAD_ROWS = 128
+
 
 def _single_rank_group() -> bool:
     """``SD_DIST_SINGLE_RANK_GROUP=1``: create a process group even for ONE rank and send every payload through it.  A one-rank
@@ -227,11 +230,11 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
 
     Rank 0 holds `volume_u8` in HOST memory (other ranks pass None) and receives the (n_out, *vol_shape) uint8 result in host
     memory as well (None elsewhere; `out`: a caller-owned -- ideally page-locked -- tensor to fill instead of a fresh pinned one).
-    On a ROCm device rank 0's CPU does no per-chunk work at all: the volume is uploaded ONCE in contiguous z-slabs (one per row
-    of chunks, each just before the first round that reads it) into rank 0's HBM, chunk + halo boxes are cut there by
+    On a ROCm device rank 0's CPU does no per-chunk work at all: the volume is uploaded ONCE into rank 0's HBM, in pieces of
+    `UPLOAD_ROWS` rows x the z-planes a round needs next (2D copies, each just before the first round that reads it), chunk + halo boxes are cut there by
     `sd_tile_gather` straight into the scatter staging buffer (zeros outside the volume), gathered results are placed by
-    `sd_tile_scatter` into a device-resident result volume, and every row of chunks is downloaded as one contiguous slab per
-    output channel as soon as its last chunk has arrived -- 2 x 2 GiB over rank 0's PCIe link per 2048 x 2048 x 512 volume,
+    `sd_tile_scatter` into a device-resident result volume, and every (z-row, y-row) strip of chunks is downloaded with one 2D copy
+    per output channel as soon as its last chunk has arrived -- 2 x 2 GiB over rank 0's PCIe link per 2048 x 2048 x 512 volume,
     under the kernels (rounds 1-4 packed and stitched every chunk with host threads: 6.3-6.9 Gvox/s on the GPU box, below what
     8 GPUs predict).  CPU tensors (the gloo unit tests of the sharding logic) keep the host pack / stitch.
     Chunks of `chunk_shape` are enumerated z-major and dealt round-robin over the WORKER ranks (== ``chunkify``): all
@@ -325,7 +328,12 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
             out = torch.empty(full_shape, dtype=torch.uint8, pin_memory=True)
         stage = [torch.empty((world, *in_shape), dtype=torch.uint8, device=device) for _ in range(2)] if coll else None
         recv = [torch.empty((world, *out_shape), dtype=torch.uint8, device=device) for _ in range(2)] if coll else None
-        up_next = [0 if not vol.is_cuda else int(vs[0])]          # first z-plane of the volume not yet uploaded
+        # the volume goes up in pieces of UPLOAD_ROWS rows x the z-planes a round needs next (one 2D copy each, in the order the rounds
+        # need them): up_z[b] = first z-plane of row block b that is not in HBM yet.  (Whole z-slabs, rounds 5: the first round waited for
+        # 276 planes x all rows = 1.16 GB of the 2048 x 2048 x 512 volume, 23 ms of the ~185 ms a volume takes on 8 ranks; its 8 chunks
+        # read 1024 of the 2048 rows: 0.54 GB.)
+        n_row_blocks = -(-int(vs[1]) // UPLOAD_ROWS)
+        up_z = [0 if not vol.is_cuda else int(vs[0])] * n_row_blocks
         # results leave HBM strip by strip: a strip = the chunks (zi, yi, all x) = z-planes x a contiguous run of rows, one 2D copy per
         # output channel as soon as its last chunk has arrived (cost-sorted rounds finish whole z-rows only at the very end: row-wise
         # downloads would leave the entire result for a tail after the last kernel)
@@ -366,11 +374,21 @@ def predict_volume_distributed(volume_u8: Optional[torch.Tensor], vol_shape: Seq
             with torch.cuda.stream(s_in):
                 if r >= 2:       # round r-2's scatter has consumed stage[s] (world > 1) / its kernels have consumed in_buf[s]
                     s_in.wait_event(ev_scat[s] if coll else ev_pred[s])
-                need = min(int(vs[0]), max((int(c[0]) + 1) * int(cs[0]) + int(ol[0]) for c in rounds[r]))
-                while up_next[0] < need:
-                    z1 = min(int(vs[0]), (up_next[0] // int(cs[0]) + 1) * int(cs[0]))
-                    vol_dev[up_next[0]:z1].copy_(vol[up_next[0]:z1], non_blocking=True)
-                    up_next[0] = z1
+                plane, row = int(vs[1]) * int(vs[2]), int(vs[2])
+                for c in rounds[r]:
+                    z_need = min(int(vs[0]), (int(c[0]) + 1) * int(cs[0]) + int(ol[0]))
+                    y_lo = max(0, int(c[1]) * int(cs[1]) - int(ol[1]))
+                    y_hi = min(int(vs[1]), (int(c[1]) + 1) * int(cs[1]) + int(ol[1]))
+                    for b in range(y_lo // UPLOAD_ROWS, (y_hi - 1) // UPLOAD_ROWS + 1 if y_hi > y_lo else 0):
+                        if up_z[b] >= z_need:
+                            continue
+                        y0, y1 = b * UPLOAD_ROWS, min(int(vs[1]), (b + 1) * UPLOAD_ROWS)
+                        off = up_z[b] * plane + y0 * row
+                        rc = lib.sd_memcpy2d_async(vol_dev.data_ptr() + off, plane, vol.data_ptr() + off, plane, (y1 - y0) * row,
+                                                   z_need - up_z[b], 0, s_in.cuda_stream)
+                        if rc != 0:
+                            raise RuntimeError('sd_memcpy2d_async failed: ' + lib.sd_last_error().decode(errors='replace'))
+                        up_z[b] = z_need
                 for k, c in enumerate(rounds[r]):
                     lo = np.asarray(c, dtype=np.int64) * cs - ol
                     tile_gather(vol_dev, lo, in_shape, stage[s][workers[k]] if coll else in_buf[s])
