@@ -334,32 +334,28 @@ def labels_box(vol: torch.Tensor, lo, size, lut: Optional[torch.Tensor] = None) 
     return out
 
 
-def stitch_pairs(chunk_a: torch.Tensor, chunk_b: torch.Tensor, dim: int, overlap, stitch_overlap) -> set:
-    """The inner part of ``_make_stitch_list_thread`` (object_extraction_steps.py:555-611, ``overlap_thresh == 0``) for one chunk
-    and its neighbour in +`dim`: both are unique-label volumes of size chunk + 2 * overlap; the slab of `stitch_overlap` voxels
-    on either side of the common chunk face is ``a[-overlap - stitch : -overlap + stitch]`` in the first and ``b[overlap - stitch :
-    overlap + stitch]`` in the second (``cut_array_in_one_dim``, proc/general.py:45-82) -- the same voxels, labelled twice.
-    Returns the set of ``tuple(sorted((id_a, id_b)))`` over the voxels where both are non-zero.  The co-occurrence table is the
-    device native behind ``map_subcell_C`` (`sd_segstats_scan`: one pass over the two slabs)."""
-    from .find_object_properties import segstats
-    ol, so = int(overlap[dim]), int(stitch_overlap[dim])
-    if so > ol or so < 1:
-        raise ValueError('stitch overlap has to be >= 1 and <= the chunk overlap')
-    na, nb = int(chunk_a.shape[dim]), int(chunk_b.shape[dim])
-    lo_a, lo_b, size = [0, 0, 0], [0, 0, 0], [int(v) for v in chunk_a.shape]
+def stitch_pairs(chunk_a: torch.Tensor, chunk_b: torch.Tensor, dim: int, overlap, stitch_overlap, overlap_thresh: float = 0) -> set:
+    """The inner part of ``_make_stitch_list_thread`` (object_extraction_steps.py:555-615) for one chunk and its neighbour in +`dim`:
+    both are unique-label volumes of size chunk + 2 * overlap; the slab of `stitch_overlap` voxels on either side of the common
+    chunk face is ``a[-overlap - stitch : -overlap + stitch]`` in the first and ``b[overlap - stitch : overlap + stitch]`` in the
+    second (``cut_array_in_one_dim``, proc/general.py:45-82) -- the same voxels, labelled twice.  Returns the set of
+    ``tuple(sorted((id_a, id_b)))`` over the voxels where both are non-zero; with ``overlap_thresh > 0`` (:597-615) only the pairs whose
+    objects coincide in more than 10 % of their voxels (`overlapping_pairs`).  The co-occurrence table is the device native behind
+    ``map_subcell_C`` (`sd_segstats_scan`: one pass over the two slabs)."""
     if any(int(chunk_a.shape[d]) != int(chunk_b.shape[d]) for d in range(3) if d != dim):
         raise ValueError('neighbouring chunks differ in the face extents')
-    lo_a[dim], lo_b[dim], size[dim] = na - ol - so, ol - so, 2 * so
-    if lo_a[dim] < 0 or lo_b[dim] + 2 * so > nb:
-        raise ValueError('chunk smaller than its overlap')
-    return slab_pairs(labels_box(chunk_a, lo_a, size), labels_box(chunk_b, lo_b, size))
+    if not overlap_thresh:
+        return slab_pairs(face_slab(chunk_a, dim, True, overlap, stitch_overlap), face_slab(chunk_b, dim, False, overlap, stitch_overlap))
+    return overlapping_pairs(face_slab(chunk_a, dim, True, overlap, overlap), face_slab(chunk_b, dim, False, overlap, overlap), dim, overlap,
+                             stitch_overlap, object_sizes(chunk_a), object_sizes(chunk_b))
 
 
-def face_slab(chunk: torch.Tensor, dim: int, high: bool, overlap, stitch_overlap) -> torch.Tensor:
-    """The ``2 * stitch_overlap[dim]`` planes around the chunk face in +`dim` (`high`: the slab this chunk shares with its +`dim`
-    neighbour, ``[-overlap - stitch, -overlap + stitch)``) or in -`dim` (``[overlap - stitch, overlap + stitch)``), as a contiguous
-    copy: all ``stitch_pairs`` reads of a chunk, so a chunk's volume need not outlive the loop iteration that made it."""
-    ol, so = int(overlap[dim]), int(stitch_overlap[dim])
+def face_slab(chunk: torch.Tensor, dim: int, high: bool, overlap, width) -> torch.Tensor:
+    """The ``2 * width[dim]`` planes around the chunk face in +`dim` (`high`: the slab this chunk shares with its +`dim` neighbour,
+    ``[-overlap - width, -overlap + width)``) or in -`dim` (``[overlap - width, overlap + width)``), as a contiguous copy.
+    ``width = stitch_overlap``: all ``stitch_pairs`` reads of a chunk (so a chunk's volume need not outlive the loop iteration that
+    made it); ``width = overlap``: everything the chunk shares with that neighbour (the ``overlap_thresh`` test)."""
+    ol, so = int(overlap[dim]), int(width[dim])
     if so > ol or so < 1:
         raise ValueError('stitch overlap has to be >= 1 and <= the chunk overlap')
     n = int(chunk.shape[dim])
@@ -370,17 +366,52 @@ def face_slab(chunk: torch.Tensor, dim: int, high: bool, overlap, stitch_overlap
     return labels_box(chunk, lo, size)
 
 
-def slab_pairs(slab_a: torch.Tensor, slab_b: torch.Tensor) -> set:
-    """``tuple(sorted((id_a, id_b)))`` over the voxels where both slabs (the same voxels, labelled by two chunks) are non-zero."""
+def slab_pairs(slab_a: torch.Tensor, slab_b: torch.Tensor, counts: bool = False):
+    """``tuple(sorted((id_a, id_b)))`` over the voxels where both slabs (the same voxels, labelled by two chunks) are non-zero;
+    `counts`: ``{(id_a, id_b): voxels}`` instead (ids in argument order)."""
     from .find_object_properties import segstats
     if tuple(slab_a.shape) != tuple(slab_b.shape):
         raise ValueError('neighbouring chunks differ in the face extents')
     r = segstats(slab_a, [slab_b], want_props=False)
-    ids_b, ids_a, _ = r.pairs[0]
+    ids_b, ids_a, n = r.pairs[0]
+    if counts:
+        return {(int(x), int(y)): int(c) for x, y, c in zip(ids_a.tolist(), ids_b.tolist(), n.tolist())}
     return {(int(min(x, y)), int(max(x, y))) for x, y in zip(ids_a.tolist(), ids_b.tolist())}
 
 
-def make_stitch_list(chunks: dict, grid_pos: dict, overlap, stitch_overlap) -> list:
+def object_sizes(vol: torch.Tensor) -> dict:
+    """id -> voxels of a unique-label volume (``len(np.nonzero(cc_data == id))`` of object_extraction_steps.py:598-600, for every id)."""
+    from .find_object_properties import segstats
+    ids, _, size, _ = segstats(vol).cell
+    return dict(zip(ids.tolist(), size.tolist()))
+
+
+def overlapping_pairs(wide_a: torch.Tensor, wide_b: torch.Tensor, dim: int, overlap, stitch_overlap, sizes_a: dict, sizes_b: dict) -> set:
+    """``overlap_thresh > 0`` (object_extraction_steps.py:597-615).  The reference takes every pair of ids that touch inside the stitch
+    slab, builds a cKDTree over the GLOBAL voxel coordinates of the one object and asks for every voxel of the other whether its
+    distance is zero: ``match_vx`` = voxels where the first chunk carries the one id and the second chunk the other, over everything
+    the two chunk volumes share (their ``2 * overlap`` planes around the face); the pair is kept iff ``2 * match_vx / (size_a + size_b)``
+    exceeds 0.1 (object sizes inside the chunk volumes, the constant is the reference's).  Here: one co-occurrence pass over the two
+    ``2 * overlap`` slabs (`wide_a` / `wide_b` = ``face_slab(..., width=overlap)``) gives every ``match_vx`` at once, the candidates
+    are the pairs of the stitch slab in its middle."""
+    ol, so = int(overlap[dim]), int(stitch_overlap[dim])
+    if so > ol or so < 1:
+        raise ValueError('stitch overlap has to be >= 1 and <= the chunk overlap')
+    matches = slab_pairs(wide_a, wide_b, counts=True)
+    if so == ol:
+        cands = set(matches)
+    else:
+        lo, size = [0, 0, 0], [int(v) for v in wide_a.shape]
+        lo[dim], size[dim] = ol - so, 2 * so
+        cands = set(slab_pairs(labels_box(wide_a, lo, size), labels_box(wide_b, lo, size), counts=True))
+    keep = set()
+    for a, b in cands:
+        if 2.0 * float(matches[(a, b)]) / (sizes_a[a] + sizes_b[b]) > 0.1:
+            keep.add((min(a, b), max(a, b)))
+    return keep
+
+
+def make_stitch_list(chunks: dict, grid_pos: dict, overlap, stitch_overlap, overlap_thresh: float = 0) -> list:
     """``make_stitch_list`` / ``_make_stitch_list_thread`` (object_extraction_steps.py:446-617) for one label name: `chunks` maps a
     chunk number to its unique-label device volume, `grid_pos` a chunk number to its (ix, iy, iz) position in the chunk grid; every
     chunk is compared with its neighbours in +x, +y, +z (the upper half of the 6-neighbourhood, :548-554).  Returns the list of
@@ -394,7 +425,7 @@ def make_stitch_list(chunks: dict, grid_pos: dict, overlap, stitch_overlap) -> l
             q[dim] += 1
             m = by_pos.get(tuple(q))
             if m is not None:
-                pairs |= stitch_pairs(vol, chunks[m], dim, overlap, stitch_overlap)
+                pairs |= stitch_pairs(vol, chunks[m], dim, overlap, stitch_overlap, overlap_thresh)
     return sorted(pairs)
 
 

@@ -4,8 +4,7 @@
 chunk to each other (connected components -> max labels -> unique labels -> stitch list -> merge list -> apply merge list ->
 export); here a chunk's label volume is produced on the GPU and stays a device tensor until its stitched uint64 volume is written
 into the target KnossosDataset's overlay cubes.  Per-chunk arithmetic: ``object_extraction_steps`` (HIP library, no CPU fallback).
-Not reproduced: `transform_func`, the membrane hook on h5 chunk files (`membrane_filename`; `membrane_kd_path` is), `swapdata`,
-``overlap_thresh > 0`` (a cKDTree test on whole objects; the default is 0)."""
+Not reproduced: `transform_func`, the membrane hook on h5 chunk files (`membrane_filename`; `membrane_kd_path` is), `swapdata`."""
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -114,8 +113,6 @@ def from_probabilities_to_kd(target_kd_paths: Optional[Dict[str, str]], cset, fi
     for k, v in unsupported.items():
         if v:
             raise NotImplementedError(f'from_probabilities_to_kd: `{k}` is not part of the dense-prediction consumers built here')
-    if overlap_thresh:
-        raise NotImplementedError('from_probabilities_to_kd: overlap_thresh > 0 (whole-object cKDTree test) is not built')
     if prob_kd_path_dict is None:
         raise NotImplementedError('from_probabilities_to_kd: source data inside the ChunkDataset (h5 files) is not built')
     kd_keys = list(prob_kd_path_dict.keys())
@@ -168,17 +165,30 @@ def from_probabilities_to_kd(target_kd_paths: Optional[Dict[str, str]], cset, fi
         # dropped at the end of its iteration; what waits for a later neighbour is only the face slab that neighbour shares with it
         # (2 * stitch_overlap planes): at most one row of slabs per dimension is alive, whatever the size of the dataset.
         by_pos = {p: n for n, p in grid_pos.items()}
+        # (`overlap_thresh > 0`, object_extraction_steps.py:597-615: a pair is kept only if the two objects coincide in more than 10 % of
+        # their voxels -- then the slab that waits is everything the two chunk volumes share, 2 * overlap planes, and with it the
+        # chunk's object sizes)
         waiting, pairs = {}, set()                      # (chunk, dim) -> its +dim face slab, until the +dim neighbour has been made
+        width = overlap if overlap_thresh else stitch_overlap
+        sizes_of = {}
         for n in sorted(chunk_list, key=lambda k: grid_pos[k]):      # (any -d neighbour then precedes its +d neighbour)
             p = grid_pos[n]
             vol = unique(n, name)
+            if overlap_thresh:
+                sizes_of[n] = oes.object_sizes(vol)
             for d in range(3):
                 before = by_pos.get(tuple(p[k] - (1 if k == d else 0) for k in range(3)))
                 if before is not None and (before, d) in waiting:
-                    pairs |= oes.slab_pairs(waiting.pop((before, d)), oes.face_slab(vol, d, False, overlap, stitch_overlap))
+                    mine = oes.face_slab(vol, d, False, overlap, width)
+                    if overlap_thresh:
+                        pairs |= oes.overlapping_pairs(waiting.pop((before, d)), mine, d, overlap, stitch_overlap, sizes_of[before], sizes_of[n])
+                    else:
+                        pairs |= oes.slab_pairs(waiting.pop((before, d)), mine)
                 if by_pos.get(tuple(p[k] + (1 if k == d else 0) for k in range(3))) is not None:
-                    waiting[(n, d)] = oes.face_slab(vol, d, True, overlap, stitch_overlap)
+                    waiting[(n, d)] = oes.face_slab(vol, d, True, overlap, width)
             del vol
+            for m in [k for k in sizes_of if not any((k, d) in waiting for d in range(3)) and k != n]:
+                del sizes_of[m]                     # (no neighbour is waiting for this chunk any more)
         assert not waiting, 'chunk order: a +neighbour was processed before its -neighbour'
         stitch_list[name] = sorted(pairs)
         # ---- merge list (:343-347) and its application + export (:352-366)

@@ -92,6 +92,23 @@ def test_unique_stitch_apply_against_reference(gpu, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('name', NAMES)
+def test_stitch_list_with_overlap_threshold_against_reference(gpu, name):
+    """``overlap_thresh > 0`` (object_extraction_steps.py:597-615): the reference keeps a touching pair only if a cKDTree over the
+    global voxel coordinates finds more than 10 % of the two objects' voxels coincident; tests/golden/g14_stitch_thresh.npz holds the
+    pair lists its own function gives on the inputs of g11.  Here: co-occurrence counts over the 2 * overlap planes two chunk volumes
+    share + the chunks' object sizes, on the device."""
+    from syconn_amd.extraction import object_extraction_steps as oes
+    g14 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g14_stitch_thresh.npz'))
+    pos = _grid(name)
+    ol, so = G[f'{name}_overlap'], G[f'{name}_stitch_overlap']
+    uniq = {n: oes.make_unique_labels(torch.from_numpy(G[f'{name}_labels_{n}']).to(gpu), int(G[f'{name}_offsets'][n])) for n in pos}
+    want = [tuple(p) for p in g14[f'{name}_pairs_thresh'].tolist()]
+    assert oes.make_stitch_list(uniq, pos, ol, so, overlap_thresh=1) == want
+    assert set(want) <= set(oes.make_stitch_list(uniq, pos, ol, so))
+
+
+@pytest.mark.gpu
 def test_from_probabilities_to_kd_gives_the_connected_components_of_the_whole_volume(gpu, tmp_path):
     """End to end on a KnossosDataset: per-chunk components (no morphology) + stitching = the 6-connected components of the
     thresholded WHOLE volume, as a partition of the voxels; ids are globally unique; the target dataset holds them."""
@@ -122,6 +139,23 @@ def test_from_probabilities_to_kd_gives_the_connected_components_of_the_whole_vo
     pairs = np.unique(np.stack([a, b], 1), axis=0)
     assert len(pairs) == n_want == len(np.unique(b)) and len(np.unique(pairs[:, 0])) == len(np.unique(pairs[:, 1]))
     assert n_want >= 4 and len(res['stitch_list']['obj']) > 0 and res['max_labels']['obj'] > n_want
+    # the same call with the reference's overlap test switched on: the driver's slab bookkeeping (only face slabs and object sizes of
+    # a chunk wait for its later neighbours) gives what the all-volumes-in-memory form gives
+    from syconn_amd.extraction import object_extraction_steps as oes
+    res_t = from_probabilities_to_kd(None, cd, 'obj', ['obj'], prob_kd_path_dict={'obj': str(tmp_path / 'prob')}, thresholds=[thr],
+                                     overlap=np.array([2, 2, 2]), device=gpu, morph_ops={'obj': []}, min_seed_vx={'obj': 0},
+                                     scaling=(10, 10, 20), overlap_thresh=1)
+    _, (ol_used, so_used), _, labels = oes.object_segmentation(cd, ['obj'], {'obj': str(tmp_path / 'prob')}, [thr], overlap=np.array([2, 2, 2]),
+                                                              with_properties=False, device=gpu, keep_labels=True, morph_ops={'obj': []},
+                                                              min_seed_vx={'obj': 0}, scaling=(10, 10, 20))
+    nb = np.zeros(len(cd.chunk_dict), dtype=np.int64)
+    for n_chunk, _, n_cc in res['cc_info_list']:
+        nb[n_chunk] = n_cc
+    offs, _ = oes.label_offsets(nb)
+    uniq = {n: oes.make_unique_labels(labels[(n, 'obj')].to(gpu), int(offs[n])) for n in cd.chunk_dict}
+    gpos = {n: tuple(int(v) for v in np.asarray(c.coordinates) // np.array([48, 40, 20])) for n, c in cd.chunk_dict.items()}
+    assert res_t['stitch_list']['obj'] == oes.make_stitch_list(uniq, gpos, ol_used, so_used, overlap_thresh=1)
+    assert set(res_t['stitch_list']['obj']) <= set(res['stitch_list']['obj'])
 
 
 @pytest.mark.gpu
