@@ -207,9 +207,12 @@ def timed(fn_step, fn_drain, steps, par, dev):
         fn_step()
     fn_drain()
     torch.cuda.synchronize(dev)
+    mine = time.perf_counter() - t0          # this rank's own K steps (before it waits for the others): who the straggler is
     par.barrier()
     torch.cuda.synchronize(dev)
-    return par.max_over_ranks(time.perf_counter() - t0, device=dev)
+    total = par.max_over_ranks(time.perf_counter() - t0, device=dev)
+    timed.rank_seconds = par.values_of_all_ranks(mine, device=dev)
+    return total
 
 
 def main():
@@ -281,6 +284,7 @@ def main():
     pipe.drain()
     dm.profile(nbatch * args.steps)              # event ring: every launch set of the timed region keeps its own slot
     elapsed = timed(pipe.step, pipe.drain, args.steps, par, dev)
+    rank_seconds = list(timed.rank_seconds)
     vox_total = float(T) * S ** 3 * world * args.steps
     value = vox_total / elapsed / 1e6
 
@@ -447,7 +451,8 @@ def main():
                            'device_resident_value': value_res,
                            'device_resident_ms_per_step': elapsed_res / args.steps * 1e3,
                            'pcie_bytes_per_step_each_way': T * S ** 3, 'labels_sha256': labels_sha},
-                'roofline': roof, 'network': net, 'cpu_baseline': cpu, 'distributed': dist_info(par)}
+                'roofline': roof, 'network': net, 'cpu_baseline': cpu,
+                'distributed': dict(dist_info(par), rank_ms_per_step=[round(v / args.steps * 1e3, 3) for v in rank_seconds])}
         print(json.dumps(line))
     if par.collectives_active():
         par.barrier()
@@ -542,6 +547,7 @@ def volume_main(args):
         out[0] = par.predict_volume_distributed(vol, vol_shape, chunk, halo, predict_fn, n_out=1, device=dev, out=res_host,
                                                 chunk_cost=chunk_cost)
     elapsed = timed(step, lambda: None, steps, par, dev)
+    rank_seconds = list(timed.rank_seconds)
     if pred.overflowed():
         raise SystemExit('fp16 activation overflow during the volume workload: rerun with bf16')
     nvox = float(np.prod(vol_shape))
@@ -562,7 +568,7 @@ def volume_main(args):
                            'modelled_speedup_8_ranks': dict(zip(('z_major', 'cost_sorted'), _modelled(par, cm, vol_shape, chunk, halo))),
                            'collective': 'RCCL scatter of uint8 chunks / gather of uint8 results; volume and result resident in rank 0\'s HBM, '
                                          'one contiguous PCIe stream each way' if par.collectives_active() else 'none'},
-                'distributed': dist_info(par)}
+                'distributed': dict(dist_info(par), rank_ms_per_step=[round(v / steps * 1e3, 3) for v in rank_seconds])}
         print(json.dumps(line))
     if par.collectives_active():
         par.barrier()

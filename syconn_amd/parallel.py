@@ -566,6 +566,16 @@ def barrier():
         dist.barrier()
 
 
+def values_of_all_ranks(value: float, device: Optional[torch.device] = None) -> List[float]:
+    """`value` of every rank, in rank order, on every rank (one small all-gather; [value] without a process group)."""
+    if not _collectives():
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=device if (device is not None and dist.get_backend() == 'nccl') else 'cpu')
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def max_over_ranks(value: float, device: Optional[torch.device] = None) -> float:
     if not _collectives():
         return value

@@ -50,6 +50,7 @@ def _worker(rank, world, port, n_units, q):
     if rank == 0:
         assert all(torch.equal(a, b) for a, b in zip(got, got_async))
     t = par.max_over_ranks(float(rank + 1))
+    assert par.values_of_all_ranks(10.0 * (rank + 1)) == [10.0 * (k + 1) for k in range(world)]      # (what bench.py reports per rank)
     par.barrier()
     if rank == 0:
         vol = np.zeros(n_units, np.int64)
